@@ -1,0 +1,217 @@
+"""Generate golden vectors by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py
+
+imports the unmodified reference hot-path modules from ``/root/reference``
+through ``ref_shim`` and records, for small seeded synthetic scenes
+(``super_amd.synth``), the inputs at the drop-in boundary and the reference's
+outputs: per-term residuals and sparse Jacobians (captured by wrapping
+``LossTool.prepare_jtj_jtl``), dense JtJ / jtl from ``prepareCostTerm``, the
+match mask (from ``pcd2depth`` + ``bilinear_intrpl_block`` outputs), the
+per-iteration ``{loss, u, accepted, beta}`` trace of ``LM_Solver.LM``, its final
+beta, ``Surfels.update`` outputs and the KNN feeder outputs.  The ``.npz`` files
+are committed; the reference never leaves this box (fixtures are data only).
+"""
+from __future__ import annotations
+
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "python-super_amd"))
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+from super_amd import synth  # noqa: E402
+
+torch.set_num_threads(1)  # bit-deterministic fixtures
+
+SCENES = {
+    # name: (scene kwargs, lm opt kwargs, store dense JtJ)
+    # target border wider than the source border + 2 % target holes: some surfels
+    # project onto invalid pixels / unmapped taps, so the match set is a strict subset
+    "s60x80_j48": (dict(N=1500, J=48, H=60, W=80, seed=1, src_border=4, tgt_border=6,
+                        tgt_holes=0.02), dict(), True),
+    "s120x160_j108": (dict(N=6000, J=108, H=120, W=160, seed=2, src_border=6, tgt_border=8,
+                           tgt_holes=0.01), dict(), False),
+    "s60x80_j48_dataonly": (dict(N=1500, J=48, H=60, W=80, seed=3, src_border=5, tgt_border=2),
+                            dict(mesh_arap=False, mesh_rot=False), False),
+    # large motion (dphi) so that some LM steps are rejected
+    "s60x80_j48_reject": (dict(N=1500, J=48, H=60, W=80, seed=4, src_border=5, tgt_border=2,
+                               dphi=0.9), dict(), False),
+}
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def capture_terms(ref, solver, sf, inputs, new_data, beta):
+    """Run prepareCostTerm(grad=True) at ``beta`` recording each term's sparse J and r."""
+    rec = []
+    orig = ref.loss.LossTool.prepare_jtj_jtl
+
+    def wrapped(Jacobian, loss):
+        Jc = Jacobian.coalesce()
+        rec.append(dict(idx=_np(Jc.indices()).astype(np.int32), val=_np(Jc.values()).astype(np.float64),
+                        shape=tuple(Jc.shape), r=_np(loss).reshape(-1).astype(np.float64)))
+        return orig(Jacobian, loss)
+
+    # match-mask capture: outputs of the reference's own projection + bilinear gather
+    cap = {}
+    orig_p2d = ref.loss.pcd2depth
+    orig_bil = ref.loss.LossTool.bilinear_intrpl_block
+
+    def p2d(inp, pcd, **kw):
+        out = orig_p2d(inp, pcd, **kw)
+        cap["proj"] = tuple(_np(o) for o in out)
+        cap["T"] = _np(pcd)
+        return out
+
+    def bil(v, u, target_, **kw):
+        out = orig_bil(v, u, target_, **kw)
+        cap.setdefault("bil", []).append(_np(out[0]))
+        return out
+
+    ref.loss.LossTool.prepare_jtj_jtl = staticmethod(wrapped)
+    ref.loss.pcd2depth = p2d
+    ref.loss.LossTool.bilinear_intrpl_block = staticmethod(bil)
+    try:
+        for t in solver.losses:
+            t.prepare(sf, new_data)
+        jtj, jtl = solver.prepareCostTerm(sf, inputs, new_data, beta, grad=True)
+    finally:
+        ref.loss.LossTool.prepare_jtj_jtl = staticmethod(orig)
+        ref.loss.pcd2depth = orig_p2d
+        ref.loss.LossTool.bilinear_intrpl_block = staticmethod(orig_bil)
+    loss = solver.prepareCostTerm(sf, inputs, new_data, beta, grad=False)
+
+    out = dict(jtj=_np(jtj), jtl=_np(jtl).reshape(-1), loss=float(loss))
+    names = [n for n, on in (("data", solver.opt.sf_point_plane), ("arap", solver.opt.mesh_arap),
+                             ("rot", solver.opt.mesh_rot)) if on]
+    for n, r in zip(names, rec):
+        out[f"{n}_Jidx"], out[f"{n}_Jval"], out[f"{n}_r"] = r["idx"], r["val"], r["r"]
+        out[f"{n}_Jshape"] = np.array(r["shape"])
+    if "proj" in cap:
+        v_, u_, coords, proj_valid = cap["proj"]
+        valid = _np(new_data.valid)
+        vp = valid[np.clip(coords, 0, len(valid) - 1)] & (coords >= 0) & (coords < len(valid))
+        o, n = cap["bil"][0], cap["bil"][1]
+        ok = ~(np.isnan(o).any(1) | np.isnan(n).any(1))
+        cand = np.nonzero(vp)[0]
+        # reference: sf_indicies = proj_valid[valid_pair][intrpl_valid] must be all-True (D2)
+        assert proj_valid[cand][ok].all(), "scene triggers reference defect D2"
+        out["match"] = cand[ok]
+        out["T"] = cap["T"]
+        out["v_"], out["u_"], out["coords"] = v_, u_, coords
+        out["o"], out["n"] = o[ok], n[ok]
+    return out
+
+
+def capture_lm(ref, solver, sf, inputs, new_data):
+    calls = []
+    orig = solver.prepareCostTerm
+
+    def wrapped(sf_, inputs_, new_data_, beta, grad=False):
+        res = orig(sf_, inputs_, new_data_, beta, grad=grad)
+        if grad:
+            calls.append(("grad", _np(beta)))
+        else:
+            calls.append(("loss", _np(beta), float(res)))
+        return res
+
+    solver.prepareCostTerm = wrapped
+    try:
+        beta = solver.LM(sf, inputs, new_data)
+    finally:
+        solver.prepareCostTerm = orig
+    losses = [c[2] for c in calls if c[0] == "loss"]
+    betas_try = [c[1] for c in calls if c[0] == "loss"]
+    betas_in = [c[1] for c in calls if c[0] == "grad"]
+    u, v, best = 10.0, 7.5, 1e10
+    us, acc = [], []
+    for L in losses:
+        us.append(u)
+        if L < best:
+            best = L
+            u /= v
+            acc.append(True)
+        else:
+            u *= v
+            acc.append(False)
+    return dict(lm_beta=_np(beta), lm_loss=np.array(losses), lm_u=np.array(us),
+                lm_accepted=np.array(acc), lm_beta_try=np.stack(betas_try),
+                lm_beta_in=np.stack(betas_in))
+
+
+def capture_update(ref, sc, opt, beta):
+    sf, _, _ = ref_shim.torch_frame(sc)
+    sf.opt = opt
+    ref.nodes.Surfels.update(sf, torch.from_numpy(beta))
+    return dict(upd_points=_np(sf.points), upd_norms=_np(sf.norms),
+                upd_ed_points=_np(sf.ED_nodes.points), upd_ed_norms=_np(sf.ED_nodes.norms))
+
+
+def capture_knn(ref, sc, opt):
+    sf, _, _ = ref_shim.torch_frame(sc)
+    sf.opt, sf.hard_seg = opt, False
+    sf.isStable = torch.ones(sc.N, dtype=torch.bool)
+    ref.nodes.Surfels.update_ed(sf)
+    ref.nodes.Surfels.update_sfed_knn(sf)
+    return dict(knn_sf_idx=_np(sf.knn_indices), knn_sf_w=_np(sf.knn_w),
+                knn_sf_stable=_np(sf.isStable), knn_ed_idx=_np(sf.ED_nodes.knn_indices),
+                knn_ed_w=_np(sf.ED_nodes.knn_w))
+
+
+def main():
+    ref = ref_shim.install()
+    for name, (skw, okw, store_jtj) in SCENES.items():
+        sc = synth.make_scene(**skw)
+        opt = ref_shim.ref_opt(**okw)
+        sf, inputs, new_data = ref_shim.torch_frame(sc)
+        solver = ref.LM.LM_Solver(opt)
+        g = dict(H=sc.H, W=sc.W, K=sc.K)
+        for f in ("sf_points", "sf_norms", "sf_knn_idx", "sf_knn_w", "ed_points", "ed_norms",
+                  "ed_radii", "ed_knn_idx", "ed_knn_w", "tgt_points", "tgt_norms", "index_map",
+                  "valid"):
+            g["in_" + f] = getattr(sc, f)
+        g["opt_flags"] = np.array([opt.sf_point_plane, opt.mesh_arap, opt.mesh_rot], dtype=bool)
+        g["opt_weights"] = np.array([opt.sf_point_plane_weight, opt.mesh_arap_weight,
+                                     opt.mesh_rot_weight])
+
+        rng = np.random.default_rng(100 + skw["seed"])
+        beta0 = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (sc.J, 1))
+        beta1 = beta0 + np.concatenate([rng.normal(0, 0.02, (sc.J, 4)),
+                                        rng.normal(0, 0.004, (sc.J, 3))], axis=1)
+        for tag, b in (("b0", beta0), ("b1", beta1)):
+            t = capture_terms(ref, solver, sf, inputs, new_data, torch.from_numpy(b.copy()))
+            # dense JtJ -> its non-zeros (same information, smaller file)
+            nz = np.nonzero(t["jtj"])
+            t["jtj_nz_idx"], t["jtj_nz_val"] = np.stack(nz).astype(np.int32), t["jtj"][nz]
+            t.pop("jtj")
+            if not store_jtj:      # big scenes: keep r / jtl / loss / match, drop J and JtJ
+                for k in [k for k in t if "_Jidx" in k or "_Jval" in k or k.startswith("jtj_nz")]:
+                    t.pop(k)
+            for k in ("T", "v_", "u_", "coords"):
+                if tag == "b1" or not store_jtj:
+                    t.pop(k, None)
+            g[f"{tag}_beta"] = b
+            for k, v in t.items():
+                g[f"{tag}_{k}"] = v
+        g.update(capture_lm(ref, solver, sf, inputs, new_data))
+        g.update(capture_update(ref, sc, opt, g["lm_beta"]))
+        g.update(capture_knn(ref, sc, opt))
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **g)
+        print(f"{name}: N={sc.N} J={sc.J} M(b0)={len(g['b0_match'])} "
+              f"losses={np.array2string(g['lm_loss'], precision=4)} "
+              f"accepted={g['lm_accepted'].astype(int)} -> {os.path.getsize(path)/1024:.0f} KB")
+
+
+if __name__ == "__main__":
+    main()
