@@ -1,0 +1,177 @@
+/*
+ * super_lm.h -- C ABI of libsuper_lm.so: the MI355X (gfx950) implementation of
+ * SuPer's per-frame embedded-deformation Levenberg-Marquardt step.
+ *
+ * Drop-in boundary.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repository root):
+ *
+ *   slm_create / slm_destroy   <- LM_Solver.__init__            super/LM.py:11-34
+ *   slm_bind_frame             <- {Data,ARAP,Rot}Loss.prepare   super/loss.py:212-220,408-426,480-485
+ *   slm_run                    <- LM_Solver.LM                  super/LM.py:81-122
+ *   slm_assemble               <- LM_Solver.prepareCostTerm(grad=True)   super/LM.py:54-68
+ *   slm_loss                   <- LM_Solver.prepareCostTerm(grad=False)  super/LM.py:70-78
+ *   slm_solve / slm_solve_dense <- LM_Solver.Solver             super/LM.py:37-51
+ *   slm_data_residuals         <- DataLoss.forward internals    super/loss.py:222-255
+ *   slm_apply_update           <- Surfels.update                super/nodes.py:193-223
+ *   slm_knn                    <- Surfels.update_sfed_knn / update_ed / find_knn
+ *                                                               super/nodes.py:154-191, utils/utils.py:212-221
+ *
+ * Conventions
+ *   - Every pointer marked "device" is a HIP device pointer owned by the caller;
+ *     the library never frees or reallocates caller memory.
+ *   - Streamed inputs are float32 / int32 in HBM; all arithmetic, the normal
+ *     equations and the solve are float64 (the reference computes in float64).
+ *   - beta is (J,7) float64 row-major [qw,qx,qy,qz,bx,by,bz] (super/LM.py:85-88).
+ *   - Every call returns an int status (SLM_OK == 0), never throws, and takes the
+ *     hipStream_t (as void*) it enqueues on.  Only slm_bind_frame (one 4-byte
+ *     read-back to size the band), slm_get_records and slm_status synchronise.
+ *   - A solver owns `max_frames` independent slots; slm_run advances the LM
+ *     problems of slots [0, n_frames) together in the same launches (the
+ *     many-frame / many-hypothesis batch dimension).
+ */
+#ifndef SUPER_LM_H
+#define SUPER_LM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SLM_OK = 0,
+  SLM_ERR_INVALID = 1,      /* bad argument */
+  SLM_ERR_HIP = 2,          /* a HIP runtime call failed (slm_last_error has the text) */
+  SLM_ERR_NO_DEVICE = 3,    /* no gfx950 device / kernels cannot run */
+  SLM_ERR_UNBOUND = 4,      /* slot used before slm_bind_frame */
+  SLM_ERR_UNSUPPORTED = 5   /* e.g. num_neighbors != 4 */
+};
+
+/* per-iteration status in slm_iter_record.status */
+enum {
+  SLM_ITER_OK = 0,
+  SLM_ITER_SOLVER_FAILED = 1, /* Cholesky pivot <= 0: "Solver failed: Ill-posed system!" (super/LM.py:99-103) */
+  SLM_ITER_NOT_RUN = 2        /* iteration skipped because an earlier one stopped the loop */
+};
+
+typedef struct slm_solver slm_solver; /* opaque */
+
+/* Flags read from `opt` by LM_Solver.__init__/LM (super/LM.py:18-31,81-82). */
+typedef struct slm_config {
+  int32_t num_iterations;   /* opt.num_optimize_iterations (options.py:42), default 10 */
+  int32_t phase_test;       /* opt.phase == "test": accept/reject; 0 = "train": always accept */
+  int32_t use_data;         /* opt.sf_point_plane */
+  int32_t use_arap;         /* opt.mesh_arap */
+  int32_t use_rot;          /* opt.mesh_rot */
+  int32_t max_frames;       /* number of slots (>= 1) */
+  double w_data;            /* opt.sf_point_plane_weight (1.0) */
+  double w_arap;            /* opt.mesh_arap_weight (10.0) */
+  double w_rot;             /* opt.mesh_rot_weight (1.0) */
+  double u0;                /* LM(..., u=10)            super/LM.py:81 */
+  double v;                 /* LM(..., v=7.5)                          */
+  double minimal_loss0;     /* LM(..., minimal_loss=1e10)              */
+} slm_config;
+
+/* What LM reads from sf / inputs / new_data, as device pointers. */
+typedef struct slm_frame {
+  int32_t N;                /* surfels */
+  int32_t J;                /* ED nodes (sf.ED_nodes.num) */
+  int32_t T;                /* rows of the target tables */
+  int32_t H, W;             /* image size (inputs[("color",0)] shape) */
+  int32_t K;                /* surfel->node neighbours (opt.num_neighbors); must be 4 */
+  int32_t K_ED;             /* node->node neighbours (opt.num_ED_neighbors), 1..8 */
+  float fx, fy, cx, cy;     /* inputs["K"][0] entries [0,0],[1,1],[0,2],[1,2] (float32 like the reference) */
+  const float* sf_points;     /* device (N,3)      sf.points */
+  const int32_t* sf_knn_idx;  /* device (N,K)      sf.knn_indices */
+  const float* sf_knn_w;      /* device (N,K)      sf.knn_w */
+  const float* ed_points;     /* device (J,3)      sf.ED_nodes.points */
+  const int32_t* ed_knn_idx;  /* device (J,K_ED)   sf.ED_nodes.knn_indices */
+  const float* tgt_points;    /* device (T,3)      new_data.points */
+  const float* tgt_norms;     /* device (T,3)      new_data.norms */
+  const int32_t* index_map;   /* device (H,W)      new_data.index_map, -1 = invalid */
+  const uint8_t* tgt_valid;   /* device (H*W)      new_data.valid */
+} slm_frame;
+
+typedef struct slm_iter_record {
+  double loss;        /* sum of squared residuals at the trial beta (super/LM.py:107) */
+  double u;           /* damping used for this iteration's solve */
+  int32_t accepted;   /* 1 = step accepted */
+  int32_t status;     /* SLM_ITER_* */
+  int32_t M_grad;     /* matched surfels in the Jacobian pass */
+  int32_t M_loss;     /* matched surfels in the loss pass (fresh match set) */
+} slm_iter_record;
+
+/* -- lifetime ------------------------------------------------------------------ */
+int slm_create(const slm_config* cfg, slm_solver** out);
+int slm_destroy(slm_solver* s);
+const char* slm_last_error(void);
+/* number of visible HIP devices, or 0 (never initialises a context) */
+int slm_device_count(void);
+
+/* -- per-frame binding (loss_term.prepare) ------------------------------------- */
+/* Binds device pointers to `slot`, computes the tile half-bandwidth of the normal
+ * matrix from the KNN tables (one 4-byte device->host read, stream-synchronising)
+ * and (re)sizes the slot's workspace.  Resets beta to identity. */
+int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* frame, void* stream);
+
+/* -- the LM loop ------------------------------------------------------------------ */
+/* Enqueues num_iterations damped accept/reject iterations for slots [0,n_frames),
+ * entirely on the device (no host synchronisation). */
+int slm_run(slm_solver* s, int32_t n_frames, void* stream);
+/* Copies the slot's current beta (J*7 doubles) into caller device memory. */
+int slm_get_beta(slm_solver* s, int32_t slot, double* beta_out_device, void* stream);
+/* Overwrites the slot's beta from caller device memory (hypotheses / warm start / tests). */
+int slm_set_beta(slm_solver* s, int32_t slot, const double* beta_in_device, void* stream);
+/* Synchronises `stream` and copies the per-iteration records to HOST memory. */
+int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int32_t max_records,
+                    void* stream);
+
+/* -- parity / building-block entry points -------------------------------------- */
+/* JtJ and jtl = -Jt r at the slot's current beta.  jtj_dense_device is (P,P)
+ * float64 row-major (symmetric, full) or NULL; jtl_device is (P) or NULL. P = 7J. */
+int slm_assemble(slm_solver* s, int32_t slot, double* jtj_dense_device, double* jtl_device,
+                 void* stream);
+/* Sum of squared residuals per term at the slot's current beta:
+ * out_device[0..2] = data, arap, rot; out_device[3] = matched count (as double). */
+int slm_loss(slm_solver* s, int32_t slot, double* out_device, void* stream);
+/* Assemble at the current beta, add u to the diagonal, Cholesky-solve; writes delta (P).
+ * status_device (int32) receives SLM_ITER_OK or SLM_ITER_SOLVER_FAILED. */
+int slm_solve(slm_solver* s, int32_t slot, double u, double* delta_device,
+              int32_t* status_device, void* stream);
+/* LM_Solver.Solver(A, b, "cholesky") on a caller-supplied dense system: A_device is
+ * (P,P) float64 row-major symmetric positive definite, b_device (P); writes x (P) and
+ * status (SLM_ITER_OK / SLM_ITER_SOLVER_FAILED).  Compatibility entry point (allocates
+ * and frees its workspace, synchronises `stream`); the LM loop never uses it. */
+int slm_solve_dense(int32_t P, const double* A_device, const double* b_device, double* x_device,
+                    int32_t* status_device, void* stream);
+/* Per-surfel data-term internals at the current beta: r_device (N) float64
+ * (lambda * n.(T(p)-o), 0 where unmatched), match_device (N) uint8,
+ * taps_device (N,4) int32 target rows of the four bilinear taps (-1 invalid). */
+int slm_data_residuals(slm_solver* s, int32_t slot, double* r_device, uint8_t* match_device,
+                       int32_t* taps_device, void* stream);
+
+/* -- Surfels.update (LM variant, no global row) ---------------------------------- */
+/* In place on float32 device arrays: skin points, blend+normalise normals, move
+ * nodes, rotate node normals.  beta_device is (J,7) float64. */
+int slm_apply_update(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
+                     const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
+                     float* ed_norms, const double* beta_device, void* stream);
+
+/* -- KNN feeder --------------------------------------------------------------------- */
+/* K nearest `nodes` for every query point: squared L2 in float64, ascending, ties ->
+ * lowest index.  skip_self != 0 drops the first (self) hit (update_ed).  Outputs:
+ * idx (Nq,K) int32, dist (Nq,K) float32 = sqrt(d2). */
+int slm_knn(int32_t Nq, int32_t Nn, int32_t K, int32_t skip_self, const float* query_points,
+            const float* node_points, int32_t* idx_out, float* dist_out, void* stream);
+/* softmax(exp(-dist/radius)) weights (super/nodes.py:166,191) and the stability
+ * test any(dist <= radius) (super/nodes.py:182).  radius_mode 0: radius of each
+ * neighbour node (surfels); 1: radius of the query node itself (node-node).
+ * stable_io (Nq) uint8 is AND-ed in place, may be NULL. */
+int slm_knn_weights(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* idx,
+                    const float* dist, const float* node_radii, float* w_out,
+                    uint8_t* stable_io, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUPER_LM_H */

@@ -1,0 +1,424 @@
+// slm_api.hip -- the C ABI of libsuper_lm.so (include/super_lm.h): slot workspaces,
+// the on-device LM loop, parity entry points.  Host side only orchestrates launches.
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+#include "slm_common.h"
+
+// launchers defined next to their kernels
+void launch_data_grad(const FrameDev*, int, int, double, hipStream_t);
+void launch_data_loss(const FrameDev*, int, int, double, int, hipStream_t);
+void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
+void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
+void launch_reg_loss(const FrameDev*, int, int, int, double, int, double, int, hipStream_t);
+void launch_bandwidth(const slm_frame&, int*, hipStream_t);
+void launch_band_solve(const FrameDev*, int, int, int, double, hipStream_t);
+void launch_band_to_dense(const FrameDev*, int, double*, hipStream_t);
+void launch_dense_to_band(const FrameDev*, const double*, const double*, hipStream_t);
+void launch_init_slot(const FrameDev*, int, int, const slm_config&, hipStream_t);
+void launch_iter_begin(const FrameDev*, int, hipStream_t);
+void launch_accept(const FrameDev*, int, int, int, hipStream_t);
+void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
+void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
+void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
+                   hipStream_t);
+void launch_knn(int, int, int, int, const float*, const float*, int*, float*, hipStream_t);
+void launch_knn_weights(int, int, int, const int*, const float*, const float*, float*, uint8_t*,
+                        hipStream_t);
+
+static thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return SLM_ERR_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+
+static int fail(int code, const char* msg) {
+  g_err = msg;
+  return code;
+}
+
+namespace {
+constexpr int kLossBlocks = 512;   // data-loss partial sums per slot
+constexpr int kRegBlocksMax = 64;
+
+struct Slot {
+  FrameDev h{};                 // host mirror of the device descriptor
+  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0;
+};
+}  // namespace
+
+struct slm_solver {
+  slm_config cfg{};
+  std::vector<Slot> slots;
+  FrameDev* frames_dev = nullptr;
+  int* bw_dev = nullptr;
+  int* bw_host = nullptr;       // pinned
+};
+
+template <typename T>
+static hipError_t grow(T*& p, size_t& cap, size_t need) {
+  if (need <= cap) return hipSuccess;
+  if (p) {
+    hipError_t e = hipFree(p);
+    if (e != hipSuccess) return e;
+    p = nullptr;
+  }
+  size_t want = need + need / 8;
+  hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+  if (e == hipSuccess) cap = want;
+  return e;
+}
+
+extern "C" {
+
+const char* slm_last_error(void) { return g_err.c_str(); }
+
+int slm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int slm_create(const slm_config* cfg, slm_solver** out) {
+  if (!cfg || !out) return fail(SLM_ERR_INVALID, "slm_create: null argument");
+  if (cfg->max_frames < 1 || cfg->num_iterations < 0 || !(cfg->v > 0.0))
+    return fail(SLM_ERR_INVALID, "slm_create: bad config");
+  if (slm_device_count() < 1) return fail(SLM_ERR_NO_DEVICE, "slm_create: no HIP device visible");
+  slm_solver* s = new slm_solver();
+  s->cfg = *cfg;
+  s->slots.resize(cfg->max_frames);
+  hipError_t e = hipMalloc((void**)&s->frames_dev, sizeof(FrameDev) * cfg->max_frames);
+  if (e == hipSuccess) e = hipMemset(s->frames_dev, 0, sizeof(FrameDev) * cfg->max_frames);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->bw_dev, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->bw_host, sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    g_err = std::string("slm_create: ") + hipGetErrorString(e);
+    slm_destroy(s);
+    return SLM_ERR_HIP;
+  }
+  *out = s;
+  return SLM_OK;
+}
+
+int slm_destroy(slm_solver* s) {
+  if (!s) return SLM_OK;
+  for (Slot& sl : s->slots) {
+    FrameDev& h = sl.h;
+    if (h.beta) (void)hipFree(h.beta);
+    if (h.delta) (void)hipFree(h.delta);
+    if (h.rhs) (void)hipFree(h.rhs);
+    if (h.band) (void)hipFree(h.band);
+    if (h.linv) (void)hipFree(h.linv);
+    if (h.loss_part) (void)hipFree(h.loss_part);
+    if (h.st) (void)hipFree(h.st);
+    if (h.rec) (void)hipFree(h.rec);
+  }
+  if (s->frames_dev) (void)hipFree(s->frames_dev);
+  if (s->bw_dev) (void)hipFree(s->bw_dev);
+  if (s->bw_host) (void)hipHostFree(s->bw_host);
+  delete s;
+  return SLM_OK;
+}
+
+int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream) {
+  if (!s || !f) return fail(SLM_ERR_INVALID, "slm_bind_frame: null argument");
+  if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad slot");
+  if (f->K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_neighbors must be 4");
+  if (f->K_ED < 1 || f->K_ED > SLM_MAX_KED)
+    return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_ED_neighbors must be in 1..8");
+  if (f->N < 0 || f->J < 1 || f->H < 2 || f->W < 2 || f->T < 0)
+    return fail(SLM_ERR_INVALID, "slm_bind_frame: bad sizes");
+  if (!f->sf_points || !f->sf_knn_idx || !f->sf_knn_w || !f->ed_points || !f->ed_knn_idx ||
+      !f->tgt_points || !f->tgt_norms || !f->index_map || !f->tgt_valid)
+    return fail(SLM_ERR_INVALID, "slm_bind_frame: null device pointer");
+  hipStream_t st = (hipStream_t)stream;
+  Slot& sl = s->slots[slot];
+  FrameDev& h = sl.h;
+
+  // tile half-bandwidth of the normal matrix (one 4-byte read-back)
+  launch_bandwidth(*f, s->bw_dev, st);
+  HIPCHK(hipMemcpyAsync(s->bw_host, s->bw_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int P = 7 * f->J;
+  const int nt = (P + SLM_NB - 1) / SLM_NB;
+  int wb = *s->bw_host;
+  if (wb > nt - 1) wb = nt - 1;
+
+  h.f = *f;
+  h.P = P;
+  h.nt = nt;
+  h.wb = wb;
+  h.n_loss_part = s->cfg.use_data ? kLossBlocks : 0;
+  size_t cap_dummy;
+  HIPCHK(grow(h.beta, sl.cap_beta, (size_t)P));
+  {
+    size_t need = (size_t)nt * SLM_NB, c1 = sl.cap_vec, c2 = sl.cap_vec;
+    HIPCHK(grow(h.delta, c1, need));
+    HIPCHK(grow(h.rhs, c2, need));
+    sl.cap_vec = c1 < c2 ? c1 : c2;
+  }
+  HIPCHK(grow(h.band, sl.cap_band, (size_t)nt * (wb + 1) * SLM_NB * SLM_NB));
+  HIPCHK(grow(h.linv, sl.cap_linv, (size_t)nt * SLM_NB * SLM_NB));
+  if (!h.loss_part) {
+    cap_dummy = 0;
+    HIPCHK(grow(h.loss_part, cap_dummy, (size_t)2 * (kLossBlocks + kRegBlocksMax)));
+    HIPCHK(hipMemsetAsync(h.loss_part, 0, sizeof(double) * 2 * (kLossBlocks + kRegBlocksMax), st));
+  }
+  if (!h.st) HIPCHK(hipMalloc((void**)&h.st, sizeof(LMState)));
+  if (!h.rec) {
+    int n = s->cfg.num_iterations > 0 ? s->cfg.num_iterations : 1;
+    HIPCHK(hipMalloc((void**)&h.rec, sizeof(slm_iter_record) * n));
+  }
+  h.bound = 1;
+  HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // h is reused by later binds
+  launch_init_slot(s->frames_dev, slot, f->J, s->cfg, st);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+}  // extern "C"
+
+static int check_slots(slm_solver* s, int first, int n) {
+  if (!s) return fail(SLM_ERR_INVALID, "null solver");
+  if (first < 0 || n < 1 || first + n > (int)s->slots.size())
+    return fail(SLM_ERR_INVALID, "slot range out of bounds");
+  for (int i = first; i < first + n; ++i)
+    if (!s->slots[i].h.bound) return fail(SLM_ERR_UNBOUND, "slot used before slm_bind_frame");
+  return SLM_OK;
+}
+
+namespace {
+struct BatchDims {
+  int maxN = 0, maxJKe = 0, nt_max = 0, wb_cap = 0, n_reg_part = 0;
+};
+BatchDims dims_of(slm_solver* s, int first, int n) {
+  BatchDims d;
+  for (int i = first; i < first + n; ++i) {
+    const FrameDev& h = s->slots[i].h;
+    d.maxN = std::max(d.maxN, h.f.N);
+    d.maxJKe = std::max(d.maxJKe, h.f.J * h.f.K_ED);
+    d.nt_max = std::max(d.nt_max, h.nt);
+    d.wb_cap = std::max(d.wb_cap, h.wb);
+  }
+  if (s->cfg.use_arap || s->cfg.use_rot)
+    d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);
+  return d;
+}
+
+void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, hipStream_t st) {
+  launch_iter_begin(fr, n, st);
+  if (s->cfg.use_data) launch_data_grad(fr, n, d.maxN, s->cfg.w_data, st);
+  launch_reg_grad(fr, n, d.maxJKe, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
+}
+
+void enqueue_loss(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, int use_delta,
+                  hipStream_t st) {
+  if (s->cfg.use_data) launch_data_loss(fr, n, kLossBlocks, s->cfg.w_data, use_delta, st);
+  if (d.n_reg_part > 0)
+    launch_reg_loss(fr, n, d.n_reg_part, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot,
+                    s->cfg.w_rot, use_delta, st);
+}
+}  // namespace
+
+extern "C" {
+
+int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
+  int rc = check_slots(s, 0, n_frames);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const BatchDims d = dims_of(s, 0, n_frames);
+  const FrameDev* fr = s->frames_dev;
+  for (int it = 0; it < s->cfg.num_iterations; ++it) {
+    enqueue_assemble(s, fr, n_frames, d, st);
+    launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
+    enqueue_loss(s, fr, n_frames, d, 1, st);
+    launch_accept(fr, n_frames, s->cfg.phase_test, d.n_reg_part, st);
+  }
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_get_beta(slm_solver* s, int32_t slot, double* out, void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  if (!out) return fail(SLM_ERR_INVALID, "slm_get_beta: null output");
+  const FrameDev& h = s->slots[slot].h;
+  HIPCHK(hipMemcpyAsync(out, h.beta, sizeof(double) * h.P, hipMemcpyDeviceToDevice,
+                        (hipStream_t)stream));
+  return SLM_OK;
+}
+
+int slm_set_beta(slm_solver* s, int32_t slot, const double* in, void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  if (!in) return fail(SLM_ERR_INVALID, "slm_set_beta: null input");
+  const FrameDev& h = s->slots[slot].h;
+  hipStream_t st = (hipStream_t)stream;
+  // fresh LM state (u0, minimal_loss0, records), then the caller's beta
+  launch_init_slot(s->frames_dev, slot, h.f.J, s->cfg, st);
+  HIPCHK(hipMemcpyAsync(h.beta, in, sizeof(double) * h.P, hipMemcpyDeviceToDevice, st));
+  return SLM_OK;
+}
+
+int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int32_t max_records,
+                    void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  if (!host_out || max_records < 0) return fail(SLM_ERR_INVALID, "slm_get_records: bad output");
+  int n = std::min(max_records, s->cfg.num_iterations);
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0)
+    HIPCHK(hipMemcpyAsync(host_out, s->slots[slot].h.rec, sizeof(slm_iter_record) * n,
+                          hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return SLM_OK;
+}
+
+static int clear_flags(slm_solver* s, int slot, hipStream_t st) {
+  // stopped / counters live at the tail of LMState: zero {iter..pad}
+  LMState* p = s->slots[slot].h.st;
+  HIPCHK(hipMemsetAsync(&p->stopped, 0, sizeof(int32_t) * 4, st));
+  return SLM_OK;
+}
+
+int slm_assemble(slm_solver* s, int32_t slot, double* jtj_dense, double* jtl, void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  rc = clear_flags(s, slot, st);
+  if (rc) return rc;
+  const BatchDims d = dims_of(s, slot, 1);
+  const FrameDev& h = s->slots[slot].h;
+  enqueue_assemble(s, s->frames_dev + slot, 1, d, st);
+  if (jtj_dense) launch_band_to_dense(s->frames_dev, slot, jtj_dense, st);
+  if (jtl)
+    HIPCHK(hipMemcpyAsync(jtl, h.rhs, sizeof(double) * h.P, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_loss(slm_solver* s, int32_t slot, double* out, void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  if (!out) return fail(SLM_ERR_INVALID, "slm_loss: null output");
+  hipStream_t st = (hipStream_t)stream;
+  rc = clear_flags(s, slot, st);
+  if (rc) return rc;
+  const BatchDims d = dims_of(s, slot, 1);
+  enqueue_loss(s, s->frames_dev + slot, 1, d, 0, st);
+  launch_loss_out(s->frames_dev, slot, d.n_reg_part, out, st);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_solve(slm_solver* s, int32_t slot, double u, double* delta, int32_t* status, void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  if (!delta || !(u >= 0.0)) return fail(SLM_ERR_INVALID, "slm_solve: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  rc = clear_flags(s, slot, st);
+  if (rc) return rc;
+  const BatchDims d = dims_of(s, slot, 1);
+  const FrameDev& h = s->slots[slot].h;
+  enqueue_assemble(s, s->frames_dev + slot, 1, d, st);
+  launch_band_solve(s->frames_dev + slot, 1, d.nt_max, d.wb_cap, u, st);
+  HIPCHK(hipMemcpyAsync(delta, h.delta, sizeof(double) * h.P, hipMemcpyDeviceToDevice, st));
+  if (status)
+    HIPCHK(hipMemcpyAsync(status, &h.st->chol_fail, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_solve_dense(int32_t P, const double* A, const double* b, double* x, int32_t* status,
+                    void* stream) {
+  if (P < 1 || !A || !b || !x) return fail(SLM_ERR_INVALID, "slm_solve_dense: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  FrameDev h{};
+  h.P = P;
+  h.nt = (P + SLM_NB - 1) / SLM_NB;
+  h.wb = h.nt - 1;
+  h.bound = 1;
+  const size_t nvec = (size_t)h.nt * SLM_NB;
+  const size_t nband = (size_t)h.nt * (h.wb + 1) * SLM_NB * SLM_NB;
+  const size_t nlinv = (size_t)h.nt * SLM_NB * SLM_NB;
+  char* ws = nullptr;
+  const size_t bytes = sizeof(double) * (2 * nvec + nband + nlinv) + sizeof(LMState) + sizeof(FrameDev);
+  HIPCHK(hipMalloc((void**)&ws, bytes));
+  double* p = reinterpret_cast<double*>(ws);
+  h.delta = p;
+  h.rhs = p + nvec;
+  h.band = p + 2 * nvec;
+  h.linv = h.band + nband;
+  h.st = reinterpret_cast<LMState*>(h.linv + nlinv);
+  FrameDev* fdev = reinterpret_cast<FrameDev*>(h.st + 1);
+  int rc = SLM_OK;
+  hipError_t e = hipMemsetAsync(h.st, 0, sizeof(LMState), st);
+  if (e == hipSuccess) e = hipMemcpyAsync(fdev, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    launch_dense_to_band(fdev, A, b, st);
+    launch_band_solve(fdev, 1, h.nt, h.wb, 0.0, st);
+    e = hipMemcpyAsync(x, h.delta, sizeof(double) * P, hipMemcpyDeviceToDevice, st);
+  }
+  if (e == hipSuccess && status)
+    e = hipMemcpyAsync(status, &h.st->chol_fail, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_err = std::string("slm_solve_dense: ") + hipGetErrorString(e);
+    rc = SLM_ERR_HIP;
+  }
+  (void)hipFree(ws);
+  return rc;
+}
+
+int slm_data_residuals(slm_solver* s, int32_t slot, double* r, uint8_t* match, int32_t* taps,
+                       void* stream) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  const FrameDev& h = s->slots[slot].h;
+  launch_data_resid(s->frames_dev, slot, h.f.N, s->cfg.w_data, r, match, taps, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_apply_update(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
+                     const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
+                     float* ed_norms, const double* beta, void* stream) {
+  if (K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_apply_update: num_neighbors must be 4");
+  if (N < 0 || J < 1 || !ed_points || !ed_norms || !beta || (N > 0 && (!sf_points || !sf_norms ||
+      !sf_knn_idx || !sf_knn_w)))
+    return fail(SLM_ERR_INVALID, "slm_apply_update: bad argument");
+  launch_update(N, J, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, beta,
+                (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_knn(int32_t Nq, int32_t Nn, int32_t K, int32_t skip_self, const float* q, const float* nodes,
+            int32_t* idx, float* dist, void* stream) {
+  if (Nq < 0 || Nn < 1 || K < 1 || K + (skip_self ? 1 : 0) > 9 || !nodes || !idx || !dist ||
+      (Nq > 0 && !q))
+    return fail(SLM_ERR_INVALID, "slm_knn: bad argument (K + skip_self <= 9)");
+  launch_knn(Nq, Nn, K, skip_self, q, nodes, idx, dist, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_knn_weights(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* idx, const float* dist,
+                    const float* radii, float* w, uint8_t* stable, void* stream) {
+  if (Nq < 0 || K < 1 || K > 9 || !idx || !dist || !radii || !w)
+    return fail(SLM_ERR_INVALID, "slm_knn_weights: bad argument");
+  launch_knn_weights(Nq, K, radius_mode, idx, dist, radii, w, stable, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+}  // extern "C"

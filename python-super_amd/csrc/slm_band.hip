@@ -1,0 +1,314 @@
+// slm_band.hip -- damped normal equations (JtJ + uI) delta = jtl as a block-banded
+// float64 Cholesky (replaces the reference's dense torch.linalg.cholesky +
+// cholesky_solve on a (7J)^2 matrix, super/LM.py:37-51,97-100).
+//
+// Storage: lower band in NB x NB tiles, column-major inside a tile; tile (r,c),
+// c <= r <= c+wb, at band[(c*(wb+1) + (r-c)) * NB*NB].  The ED graph couples only
+// nearby nodes, so wb << nt (half-bandwidth ~156 node blocks at J=2k).
+//
+// Per tile column c (right-looking):
+//   k_panel(c)  block d: factor A(c,c)+uI = L L^T and form L^-1 in LDS (every block,
+//               redundantly); d=0 stores L^-1 and forward-substitutes y_c = L^-1 b_c;
+//               d>=1: L(c+d,c) = A(c+d,c) L^-T on the f64 MFMA (v_mfma_f64_16x16x4_f64).
+//   k_trail(c)  A(r,s) -= L(r,c) L(s,c)^T for the wb x wb window (MFMA); b_s -= L(s,c) y_c.
+// Back substitution k_backsub(c), c = nt-1..0: x_c = L_cc^-T y_c, y_(c-d) -= L(c,c-d)^T x_c.
+// A non-positive pivot sets st->chol_fail (reference: RuntimeError -> "Solver failed").
+#include "slm_common.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define NB SLM_NB
+#define TILE (NB * NB)
+
+// ---------------------------------------------------------------------------------
+// Tile half-bandwidth from the KNN tables: max over coupled node pairs (a >= b) of
+// tile(7a+6) - tile(7b).  Surfel tuples couple all pairs among their K nodes
+// (loss.py:277-288); ARAP couples (j, k) (loss.py:414-426).
+__global__ void __launch_bounds__(256) k_bandwidth(slm_frame f, int* __restrict__ out) {
+  int wmax = 0;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < f.N; i += stride) {
+    const int4 id = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
+    int lo = min(min(id.x, id.y), min(id.z, id.w));
+    int hi = max(max(id.x, id.y), max(id.z, id.w));
+    wmax = max(wmax, (7 * hi + 6) / NB - (7 * lo) / NB);
+  }
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < f.J * f.K_ED; t += stride) {
+    const int j = t / f.K_ED, k = f.ed_knn_idx[t];
+    int lo = min(j, k), hi = max(j, k);
+    wmax = max(wmax, (7 * hi + 6) / NB - (7 * lo) / NB);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_down(wmax, o, 64));
+  if ((threadIdx.x & 63) == 0 && wmax > 0) atomicMax(out, wmax);
+}
+
+// ---------------------------------------------------------------------------------
+// C(64x64) = Cinit + sign * A B^T on the f64 MFMA; A, B, C column-major 64x64.
+// 256 threads = 4 waves; wave w owns rows [16w,16w+16) of C.  The product is formed
+// transposed (first operand = B fragment, second = A fragment) so that lane&15 runs
+// along rows of C and the stores are 128-byte contiguous.
+//   acc[ni][r] <-> C[16w + (l&15)][16ni + (l>>4) + 4r]
+template <bool LOAD_C, bool NEGATE>
+__device__ __forceinline__ void tile_ABt(const double* __restrict__ A, const double* __restrict__ B,
+                                         const double* Cin, double* Cout) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = l & 15, lk = l >> 4;
+  double4_t acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[ni][r] = LOAD_C ? Cin[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * r) * NB] : 0.0;
+  }
+#pragma unroll 4
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const int p = 4 * ks + lk;
+    double a = A[(16 * w + lr) + p * NB];
+    if (NEGATE) a = -a;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const double b = B[(16 * ni + lr) + p * NB];
+      acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[ni], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cout[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * r) * NB] = acc[ni][r];
+}
+
+// ---------------------------------------------------------------------------------
+// Factor the diagonal tile in LDS: on exit s holds L (lower, column-major, zero above)
+// and m holds L^-1 (lower).  Symmetric elimination without pivoting, one barrier per
+// column; the same row operations applied to the identity give L~^-1, and
+// L = U^T diag(p)^-1/2, L^-1 = diag(p)^-1/2 L~^-1.  Returns false on a pivot <= 0 / NaN.
+__device__ __forceinline__ bool potrf_inv_lds(double* s, double* m, double* piv) {
+  const int ti = threadIdx.x & 63, tk = threadIdx.x >> 6;
+  bool ok = true;
+  for (int j = 0; j < NB; ++j) {
+    const double p = s[j + j * NB];
+    if (!(p > 0.0)) ok = false;
+    const double inv = 1.0 / p;
+    const int i = ti;
+    if (i > j) {
+      const double fi = s[i + j * NB] * inv;
+      for (int k = tk; k < NB; k += 4) {
+        if (k <= j) {
+          m[i + k * NB] -= fi * m[j + k * NB];
+        } else if (k <= i) {
+          s[i + k * NB] -= fi * s[k + j * NB];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < NB) piv[threadIdx.x] = 1.0 / sqrt(s[threadIdx.x + threadIdx.x * NB]);
+  __syncthreads();
+  for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
+    const int i = e % NB, k = e / NB;
+    s[e] = (i >= k) ? s[e] * piv[k] : 0.0;
+    m[e] = (i >= k) ? m[e] * piv[i] : 0.0;
+  }
+  __syncthreads();
+  return ok;
+}
+
+// Load the (symmetric) diagonal tile c into LDS with damping u and unit padding rows.
+__device__ __forceinline__ void load_diag_tile(const FrameDev& fd, int c, double u, double* s,
+                                               double* m) {
+  const double* src = fd.band + (size_t)c * (fd.wb + 1) * TILE;
+  for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
+    const int i = e % NB, k = e / NB;
+    double v = (i >= k) ? src[i + k * NB] : src[k + i * NB];
+    if (i == k) {
+      const int gi = c * NB + i;
+      v = (gi < fd.P) ? v + u : 1.0;
+    }
+    s[e] = v;
+    m[e] = (i == k) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+}
+
+// grid = (wb_cap + 1, n_frames), 256 threads, 64 KB + LDS
+__global__ void __launch_bounds__(256) k_panel(const FrameDev* __restrict__ frames, int c,
+                                                double u_override) {
+  extern __shared__ double lds[];
+  double* s = lds;
+  double* m = lds + TILE;
+  double* piv = lds + 2 * TILE;
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped || c >= fd.nt) return;
+  const int d = blockIdx.x;
+  if (d > fd.wb || c + d >= fd.nt) return;
+  const double u = (u_override >= 0.0) ? u_override : fd.st->u;
+
+  load_diag_tile(fd, c, u, s, m);
+  const bool ok = potrf_inv_lds(s, m, piv);
+
+  if (d == 0) {
+    if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
+    double* linv = fd.linv + (size_t)c * TILE;
+    for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = m[e];
+    // forward substitution of this block row: y_c = L^-1 b_c
+    double* b = fd.rhs + (size_t)c * NB;
+    if (threadIdx.x < NB) piv[threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < NB) {
+      const int i = threadIdx.x;
+      double acc = 0.0;
+      for (int k = 0; k <= i; ++k) acc += m[i + k * NB] * piv[k];
+      b[i] = acc;
+    }
+  } else {
+    // L(c+d, c) = A(c+d, c) L^-T, in place (each wave reads and writes only its own rows)
+    double* At = fd.band + ((size_t)c * (fd.wb + 1) + d) * TILE;
+    tile_ABt<false, false>(At, m, nullptr, At);
+  }
+}
+
+// grid = (wb_cap*(wb_cap+1)/2 + wb_cap, n_frames)
+__global__ void __launch_bounds__(256) k_trail(const FrameDev* __restrict__ frames, int c,
+                                                int wb_cap) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped || c >= fd.nt) return;
+  const int ntri = wb_cap * (wb_cap + 1) / 2;
+  int t = blockIdx.x;
+  if (t < ntri) {
+    // (a,b), 1 <= b <= a <= wb_cap, row-major over the lower triangle
+    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    while (a * (a + 1) / 2 > t) --a;
+    const int b = t - a * (a + 1) / 2;
+    const int da = a + 1, db = b + 1;
+    if (da > fd.wb || c + da >= fd.nt) return;
+    const size_t col = (size_t)c * (fd.wb + 1);
+    const double* Lr = fd.band + (col + da) * TILE;
+    const double* Ls = fd.band + (col + db) * TILE;
+    double* Ct = fd.band + ((size_t)(c + db) * (fd.wb + 1) + (da - db)) * TILE;
+    tile_ABt<true, true>(Lr, Ls, Ct, Ct);
+  } else {
+    // rhs: b_s -= L(s,c) y_c, s = c + db
+    const int db = t - ntri + 1;
+    if (db > fd.wb || c + db >= fd.nt) return;
+    __shared__ double y[NB];
+    __shared__ double part[4][NB];
+    const double* Ls = fd.band + ((size_t)c * (fd.wb + 1) + db) * TILE;
+    if (threadIdx.x < NB) y[threadIdx.x] = fd.rhs[(size_t)c * NB + threadIdx.x];
+    __syncthreads();
+    const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int k = 16 * q; k < 16 * q + 16; ++k) acc += Ls[i + k * NB] * y[k];
+    part[q][i] = acc;
+    __syncthreads();
+    if (threadIdx.x < NB)
+      fd.rhs[(size_t)(c + db) * NB + i] -= part[0][i] + part[1][i] + part[2][i] + part[3][i];
+  }
+}
+
+// grid = (wb_cap + 1, n_frames)
+__global__ void __launch_bounds__(256) k_backsub(const FrameDev* __restrict__ frames, int c_from_end) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  const int c = fd.nt - 1 - c_from_end;
+  if (c < 0) return;
+  const int d = blockIdx.x;
+  if (d > fd.wb || c - d < 0) return;
+  __shared__ double y[NB];
+  __shared__ double x[NB];
+  __shared__ double part[4][NB];
+  const double* linv = fd.linv + (size_t)c * TILE;
+  if (threadIdx.x < NB) y[threadIdx.x] = fd.rhs[(size_t)c * NB + threadIdx.x];
+  __syncthreads();
+  {
+    // x_c = L^-T y_c : x[k] = sum_{i>=k} Linv[i][k] y[i]
+    const int k = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int i = 16 * q; i < 16 * q + 16; ++i) acc += linv[i + k * NB] * y[i];
+    part[q][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < NB) x[k] = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+    __syncthreads();
+  }
+  if (d == 0) {
+    if (threadIdx.x < NB) fd.delta[(size_t)c * NB + threadIdx.x] = x[threadIdx.x];
+  } else {
+    // y_(c-d) -= L(c, c-d)^T x_c ; tile (c, c-d) is at column c-d, offset d
+    const double* Lt = fd.band + ((size_t)(c - d) * (fd.wb + 1) + d) * TILE;
+    const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
+    double acc = 0.0;
+    for (int mrow = 16 * q; mrow < 16 * q + 16; ++mrow) acc += Lt[mrow + n * NB] * x[mrow];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q == 0) fd.rhs[(size_t)(c - d) * NB + n] -= acc;
+  }
+}
+
+// Expand the assembled lower band to a dense symmetric (P,P) row-major matrix (parity tests).
+__global__ void __launch_bounds__(256) k_band_to_dense(const FrameDev* __restrict__ frames, int slot,
+                                                        double* __restrict__ out) {
+  const FrameDev& fd = frames[slot];
+  const size_t P = fd.P;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < P * P;
+       e += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / P), j = (int)(e % P);
+    int hi = max(i, j), lo = min(i, j);
+    double v = 0.0;
+    if (hi / NB - lo / NB <= fd.wb) v = *band_entry(fd, hi, lo);
+    out[e] = v;
+  }
+}
+
+// Pack a dense symmetric (P,P) row-major matrix into the (full-width) band (slm_solve_dense).
+__global__ void __launch_bounds__(256) k_dense_to_band(const FrameDev* __restrict__ frames,
+                                                        const double* __restrict__ A,
+                                                        const double* __restrict__ b) {
+  const FrameDev& fd = frames[0];
+  const size_t P = fd.P, Ppad = (size_t)fd.nt * NB;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < Ppad * Ppad;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / Ppad), j = (int)(e % Ppad);
+    if (i < j) continue;
+    *band_entry(fd, i, j) = (i < (int)P && j < (int)P) ? A[(size_t)i * P + j] : 0.0;
+  }
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < Ppad;
+       e += (size_t)gridDim.x * blockDim.x)
+    fd.rhs[e] = e < P ? b[e] : 0.0;
+}
+
+// ---- host launchers --------------------------------------------------------------
+void launch_dense_to_band(const FrameDev* frames_dev, const double* A, const double* b,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_dense_to_band, dim3(1024), dim3(256), 0, st, frames_dev, A, b);
+}
+
+void launch_bandwidth(const slm_frame& f, int* out_dev, hipStream_t st) {
+  (void)hipMemsetAsync(out_dev, 0, sizeof(int), st);
+  hipLaunchKernelGGL(k_bandwidth, dim3(256), dim3(256), 0, st, f, out_dev);
+}
+
+// Factor + forward substitution + back substitution for all frames; nt_max / wb_cap are
+// the maxima over the batch (blocks beyond a frame's own nt / wb exit immediately).
+void launch_band_solve(const FrameDev* frames_dev, int n_frames, int nt_max, int wb_cap,
+                       double u_override, hipStream_t st) {
+  const size_t lds = (2 * TILE + NB) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int ntrail = wb_cap * (wb_cap + 1) / 2 + wb_cap;
+  for (int c = 0; c < nt_max; ++c) {
+    hipLaunchKernelGGL(k_panel, dim3(wb_cap + 1, n_frames), dim3(256), lds, st, frames_dev, c,
+                       u_override);
+    if (ntrail > 0)
+      hipLaunchKernelGGL(k_trail, dim3(ntrail, n_frames), dim3(256), 0, st, frames_dev, c, wb_cap);
+  }
+  for (int e = 0; e < nt_max; ++e)
+    hipLaunchKernelGGL(k_backsub, dim3(wb_cap + 1, n_frames), dim3(256), 0, st, frames_dev, e);
+}
+
+void launch_band_to_dense(const FrameDev* frames_dev, int slot, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_band_to_dense, dim3(1024), dim3(256), 0, st, frames_dev, slot, out);
+}

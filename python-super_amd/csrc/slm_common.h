@@ -1,0 +1,125 @@
+// slm_common.h -- shared device-side types and f64 math for libsuper_lm (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "super_lm.h"
+
+#define SLM_NB 64            // scalar tile edge of the banded normal matrix
+#define SLM_MAX_KED 8
+#define SLM_K 4              // surfel->node neighbours (28-wide Jacobian rows)
+
+// ---------------------------------------------------------------------------------
+// Per-slot LM state, resident in HBM; every kernel reads it, k_accept advances it.
+struct LMState {
+  double u;              // current damping
+  double v;              // damping factor
+  double minimal_loss;   // best loss so far
+  int32_t iter;          // iterations finished
+  int32_t stopped;       // 1 after a solver failure: later kernels become no-ops
+  int32_t m_grad;        // matched-surfel counter of the current Jacobian pass
+  int32_t m_loss;        // matched-surfel counter of the current loss pass
+  int32_t chol_fail;     // set by the factorisation of the current iteration
+  int32_t pad;
+};
+
+// Per-slot descriptor, resident in HBM as an array indexed by blockIdx.y.
+struct FrameDev {
+  slm_frame f;           // caller's device pointers + sizes
+  int32_t P;             // 7*J
+  int32_t nt;            // tile columns = ceil(P / NB)
+  int32_t wb;            // sub-diagonal tiles per tile column (tile half-bandwidth)
+  int32_t bound;         // 1 once slm_bind_frame ran
+  double* beta;          // (J,7) current (== best in test phase)
+  double* delta;         // (nt*NB) solution of the damped system
+  double* rhs;           // (nt*NB) jtl, overwritten by the forward substitution
+  double* band;          // nt*(wb+1) tiles of NB*NB doubles, column-major inside a tile
+  double* linv;          // nt tiles: inverse of each diagonal Cholesky block
+  double* loss_part;     // per-block partial sums of the loss passes
+  int32_t n_loss_part;
+  int32_t pad2;
+  LMState* st;
+  slm_iter_record* rec;  // (num_iterations)
+};
+
+struct d3 {
+  double x, y, z;
+};
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// R(q)x = x + 2w(v x x) + 2 v x (v x x), un-normalised q (reference super/utils.py:49-54).
+__device__ __forceinline__ d3 quat_apply(double w, d3 v, d3 x) {
+  d3 c = cross(v, x);
+  d3 c2 = cross(v, c);
+  return {x.x + 2.0 * w * c.x + 2.0 * c2.x, x.y + 2.0 * w * c.y + 2.0 * c2.y,
+          x.z + 2.0 * w * c.z + 2.0 * c2.z};
+}
+
+// c^T d(R(q)x)/dq for a row vector c: out[0] = d/dw, out[1..3] = d/dv
+// (reference super/utils.py:59-69 contracted with c):
+//   c.dw = 2 c.(v x x);  c.dv = 2[(v.x)c + (c.v)x - 2(c.x)v - w (c x x)]
+__device__ __forceinline__ void quat_jac_row(double w, d3 v, d3 x, d3 c, double out[4]) {
+  d3 vx = cross(v, x);
+  out[0] = 2.0 * dot(c, vx);
+  double vdx = dot(v, x), cdv = dot(c, v), cdx = dot(c, x);
+  d3 cxx = cross(c, x);
+  out[1] = 2.0 * (vdx * c.x + cdv * x.x - 2.0 * cdx * v.x - w * cxx.x);
+  out[2] = 2.0 * (vdx * c.y + cdv * x.y - 2.0 * cdx * v.y - w * cxx.y);
+  out[3] = 2.0 * (vdx * c.z + cdv * x.z - 2.0 * cdx * v.z - w * cxx.z);
+}
+
+// Full 3x4 Jacobian d(R(q)x)/dq, Jq[i][j] (used by the ARAP rows).
+__device__ __forceinline__ void quat_jac(double w, d3 v, d3 x, double Jq[3][4]) {
+  d3 c = cross(v, x);
+  Jq[0][0] = 2.0 * c.x;
+  Jq[1][0] = 2.0 * c.y;
+  Jq[2][0] = 2.0 * c.z;
+  double vdx = dot(v, x);
+  double vv[3] = {v.x, v.y, v.z}, xx[3] = {x.x, x.y, x.z};
+  // skew(x)[i][j]: [x]x
+  double S[3][3] = {{0.0, -x.z, x.y}, {x.z, 0.0, -x.x}, {-x.y, x.x, 0.0}};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      Jq[i][j + 1] = 2.0 * ((i == j ? vdx : 0.0) + vv[i] * xx[j] - 2.0 * xx[i] * vv[j] - w * S[i][j]);
+}
+
+// address of entry (i,j), i >= j, of the lower band, tiles column-major, NB x NB
+__device__ __forceinline__ double* band_entry(const FrameDev& fd, int i, int j) {
+  int tr = i / SLM_NB, tc = j / SLM_NB;
+  size_t tile = (size_t)tc * (fd.wb + 1) + (tr - tc);
+  return fd.band + tile * (SLM_NB * SLM_NB) + (i - tr * SLM_NB) + (size_t)(j - tc * SLM_NB) * SLM_NB;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+  // lowers to one global_atomic_add_f64 on gfx950 (no compare-and-swap loop)
+  unsafeAtomicAdd(p, v);
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return x;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in thread 0
+__device__ __forceinline__ double block_sum(double x, double* smem /* >= 16 doubles */) {
+  x = wave_sum(x);
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) smem[wv] = x;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  __syncthreads();
+  return r;
+}

@@ -1,0 +1,139 @@
+// slm_data.h -- per-surfel evaluation of the point-to-plane data term (device, f64).
+//
+// Restates SURVEY.md Appendix A.2-A.5 (reference super/utils.py:17-71,
+// utils/utils.py:161-184, super/loss.py:106-173,222-290) as one fused per-surfel
+// function: skin -> project -> validity -> bilinear gather -> residual -> the
+// 28 Jacobian-row entries.  Nothing is materialised in HBM.
+#pragma once
+#include "slm_common.h"
+
+struct SurfelEval {
+  bool match;
+  double r;            // lambda * n.(T(p) - o)
+  int id[SLM_K];       // node ids of the four neighbours
+  double row[SLM_K * 7];  // lambda * [w_k c.Jq_k | w_k c]  (GRAD only)
+  int taps[4];         // target rows of the four bilinear taps (-1 invalid)
+};
+
+// beta may be offset by delta (trial point beta + delta of the LM loss pass).
+template <bool GRAD>
+__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* beta,
+                                            const double* delta, int i, SurfelEval& out) {
+  const slm_frame& f = fd.f;
+  const d3 p = {(double)f.sf_points[3 * i], (double)f.sf_points[3 * i + 1],
+                (double)f.sf_points[3 * i + 2]};
+  const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
+  const float4 wf = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
+  const int id[4] = {ids.x, ids.y, ids.z, ids.w};
+  const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
+
+  double qw[4];
+  d3 qv[4], dk[4];
+  d3 T = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    out.id[k] = id[k];
+    const double* b = beta + 7 * id[k];
+    double bb[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) bb[c] = b[c];
+    if (delta) {
+      const double* dl = delta + 7 * id[k];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) bb[c] += dl[c];
+    }
+    d3 g = {(double)f.ed_points[3 * id[k]], (double)f.ed_points[3 * id[k] + 1],
+            (double)f.ed_points[3 * id[k] + 2]};
+    qw[k] = bb[0];
+    qv[k] = {bb[1], bb[2], bb[3]};
+    dk[k] = p - g;
+    d3 t = quat_apply(qw[k], qv[k], dk[k]);
+    t = {t.x + bb[4] + g.x, t.y + bb[5] + g.y, t.z + bb[6] + g.z};
+    T = {T.x + w[k] * t.x, T.y + w[k] * t.y, T.z + w[k] * t.z};
+  }
+
+  out.match = false;
+  out.r = 0.0;
+  out.taps[0] = out.taps[1] = out.taps[2] = out.taps[3] = -1;
+
+  // ---- projection + validity on ROUNDED coordinates (utils/utils.py:171-181) ----
+  const double fx = (double)f.fx, fy = (double)f.fy, cx = (double)f.cx, cy = (double)f.cy;
+  const double Ze = T.z + 1e-8;
+  const double u_ = T.x * fx / Ze + cx;
+  const double v_ = T.y * fy / Ze + cy;
+  const double ur = rint(u_), vr = rint(v_);   // torch.round: half to even
+  const int H = f.H, W = f.W;
+  // proj_valid (false for NaN): 0 <= v < H-1, 0 <= u < W-1
+  if (!(vr >= 0.0 && vr < (double)(H - 1) && ur >= 0.0 && ur < (double)(W - 1))) return;
+  const int coords = (int)vr * W + (int)ur;
+  if (!f.tgt_valid[coords]) return;   // valid_pair (loss.py:229-234)
+
+  // ---- bilinear taps (loss.py:107-129) ----
+  const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
+  const double nn[4] = {fv, fv, cv, cv};
+  const double mm[4] = {fu, cu, fu, cu};
+  int rows[4];
+  bool all_ok = true;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int ni = (int)nn[t], mi = (int)mm[t];
+    bool inside = (ni >= 0) && (ni < H) && (mi >= 0) && (mi < W);
+    int row = inside ? f.index_map[ni * W + mi] : -1;
+    rows[t] = row;
+    out.taps[t] = row;
+    all_ok = all_ok && (row >= 0);
+  }
+  if (!all_ok) return;   // NaN fill -> surfel dropped (loss.py:241)
+
+  d3 o = {0, 0, 0}, n = {0, 0, 0};
+  d3 dou = {0, 0, 0}, dov = {0, 0, 0}, dnu = {0, 0, 0}, dnv = {0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const double dn = nn[t] - v_, dm = mm[t] - u_;
+    const double an = fmax(1.0 - fabs(dn), 0.0), am = fmax(1.0 - fabs(dm), 0.0);
+    const float* tp = f.tgt_points + 3 * (size_t)rows[t];
+    const float* tn = f.tgt_norms + 3 * (size_t)rows[t];
+    const d3 P = {(double)tp[0], (double)tp[1], (double)tp[2]};
+    const d3 Nn = {(double)tn[0], (double)tn[1], (double)tn[2]};
+    const double wv = an * am;
+    o = {o.x + P.x * wv, o.y + P.y * wv, o.z + P.z * wv};
+    n = {n.x + Nn.x * wv, n.y + Nn.y * wv, n.z + Nn.z * wv};
+    if (GRAD) {
+      const double sn = dn >= 0.0 ? 1.0 : -1.0, sm = dm >= 0.0 ? 1.0 : -1.0;
+      const double gu = an * sm, gv = am * sn;   // d/du, d/dv weights
+      dou = {dou.x + P.x * gu, dou.y + P.y * gu, dou.z + P.z * gu};
+      dov = {dov.x + P.x * gv, dov.y + P.y * gv, dov.z + P.z * gv};
+      dnu = {dnu.x + Nn.x * gu, dnu.y + Nn.y * gu, dnu.z + Nn.z * gu};
+      dnv = {dnv.x + Nn.x * gv, dnv.y + Nn.y * gv, dnv.z + Nn.z * gv};
+    }
+  }
+  // NaN in the tables behaves like the reference's isnan filter
+  if (!(o.x == o.x && o.y == o.y && o.z == o.z && n.x == n.x && n.y == n.y && n.z == n.z)) return;
+
+  const d3 e = T - o;
+  out.match = true;
+  out.r = lam * dot(n, e);
+  if (!GRAD) return;
+
+  // ---- c = n^T (I - A) + e^T B, A = do/d(u,v) Pi, B = dn/d(u,v) Pi (loss.py:257-281) ----
+  const double Z = T.z;   // no epsilon in dPi (loss.py:161-173)
+  const d3 Pi0 = {fx / Z, 0.0, -fx * T.x / (Z * Z)};
+  const d3 Pi1 = {0.0, fy / Z, -fy * T.y / (Z * Z)};
+  const double s0 = dot(e, dnu) - dot(n, dou);
+  const double s1 = dot(e, dnv) - dot(n, dov);
+  const d3 c = {n.x + s0 * Pi0.x + s1 * Pi1.x, n.y + s0 * Pi0.y + s1 * Pi1.y,
+                n.z + s0 * Pi0.z + s1 * Pi1.z};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double jq[4];
+    quat_jac_row(qw[k], qv[k], dk[k], c, jq);
+    const double lw = lam * w[k];
+    out.row[7 * k + 0] = lw * jq[0];
+    out.row[7 * k + 1] = lw * jq[1];
+    out.row[7 * k + 2] = lw * jq[2];
+    out.row[7 * k + 3] = lw * jq[3];
+    out.row[7 * k + 4] = lw * c.x;
+    out.row[7 * k + 5] = lw * c.y;
+    out.row[7 * k + 6] = lw * c.z;
+  }
+}

@@ -1,0 +1,98 @@
+// slm_data.hip -- data-term passes (point-to-plane ICP), v0: one thread per surfel.
+//
+//   k_data_grad   : JtJ (lower band) and jtl = -Jt r accumulation  (loss.py:222-288)
+//   k_data_loss   : sum r^2 at beta (+ delta), fresh match set     (loss.py:222-255,290)
+//   k_data_resid  : per-surfel r / match / taps for parity tests
+#include "slm_data.h"
+
+// grid = (ceil(maxN/256), n_frames)
+__global__ void __launch_bounds__(256) k_data_grad(const FrameDev* __restrict__ frames, double lam) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  SurfelEval ev;
+  ev.match = false;
+  if (i < fd.f.N) eval_surfel<true>(fd, lam, fd.beta, nullptr, i, ev);
+
+  // matched-surfel count: one atomic per wave
+  unsigned long long m = __ballot(ev.match);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&fd.st->m_grad, __popcll(m));
+  if (!ev.match) return;
+
+  // scatter row^T row into the lower band and -row^T r into rhs
+#pragma unroll 1
+  for (int a = 0; a < 28; ++a) {
+    const int ia = 7 * ev.id[a / 7] + a % 7;
+    const double ja = ev.row[a];
+    atomic_add_f64(fd.rhs + ia, -ja * ev.r);
+#pragma unroll 1
+    for (int b = 0; b < 28; ++b) {
+      const int ib = 7 * ev.id[b / 7] + b % 7;
+      if (ia >= ib) atomic_add_f64(band_entry(fd, ia, ib), ja * ev.row[b]);
+    }
+  }
+}
+
+// grid = (n_loss_blocks, n_frames); grid-stride over surfels; partial sums per block
+__global__ void __launch_bounds__(256) k_data_loss(const FrameDev* __restrict__ frames, double lam,
+                                                    int use_delta) {
+  __shared__ double sm[16];
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  double acc = 0.0;
+  int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fd.f.N; i += gridDim.x * blockDim.x) {
+    SurfelEval ev;
+    eval_surfel<false>(fd, lam, fd.beta, use_delta ? fd.delta : nullptr, i, ev);
+    if (ev.match) {
+      acc += ev.r * ev.r;
+      ++cnt;
+    }
+  }
+  double s = block_sum(acc, sm);
+  double c = block_sum((double)cnt, sm);
+  if (threadIdx.x == 0) {
+    fd.loss_part[2 * blockIdx.x] = s;
+    fd.loss_part[2 * blockIdx.x + 1] = c;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_data_resid(const FrameDev* __restrict__ frames, int slot,
+                                                     double lam, double* __restrict__ r_out,
+                                                     uint8_t* __restrict__ match_out,
+                                                     int32_t* __restrict__ taps_out) {
+  const FrameDev& fd = frames[slot];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= fd.f.N) return;
+  SurfelEval ev;
+  eval_surfel<false>(fd, lam, fd.beta, nullptr, i, ev);
+  if (r_out) r_out[i] = ev.match ? ev.r : 0.0;
+  if (match_out) match_out[i] = ev.match ? 1 : 0;
+  if (taps_out) {
+    taps_out[4 * i + 0] = ev.taps[0];
+    taps_out[4 * i + 1] = ev.taps[1];
+    taps_out[4 * i + 2] = ev.taps[2];
+    taps_out[4 * i + 3] = ev.taps[3];
+  }
+}
+
+// ---- host launchers (called from slm_api.hip) ------------------------------------
+void launch_data_grad(const FrameDev* frames_dev, int n_frames, int maxN, double lam,
+                      hipStream_t st) {
+  if (maxN <= 0) return;
+  dim3 grid((maxN + 255) / 256, n_frames);
+  hipLaunchKernelGGL(k_data_grad, grid, dim3(256), 0, st, frames_dev, lam);
+}
+
+void launch_data_loss(const FrameDev* frames_dev, int n_frames, int n_blocks, double lam,
+                      int use_delta, hipStream_t st) {
+  dim3 grid(n_blocks, n_frames);
+  hipLaunchKernelGGL(k_data_loss, grid, dim3(256), 0, st, frames_dev, lam, use_delta);
+}
+
+void launch_data_resid(const FrameDev* frames_dev, int slot, int N, double lam, double* r,
+                       uint8_t* match, int32_t* taps, hipStream_t st) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_data_resid, dim3((N + 255) / 256), dim3(256), 0, st, frames_dev, slot, lam,
+                     r, match, taps);
+}

@@ -1,0 +1,146 @@
+// slm_reg.hip -- ARAP and Rot regularisers (fixed sparsity, tiny): Jacobian pass and loss pass.
+//
+// ARAP (reference super/loss.py:408-455): r_{jk} = lam [R(q_k) d + b_k - d - b_j],
+//   d = g_j - g_k, k in KNN_ED(j), un-weighted; row c has 6 non-zeros:
+//   cols 7k+0..3 <- lam dR(q_k)d/dq [c,:], col 7k+4+c <- +lam, col 7j+4+c <- -lam.
+// Rot (reference super/loss.py:480-499): r_j = lam (1 - |q_j|^2) evaluated in FLOAT32,
+//   cols 7j+0..3 <- -2 lam q_j; its JtJ / jtl products are float32 too.
+#include "slm_common.h"
+
+__device__ __forceinline__ void load_beta(const double* beta, const double* delta, int j,
+                                          double bb[7]) {
+#pragma unroll
+  for (int c = 0; c < 7; ++c) bb[c] = beta[7 * j + c];
+  if (delta) {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) bb[c] += delta[7 * j + c];
+  }
+}
+
+__device__ __forceinline__ void arap_residual(const FrameDev& fd, const double* beta,
+                                              const double* delta, int j, int k, double lam,
+                                              double r[3], double bk[7], d3& d) {
+  const float* g = fd.f.ed_points;
+  d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
+       (double)g[3 * j + 2] - (double)g[3 * k + 2]};
+  double bj[7];
+  load_beta(beta, delta, k, bk);
+  load_beta(beta, delta, j, bj);
+  d3 t = quat_apply(bk[0], {bk[1], bk[2], bk[3]}, d);
+  r[0] = lam * (t.x + bk[4] - d.x - bj[4]);
+  r[1] = lam * (t.y + bk[5] - d.y - bj[5]);
+  r[2] = lam * (t.z + bk[6] - d.z - bj[6]);
+}
+
+// float32 Rot residual, mirroring the reference's dtype (sequential f32 sum, no contraction)
+__device__ __forceinline__ float rot_residual32(const double bb[7], float lam32, float q[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) q[c] = (float)bb[c];
+  float s = __fmul_rn(q[0], q[0]);
+  s = __fadd_rn(s, __fmul_rn(q[1], q[1]));
+  s = __fadd_rn(s, __fmul_rn(q[2], q[2]));
+  s = __fadd_rn(s, __fmul_rn(q[3], q[3]));
+  return __fmul_rn(lam32, __fsub_rn(1.0f, s));
+}
+
+// grid = (ceil(maxJ*K_ED / 256), n_frames): one thread per (node, neighbour slot);
+// threads with slot 0 also do the node's Rot row.
+__global__ void __launch_bounds__(256) k_reg_grad(const FrameDev* __restrict__ frames, int use_arap,
+                                                   double lam_a, int use_rot, double lam_r) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  const int Ke = fd.f.K_ED;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = t / Ke, slot = t % Ke;
+  if (j >= fd.f.J) return;
+
+  if (use_arap) {
+    const int k = fd.f.ed_knn_idx[j * Ke + slot];
+    double r[3], bk[7];
+    d3 d;
+    arap_residual(fd, fd.beta, nullptr, j, k, lam_a, r, bk, d);
+    double Jq[3][4];
+    quat_jac(bk[0], {bk[1], bk[2], bk[3]}, d, Jq);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // the 6 non-zeros of residual row c
+      int col[6] = {7 * k, 7 * k + 1, 7 * k + 2, 7 * k + 3, 7 * k + 4 + c, 7 * j + 4 + c};
+      double val[6] = {lam_a * Jq[c][0], lam_a * Jq[c][1], lam_a * Jq[c][2], lam_a * Jq[c][3],
+                       lam_a, -lam_a};
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        atomic_add_f64(fd.rhs + col[a], -val[a] * r[c]);
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+          if (col[a] >= col[b]) atomic_add_f64(band_entry(fd, col[a], col[b]), val[a] * val[b]);
+      }
+    }
+  }
+  if (use_rot && slot == 0) {
+    double bb[7];
+    load_beta(fd.beta, nullptr, j, bb);
+    float q[4];
+    const float lam32 = (float)lam_r;
+    const float r = rot_residual32(bb, lam32, q);
+    float jv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) jv[c] = __fmul_rn(__fmul_rn(-lam32, 2.0f), q[c]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      atomic_add_f64(fd.rhs + 7 * j + a, (double)(-__fmul_rn(jv[a], r)));
+#pragma unroll
+      for (int b = 0; b <= a; ++b)
+        atomic_add_f64(band_entry(fd, 7 * j + a, 7 * j + b), (double)__fmul_rn(jv[a], jv[b]));
+    }
+  }
+}
+
+// grid = (n_reg_blocks, n_frames); partial sums (arap, rot) per block after the data partials
+__global__ void __launch_bounds__(256) k_reg_loss(const FrameDev* __restrict__ frames, int use_arap,
+                                                   double lam_a, int use_rot, double lam_r,
+                                                   int use_delta) {
+  __shared__ double sm[16];
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  const double* delta = use_delta ? fd.delta : nullptr;
+  const int Ke = fd.f.K_ED;
+  double sa = 0.0, sr = 0.0;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < fd.f.J * Ke; t += gridDim.x * blockDim.x) {
+    const int j = t / Ke, slot = t % Ke;
+    if (use_arap) {
+      const int k = fd.f.ed_knn_idx[j * Ke + slot];
+      double r[3], bk[7];
+      d3 d;
+      arap_residual(fd, fd.beta, delta, j, k, lam_a, r, bk, d);
+      sa += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    }
+    if (use_rot && slot == 0) {
+      double bb[7];
+      load_beta(fd.beta, delta, j, bb);
+      float q[4];
+      const float r = rot_residual32(bb, (float)lam_r, q);
+      sr += (double)__fmul_rn(r, r);
+    }
+  }
+  double a = block_sum(sa, sm);
+  double b = block_sum(sr, sm);
+  if (threadIdx.x == 0) {
+    double* out = fd.loss_part + 2 * (size_t)fd.n_loss_part;
+    out[2 * blockIdx.x] = a;
+    out[2 * blockIdx.x + 1] = b;
+  }
+}
+
+void launch_reg_grad(const FrameDev* frames_dev, int n_frames, int maxJKe, int use_arap, double lam_a,
+                     int use_rot, double lam_r, hipStream_t st) {
+  if (maxJKe <= 0 || (!use_arap && !use_rot)) return;
+  dim3 grid((maxJKe + 255) / 256, n_frames);
+  hipLaunchKernelGGL(k_reg_grad, grid, dim3(256), 0, st, frames_dev, use_arap, lam_a, use_rot, lam_r);
+}
+
+void launch_reg_loss(const FrameDev* frames_dev, int n_frames, int n_blocks, int use_arap,
+                     double lam_a, int use_rot, double lam_r, int use_delta, hipStream_t st) {
+  dim3 grid(n_blocks, n_frames);
+  hipLaunchKernelGGL(k_reg_loss, grid, dim3(256), 0, st, frames_dev, use_arap, lam_a, use_rot, lam_r,
+                     use_delta);
+}

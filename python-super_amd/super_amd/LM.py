@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's ``LM_Solver`` (``super/LM.py:10-122``) over
+libsuper_lm.so.
+
+Same names, argument meaning and error behaviour as the reference class, so that
+``SuPer.__init__`` / ``SuPer.fusion`` (``super/super.py:18-19,68``) can construct and
+call it unchanged when ``--use_derived_gradient`` is set:
+
+    self.lm = LM_Solver(self.opt)
+    deform_param = self.lm.LM(self.sf, inputs, sfdata)        # (J,7) float64
+
+Everything numerical happens in the HIP library; this file only converts the caller's
+tensors to the storage layout of the C ABI (float32 / int32, contiguous), passes device
+pointers, and converts results back.  PyTorch is plumbing (device memory, streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SlmConfig, SlmFrame, SlmIterRecord
+
+
+def _dev_ptr(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise _lib.SuperLMError("super_amd needs tensors on a HIP device (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _as(t, dtype, device):
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+class BoundFrame:
+    """Device-resident, ABI-layout copy of what LM reads from ``sf`` / ``inputs`` /
+    ``new_data``.  Holds the tensors alive while the library uses them."""
+
+    def __init__(self, sf, inputs, new_data, device=None):
+        dev = device if device is not None else sf.points.device
+        if dev.type != "cuda":
+            raise _lib.SuperLMError("super_amd needs tensors on a HIP device (no CPU fallback)")
+        ed = sf.ED_nodes
+        f32, i32 = torch.float32, torch.int32
+        self.device = dev
+        self.sf_points = _as(sf.points, f32, dev)
+        self.sf_knn_idx = _as(sf.knn_indices, i32, dev)
+        self.sf_knn_w = _as(sf.knn_w, f32, dev)
+        self.ed_points = _as(ed.points, f32, dev)
+        self.ed_knn_idx = _as(ed.knn_indices, i32, dev)
+        self.tgt_points = _as(new_data.points, f32, dev)
+        self.tgt_norms = _as(new_data.norms, f32, dev)
+        self.index_map = _as(new_data.index_map, i32, dev)
+        self.tgt_valid = _as(new_data.valid, torch.uint8, dev)
+        H, W = inputs[("color", 0)].shape[-2:]
+        K = inputs["K"]
+        Kh = K[0].detach().to("cpu", torch.float32)        # one tiny D2H read per frame
+        self.J = int(self.ed_points.shape[0])
+        fr = SlmFrame()
+        fr.N, fr.J, fr.T = int(self.sf_points.shape[0]), self.J, int(self.tgt_points.shape[0])
+        fr.H, fr.W = int(H), int(W)
+        fr.K, fr.K_ED = int(self.sf_knn_idx.shape[1]), int(self.ed_knn_idx.shape[1])
+        fr.fx, fr.fy, fr.cx, fr.cy = float(Kh[0, 0]), float(Kh[1, 1]), float(Kh[0, 2]), float(Kh[1, 2])
+        for name in ("sf_points", "sf_knn_idx", "sf_knn_w", "ed_points", "ed_knn_idx", "tgt_points",
+                     "tgt_norms", "index_map", "tgt_valid"):
+            setattr(fr, name, _dev_ptr(getattr(self, name)))
+        self.c = fr
+
+
+class LM_Solver():
+    """Drop-in for ``super.LM.LM_Solver``; see module docstring."""
+
+    def __init__(self, opt, convs=None, max_frames=1):
+        self.opt = opt
+        self.lib = _lib.load()                       # raises if the HIP library is missing
+        self.device = torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        if self.device is None:
+            raise _lib.SuperLMError("no HIP device visible: super_amd has no CPU fallback")
+        self.phase = opt.phase
+        if self.phase == "train":
+            self.convs = convs
+        self.max_frames = max_frames
+        self._solvers = {}                           # (u, v, minimal_loss) -> handle
+        self._bound = [None] * max_frames
+        self.last_records = None
+
+    # ---- library handle --------------------------------------------------------------
+    def _config(self, u, v, minimal_loss):
+        o = self.opt
+        c = SlmConfig()
+        c.num_iterations = int(o.num_optimize_iterations)
+        c.phase_test = 1 if o.phase == "test" else 0
+        c.use_data, c.use_arap, c.use_rot = int(bool(o.sf_point_plane)), int(bool(o.mesh_arap)), \
+            int(bool(o.mesh_rot))
+        c.max_frames = self.max_frames
+        c.w_data = float(getattr(o, "sf_point_plane_weight", 1.0))
+        c.w_arap = float(getattr(o, "mesh_arap_weight", 10.0))
+        c.w_rot = float(getattr(o, "mesh_rot_weight", 1.0))
+        c.u0, c.v, c.minimal_loss0 = float(u), float(v), float(minimal_loss)
+        return c
+
+    def _handle(self, u=10, v=7.5, minimal_loss=1e10):
+        key = (float(u), float(v), float(minimal_loss))
+        h = self._solvers.get(key)
+        if h is None:
+            cfg = self._config(*key)
+            out = C.c_void_p()
+            _lib.check(self.lib.slm_create(C.byref(cfg), C.byref(out)), "slm_create")
+            h = out
+            self._solvers[key] = h
+        return h
+
+    def __del__(self):
+        try:
+            for h in self._solvers.values():
+                self.lib.slm_destroy(h)
+        except Exception:
+            pass
+
+    def _bind(self, h, slot, sf, inputs, new_data):
+        bf = BoundFrame(sf, inputs, new_data)
+        _lib.check(self.lib.slm_bind_frame(h, slot, C.byref(bf.c), _stream_ptr(bf.device)),
+                   "slm_bind_frame")
+        self._bound[slot] = bf
+        return bf
+
+    # ---- reference surface -------------------------------------------------------------
+    @staticmethod
+    def Solver(A, b, method="cholesky"):
+        """(reference ``super/LM.py:37-51``) solve A x = b for SPD A on the device; raises
+        ``RuntimeError`` when the factorisation fails, like ``torch.linalg.cholesky``."""
+        if method not in ("cholesky", "lu"):
+            raise ValueError(method)
+        lib = _lib.load()
+        dev = A.device
+        A64 = _as(A, torch.float64, dev)
+        b64 = _as(b, torch.float64, dev).reshape(-1)
+        P = A64.shape[0]
+        x = torch.empty(P, dtype=torch.float64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.slm_solve_dense(P, _dev_ptr(A64), _dev_ptr(b64), _dev_ptr(x),
+                                       _dev_ptr(status), _stream_ptr(dev)), "slm_solve_dense")
+        if int(status.item()) != 0:
+            raise RuntimeError("cholesky: the input is not positive-definite")
+        return x.reshape(b.shape).to(b.dtype)
+
+    def prepareCostTerm(self, sf, inputs, new_data, beta, grad=False):
+        """(reference ``super/LM.py:54-78``) ``grad=True`` -> (dense JtJ (P,P), jtl (P,1));
+        ``grad=False`` -> scalar sum of squared residuals.  For inspection / parity: the LM
+        loop itself never materialises the dense matrix."""
+        h = self._handle()
+        bf = self._bind(h, 0, sf, inputs, new_data)
+        st = _stream_ptr(bf.device)
+        b64 = _as(beta, torch.float64, bf.device)
+        _lib.check(self.lib.slm_set_beta(h, 0, _dev_ptr(b64), st), "slm_set_beta")
+        P = 7 * bf.J
+        if grad:
+            jtj = torch.empty((P, P), dtype=torch.float64, device=bf.device)
+            jtl = torch.empty((P, 1), dtype=torch.float64, device=bf.device)
+            _lib.check(self.lib.slm_assemble(h, 0, _dev_ptr(jtj), _dev_ptr(jtl), st), "slm_assemble")
+            return jtj, jtl
+        out = torch.empty(4, dtype=torch.float64, device=bf.device)
+        _lib.check(self.lib.slm_loss(h, 0, _dev_ptr(out), st), "slm_loss")
+        return out[:3].sum()
+
+    def LM(self, sf, inputs, new_data, u=10, v=7.5, minimal_loss=1e10):
+        """(reference ``super/LM.py:81-122``) run ``opt.num_optimize_iterations`` damped
+        iterations on the device; returns beta (J,7) float64 on ``sf``'s device."""
+        return self.LM_batch([(sf, inputs, new_data)], u=u, v=v, minimal_loss=minimal_loss)[0]
+
+    def LM_batch(self, frames, u=10, v=7.5, minimal_loss=1e10):
+        """Many independent frames / hypotheses advanced together in the same launches
+        (one slot each).  ``frames`` is a list of ``(sf, inputs, new_data)``."""
+        n = len(frames)
+        if n < 1 or n > self.max_frames:
+            raise ValueError(f"need 1..{self.max_frames} frames, got {n}")
+        h = self._handle(u, v, minimal_loss)
+        bfs = [self._bind(h, i, *fr) for i, fr in enumerate(frames)]
+        dev = bfs[0].device
+        st = _stream_ptr(dev)
+        _lib.check(self.lib.slm_run(h, n, st), "slm_run")
+        betas, self.last_records = [], []
+        for i, (bf, fr) in enumerate(zip(bfs, frames)):
+            beta = torch.empty((bf.J, 7), dtype=torch.float64, device=dev)
+            _lib.check(self.lib.slm_get_beta(h, i, _dev_ptr(beta), st), "slm_get_beta")
+            betas.append(beta)
+            recs = self.records(h, i, st)
+            self.last_records.append(recs)
+            self._report(fr[0], fr[1], recs)
+        return betas
+
+    # ---- helpers -----------------------------------------------------------------------
+    def records(self, h, slot, stream):
+        n = int(self.opt.num_optimize_iterations)
+        arr = (SlmIterRecord * max(n, 1))()
+        _lib.check(self.lib.slm_get_records(h, slot, arr, n, stream), "slm_get_records")
+        return [dict(loss=r.loss, u=r.u, accepted=bool(r.accepted), status=int(r.status),
+                     M_grad=int(r.M_grad), M_loss=int(r.M_loss)) for r in arr[:n]]
+
+    def _report(self, sf, inputs, recs):
+        for r in recs:
+            if r["status"] == _lib.SLM_ITER_SOLVER_FAILED:
+                print("\t\tSolver failed: Ill-posed system!")        # super/LM.py:102
+        done = [r for r in recs if r["status"] == _lib.SLM_ITER_OK]
+        logger = getattr(sf, "logger", None)                         # defect D1: may be absent
+        if self.opt.phase == "test" and logger is not None and done:
+            fid = inputs["ID"].item() if "ID" in inputs else -1
+            logger.info(f"{fid} loss: {done[-1]['loss']}")

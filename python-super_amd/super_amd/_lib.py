@@ -1,0 +1,96 @@
+"""ctypes binding of libsuper_lm.so (the C ABI declared in include/super_lm.h).
+
+There is no fallback: if the shared library is missing or a call fails, this module
+raises -- the product path never routes through a CPU or PyTorch implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libsuper_lm.so")
+
+SLM_OK = 0
+SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN = 0, 1, 2
+
+EXPORTS = [
+    "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame",
+    "slm_run", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
+    "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
+    "slm_knn_weights",
+]
+
+
+class SlmConfig(C.Structure):
+    _fields_ = [("num_iterations", C.c_int32), ("phase_test", C.c_int32), ("use_data", C.c_int32),
+                ("use_arap", C.c_int32), ("use_rot", C.c_int32), ("max_frames", C.c_int32),
+                ("w_data", C.c_double), ("w_arap", C.c_double), ("w_rot", C.c_double),
+                ("u0", C.c_double), ("v", C.c_double), ("minimal_loss0", C.c_double)]
+
+
+class SlmFrame(C.Structure):
+    _fields_ = [("N", C.c_int32), ("J", C.c_int32), ("T", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("K", C.c_int32), ("K_ED", C.c_int32),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("sf_points", C.c_void_p), ("sf_knn_idx", C.c_void_p), ("sf_knn_w", C.c_void_p),
+                ("ed_points", C.c_void_p), ("ed_knn_idx", C.c_void_p), ("tgt_points", C.c_void_p),
+                ("tgt_norms", C.c_void_p), ("index_map", C.c_void_p), ("tgt_valid", C.c_void_p)]
+
+
+class SlmIterRecord(C.Structure):
+    _fields_ = [("loss", C.c_double), ("u", C.c_double), ("accepted", C.c_int32),
+                ("status", C.c_int32), ("M_grad", C.c_int32), ("M_loss", C.c_int32)]
+
+
+class SuperLMError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare the signatures; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SuperLMError(
+            f"{LIB_PATH} not found: build it with `python python-super_amd/super_amd/build.py` "
+            "(hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, dbl = C.c_void_p, C.c_int32, C.c_double
+    lib.slm_last_error.restype = C.c_char_p
+    lib.slm_last_error.argtypes = []
+    lib.slm_device_count.restype = C.c_int
+    lib.slm_device_count.argtypes = []
+    sig = {
+        "slm_create": [C.POINTER(SlmConfig), C.POINTER(vp)],
+        "slm_destroy": [vp],
+        "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
+        "slm_run": [vp, i32, vp],
+        "slm_get_beta": [vp, i32, vp, vp],
+        "slm_set_beta": [vp, i32, vp, vp],
+        "slm_get_records": [vp, i32, C.POINTER(SlmIterRecord), i32, vp],
+        "slm_assemble": [vp, i32, vp, vp, vp],
+        "slm_loss": [vp, i32, vp, vp],
+        "slm_solve": [vp, i32, dbl, vp, vp, vp],
+        "slm_solve_dense": [i32, vp, vp, vp, vp, vp],
+        "slm_data_residuals": [vp, i32, vp, vp, vp, vp],
+        "slm_apply_update": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "slm_knn": [i32, i32, i32, i32, vp, vp, vp, vp, vp],
+        "slm_knn_weights": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != SLM_OK:
+        msg = load().slm_last_error().decode(errors="replace")
+        raise SuperLMError(f"{what} failed with status {rc}: {msg}")

@@ -1,0 +1,74 @@
+"""Build libsuper_lm.so (gfx950 only) in-tree with hipcc.
+
+    python -m super_amd.build            # from python-super_amd/
+    python python-super_amd/super_amd/build.py
+
+The shared library lands in ``python-super_amd/lib/`` (git-ignored, but it travels
+with the gpurun snapshot).  hipcc cross-compiles for gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # python-super_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_DIR = os.path.join(PKG_ROOT, "lib")
+OBJ_DIR = os.path.join(PKG_ROOT, "build")
+LIB_PATH = os.path.join(LIB_DIR, "libsuper_lm.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+         "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(REPO_ROOT, "include", "super_lm.h"))
+    srcs = sources()
+    objs = [os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if not force and not _stale(obj, [src] + headers):
+            return None
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        logs = list(ex.map(compile_one, zip(srcs, objs)))
+    if force or _stale(LIB_PATH, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        for lg in logs:
+            if lg:
+                print(lg)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,95 @@
+"""Host-side mirrors of the ``Surfels`` methods on the hot path (``super/nodes.py``):
+
+* :func:`update`          <- ``Surfels.update``            (``super/nodes.py:193-223``)
+* :func:`update_sfed_knn` <- ``Surfels.update_sfed_knn``   (``super/nodes.py:170-191``)
+* :func:`update_ed`       <- ``Surfels.update_ed``         (``super/nodes.py:154-168``)
+* :func:`find_knn`        <- ``utils.utils.find_knn``      (``utils/utils.py:212-221``)
+
+Each takes the reference's ``sf`` object (anything with the same attributes), runs the
+HIP kernels through the C ABI and writes the results back with the reference's
+attribute names and dtypes.  They can be bound onto the reference class:
+``Surfels.update = super_amd.nodes.update``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .LM import _as, _dev_ptr, _stream_ptr
+
+
+def find_knn(points1, points2, k=20, skip_self=False):
+    """K nearest rows of ``points2`` for each row of ``points1``: returns
+    ``(dists (N,k) float64 = sqrt(d2), idx (N,k) int64)``, squared-L2 ascending,
+    ties -> lowest index."""
+    lib = _lib.load()
+    dev = points1.device
+    q = _as(points1, torch.float32, dev)
+    n = _as(points2, torch.float32, dev)
+    idx = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
+    dist = torch.empty((q.shape[0], k), dtype=torch.float32, device=dev)
+    _lib.check(lib.slm_knn(q.shape[0], n.shape[0], k, int(skip_self), _dev_ptr(q), _dev_ptr(n),
+                           _dev_ptr(idx), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn")
+    return dist.to(torch.float64), idx.to(torch.int64)
+
+
+def _weights(idx, dist, radii, radius_mode, stable=None):
+    lib = _lib.load()
+    dev = idx.device
+    idx32 = _as(idx, torch.int32, dev)
+    d32 = _as(dist, torch.float32, dev)
+    r32 = _as(radii, torch.float32, dev)
+    w = torch.empty(idx.shape, dtype=torch.float32, device=dev)
+    st8 = None
+    if stable is not None:
+        st8 = _as(stable, torch.uint8, dev)
+    _lib.check(lib.slm_knn_weights(idx.shape[0], idx.shape[1], radius_mode, _dev_ptr(idx32),
+                                   _dev_ptr(d32), _dev_ptr(r32), _dev_ptr(w),
+                                   _dev_ptr(st8) if st8 is not None else None,
+                                   _stream_ptr(dev)), "slm_knn_weights")
+    return w, st8
+
+
+def update_ed(sf):
+    """Node-node KNN + ``softmax(exp(-dist/radius_self))`` weights (K_ED+1 nearest, self
+    dropped)."""
+    ed = sf.ED_nodes
+    k = int(sf.opt.num_ED_neighbors)
+    dist, idx = find_knn(ed.points, ed.points, k=k, skip_self=True)
+    w, _ = _weights(idx, dist, ed.radii, 1)
+    ed.knn_w = w.to(torch.float64)
+    ed.knn_indices = idx
+
+
+def update_sfed_knn(sf):
+    """Surfel-node KNN, stability test ``any(dist <= radius)`` and
+    ``softmax(exp(-dist/radius))`` weights."""
+    ed = sf.ED_nodes
+    k = int(sf.opt.num_neighbors)
+    dist, idx = find_knn(sf.points, ed.points, k=k)
+    w, st8 = _weights(idx, dist, ed.radii, 0, stable=sf.isStable)
+    sf.knn_indices = idx
+    sf.knn_w = w.to(torch.float64)
+    sf.isStable = st8.to(torch.bool)
+
+
+def update(sf, deform):
+    """Apply the solved warp (LM variant: no global row): skin surfel points, blend and
+    normalise surfel normals, translate nodes, rotate node normals."""
+    if deform is None:
+        return
+    lib = _lib.load()
+    dev = sf.points.device
+    ed = sf.ED_nodes
+    f32 = torch.float32
+    pts, nrm = _as(sf.points, f32, dev).clone(), _as(sf.norms, f32, dev).clone()
+    epts, enrm = _as(ed.points, f32, dev).clone(), _as(ed.norms, f32, dev).clone()
+    idx = _as(sf.knn_indices, torch.int32, dev)
+    w = _as(sf.knn_w, f32, dev)
+    beta = _as(deform, torch.float64, dev)
+    _lib.check(lib.slm_apply_update(pts.shape[0], epts.shape[0], idx.shape[1], _dev_ptr(pts),
+                                    _dev_ptr(nrm), _dev_ptr(idx), _dev_ptr(w), _dev_ptr(epts),
+                                    _dev_ptr(enrm), _dev_ptr(beta), _stream_ptr(dev)),
+               "slm_apply_update")
+    sf.points, sf.norms = pts.to(sf.points.dtype), nrm.to(sf.norms.dtype)
+    ed.points, ed.norms = epts.to(ed.points.dtype), enrm.to(ed.norms.dtype)

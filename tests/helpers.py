@@ -26,3 +26,30 @@ def coo_dense(idx, val, shape):
     out = np.zeros(tuple(int(s) for s in shape))
     np.add.at(out, (idx[0], idx[1]), val)
     return out
+
+
+def torch_frame(sc, device="cuda"):
+    """Reference-shaped ``sf`` / ``inputs`` / ``new_data`` objects (f64 / i64 torch tensors
+    on ``device``) from a Scene -- what ``SuPer.fusion`` hands to ``LM_Solver.LM``."""
+    import torch
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
+    ed = SimpleNamespace(points=t(sc.ed_points), norms=t(sc.ed_norms), radii=t(sc.ed_radii),
+                         knn_indices=t(sc.ed_knn_idx, torch.long), knn_w=t(sc.ed_knn_w),
+                         num=sc.J, param_num=7 * sc.J)
+    sf = SimpleNamespace(points=t(sc.sf_points), norms=t(sc.sf_norms),
+                         knn_indices=t(sc.sf_knn_idx, torch.long), knn_w=t(sc.sf_knn_w),
+                         ED_nodes=ed, isStable=torch.ones(sc.N, dtype=torch.bool, device=device))
+    inputs = {("color", 0): torch.zeros(1, 3, sc.H, sc.W), "K": torch.from_numpy(sc.K)[None].to(device),
+              "ID": torch.tensor([1])}
+    new_data = SimpleNamespace(points=t(sc.tgt_points), norms=t(sc.tgt_norms),
+                               index_map=t(sc.index_map, torch.long), valid=t(sc.valid, torch.bool))
+    return sf, inputs, new_data
+
+
+def ref_opt(opt):
+    """oracle opt namespace -> adds the attributes the host mirrors read."""
+    o = SimpleNamespace(**vars(opt))
+    o.use_derived_gradient = True
+    o.num_neighbors = 4
+    o.num_ED_neighbors = 4
+    return o

@@ -1,0 +1,163 @@
+"""HIP path vs oracle / golden fixtures, through the C ABI.  Needs an MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from helpers import GOLDENS, coo_dense, load_golden, ref_opt, torch_frame
+from oracle import lm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_BETA = 1e-4      # north_star: node poses within 1e-4
+TOL_F64 = 1e-9       # same f64 arithmetic, different reduction order
+
+
+def _solver(opt, **kw):
+    from super_amd.LM import LM_Solver
+    return LM_Solver(ref_opt(opt), **kw)
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("tag", ["b0", "b1"])
+def test_assemble_matches_reference_golden(name, tag):
+    import torch
+    g, sc, opt = load_golden(name)
+    sf, inputs, new_data = torch_frame(sc)
+    lm = _solver(opt)
+    beta = torch.from_numpy(g[f"{tag}_beta"]).cuda()
+    jtj, jtl = lm.prepareCostTerm(sf, inputs, new_data, beta, grad=True)
+    loss = lm.prepareCostTerm(sf, inputs, new_data, beta, grad=False)
+    np.testing.assert_allclose(jtl.cpu().numpy().reshape(-1), g[f"{tag}_jtl"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-8)
+    P = 7 * sc.J
+    fr = orc.Frame.from_scene(sc)
+    JtJ, _, _ = orc.normal_equations(fr, g[f"{tag}_beta"], opt)
+    np.testing.assert_allclose(jtj.cpu().numpy(), JtJ, rtol=0, atol=1e-7 * max(1.0, np.abs(JtJ).max()))
+    if f"{tag}_jtj_nz_idx" in g.files:
+        ref = coo_dense(g[f"{tag}_jtj_nz_idx"], g[f"{tag}_jtj_nz_val"], (P, P))
+        np.testing.assert_allclose(jtj.cpu().numpy(), ref, rtol=0, atol=1e-7 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_match_set_and_residuals_bit_exact_indices(name):
+    import ctypes as C
+    import torch
+    from super_amd import _lib
+    from super_amd.LM import _dev_ptr, _stream_ptr
+    g, sc, opt = load_golden(name)
+    if not opt.sf_point_plane:
+        pytest.skip("no data term")
+    sf, inputs, new_data = torch_frame(sc)
+    lm = _solver(opt)
+    h = lm._handle()
+    for tag in ("b0", "b1"):
+        bf = lm._bind(h, 0, sf, inputs, new_data)
+        beta = torch.from_numpy(g[f"{tag}_beta"]).cuda()
+        st = _stream_ptr(bf.device)
+        _lib.check(lm.lib.slm_set_beta(h, 0, _dev_ptr(beta), st), "set_beta")
+        r = torch.empty(sc.N, dtype=torch.float64, device="cuda")
+        m = torch.empty(sc.N, dtype=torch.uint8, device="cuda")
+        taps = torch.empty((sc.N, 4), dtype=torch.int32, device="cuda")
+        _lib.check(lm.lib.slm_data_residuals(h, 0, _dev_ptr(r), _dev_ptr(m), _dev_ptr(taps), st), "resid")
+        match = np.nonzero(m.cpu().numpy())[0]
+        np.testing.assert_array_equal(match, g[f"{tag}_match"])                 # bit-exact
+        np.testing.assert_allclose(r.cpu().numpy()[match], g[f"{tag}_data_r"], rtol=0, atol=TOL_F64)
+        t = orc.data_term(orc.Frame.from_scene(sc), g[f"{tag}_beta"], opt.sf_point_plane_weight)
+        np.testing.assert_array_equal(taps.cpu().numpy()[match], t.taps)        # tap rows bit-exact
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_lm_matches_reference_golden(name):
+    g, sc, opt = load_golden(name)
+    sf, inputs, new_data = torch_frame(sc)
+    lm = _solver(opt)
+    beta = lm.LM(sf, inputs, new_data).cpu().numpy()
+    recs = lm.last_records[0]
+    assert all(r["status"] == 0 for r in recs)
+    loss = np.array([r["loss"] for r in recs])
+    np.testing.assert_allclose(loss, g["lm_loss"], rtol=1e-6, atol=1e-12)
+    # accept flags must agree wherever the decision is not a rounding-level tie
+    best = np.minimum.accumulate(np.concatenate([[1e10], g["lm_loss"]]))[:-1]
+    decisive = np.abs(g["lm_loss"] - best) > 1e-9 * np.abs(best)
+    acc = np.array([r["accepted"] for r in recs])
+    np.testing.assert_array_equal(acc[decisive], g["lm_accepted"][decisive])
+    if decisive.all():
+        np.testing.assert_allclose([r["u"] for r in recs], g["lm_u"], rtol=1e-12)
+    np.testing.assert_allclose(beta, g["lm_beta"], rtol=0, atol=TOL_BETA)
+    # residual norm within 1e-4 (north_star)
+    assert abs(np.sqrt(loss.min()) - np.sqrt(g["lm_loss"].min())) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
+def test_update_matches_reference_golden(name):
+    import torch
+    from super_amd import nodes
+    g, sc, opt = load_golden(name)
+    sf, _, _ = torch_frame(sc)
+    sf.opt = ref_opt(opt)
+    nodes.update(sf, torch.from_numpy(g["lm_beta"]).cuda())
+    for mine, key in ((sf.points, "upd_points"), (sf.norms, "upd_norms"),
+                      (sf.ED_nodes.points, "upd_ed_points"), (sf.ED_nodes.norms, "upd_ed_norms")):
+        np.testing.assert_allclose(mine.cpu().numpy(), g[key], rtol=0, atol=2e-7)   # f32 storage
+
+
+@pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
+def test_knn_feeder_matches_reference_golden(name):
+    from super_amd import nodes
+    g, sc, opt = load_golden(name)
+    sf, _, _ = torch_frame(sc)
+    sf.opt = ref_opt(opt)
+    nodes.update_ed(sf)
+    nodes.update_sfed_knn(sf)
+    np.testing.assert_array_equal(sf.knn_indices.cpu().numpy(), g["knn_sf_idx"])   # bit-exact
+    np.testing.assert_array_equal(sf.ED_nodes.knn_indices.cpu().numpy(), g["knn_ed_idx"])
+    np.testing.assert_allclose(sf.knn_w.cpu().numpy(), g["knn_sf_w"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sf.ED_nodes.knn_w.cpu().numpy(), g["knn_ed_w"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(sf.isStable.cpu().numpy(), g["knn_sf_stable"])
+
+
+def test_dense_solver_and_failure_status():
+    import torch
+    from super_amd.LM import LM_Solver
+    rng = np.random.default_rng(0)
+    for P in (7, 64, 200):
+        A = rng.normal(size=(P, P))
+        A = A @ A.T + P * np.eye(P)
+        b = rng.normal(size=(P, 1))
+        x = LM_Solver.Solver(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda())
+        np.testing.assert_allclose(x.cpu().numpy(), np.linalg.solve(A, b), rtol=1e-9, atol=1e-11)
+    A = -np.eye(5)
+    with pytest.raises(RuntimeError):
+        LM_Solver.Solver(torch.from_numpy(A).cuda(), torch.ones(5, 1, dtype=torch.float64).cuda())
+
+
+def test_batch_of_frames_matches_single():
+    from super_amd import synth
+    scs = [synth.make_scene(N=3000, J=48, H=60, W=80, seed=s, src_border=5, tgt_border=3)
+           for s in (11, 12, 13)]
+    opt = orc.default_opt()
+    lm1 = _solver(opt)
+    singles = [lm1.LM(*torch_frame(sc)).cpu().numpy() for sc in scs]
+    lmb = _solver(opt, max_frames=3)
+    batch = lmb.LM_batch([torch_frame(sc) for sc in scs])
+    for a, b in zip(singles, batch):
+        np.testing.assert_allclose(b.cpu().numpy(), a, rtol=0, atol=1e-9)
+    # and against the oracle
+    ob = orc.lm(orc.Frame.from_scene(scs[0]), opt)
+    np.testing.assert_allclose(singles[0], ob, rtol=0, atol=TOL_BETA)
+
+
+@pytest.mark.parametrize("N,J", [(20000, 300), (50000, 512)])
+def test_mid_size_vs_oracle(N, J):
+    """C1-sized parity against the NumPy oracle (seconds on CPU)."""
+    from super_amd import synth
+    sc = synth.make_scene(N=N, J=J, H=240 if N <= 20000 else 480, W=320 if N <= 20000 else 640,
+                          seed=5)
+    opt = orc.default_opt(num_optimize_iterations=3)
+    lm = _solver(opt)
+    beta = lm.LM(*torch_frame(sc)).cpu().numpy()
+    trace = []
+    ob = orc.lm(orc.Frame.from_scene(sc), opt, trace=trace)
+    np.testing.assert_allclose(beta, ob, rtol=0, atol=TOL_BETA)
+    np.testing.assert_allclose([r["loss"] for r in lm.last_records[0]],
+                               [t["loss"] for t in trace], rtol=1e-6)
+    assert [r["M_loss"] for r in lm.last_records[0]] == [t["M_loss"] for t in trace]
