@@ -34,13 +34,34 @@ __device__ __forceinline__ void arap_residual(const FrameDev& fd, const double* 
 
 // float32 Rot residual, mirroring the reference's dtype (sequential f32 sum, no contraction)
 __device__ __forceinline__ float rot_residual32(const double bb[7], float lam32, float q[4]) {
+#pragma clang fp contract(off)   // keep mul and add separately rounded, like the reference's f32 ops
 #pragma unroll
   for (int c = 0; c < 4; ++c) q[c] = (float)bb[c];
-  float s = __fmul_rn(q[0], q[0]);
-  s = __fadd_rn(s, __fmul_rn(q[1], q[1]));
-  s = __fadd_rn(s, __fmul_rn(q[2], q[2]));
-  s = __fadd_rn(s, __fmul_rn(q[3], q[3]));
-  return __fmul_rn(lam32, __fsub_rn(1.0f, s));
+  float s = q[0] * q[0];
+  s = s + q[1] * q[1];
+  s = s + q[2] * q[2];
+  s = s + q[3] * q[3];
+  return lam32 * (1.0f - s);
+}
+
+// float32 products of the Rot Jacobian row (-2 lam q) with itself and with r
+__device__ __forceinline__ void rot_products32(const float q[4], float lam32, float r, float jtj[4][4],
+                                               float jtr[4]) {
+#pragma clang fp contract(off)
+  float jv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) jv[c] = (-lam32 * 2.0f) * q[c];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    jtr[a] = -(jv[a] * r);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) jtj[a][b] = jv[a] * jv[b];
+  }
+}
+
+__device__ __forceinline__ float sq32(float r) {
+#pragma clang fp contract(off)
+  return r * r;
 }
 
 // grid = (ceil(maxJ*K_ED / 256), n_frames): one thread per (node, neighbour slot);
@@ -82,15 +103,14 @@ __global__ void __launch_bounds__(256) k_reg_grad(const FrameDev* __restrict__ f
     float q[4];
     const float lam32 = (float)lam_r;
     const float r = rot_residual32(bb, lam32, q);
-    float jv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) jv[c] = __fmul_rn(__fmul_rn(-lam32, 2.0f), q[c]);
+    float jtj[4][4], jtr[4];
+    rot_products32(q, lam32, r, jtj, jtr);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      atomic_add_f64(fd.rhs + 7 * j + a, (double)(-__fmul_rn(jv[a], r)));
+      atomic_add_f64(fd.rhs + 7 * j + a, (double)jtr[a]);
 #pragma unroll
       for (int b = 0; b <= a; ++b)
-        atomic_add_f64(band_entry(fd, 7 * j + a, 7 * j + b), (double)__fmul_rn(jv[a], jv[b]));
+        atomic_add_f64(band_entry(fd, 7 * j + a, 7 * j + b), (double)jtj[a][b]);
     }
   }
 }
@@ -119,7 +139,7 @@ __global__ void __launch_bounds__(256) k_reg_loss(const FrameDev* __restrict__ f
       load_beta(fd.beta, delta, j, bb);
       float q[4];
       const float r = rot_residual32(bb, (float)lam_r, q);
-      sr += (double)__fmul_rn(r, r);
+      sr += (double)sq32(r);
     }
   }
   double a = block_sum(sa, sm);

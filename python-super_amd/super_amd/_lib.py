@@ -55,6 +55,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; import it first so that this library binds to the
+    # SAME HIP runtime instance (device pointers and streams are shared with torch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise SuperLMError(
             f"{LIB_PATH} not found: build it with `python python-super_amd/super_amd/build.py` "

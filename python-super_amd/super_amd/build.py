@@ -21,7 +21,7 @@ OBJ_DIR = os.path.join(PKG_ROOT, "build")
 LIB_PATH = os.path.join(LIB_DIR, "libsuper_lm.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast-honor-pragmas",
          "-I" + os.path.join(REPO_ROOT, "include"), "-I" + CSRC]
 
 
