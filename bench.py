@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- LM iterations/s and ms/frame of the embedded-deformation LM hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2] [--frames-per-gpu B]
+
+One *step* = one pass of the hot path over one batch of synthetic input: for each of the
+B independent frames resident on a GPU, bind the frame (``loss_term.prepare``), run
+``num_optimize_iterations`` = 10 damped LM iterations on the device (Jacobian pass, banded
+Cholesky solve, loss pass, accept/reject) and apply ``Surfels.update``.  Inputs are in HBM
+before the timed region starts.  N > 1: one process per GPU (torchrun), frames sharded
+across ranks (weak scaling, B frames per GPU), end-of-frame RCCL all-gather of beta
+(SURVEY.md section 8e); rank 0 prints ONE JSON line.
+
+`value` = whole-job LM iterations per second; `roofline` = the fused data-term Jacobian
+pass (one kernel launch per LM iteration), timed with HIP events on its launch stream
+inside the timed region; `cpu_baseline` = the NumPy oracle (a port of the reference
+algorithm) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "python-super_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F64_MFMA_PEAK_TFLOPS = 78.6  # SURVEY.md 8d (FP64 matrix, nominal gfx950)
+NB = 64                      # tile edge of the banded solver (csrc/slm_common.h)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C4", "tiny"])
+    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event phase timing")
+    return ap.parse_args()
+
+
+def workload_dims(name):
+    from super_amd import synth
+    if name == "tiny":
+        return dict(N=3000, J=48, H=60, W=80, src_border=5, tgt_border=3)
+    return dict(synth.WORKLOADS[name])
+
+
+def cpu_baseline(dims, seed):
+    """Oracle (NumPy/SciPy float64 port of the reference LM path) on the host cores:
+    ONE LM iteration (Jacobian pass + dense Cholesky solve + loss pass) of one frame."""
+    import numpy as np  # noqa: F401
+    from oracle import lm_oracle as orc
+    from super_amd import synth
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    sc = synth.make_scene(seed=seed, **dims)
+    fr = orc.Frame.from_scene(sc)
+    opt = orc.default_opt(num_optimize_iterations=1)
+    t0 = time.perf_counter()
+    orc.lm(fr, opt)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "LM it/s", "cores": int(cores), "kind": "port",
+            "sample": f"1 LM iteration (of 10) of one {sc.N}-surfel / {sc.J}-node frame, "
+                      f"NumPy/SciPy float64 oracle incl. dense Cholesky, {dt:.1f} s",
+            "seconds": dt}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N "
+                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+
+    dims = workload_dims(a.workload)
+    B = a.frames_per_gpu
+    iters = 10
+    # ---- synthetic frames of this rank (seeds are global frame ids) ------------------
+    scenes = [synth.make_scene(seed=rank * B + i, **dims) for i in range(B)]
+    pristine = [DeviceFrame.from_scene(sc, device) for sc in scenes]
+    work = [DeviceFrame.from_scene(sc, device) for sc in scenes]   # updated in place per step
+    N, J = scenes[0].N, scenes[0].J
+    eng = Engine(device, max_frames=B, num_iterations=iters)
+    betas = [torch.empty((J, 7), dtype=torch.float64, device=device) for _ in range(B)]
+    gathered = torch.empty((world * B, J, 7), dtype=torch.float64, device=device) if world > 1 else None
+    local = torch.empty((B, J, 7), dtype=torch.float64, device=device)
+
+    def step():
+        for p, w in zip(pristine, work):                 # same problem every step
+            w.sf_points.copy_(p.sf_points)
+            w.sf_norms.copy_(p.sf_norms)
+            w.ed_points.copy_(p.ed_points)
+            w.ed_norms.copy_(p.ed_norms)
+        for i, w in enumerate(work):
+            eng.bind(i, w)                               # loss_term.prepare (LM.py:93-94)
+        eng.run(B)                                       # LM_Solver.LM         (LM.py:95-117)
+        for i in range(B):
+            eng.beta(i, betas[i])
+            eng.apply_update(i, betas[i])                # Surfels.update      (nodes.py:193-223)
+        if world > 1:                                    # end-of-frame exchange
+            torch.stack(betas, out=local)
+            dist.all_gather_into_tensor(gathered, local)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    if not a.no_profile:
+        eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read() if not a.no_profile else None
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    recs = eng.records(0)
+    final_loss = [r["loss"] for r in recs if r["status"] == 0]
+    n_ok = sum(1 for r in recs if r["status"] == 0)
+
+    if rank == 0:
+        total_iters = world * B * iters * a.steps
+        out = {
+            "metric": "LM iterations/s (embedded-deformation LM, point-to-plane + ARAP + Rot)",
+            "value": total_iters / elapsed,
+            "unit": "LM it/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "ms_per_frame": 1e3 * elapsed / (a.steps * B),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {N} surfels / {J} ED nodes / KNN=4, "
+                                   f"point-to-plane + ARAP + Rot, {iters} LM iterations + "
+                                   f"Surfels.update per frame",
+                       "frames_per_gpu": B, "global_frames": world * B, "image": [dims["H"], dims["W"]],
+                       "storage": "f32/i32 in HBM, f64 arithmetic and solve",
+                       "parallelism": f"frames sharded over {world} GPU(s), beta all-gather"},
+            "lm_iterations_ok_frame0": n_ok,
+            "final_loss_frame0": final_loss[-1] if final_loss else None,
+        }
+        if prof is not None:
+            g = prof["data_grad"]
+            per_launch_bytes = B * (72.0 * N + 3165.0 * J)     # grad pass, f32/i32
+            avg_s = g["ms"] / max(g["count"], 1) * 1e-3
+            ach = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+            out["roofline"] = {"kernel": "k_data_grad", "bound": "hbm", "achieved": ach,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
+                               "algorithmic_bytes_per_launch": per_launch_bytes}
+            nt = (7 * J + NB - 1) // NB
+            lo = np.min(scenes[0].sf_knn_idx, axis=1)
+            hi = np.max(scenes[0].sf_knn_idx, axis=1)
+            wb = int(((7 * hi + 6) // NB - (7 * lo) // NB).max())
+            flops = B * nt * (wb * (wb + 1) / 2 + wb) * 2.0 * NB ** 3   # SYRK + TRSM tiles
+            s = prof["solve"]
+            savg = s["ms"] / max(s["count"], 1) * 1e-3
+            tf = flops / savg / 1e12 if savg > 0 else 0.0
+            out["roofline_solver"] = {"phase": "banded Cholesky factor+solve (all launches)",
+                                      "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
+                                      "avg_phase_ms": savg * 1e3, "tile_cols": nt, "tile_halfband": wb}
+            out["phase_ms_per_iteration"] = {k: v["ms"] / max(v["count"], 1) for k, v in prof.items()}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, seed=0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,24 @@ int slm_set_beta(slm_solver* s, int32_t slot, const double* beta_in_device, void
 int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int32_t max_records,
                     void* stream);
 
+/* -- phase timing (bench.py roofline leg) ----------------------------------------- */
+/* With profiling on, slm_run brackets each phase of every LM iteration with HIP events
+ * recorded on the launch stream.  Phases: */
+enum {
+  SLM_PH_ZERO = 0,       /* band / rhs zeroing */
+  SLM_PH_DATA_GRAD = 1,  /* fused data-term Jacobian pass: exactly ONE kernel launch per iteration */
+  SLM_PH_REG_GRAD = 2,   /* ARAP + Rot Jacobian pass */
+  SLM_PH_SOLVE = 3,      /* banded Cholesky factor + substitutions (many launches) */
+  SLM_PH_DATA_LOSS = 4,  /* fused data-term loss pass: exactly ONE kernel launch per iteration */
+  SLM_PH_ACCEPT = 5,     /* regulariser loss + accept/reject */
+  SLM_PH_COUNT = 6
+};
+int slm_profile_enable(slm_solver* s, int32_t on);
+/* Synchronises the recorded events; adds per-phase elapsed milliseconds and interval
+ * counts into ms_out[SLM_PH_COUNT] / count_out[SLM_PH_COUNT] (host arrays, overwritten),
+ * then clears the accumulated intervals. */
+int slm_profile_read(slm_solver* s, double* ms_out, int64_t* count_out);
+
 /* -- parity / building-block entry points -------------------------------------- */
 /* JtJ and jtl = -Jt r at the slot's current beta.  jtj_dense_device is (P,P)
  * float64 row-major (symmetric, full) or NULL; jtl_device is (P) or NULL. P = 7J. */

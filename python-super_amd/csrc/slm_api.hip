@@ -55,6 +55,9 @@ struct Slot {
 }  // namespace
 
 struct slm_solver {
+  bool profile = false;
+  std::vector<hipEvent_t> ev_pool;            // recycled events
+  std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
   slm_config cfg{};
   std::vector<Slot> slots;
   FrameDev* frames_dev = nullptr;
@@ -120,6 +123,10 @@ int slm_destroy(slm_solver* s) {
     if (h.st) (void)hipFree(h.st);
     if (h.rec) (void)hipFree(h.rec);
   }
+  for (auto& evs : s->ev_runs)
+    for (hipEvent_t e : evs)
+      if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->frames_dev) (void)hipFree(s->frames_dev);
   if (s->bw_dev) (void)hipFree(s->bw_dev);
   if (s->bw_host) (void)hipHostFree(s->bw_host);
@@ -230,19 +237,83 @@ void enqueue_loss(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, 
 
 extern "C" {
 
+static hipEvent_t take_event(slm_solver* s) {
+  if (!s->ev_pool.empty()) {
+    hipEvent_t e = s->ev_pool.back();
+    s->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
 int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
   int rc = check_slots(s, 0, n_frames);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const BatchDims d = dims_of(s, 0, n_frames);
   const FrameDev* fr = s->frames_dev;
-  for (int it = 0; it < s->cfg.num_iterations; ++it) {
-    enqueue_assemble(s, fr, n_frames, d, st);
+  const slm_config& c = s->cfg;
+  for (int it = 0; it < c.num_iterations; ++it) {
+    std::vector<hipEvent_t>* evs = nullptr;
+    if (s->profile) {
+      s->ev_runs.emplace_back();
+      evs = &s->ev_runs.back();
+    }
+    auto mark = [&]() {
+      if (!evs) return;
+      hipEvent_t e = take_event(s);
+      if (e) (void)hipEventRecord(e, st);
+      evs->push_back(e);
+    };
+    mark();
+    launch_iter_begin(fr, n_frames, st);
+    mark();
+    if (c.use_data) launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
+    mark();
+    launch_reg_grad(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+    mark();
     launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
-    enqueue_loss(s, fr, n_frames, d, 1, st);
-    launch_accept(fr, n_frames, s->cfg.phase_test, d.n_reg_part, st);
+    mark();
+    if (c.use_data) launch_data_loss(fr, n_frames, kLossBlocks, c.w_data, 1, st);
+    mark();
+    if (d.n_reg_part > 0)
+      launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
+    launch_accept(fr, n_frames, c.phase_test, d.n_reg_part, st);
+    mark();
   }
   HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_profile_enable(slm_solver* s, int32_t on) {
+  if (!s) return fail(SLM_ERR_INVALID, "slm_profile_enable: null solver");
+  s->profile = on != 0;
+  return SLM_OK;
+}
+
+int slm_profile_read(slm_solver* s, double* ms_out, int64_t* count_out) {
+  if (!s || !ms_out || !count_out) return fail(SLM_ERR_INVALID, "slm_profile_read: null argument");
+  for (int p = 0; p < SLM_PH_COUNT; ++p) {
+    ms_out[p] = 0.0;
+    count_out[p] = 0;
+  }
+  for (auto& evs : s->ev_runs) {
+    if ((int)evs.size() == SLM_PH_COUNT + 1 && evs.back()) {
+      HIPCHK(hipEventSynchronize(evs.back()));
+      for (int p = 0; p < SLM_PH_COUNT; ++p) {
+        if (!evs[p] || !evs[p + 1]) continue;
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, evs[p], evs[p + 1]));
+        ms_out[p] += ms;
+        count_out[p] += 1;
+      }
+    }
+    for (hipEvent_t e : evs)
+      if (e) s->ev_pool.push_back(e);
+  }
+  s->ev_runs.clear();
   return SLM_OK;
 }
 

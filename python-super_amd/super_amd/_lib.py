@@ -13,10 +13,11 @@ LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libsuper_lm.so")
 
 SLM_OK = 0
 SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN = 0, 1, 2
+PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 
 EXPORTS = [
     "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame",
-    "slm_run", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
+    "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
     "slm_knn_weights",
 ]
@@ -73,6 +74,8 @@ def load():
         "slm_destroy": [vp],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
+        "slm_profile_enable": [vp, i32],
+        "slm_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
         "slm_get_beta": [vp, i32, vp, vp],
         "slm_set_beta": [vp, i32, vp, vp],
         "slm_get_records": [vp, i32, C.POINTER(SlmIterRecord), i32, vp],
