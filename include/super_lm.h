@@ -64,6 +64,9 @@ typedef struct slm_config {
   int32_t use_arap;         /* opt.mesh_arap */
   int32_t use_rot;          /* opt.mesh_rot */
   int32_t max_frames;       /* number of slots (>= 1) */
+  int32_t data_path;        /* 0 = tuple-sorted MFMA assembly (default); 1 = per-entry f64 atomics
+                               (simple cross-check path, also used when J >= 65536) */
+  int32_t reserved;         /* must be 0 */
   double w_data;            /* opt.sf_point_plane_weight (1.0) */
   double w_arap;            /* opt.mesh_arap_weight (10.0) */
   double w_rot;             /* opt.mesh_rot_weight (1.0) */
@@ -132,7 +135,7 @@ int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int3
 enum {
   SLM_PH_ZERO = 0,       /* band / rhs zeroing */
   SLM_PH_DATA_GRAD = 1,  /* fused data-term Jacobian pass: exactly ONE kernel launch per iteration */
-  SLM_PH_REG_GRAD = 2,   /* ARAP + Rot Jacobian pass */
+  SLM_PH_REG_GRAD = 2,   /* 7x7 block gather into the band + ARAP / Rot Jacobian pass */
   SLM_PH_SOLVE = 3,      /* banded Cholesky factor + substitutions (many launches) */
   SLM_PH_DATA_LOSS = 4,  /* fused data-term loss pass: exactly ONE kernel launch per iteration */
   SLM_PH_ACCEPT = 5,     /* regulariser loss + accept/reject */

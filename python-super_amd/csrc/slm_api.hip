@@ -6,11 +6,14 @@
 #include <cstring>
 
 #include "slm_common.h"
+#include "slm_prep.h"
 
 // launchers defined next to their kernels
 void launch_data_grad(const FrameDev*, int, int, double, hipStream_t);
 void launch_data_loss(const FrameDev*, int, int, double, int, hipStream_t);
 void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
+void launch_data_gram(const FrameDev*, int, int, double, hipStream_t);
+void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_reg_loss(const FrameDev*, int, int, int, double, int, double, int, hipStream_t);
 void launch_bandwidth(const slm_frame&, int*, hipStream_t);
@@ -51,10 +54,12 @@ constexpr int kRegBlocksMax = 64;
 struct Slot {
   FrameDev h{};                 // host mirror of the device descriptor
   size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0;
+  V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
 };
 }  // namespace
 
 struct slm_solver {
+  PrepBuffers* prep = nullptr;
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
@@ -101,6 +106,10 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   if (e == hipSuccess) e = hipMemset(s->frames_dev, 0, sizeof(FrameDev) * cfg->max_frames);
   if (e == hipSuccess) e = hipMalloc((void**)&s->bw_dev, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->bw_host, sizeof(int), hipHostMallocDefault);
+  if (e == hipSuccess) {
+    s->prep = prep_create();
+    if (!s->prep) e = hipErrorOutOfMemory;
+  }
   if (e != hipSuccess) {
     g_err = std::string("slm_create: ") + hipGetErrorString(e);
     slm_destroy(s);
@@ -122,7 +131,9 @@ int slm_destroy(slm_solver* s) {
     if (h.loss_part) (void)hipFree(h.loss_part);
     if (h.st) (void)hipFree(h.st);
     if (h.rec) (void)hipFree(h.rec);
+    plan_free(sl.plan);
   }
+  prep_destroy(s->prep);
   for (auto& evs : s->ev_runs)
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
@@ -179,9 +190,37 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     HIPCHK(hipMemsetAsync(h.loss_part, 0, sizeof(double) * 2 * (kLossBlocks + kRegBlocksMax), st));
   }
   if (!h.st) HIPCHK(hipMalloc((void**)&h.st, sizeof(LMState)));
+#ifdef SLM_STAMPS
+  if (!h.dbg) {
+    HIPCHK(hipMalloc((void**)&h.dbg, sizeof(unsigned long long) * 64));
+    HIPCHK(hipMemset(h.dbg, 0, sizeof(unsigned long long) * 64));
+  }
+#endif
   if (!h.rec) {
     int n = s->cfg.num_iterations > 0 ? s->cfg.num_iterations : 1;
     HIPCHK(hipMalloc((void**)&h.rec, sizeof(slm_iter_record) * n));
+  }
+  // tuple-sorted data-term assembly plan (DataLoss.prepare analogue)
+  h.v1_ready = 0;
+  if (s->cfg.use_data && s->cfg.data_path == 0 && f->J < 65536 && f->N > 0) {
+    V1Sizes sz;
+    HIPCHK(prep_v1(s->prep, *f, sl.plan, &sz, st));
+    if (sz.n_tuples > 0) {
+      h.n_tuples = sz.n_tuples;
+      h.n_pos = sz.n_pos;
+      h.n_runs = sz.n_runs;
+      h.n_blocks = sz.n_blocks;
+      h.s_pts = sl.plan.s_pts;
+      h.s_idx = sl.plan.s_idx;
+      h.s_w = sl.plan.s_w;
+      h.grp_run = sl.plan.grp_run;
+      h.run_nodes = sl.plan.run_nodes;
+      h.slab = sl.plan.slab;
+      h.blk_key = sl.plan.blk_key;
+      h.blk_start = sl.plan.blk_start;
+      h.blk_entry = sl.plan.blk_entry;
+      h.v1_ready = 1;
+    }
   }
   h.bound = 1;
   HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
@@ -205,6 +244,8 @@ static int check_slots(slm_solver* s, int first, int n) {
 namespace {
 struct BatchDims {
   int maxN = 0, maxJKe = 0, nt_max = 0, wb_cap = 0, n_reg_part = 0;
+  int max_pos = 0, max_blocks = 0;
+  bool v1 = true;   // every slot of the batch has a tuple-sorted plan
 };
 BatchDims dims_of(slm_solver* s, int first, int n) {
   BatchDims d;
@@ -214,6 +255,9 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.maxJKe = std::max(d.maxJKe, h.f.J * h.f.K_ED);
     d.nt_max = std::max(d.nt_max, h.nt);
     d.wb_cap = std::max(d.wb_cap, h.wb);
+    d.max_pos = std::max(d.max_pos, h.n_pos);
+    d.max_blocks = std::max(d.max_blocks, h.n_blocks);
+    d.v1 = d.v1 && h.v1_ready;
   }
   if (s->cfg.use_arap || s->cfg.use_rot)
     d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);
@@ -222,7 +266,14 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
 
 void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, hipStream_t st) {
   launch_iter_begin(fr, n, st);
-  if (s->cfg.use_data) launch_data_grad(fr, n, d.maxN, s->cfg.w_data, st);
+  if (s->cfg.use_data) {
+    if (d.v1) {
+      launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, st);
+      launch_band_assemble(fr, n, d.max_blocks, st);
+    } else {
+      launch_data_grad(fr, n, d.maxN, s->cfg.w_data, st);
+    }
+  }
   launch_reg_grad(fr, n, d.maxJKe, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
 }
 
@@ -270,8 +321,12 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     mark();
     launch_iter_begin(fr, n_frames, st);
     mark();
-    if (c.use_data) launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
+    if (c.use_data) {
+      if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, st);
+      else launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
+    }
     mark();
+    if (c.use_data && d.v1) launch_band_assemble(fr, n_frames, d.max_blocks, st);
     launch_reg_grad(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
     mark();
     launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
@@ -350,6 +405,15 @@ int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int3
     HIPCHK(hipMemcpyAsync(host_out, s->slots[slot].h.rec, sizeof(slm_iter_record) * n,
                           hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+#ifdef SLM_STAMPS
+  if (s->slots[slot].h.dbg) {
+    unsigned long long t[64];
+    HIPCHK(hipMemcpy(t, s->slots[slot].h.dbg, sizeof(t), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[slm stamps slot %d] deltas (cycles):", slot);
+    for (int i = 1; i < 16; ++i) fprintf(stderr, " %d:%lld", i, t[i] ? (long long)(t[i] - t[i - 1]) : -1LL);
+    fprintf(stderr, "\n");
+  }
+#endif
   return SLM_OK;
 }
 

@@ -40,7 +40,41 @@ struct FrameDev {
   int32_t pad2;
   LMState* st;
   slm_iter_record* rec;  // (num_iterations)
+  unsigned long long* dbg;  // diagnostic builds only (-DSLM_STAMPS): in-kernel s_memtime stamps
+  // ---- tuple-sorted data-term assembly (slm_prep.hip / slm_data_v1.hip) ----
+  int32_t v1_ready;      // 1 when the structures below are valid for this frame
+  int32_t n_tuples;      // distinct canonical KNN 4-tuples
+  int32_t n_pos;         // padded surfel positions (multiple of 64)
+  int32_t n_runs;        // (tuple, 64-chunk) runs = slab entries
+  int32_t n_blocks;      // distinct coupled node pairs (a >= b) of the data term
+  int32_t pad3;
+  float* s_pts;          // (n_pos,3) surfel xyz in tuple-sorted, 4-padded order
+  int32_t* s_idx;        // (n_pos,4) KNN ids (original order), -1 for padding positions
+  float* s_w;            // (n_pos,4) KNN weights
+  int32_t* grp_run;      // (n_pos/4) run id of each group of 4 positions, -1 for padding
+  int32_t* run_nodes;    // (n_runs,4) ascending node ids of each run's tuple
+  double* slab;          // (n_runs, 768) per-run Gram tiles 00,10,11 (16x16 row-major each)
+  int32_t* blk_key;      // (n_blocks) a*J + b
+  int32_t* blk_start;    // (n_blocks+1) CSR offsets into blk_entry
+  int32_t* blk_entry;    // run*16 + pa*4 + pb
 };
+#define SLM_SLAB_STRIDE 768
+
+// In-kernel stamps exist only in the diagnostic build; the shipped library executes none.
+#ifdef SLM_STAMPS
+#define SLM_STAMP(fd, cond, idx)                                                       \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if ((cond) && (fd).dbg) {                                                          \
+      unsigned long long t_;                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+      if (threadIdx.x == 0) (fd).dbg[idx] = t_;                                        \
+    }                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define SLM_STAMP(fd, cond, idx) do { } while (0)
+#endif
 
 struct d3 {
   double x, y, z;

@@ -16,14 +16,17 @@ struct SurfelEval {
 };
 
 // beta may be offset by delta (trial point beta + delta of the LM loss pass).
+// sf_pts / sf_idx / sf_w: the surfel streams to read (caller order or tuple-sorted copies).
 template <bool GRAD>
-__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* beta,
-                                            const double* delta, int i, SurfelEval& out) {
+__device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* __restrict__ sf_pts,
+                                               const int* __restrict__ sf_idx,
+                                               const float* __restrict__ sf_w, double lam,
+                                               const double* beta, const double* delta, int i,
+                                               SurfelEval& out) {
   const slm_frame& f = fd.f;
-  const d3 p = {(double)f.sf_points[3 * i], (double)f.sf_points[3 * i + 1],
-                (double)f.sf_points[3 * i + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
-  const float4 wf = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
+  const d3 p = {(double)sf_pts[3 * i], (double)sf_pts[3 * i + 1], (double)sf_pts[3 * i + 2]};
+  const int4 ids = *reinterpret_cast<const int4*>(sf_idx + 4 * i);
+  const float4 wf = *reinterpret_cast<const float4*>(sf_w + 4 * i);
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
   const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
 
@@ -136,4 +139,10 @@ __device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, cons
     out.row[7 * k + 5] = lw * c.y;
     out.row[7 * k + 6] = lw * c.z;
   }
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* beta,
+                                            const double* delta, int i, SurfelEval& out) {
+  eval_surfel_at<GRAD>(fd, fd.f.sf_points, fd.f.sf_knn_idx, fd.f.sf_knn_w, lam, beta, delta, i, out);
 }

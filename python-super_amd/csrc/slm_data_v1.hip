@@ -1,0 +1,146 @@
+// slm_data_v1.hip -- tuple-sorted data-term Jacobian pass (JtJ / jtl of the point-to-plane
+// term, reference super/loss.py:222-288 + 200-205), no per-entry atomics on the matrix:
+//
+//   k_data_gram     one wave per 64 tuple-sorted surfel positions: every lane evaluates
+//                   its surfel (skin -> project -> match -> bilinear -> residual -> 28
+//                   Jacobian entries, f64), writes the augmented row [J(28) | r | 0 0 0]
+//                   (node slots in ascending-id order) to LDS, and the wave contracts
+//                   groups of 4 surfels on the f64 MFMA:  G += row^T row  (32 x 32 as the
+//                   three 16x16 tiles 00, 10, 11).  G[28][0..27] = J^T r and G[28][28] =
+//                   sum r^2 ride along for free.  One G per (tuple, chunk) run goes to
+//                   the slab with plain coalesced stores; -J^T r goes to rhs (f64 atomics,
+//                   28 per run).
+//   k_band_assemble one wave per coupled node pair (a >= b): sums the 7x7 sub-blocks of
+//                   the runs that contain both nodes (inverted index built once per frame
+//                   by slm_prep.hip) and stores them into the lower band -- each band
+//                   entry is written by exactly one lane, bitwise reproducible.
+#include "slm_data.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define ROW_STRIDE 33   // doubles per surfel row in LDS (33: conflict-free 64-bit writes)
+
+// grid = (ceil(max n_pos / 256), n_frames), 256 threads = 4 waves, one 64-position chunk each
+__global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ frames, double lam) {
+  __shared__ double rows[4][64 * ROW_STRIDE];
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int base = (blockIdx.x * 4 + w) * 64;
+  if (base >= fd.n_pos) return;
+  const int pos = base + l;
+  double* myrow = &rows[w][l * ROW_STRIDE];
+
+  // ---- per-surfel evaluation -----------------------------------------------------
+  SurfelEval ev;
+  ev.match = false;
+  const bool live = fd.s_idx[4 * pos] >= 0;
+  if (live) eval_surfel_at<true>(fd, fd.s_pts, fd.s_idx, fd.s_w, lam, fd.beta, nullptr, pos, ev);
+  const unsigned long long mm = __ballot(ev.match);
+  if (l == 0 && mm) atomicAdd(&fd.st->m_grad, __popcll(mm));
+
+#pragma unroll
+  for (int e = 0; e < 32; ++e) myrow[e] = 0.0;
+  if (ev.match) {
+    // canonical slot of neighbour k = number of neighbour ids smaller than id[k]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int slot = 0;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) slot += (ev.id[k2] < ev.id[k]) ? 1 : 0;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) myrow[7 * slot + c] = ev.row[7 * k + c];
+    }
+    myrow[28] = ev.r;
+  }
+  // the operands below are read by other lanes of the same wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- Gram accumulation per run ---------------------------------------------------
+  const int lc = l & 15, lq = l >> 4;
+  const int my_run = fd.grp_run[(base >> 2) + lc];   // lane (l & 15) holds the run of group (l & 15)
+  double4_t g00 = {0, 0, 0, 0}, g10 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
+  int cur = -1;
+
+  auto flush = [&](int run) {
+    double* out = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      out[r * 64 + l] = g00[r];
+      out[256 + r * 64 + l] = g10[r];
+      out[512 + r * 64 + l] = g11[r];
+    }
+    // jtl = -J^T r : row 28 of G = reg 3 of lanes 0..15 (tile 10: cols 0..15, tile 11: cols 16..27)
+    if (l < 16) {
+      const int4 nd = *reinterpret_cast<const int4*>(fd.run_nodes + 4 * run);
+      const int nodes[4] = {nd.x, nd.y, nd.z, nd.w};
+      {
+        const int e = l;
+        atomic_add_f64(fd.rhs + 7 * nodes[e / 7] + e % 7, -g10[3]);
+      }
+      if (l < 12) {
+        const int e = 16 + l;
+        atomic_add_f64(fd.rhs + 7 * nodes[e / 7] + e % 7, -g11[3]);
+      }
+    }
+  };
+
+#pragma unroll 1
+  for (int g = 0; g < 16; ++g) {
+    const int run = __builtin_amdgcn_readlane(my_run, g);
+    if (run != cur) {
+      if (cur >= 0) flush(cur);
+      g00 = double4_t{0, 0, 0, 0};
+      g10 = double4_t{0, 0, 0, 0};
+      g11 = double4_t{0, 0, 0, 0};
+      cur = run;
+    }
+    if (run < 0) continue;
+    const double* rp = &rows[w][(4 * g + lq) * ROW_STRIDE];
+    const double a0 = rp[lc], a1 = rp[16 + lc];
+    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g00, 0, 0, 0);
+    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g10, 0, 0, 0);
+    g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
+  }
+  if (cur >= 0) flush(cur);
+}
+
+// G[i][j], i >= j, from a slab entry (tiles 00, 10, 11; 16x16 row-major each)
+__device__ __forceinline__ double gram_at(const double* g, int i, int j) {
+  if (i < 16) return g[16 * i + j];
+  if (j < 16) return g[256 + 16 * (i - 16) + j];
+  return g[512 + 16 * (i - 16) + (j - 16)];
+}
+
+// grid = (ceil(max n_blocks / 4), n_frames), 256 threads: one wave per node pair
+__global__ void __launch_bounds__(256) k_band_assemble(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
+  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bi >= fd.n_blocks) return;
+  const int l = threadIdx.x & 63;
+  const unsigned key = (unsigned)fd.blk_key[bi];
+  const int a = (int)(key / (unsigned)fd.f.J), b = (int)(key % (unsigned)fd.f.J);
+  const int ca = l / 7, cb = l % 7;
+  const bool act = (l < 49) && (a != b || ca >= cb);   // lower triangle only on diagonal blocks
+  const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
+  double acc = 0.0;
+  for (int s = s0; s < s1; ++s) {
+    const int pl = fd.blk_entry[s];
+    const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
+    if (act) acc += gram_at(fd.slab + (size_t)run * SLM_SLAB_STRIDE, 7 * pa + ca, 7 * pb + cb);
+  }
+  if (act) *band_entry(fd, 7 * a + ca, 7 * b + cb) = acc;
+}
+
+void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, hipStream_t st) {
+  if (max_pos <= 0) return;
+  hipLaunchKernelGGL(k_data_gram, dim3((max_pos + 255) / 256, n_frames), dim3(256), 0, st, frames_dev, lam);
+}
+
+void launch_band_assemble(const FrameDev* frames_dev, int n_frames, int max_blocks, hipStream_t st) {
+  if (max_blocks <= 0) return;
+  hipLaunchKernelGGL(k_band_assemble, dim3((max_blocks + 3) / 4, n_frames), dim3(256), 0, st, frames_dev);
+}

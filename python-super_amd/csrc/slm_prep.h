@@ -1,0 +1,34 @@
+// slm_prep.h -- host interface of the once-per-frame data-term preparation (slm_prep.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "super_lm.h"
+
+struct PrepBuffers;   // scratch shared by all slots of a solver (grow-only)
+
+// Per-slot, grow-only device buffers that the per-iteration kernels read.
+struct V1Plan {
+  float* s_pts = nullptr;
+  int32_t* s_idx = nullptr;
+  float* s_w = nullptr;
+  int32_t* grp_run = nullptr;
+  int32_t* run_nodes = nullptr;
+  double* slab = nullptr;
+  int32_t* blk_key = nullptr;
+  int32_t* blk_start = nullptr;
+  int32_t* blk_entry = nullptr;
+  size_t cap_pts = 0, cap_idx = 0, cap_w = 0, cap_grp = 0, cap_runs = 0, cap_slab = 0, cap_bkey = 0,
+         cap_bstart = 0, cap_bentry = 0;
+};
+
+struct V1Sizes {
+  int n_tuples, n_pos, n_runs, n_blocks;
+};
+
+PrepBuffers* prep_create();
+void prep_destroy(PrepBuffers*);
+// Builds the plan for frame f (stream-synchronising: two small read-backs).
+hipError_t prep_v1(PrepBuffers*, const slm_frame& f, V1Plan& plan, V1Sizes* out, hipStream_t st);
+void plan_free(V1Plan& plan);

@@ -1,0 +1,325 @@
+// slm_prep.hip -- once-per-frame preparation of the tuple-sorted data-term assembly
+// (the analogue of DataLoss.prepare, reference super/loss.py:212-220, which caches
+// per-frame gathers; here the per-frame cache is an ordering + index, not 137 MB of f64).
+//
+// The KNN tables are fixed during the LM iterations of a frame, so all scatter structure
+// is resolved once, on the device:
+//   1. canonical key of every surfel's KNN 4-tuple (ascending node ids, 4 x 16 bit)
+//   2. radix sort (rocPRIM) -> surfels grouped by tuple; run-length encode -> tuples
+//   3. every tuple's segment is padded to a multiple of 4 positions (one MFMA k-group never
+//      mixes tuples); positions are cut into 64-wide chunks (one wave each); a
+//      (tuple, chunk) pair is a "run" = one Gram-matrix slab entry
+//   4. surfel xyz / ids / weights are copied into position order (coalesced streaming)
+//   5. inverted index: for every coupled node pair (a >= b) the list of (run, slot pair)
+//      contributions, by a second sort + run-length encode
+// rocPRIM is used only for these once-per-frame sorts/scans (plumbing); every kernel on
+// the per-iteration path is hand-written.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "slm_common.h"
+#include "slm_prep.h"
+
+namespace {
+
+__device__ __forceinline__ void sort4(int& a, int& b, int& c, int& d) {
+  int t;
+#define CSWAP(x, y) if (x > y) { t = x; x = y; y = t; }
+  CSWAP(a, b) CSWAP(c, d) CSWAP(a, c) CSWAP(b, d) CSWAP(b, c)
+#undef CSWAP
+}
+
+__global__ void __launch_bounds__(256) k_tuple_keys(int N, const int* __restrict__ knn,
+                                                     unsigned long long* __restrict__ keys,
+                                                     int* __restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int4 v = *reinterpret_cast<const int4*>(knn + 4 * i);
+  int a = v.x, b = v.y, c = v.z, d = v.w;
+  sort4(a, b, c, d);
+  keys[i] = ((unsigned long long)a << 48) | ((unsigned long long)b << 32) |
+            ((unsigned long long)c << 16) | (unsigned long long)d;
+  ids[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_padded_counts(const int* __restrict__ d_nt,
+                                                        const int* __restrict__ tcount,
+                                                        int* __restrict__ pc) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < *d_nt) pc[t] = (tcount[t] + 3) & ~3;
+}
+
+__global__ void __launch_bounds__(256) k_run_counts(const int* __restrict__ d_nt,
+                                                     const int* __restrict__ pstart,
+                                                     const int* __restrict__ pc, int* __restrict__ nruns) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < *d_nt) {
+    const int ps = pstart[t], pe = ps + pc[t];
+    nruns[t] = (pe - 1) / 64 - ps / 64 + 1;
+  }
+}
+
+// scal[0] = n_tuples (already there), scal[1] = total padded positions, scal[2] = total runs
+__global__ void k_totals(int* __restrict__ scal, const int* __restrict__ pstart,
+                         const int* __restrict__ pc, const int* __restrict__ rstart,
+                         const int* __restrict__ nruns) {
+  const int nt = scal[0];
+  scal[1] = nt > 0 ? pstart[nt - 1] + pc[nt - 1] : 0;
+  scal[2] = nt > 0 ? rstart[nt - 1] + nruns[nt - 1] : 0;
+}
+
+__global__ void __launch_bounds__(256) k_fill_sorted(
+    int n_pos_bound, const int* __restrict__ scal, const slm_frame f,
+    const unsigned long long* __restrict__ tkeys, const int* __restrict__ tcount,
+    const int* __restrict__ tstart, const int* __restrict__ pstart, const int* __restrict__ rstart,
+    const int* __restrict__ sids, float* __restrict__ s_pts, int* __restrict__ s_idx,
+    float* __restrict__ s_w, int* __restrict__ grp_run, int* __restrict__ run_nodes) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n_pos_bound) return;
+  const int nt = scal[0], ptot = scal[1];
+  int4 idv = make_int4(-1, -1, -1, -1);
+  float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float px = 0.f, py = 0.f, pz = 0.f;
+  int run = -1;
+  if (pos < ptot) {
+    // tuple owning this position: last t with pstart[t] <= pos
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pstart[mid] <= pos) lo = mid; else hi = mid - 1;
+    }
+    const int t = lo, ps = pstart[t], e = pos - ps;
+    run = rstart[t] + (pos / 64 - ps / 64);
+    if (e < tcount[t]) {
+      const int i = sids[tstart[t] + e];
+      idv = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
+      wv = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
+      px = f.sf_points[3 * i];
+      py = f.sf_points[3 * i + 1];
+      pz = f.sf_points[3 * i + 2];
+    }
+    if (e == 0 || (pos & 63) == 0) {
+      const unsigned long long k = tkeys[t];
+      int4 nodes = make_int4((int)(k >> 48) & 0xFFFF, (int)(k >> 32) & 0xFFFF, (int)(k >> 16) & 0xFFFF,
+                             (int)k & 0xFFFF);
+      *reinterpret_cast<int4*>(run_nodes + 4 * run) = nodes;
+    }
+  }
+  *reinterpret_cast<int4*>(s_idx + 4 * pos) = idv;
+  *reinterpret_cast<float4*>(s_w + 4 * pos) = wv;
+  s_pts[3 * pos] = px;
+  s_pts[3 * pos + 1] = py;
+  s_pts[3 * pos + 2] = pz;
+  if ((pos & 3) == 0) grp_run[pos >> 2] = run;
+}
+
+// 10 (a >= b) node pairs per run: key = a*J + b, payload = run*16 + pa*4 + pb
+__global__ void __launch_bounds__(256) k_pairs(int n_runs_bound, const int* __restrict__ scal, int J,
+                                                const int* __restrict__ run_nodes,
+                                                unsigned* __restrict__ pkeys, int* __restrict__ pvals) {
+  const int rr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rr >= n_runs_bound) return;
+  const bool live = rr < scal[2];
+  int n[4] = {0, 0, 0, 0};
+  if (live) {
+    const int4 v = *reinterpret_cast<const int4*>(run_nodes + 4 * rr);
+    n[0] = v.x; n[1] = v.y; n[2] = v.z; n[3] = v.w;
+  }
+  int e = 0;
+#pragma unroll
+  for (int pa = 0; pa < 4; ++pa)
+#pragma unroll
+    for (int pb = 0; pb <= pa; ++pb, ++e) {
+      pkeys[10 * rr + e] = live ? (unsigned)(n[pa] * J + n[pb]) : 0xFFFFFFFFu;
+      pvals[10 * rr + e] = rr * 16 + pa * 4 + pb;
+    }
+}
+
+// scal[3] = n_blocks (unique live keys); blk_start[n_blocks] = end of the last live block
+__global__ void k_totals2(int* __restrict__ scal, const unsigned* __restrict__ ukeys,
+                          int* __restrict__ blk_start, int n_entries) {
+  int nb = scal[4];   // unique keys incl. a possible trailing 0xFFFFFFFF run
+  if (nb > 0 && ukeys[nb - 1] == 0xFFFFFFFFu) {
+    nb -= 1;          // blk_start[nb] already holds the start of the invalid run
+  } else {
+    blk_start[nb] = n_entries;
+  }
+  scal[3] = nb;
+}
+
+template <typename T>
+hipError_t grow_raw(T*& p, size_t& cap, size_t need) {
+  if (need <= cap) return hipSuccess;
+  if (p) {
+    hipError_t e = hipFree(p);
+    if (e != hipSuccess) return e;
+    p = nullptr;
+    cap = 0;
+  }
+  const size_t want = need + need / 8 + 64;
+  hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+  if (e == hipSuccess) cap = want;
+  return e;
+}
+
+}  // namespace
+
+struct PrepBuffers {
+  // phase A
+  unsigned long long *keys = nullptr, *skeys = nullptr, *tkeys = nullptr;
+  int *ids = nullptr, *sids = nullptr, *tcount = nullptr;
+  size_t cap_n = 0;
+  // phase B
+  int *tstart = nullptr, *pc = nullptr, *pstart = nullptr, *nruns = nullptr, *rstart = nullptr;
+  size_t cap_t = 0;
+  unsigned *pkeys = nullptr, *spkeys = nullptr, *ukeys = nullptr;
+  int *pvals = nullptr, *bcount = nullptr;
+  size_t cap_e = 0;
+  void* tmp = nullptr;
+  size_t cap_tmp = 0;
+  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique
+  int* scal_host = nullptr;   // pinned mirror
+};
+
+PrepBuffers* prep_create() {
+  PrepBuffers* p = new PrepBuffers();
+  if (hipMalloc((void**)&p->scal, 8 * sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&p->scal_host, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    prep_destroy(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void prep_destroy(PrepBuffers* p) {
+  if (!p) return;
+  void* ptrs[] = {p->keys, p->skeys, p->tkeys, p->ids, p->sids, p->tcount, p->tstart, p->pc, p->pstart,
+                  p->nruns, p->rstart, p->pkeys, p->spkeys, p->ukeys, p->pvals, p->bcount, p->tmp, p->scal};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  if (p->scal_host) (void)hipHostFree(p->scal_host);
+  delete p;
+}
+
+#define PCHK(expr)                      \
+  do {                                  \
+    hipError_t e_ = (expr);             \
+    if (e_ != hipSuccess) return e_;    \
+  } while (0)
+
+static hipError_t ensure_tmp(PrepBuffers* p, size_t bytes) {
+  size_t cap = p->cap_tmp;
+  char* q = (char*)p->tmp;
+  hipError_t e = grow_raw(q, cap, bytes);
+  p->tmp = q;
+  p->cap_tmp = cap;
+  return e;
+}
+
+void plan_free(V1Plan& plan) {
+  void* ptrs[] = {plan.s_pts, plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes, plan.slab, plan.blk_key,
+                  plan.blk_start, plan.blk_entry};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  plan = V1Plan();
+}
+
+hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* out, hipStream_t st) {
+  const size_t N = (size_t)f.N;
+  out->n_tuples = out->n_pos = out->n_runs = out->n_blocks = 0;
+  if (N == 0) return hipSuccess;
+  // ---- phase A: tuples ----------------------------------------------------------
+  if (N > p->cap_n) {
+    size_t c;
+    c = p->cap_n; PCHK(grow_raw(p->keys, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->skeys, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->tkeys, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->ids, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->sids, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->tcount, c, N));
+    p->cap_n = c;
+  }
+  hipLaunchKernelGGL(k_tuple_keys, dim3((N + 255) / 256), dim3(256), 0, st, (int)N, f.sf_knn_idx,
+                     p->keys, p->ids);
+  size_t b1 = 0, b2 = 0;
+  PCHK(rocprim::radix_sort_pairs(nullptr, b1, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
+  PCHK(rocprim::run_length_encode(nullptr, b2, p->skeys, N, p->tkeys, p->tcount, p->scal, st));
+  PCHK(ensure_tmp(p, b1 > b2 ? b1 : b2));
+  PCHK(rocprim::radix_sort_pairs(p->tmp, b1, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
+  PCHK(rocprim::run_length_encode(p->tmp, b2, p->skeys, N, p->tkeys, p->tcount, p->scal, st));
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, sizeof(int), hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  const size_t nt = (size_t)p->scal_host[0];
+  if (nt == 0) return hipSuccess;
+
+  // ---- phase B: layout, sorted copies, inverted index ------------------------------
+  const size_t pos_bound = (N + 3 * nt + 63) / 64 * 64;
+  const size_t runs_bound = nt + pos_bound / 64 + 1;
+  const size_t n_entries = 10 * runs_bound;
+  if (nt > p->cap_t) {
+    size_t c;
+    c = p->cap_t; PCHK(grow_raw(p->tstart, c, nt));
+    c = p->cap_t; PCHK(grow_raw(p->pc, c, nt));
+    c = p->cap_t; PCHK(grow_raw(p->pstart, c, nt));
+    c = p->cap_t; PCHK(grow_raw(p->nruns, c, nt));
+    c = p->cap_t; PCHK(grow_raw(p->rstart, c, nt));
+    p->cap_t = c;
+  }
+  if (n_entries > p->cap_e) {
+    size_t c;
+    c = p->cap_e; PCHK(grow_raw(p->pkeys, c, n_entries));
+    c = p->cap_e; PCHK(grow_raw(p->spkeys, c, n_entries));
+    c = p->cap_e; PCHK(grow_raw(p->ukeys, c, n_entries));
+    c = p->cap_e; PCHK(grow_raw(p->pvals, c, n_entries));
+    c = p->cap_e; PCHK(grow_raw(p->bcount, c, n_entries));
+    p->cap_e = c;
+  }
+  PCHK(grow_raw(plan.s_pts, plan.cap_pts, 3 * pos_bound));
+  PCHK(grow_raw(plan.s_idx, plan.cap_idx, 4 * pos_bound));
+  PCHK(grow_raw(plan.s_w, plan.cap_w, 4 * pos_bound));
+  PCHK(grow_raw(plan.grp_run, plan.cap_grp, pos_bound / 4));
+  PCHK(grow_raw(plan.run_nodes, plan.cap_runs, 4 * runs_bound));
+  PCHK(grow_raw(plan.slab, plan.cap_slab, (size_t)SLM_SLAB_STRIDE * runs_bound));
+  PCHK(grow_raw(plan.blk_key, plan.cap_bkey, n_entries));
+  PCHK(grow_raw(plan.blk_start, plan.cap_bstart, n_entries + 1));
+  PCHK(grow_raw(plan.blk_entry, plan.cap_bentry, n_entries));
+
+  const dim3 gt((nt + 255) / 256), blk(256);
+  hipLaunchKernelGGL(k_padded_counts, gt, blk, 0, st, p->scal, p->tcount, p->pc);
+  size_t bs = 0;
+  PCHK(rocprim::exclusive_scan(nullptr, bs, p->tcount, p->tstart, 0, nt, rocprim::plus<int>(), st));
+  PCHK(ensure_tmp(p, bs));
+  PCHK(rocprim::exclusive_scan(p->tmp, bs, p->tcount, p->tstart, 0, nt, rocprim::plus<int>(), st));
+  PCHK(rocprim::exclusive_scan(p->tmp, bs, p->pc, p->pstart, 0, nt, rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(k_run_counts, gt, blk, 0, st, p->scal, p->pstart, p->pc, p->nruns);
+  PCHK(rocprim::exclusive_scan(p->tmp, bs, p->nruns, p->rstart, 0, nt, rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, st, p->scal, p->pstart, p->pc, p->rstart, p->nruns);
+  hipLaunchKernelGGL(k_fill_sorted, dim3((pos_bound + 255) / 256), blk, 0, st, (int)pos_bound, p->scal, f,
+                     p->tkeys, p->tcount, p->tstart, p->pstart, p->rstart, p->sids, plan.s_pts,
+                     plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes);
+  hipLaunchKernelGGL(k_pairs, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
+                     plan.run_nodes, p->pkeys, p->pvals);
+  size_t b3 = 0, b4 = 0, b5 = 0;
+  PCHK(rocprim::radix_sort_pairs(nullptr, b3, p->pkeys, p->spkeys, p->pvals, plan.blk_entry, n_entries, 0,
+                                 32, st));
+  PCHK(rocprim::run_length_encode(nullptr, b4, p->spkeys, n_entries, p->ukeys, p->bcount, p->scal + 4, st));
+  PCHK(rocprim::exclusive_scan(nullptr, b5, p->bcount, plan.blk_start, 0, n_entries,
+                               rocprim::plus<int>(), st));
+  size_t bm = b3 > b4 ? b3 : b4;
+  bm = bm > b5 ? bm : b5;
+  PCHK(ensure_tmp(p, bm));
+  PCHK(rocprim::radix_sort_pairs(p->tmp, b3, p->pkeys, p->spkeys, p->pvals, plan.blk_entry, n_entries, 0,
+                                 32, st));
+  PCHK(rocprim::run_length_encode(p->tmp, b4, p->spkeys, n_entries, p->ukeys, p->bcount, p->scal + 4, st));
+  // scan / copy over the full bound: entries past the unique count are never read
+  PCHK(rocprim::exclusive_scan(p->tmp, b5, p->bcount, plan.blk_start, 0, n_entries, rocprim::plus<int>(), st));
+  PCHK(hipMemcpyAsync(plan.blk_key, p->ukeys, sizeof(unsigned) * n_entries, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_totals2, dim3(1), dim3(1), 0, st, p->scal, p->ukeys, plan.blk_start, (int)n_entries);
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  out->n_tuples = p->scal_host[0];
+  out->n_pos = (p->scal_host[1] + 63) / 64 * 64;
+  out->n_runs = p->scal_host[2];
+  out->n_blocks = p->scal_host[3];
+  return hipGetLastError();
+}

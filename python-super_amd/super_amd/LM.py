@@ -98,6 +98,7 @@ class LM_Solver():
         c.use_data, c.use_arap, c.use_rot = int(bool(o.sf_point_plane)), int(bool(o.mesh_arap)), \
             int(bool(o.mesh_rot))
         c.max_frames = self.max_frames
+        c.data_path = int(getattr(o, "slm_data_path", 0))
         c.w_data = float(getattr(o, "sf_point_plane_weight", 1.0))
         c.w_arap = float(getattr(o, "mesh_arap_weight", 10.0))
         c.w_rot = float(getattr(o, "mesh_rot_weight", 1.0))

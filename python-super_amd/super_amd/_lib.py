@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libsuper_lm.so")
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", os.environ.get("SLM_LIB", "libsuper_lm.so"))
 
 SLM_OK = 0
 SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN = 0, 1, 2
@@ -26,6 +26,7 @@ EXPORTS = [
 class SlmConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int32), ("phase_test", C.c_int32), ("use_data", C.c_int32),
                 ("use_arap", C.c_int32), ("use_rot", C.c_int32), ("max_frames", C.c_int32),
+                ("data_path", C.c_int32), ("reserved", C.c_int32),
                 ("w_data", C.c_double), ("w_arap", C.c_double), ("w_rot", C.c_double),
                 ("u0", C.c_double), ("v", C.c_double), ("minimal_loss0", C.c_double)]
 

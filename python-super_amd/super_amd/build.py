@@ -36,7 +36,13 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
+    """``stamps=True`` builds the DIAGNOSTIC variant (in-kernel s_memtime stamps, printed by
+    slm_get_records); never ship or time that build."""
+    global OBJ_DIR, LIB_PATH
+    if stamps:
+        OBJ_DIR = os.path.join(PKG_ROOT, "build", "stamps")
+        LIB_PATH = os.path.join(LIB_DIR, "libsuper_lm_stamps.so")
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -48,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src, obj = pair
         if not force and not _stale(obj, [src] + headers):
             return None
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + (["-DSLM_STAMPS"] if stamps else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -71,4 +77,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_struct_layouts_match_header(lib):
     from super_amd._lib import SlmConfig, SlmFrame, SlmIterRecord
-    assert C.sizeof(SlmConfig) == 6 * 4 + 6 * 8
+    assert C.sizeof(SlmConfig) == 8 * 4 + 6 * 8
     assert C.sizeof(SlmIterRecord) == 2 * 8 + 4 * 4
     assert C.sizeof(SlmFrame) == 7 * 4 + 4 * 4 + 4 + 9 * 8   # 4 bytes padding before pointers
 

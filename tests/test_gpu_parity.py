@@ -161,3 +161,23 @@ def test_mid_size_vs_oracle(N, J):
     np.testing.assert_allclose([r["loss"] for r in lm.last_records[0]],
                                [t["loss"] for t in trace], rtol=1e-6)
     assert [r["M_loss"] for r in lm.last_records[0]] == [t["M_loss"] for t in trace]
+
+
+def test_atomic_cross_check_path_agrees():
+    """data_path=1 (per-entry f64 atomics) and the default tuple-sorted MFMA assembly give
+    the same normal equations."""
+    import torch
+    g, sc, opt = load_golden("s120x160_j108")
+    sf, inputs, new_data = torch_frame(sc)
+    beta = torch.from_numpy(g["b1_beta"]).cuda()
+    outs = []
+    for path in (0, 1):
+        o = ref_opt(opt)
+        o.slm_data_path = path
+        from super_amd.LM import LM_Solver
+        lm = LM_Solver(o)
+        jtj, jtl = lm.prepareCostTerm(sf, inputs, new_data, beta, grad=True)
+        outs.append((jtj.cpu().numpy(), jtl.cpu().numpy()))
+    scale = np.abs(outs[0][0]).max()
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-11)
