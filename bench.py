@@ -52,6 +52,23 @@ def workload_dims(name):
     return dict(synth.WORKLOADS[name])
 
 
+def pmc_traffic(kernel, workload, frames_per_gpu):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_traffic.json, made by profiles/make_traffic.py from separate FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 corrections), or None when no summary matches."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("frames_per_gpu") == frames_per_gpu \
+                and kernel in d.get("kernels", {}):
+            best = d["kernels"][kernel]["traffic_bytes_per_launch"]
+    return best
+
+
 def cpu_baseline(dims, seed):
     """Oracle (NumPy/SciPy float64 port of the reference LM path) on the host cores:
     ONE LM iteration (Jacobian pass + dense Cholesky solve + loss pass) of one frame."""
@@ -97,6 +114,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from super_amd import synth
+    from super_amd.dist import all_gather_betas
     from super_amd.engine import DeviceFrame, Engine
 
     dims = workload_dims(a.workload)
@@ -109,7 +127,7 @@ def main():
     N, J = scenes[0].N, scenes[0].J
     eng = Engine(device, max_frames=B, num_iterations=iters)
     betas = [torch.empty((J, 7), dtype=torch.float64, device=device) for _ in range(B)]
-    gathered = torch.empty((world * B, J, 7), dtype=torch.float64, device=device) if world > 1 else None
+    gathered = [None]
     local = torch.empty((B, J, 7), dtype=torch.float64, device=device)
 
     def step():
@@ -126,7 +144,7 @@ def main():
             eng.apply_update(i, betas[i])                # Surfels.update      (nodes.py:193-223)
         if world > 1:                                    # end-of-frame exchange
             torch.stack(betas, out=local)
-            dist.all_gather_into_tensor(gathered, local)
+            gathered[0] = all_gather_betas(local, world * B)
 
     def fence():
         if world > 1:
@@ -179,9 +197,10 @@ def main():
             per_launch_bytes = B * (72.0 * N + 3165.0 * J)     # grad pass, f32/i32
             avg_s = g["ms"] / max(g["count"], 1) * 1e-3
             ach = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-            out["roofline"] = {"kernel": "k_data_grad", "bound": "hbm", "achieved": ach,
+            out["roofline"] = {"kernel": "k_data_gram", "bound": "hbm", "achieved": ach,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
+                               "traffic": pmc_traffic("k_data_gram", a.workload, B),
+                               "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
                                "algorithmic_bytes_per_launch": per_launch_bytes}
             nt = (7 * J + NB - 1) // NB
             lo = np.min(scenes[0].sf_knn_idx, axis=1)
