@@ -66,7 +66,8 @@ typedef struct slm_config {
   int32_t max_frames;       /* number of slots (>= 1) */
   int32_t data_path;        /* 0 = tuple-sorted MFMA assembly (default); 1 = per-entry f64 atomics
                                (simple cross-check path, also used when J >= 65536) */
-  int32_t reserved;         /* must be 0 */
+  int32_t solver_path;      /* 0 = nested-dissection multifrontal Cholesky (default, needs data_path 0);
+                               1 = block-banded Cholesky */
   double w_data;            /* opt.sf_point_plane_weight (1.0) */
   double w_arap;            /* opt.mesh_arap_weight (10.0) */
   double w_rot;             /* opt.mesh_rot_weight (1.0) */

@@ -15,6 +15,11 @@ void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int
 void launch_data_gram(const FrameDev*, int, int, double, hipStream_t);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
+void launch_front_assemble(const FrameDev*, int, int, hipStream_t);
+void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hipStream_t);
+void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
+void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
+void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
 void launch_reg_loss(const FrameDev*, int, int, int, double, int, double, int, hipStream_t);
 void launch_bandwidth(const slm_frame&, int*, hipStream_t);
 void launch_band_solve(const FrameDev*, int, int, int, double, hipStream_t);
@@ -55,6 +60,16 @@ struct Slot {
   FrameDev h{};                 // host mirror of the device descriptor
   size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0;
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
+  // nested-dissection plan: host copy + device mirrors (grow-only)
+  NDPlanHost nd;
+  std::vector<uint32_t> h_pairs;
+  std::vector<int32_t> h_knn;
+  std::vector<float> h_pts;
+  NDFront* d_fronts = nullptr;
+  int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos
+  NDDest* d_dests = nullptr;    // block_dest | pair_dest
+  double *ftiles = nullptr, *fvec = nullptr, *flinv = nullptr;
+  size_t cap_fronts = 0, cap_ints = 0, cap_dests = 0, cap_ftiles = 0, cap_fvec = 0, cap_flinv = 0;
 };
 }  // namespace
 
@@ -132,6 +147,12 @@ int slm_destroy(slm_solver* s) {
     if (h.st) (void)hipFree(h.st);
     if (h.rec) (void)hipFree(h.rec);
     plan_free(sl.plan);
+    if (sl.d_fronts) (void)hipFree(sl.d_fronts);
+    if (sl.d_ints) (void)hipFree(sl.d_ints);
+    if (sl.d_dests) (void)hipFree(sl.d_dests);
+    if (sl.ftiles) (void)hipFree(sl.ftiles);
+    if (sl.fvec) (void)hipFree(sl.fvec);
+    if (sl.flinv) (void)hipFree(sl.flinv);
   }
   prep_destroy(s->prep);
   for (auto& evs : s->ev_runs)
@@ -222,6 +243,52 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.v1_ready = 1;
     }
   }
+  // nested-dissection plan (symbolic analysis on the host from the coupled-pair list)
+  h.nd_ready = 0;
+  if (h.v1_ready && s->cfg.solver_path == 0) {
+    sl.h_pairs.resize(h.n_blocks);
+    sl.h_knn.resize((size_t)f->J * f->K_ED);
+    sl.h_pts.resize((size_t)f->J * 3);
+    HIPCHK(hipMemcpyAsync(sl.h_pairs.data(), h.blk_key, sizeof(uint32_t) * h.n_blocks, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(sl.h_knn.data(), f->ed_knn_idx, sizeof(int32_t) * sl.h_knn.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(sl.h_pts.data(), f->ed_points, sizeof(float) * sl.h_pts.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), sl.h_pairs.data(), h.n_blocks, sl.nd)) {
+      NDPlanHost& nd = sl.nd;
+      const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J;
+      const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
+      HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
+      HIPCHK(grow(sl.d_ints, sl.cap_ints, n_ints));
+      HIPCHK(grow(sl.d_dests, sl.cap_dests, n_dests));
+      HIPCHK(grow(sl.ftiles, sl.cap_ftiles, (size_t)nd.tile_doubles));
+      HIPCHK(grow(sl.fvec, sl.cap_fvec, (size_t)nd.vec_doubles));
+      HIPCHK(grow(sl.flinv, sl.cap_flinv, (size_t)nd.linv_doubles + 1));
+      HIPCHK(hipMemcpyAsync(sl.d_fronts, nd.fronts.data(), sizeof(NDFront) * nd.fronts.size(), hipMemcpyHostToDevice, st));
+      int32_t* p = sl.d_ints;
+      auto up = [&](const std::vector<int32_t>& v) -> hipError_t {
+        hipError_t e = v.empty() ? hipSuccess : hipMemcpyAsync(p, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice, st);
+        p += v.size();
+        return e;
+      };
+      h.level_start = p; HIPCHK(up(nd.level_start));
+      h.nd_nodes = p;    HIPCHK(up(nd.nodes));
+      h.nd_eamap = p;    HIPCHK(up(nd.eamap));
+      h.node_front = p;  HIPCHK(up(nd.node_front));
+      h.node_pos = p;    HIPCHK(up(nd.node_pos));
+      if (!nd.block_dest.empty())
+        HIPCHK(hipMemcpyAsync(sl.d_dests, nd.block_dest.data(), sizeof(NDDest) * nd.block_dest.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(sl.d_dests + nd.block_dest.size(), nd.pair_dest.data(), sizeof(NDDest) * nd.pair_dest.size(), hipMemcpyHostToDevice, st));
+      h.block_dest = sl.d_dests;
+      h.pair_dest = sl.d_dests + nd.block_dest.size();
+      h.fronts = sl.d_fronts;
+      h.n_fronts = (int)nd.fronts.size();
+      h.n_levels = (int)nd.level_start.size() - 1;
+      h.ftiles = sl.ftiles;
+      h.fvec = sl.fvec;
+      h.flinv = sl.flinv;
+      h.nd_ready = 1;
+    }
+  }
   h.bound = 1;
   HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // h is reused by later binds
@@ -244,8 +311,10 @@ static int check_slots(slm_solver* s, int first, int n) {
 namespace {
 struct BatchDims {
   int maxN = 0, maxJKe = 0, nt_max = 0, wb_cap = 0, n_reg_part = 0;
-  int max_pos = 0, max_blocks = 0;
+  int max_pos = 0, max_blocks = 0, maxP = 0;
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
+  bool nd = true;   // every slot of the batch has a nested-dissection plan
+  std::vector<NDLevelSched> sched;   // per-level launch bounds over the batch
 };
 BatchDims dims_of(slm_solver* s, int first, int n) {
   BatchDims d;
@@ -258,10 +327,45 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.max_pos = std::max(d.max_pos, h.n_pos);
     d.max_blocks = std::max(d.max_blocks, h.n_blocks);
     d.v1 = d.v1 && h.v1_ready;
+    d.nd = d.nd && h.nd_ready;
+    d.maxP = std::max(d.maxP, h.P);
+  }
+  if (d.nd) {
+    for (int i = first; i < first + n; ++i) {
+      const auto& sc = s->slots[i].nd.sched;
+      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0});
+      for (size_t l = 0; l < sc.size(); ++l) {
+        NDLevelSched& m = d.sched[l];
+        m.n_fronts = std::max(m.n_fronts, sc[l].n_fronts);
+        m.max_npt = std::max(m.max_npt, sc[l].max_npt);
+        m.max_nt = std::max(m.max_nt, sc[l].max_nt);
+        m.max_pairs = std::max(m.max_pairs, sc[l].max_pairs);
+        m.max_n2p = std::max(m.max_n2p, sc[l].max_n2p);
+      }
+    }
   }
   if (s->cfg.use_arap || s->cfg.use_rot)
     d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);
   return d;
+}
+
+// zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
+hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st) {
+  const FrameDev* fr = s->frames_dev + first;
+  for (int i = first; i < first + n; ++i) {
+    Slot& sl = s->slots[i];
+    hipError_t e = hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_doubles, st);
+    if (e == hipSuccess) e = hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st);
+    if (e != hipSuccess) return e;
+  }
+  launch_iter_begin_nd(fr, n, st);
+  if (s->cfg.use_data) {
+    launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, st);
+    launch_front_assemble(fr, n, d.max_blocks, st);
+  }
+  launch_reg_grad_nd(fr, n, d.maxJKe, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
+  launch_front_load_rhs(fr, n, d.maxP, st);
+  return hipSuccess;
 }
 
 void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, hipStream_t st) {
@@ -319,17 +423,33 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
       evs->push_back(e);
     };
     mark();
-    launch_iter_begin(fr, n_frames, st);
+    if (d.nd) {
+      for (int i = 0; i < n_frames; ++i) {
+        Slot& sl = s->slots[i];
+        HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_doubles, st));
+        HIPCHK(hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st));
+      }
+      launch_iter_begin_nd(fr, n_frames, st);
+    } else {
+      launch_iter_begin(fr, n_frames, st);
+    }
     mark();
     if (c.use_data) {
       if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, st);
       else launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
     }
     mark();
-    if (c.use_data && d.v1) launch_band_assemble(fr, n_frames, d.max_blocks, st);
-    launch_reg_grad(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+    if (d.nd) {
+      if (c.use_data) launch_front_assemble(fr, n_frames, d.max_blocks, st);
+      launch_reg_grad_nd(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+      launch_front_load_rhs(fr, n_frames, d.maxP, st);
+    } else {
+      if (c.use_data && d.v1) launch_band_assemble(fr, n_frames, d.max_blocks, st);
+      launch_reg_grad(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+    }
     mark();
-    launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
+    if (d.nd) launch_front_solve(fr, n_frames, d.sched.data(), (int)d.sched.size(), -1.0, st);
+    else launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
     mark();
     if (c.use_data) launch_data_loss(fr, n_frames, kLossBlocks, c.w_data, 1, st);
     mark();
@@ -463,8 +583,13 @@ int slm_solve(slm_solver* s, int32_t slot, double u, double* delta, int32_t* sta
   if (rc) return rc;
   const BatchDims d = dims_of(s, slot, 1);
   const FrameDev& h = s->slots[slot].h;
-  enqueue_assemble(s, s->frames_dev + slot, 1, d, st);
-  launch_band_solve(s->frames_dev + slot, 1, d.nt_max, d.wb_cap, u, st);
+  if (d.nd) {
+    HIPCHK(enqueue_assemble_nd(s, slot, 1, d, st));
+    launch_front_solve(s->frames_dev + slot, 1, d.sched.data(), (int)d.sched.size(), u, st);
+  } else {
+    enqueue_assemble(s, s->frames_dev + slot, 1, d, st);
+    launch_band_solve(s->frames_dev + slot, 1, d.nt_max, d.wb_cap, u, st);
+  }
   HIPCHK(hipMemcpyAsync(delta, h.delta, sizeof(double) * h.P, hipMemcpyDeviceToDevice, st));
   if (status)
     HIPCHK(hipMemcpyAsync(status, &h.st->chol_fail, sizeof(int32_t), hipMemcpyDeviceToDevice, st));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "super_lm.h"
+#include "slm_nd.h"
 
 #define SLM_NB 64            // scalar tile edge of the banded normal matrix
 #define SLM_MAX_KED 8
@@ -57,6 +58,22 @@ struct FrameDev {
   int32_t* blk_key;      // (n_blocks) a*J + b
   int32_t* blk_start;    // (n_blocks+1) CSR offsets into blk_entry
   int32_t* blk_entry;    // run*16 + pa*4 + pb
+  // ---- nested-dissection multifrontal solver (slm_nd_host.hip / slm_front.hip) ----
+  int32_t nd_ready;      // 1 when the plan below is valid for this frame
+  int32_t n_fronts;
+  int32_t n_levels;
+  int32_t pad4;
+  const int32_t* level_start;  // (n_levels+1) fronts of level l: [level_start[l], level_start[l+1])
+  const NDFront* fronts;       // processing order (deepest level first)
+  const int32_t* nd_nodes;     // per front: pivot node ids then boundary node ids
+  const int32_t* nd_eamap;     // per front: boundary index -> local node position in the parent
+  const int32_t* node_front;   // (J) front eliminating the node
+  const int32_t* node_pos;     // (J) local pivot position
+  const NDDest* block_dest;    // (n_blocks) destination of every data-term block
+  const NDDest* pair_dest;     // (J*K_ED) destination of every ARAP pair block
+  double* ftiles;              // front tile storage
+  double* fvec;                // front vectors (rhs -> y -> x)
+  double* flinv;               // inverses of the diagonal Cholesky blocks of the fronts
 };
 #define SLM_SLAB_STRIDE 768
 

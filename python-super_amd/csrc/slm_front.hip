@@ -1,0 +1,495 @@
+// slm_front.hip -- numeric phase of the nested-dissection multifrontal Cholesky (slm_nd.h).
+//
+// Per LM iteration:  zero fronts -> k_front_assemble (data-term 7x7 blocks through the
+// inverted index, one writer per entry) -> k_reg_grad_nd (ARAP / Rot rows, f64 atomics)
+// -> k_front_load_rhs -> for every tree level, deepest first:
+//        for c < max pivot tile columns: k_fpanel(c), k_ftrail(c)   dense partial Cholesky
+//        k_extend_add(child 0), k_extend_add(child 1)   Schur complements -> parents (next level)
+//    (the forward substitution rides along exactly as in the band solver)
+// -> for every level, root first: k_fback_prep, k_fbacksub(step)...   back substitution,
+//    each front scatters its pivots' solution into delta.
+// Grid convention: blockIdx.y = front within the level, blockIdx.z = frame slot.
+#include "slm_tile.h"
+
+__device__ __forceinline__ int nd_base(const NDFront& f, int p) {
+  return p < f.nv ? 7 * p : f.n1p + 7 * (p - f.nv);
+}
+
+__device__ __forceinline__ double* ftile(const FrameDev& fd, const NDFront& f, int r, int c) {
+  const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
+  return fd.ftiles + f.tile_off + t * TILE;
+}
+
+// entry (i,j), i >= j, in front-local scalar coordinates
+__device__ __forceinline__ double* front_entry(const FrameDev& fd, const NDFront& f, int i, int j) {
+  return ftile(fd, f, i >> 6, j >> 6) + (i & 63) + (size_t)(j & 63) * NB;
+}
+
+// element (x,y) of a node-pair block given as (a,b) with a >= b by id -> lower-stored location
+__device__ __forceinline__ double* dest_entry(const FrameDev& fd, const NDDest& d, int x, int y) {
+  const NDFront& f = fd.fronts[d.front];
+  const int rb = nd_base(f, d.prow), cb = nd_base(f, d.pcol);
+  return d.transpose ? front_entry(fd, f, rb + y, cb + x) : front_entry(fd, f, rb + x, cb + y);
+}
+
+// ---------------------------------------------------------------------------------
+// G[i][j], i >= j, from a slab entry (tiles 00, 10, 11; 16x16 row-major each)
+__device__ __forceinline__ double gram_at(const double* g, int i, int j) {
+  if (i < 16) return g[16 * i + j];
+  if (j < 16) return g[256 + 16 * (i - 16) + j];
+  return g[512 + 16 * (i - 16) + (j - 16)];
+}
+
+// grid = (ceil(max n_blocks / 4), n_frames): one wave per coupled node pair of the data term
+__global__ void __launch_bounds__(256) k_front_assemble(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.v1_ready || !fd.nd_ready || fd.st->stopped) return;
+  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bi >= fd.n_blocks) return;
+  const int l = threadIdx.x & 63;
+  const NDDest d = fd.block_dest[bi];
+  const int ca = l / 7, cb = l % 7;
+  const bool diag = d.prow == d.pcol;
+  const bool act = (l < 49) && (!diag || ca >= cb);
+  const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
+  double acc = 0.0;
+  for (int s = s0; s < s1; ++s) {
+    const int pl = fd.blk_entry[s];
+    const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
+    if (act) acc += gram_at(fd.slab + (size_t)run * SLM_SLAB_STRIDE, 7 * pa + ca, 7 * pb + cb);
+  }
+  if (act) *dest_entry(fd, d, ca, cb) = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// ARAP + Rot Jacobian rows into the fronts (same maths as k_reg_grad, slm_reg.hip; reference
+// super/loss.py:408-455, 480-499).  One thread per (node j, neighbour slot).
+__device__ __forceinline__ void nd_load_beta(const double* beta, int j, double bb[7]) {
+#pragma unroll
+  for (int c = 0; c < 7; ++c) bb[c] = beta[7 * j + c];
+}
+
+__device__ __forceinline__ float nd_rot_residual32(const double bb[7], float lam32, float q[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int c = 0; c < 4; ++c) q[c] = (float)bb[c];
+  float s = q[0] * q[0];
+  s = s + q[1] * q[1];
+  s = s + q[2] * q[2];
+  s = s + q[3] * q[3];
+  return lam32 * (1.0f - s);
+}
+
+__device__ __forceinline__ void nd_rot_products32(const float q[4], float lam32, float r,
+                                                  float jtj[4][4], float jtr[4]) {
+#pragma clang fp contract(off)
+  float jv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) jv[c] = (-lam32 * 2.0f) * q[c];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    jtr[a] = -(jv[a] * r);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) jtj[a][b] = jv[a] * jv[b];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict__ frames, int use_arap,
+                                                      double lam_a, int use_rot, double lam_r) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  const int Ke = fd.f.K_ED;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = t / Ke, slot = t % Ke;
+  if (j >= fd.f.J) return;
+  // diagonal block of node v: entries (x,y), x >= y
+  auto diag_add = [&](int v, int x, int y, double val) {
+    const NDFront& f = fd.fronts[fd.node_front[v]];
+    const int b = nd_base(f, fd.node_pos[v]);
+    atomic_add_f64(front_entry(fd, f, b + x, b + y), val);
+  };
+  if (use_arap) {
+    const int k = fd.f.ed_knn_idx[j * Ke + slot];
+    const float* g = fd.f.ed_points;
+    const d3 d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
+                  (double)g[3 * j + 2] - (double)g[3 * k + 2]};
+    double bk[7], bj[7];
+    nd_load_beta(fd.beta, k, bk);
+    nd_load_beta(fd.beta, j, bj);
+    const d3 tt = quat_apply(bk[0], {bk[1], bk[2], bk[3]}, d);
+    const double r[3] = {lam_a * (tt.x + bk[4] - d.x - bj[4]), lam_a * (tt.y + bk[5] - d.y - bj[5]),
+                         lam_a * (tt.z + bk[6] - d.z - bj[6])};
+    double Jq[3][4];
+    quat_jac(bk[0], {bk[1], bk[2], bk[3]}, d, Jq);
+    const NDDest pd = fd.pair_dest[j * Ke + slot];   // block (max(j,k), min(j,k))
+    const bool k_is_a = k > j;                        // is node k the block's row node "a"?
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // row c: node-k entries (components 0..3 and 4+c), node-j entry (component 4+c)
+      const int kc[5] = {0, 1, 2, 3, 4 + c};
+      const double kv[5] = {lam_a * Jq[c][0], lam_a * Jq[c][1], lam_a * Jq[c][2], lam_a * Jq[c][3], lam_a};
+      const int jc = 4 + c;
+      const double jv = -lam_a;
+#pragma unroll
+      for (int a = 0; a < 5; ++a) {
+        atomic_add_f64(fd.rhs + 7 * k + kc[a], -kv[a] * r[c]);
+#pragma unroll
+        for (int b = 0; b <= a; ++b) diag_add(k, kc[a], kc[b], kv[a] * kv[b]);   // kc ascending
+        // cross block entry between (k, kc[a]) and (j, jc)
+        const double cv = kv[a] * jv;
+        if (k_is_a) atomic_add_f64(dest_entry(fd, pd, kc[a], jc), cv);
+        else atomic_add_f64(dest_entry(fd, pd, jc, kc[a]), cv);
+      }
+      atomic_add_f64(fd.rhs + 7 * j + jc, -jv * r[c]);
+      diag_add(j, jc, jc, jv * jv);
+    }
+  }
+  if (use_rot && slot == 0) {
+    double bb[7];
+    nd_load_beta(fd.beta, j, bb);
+    float q[4];
+    const float lam32 = (float)lam_r;
+    const float r = nd_rot_residual32(bb, lam32, q);
+    float jtj[4][4], jtr[4];
+    nd_rot_products32(q, lam32, r, jtj, jtr);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      atomic_add_f64(fd.rhs + 7 * j + a, (double)jtr[a]);
+#pragma unroll
+      for (int b = 0; b <= a; ++b) diag_add(j, a, b, (double)jtj[a][b]);
+    }
+  }
+}
+
+// global jtl -> the pivot part of each front's vector (boundary parts stay zero)
+__global__ void __launch_bounds__(256) k_front_load_rhs(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= fd.P) return;
+  const int v = e / 7, c = e % 7;
+  const NDFront& f = fd.fronts[fd.node_front[v]];
+  fd.fvec[f.vec_off + 7 * fd.node_pos[v] + c] = fd.rhs[e];
+}
+
+// zero rhs + counters (the band is not used on this path)
+__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  const size_t nrhs = (size_t)fd.nt * SLM_NB;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nrhs;
+       e += (size_t)gridDim.x * blockDim.x)
+    fd.rhs[e] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    fd.st->m_grad = 0;
+    fd.st->chol_fail = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Dense partial Cholesky of the fronts of one level, tile column c.
+// grid = (max tiles below + 1, fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ frames, int level,
+                                                 int c, double u_override) {
+  extern __shared__ double lds[];
+  double* S = lds;
+  double* M = lds + TILE;
+  double* dinv = lds + 2 * TILE;
+  double* wt = dinv + 4 * 256;
+  double* vec = wt + 4 * 256;
+  int* s_ok = reinterpret_cast<int*>(vec + NB);
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  if (c >= f.npt) return;
+  const int d = blockIdx.x;
+  if (c + d >= f.nt) return;
+  const double u = (u_override >= 0.0) ? u_override : fd.st->u;
+
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  double* At = ftile(fd, f, c + d, c);
+  double* yv = fd.fvec + f.vec_off + (size_t)c * NB;
+  double4_t a[4];
+  if (d > 0) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[kb][r] = At[(16 * w + lr) + (size_t)(16 * kb + lk + 4 * r) * NB];
+  } else if (threadIdx.x < NB) {
+    vec[threadIdx.x] = yv[threadIdx.x];
+  }
+  {
+    // diagonal tile -> LDS: damping on real pivots, identity on the padding rows
+    const double* src = ftile(fd, f, c, c);
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = src[threadIdx.x + 256 * t];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = threadIdx.x + 256 * t;
+      const int i = e % NB, k = e / NB;
+      double x = (i >= k) ? v[t] : 0.0;
+      if (i == k) x = (c * NB + i < f.n1) ? x + u : 1.0;
+      S[i + k * LD] = x;
+    }
+  }
+  __syncthreads();
+  const bool ok = potrf64(S, dinv, s_ok, fd, false);
+
+  if (d == 0) {
+    if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
+    inverse_assemble64(S, M, dinv, wt);
+    double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+    for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];
+    if (threadIdx.x < NB) {
+      const int i = threadIdx.x;
+      double acc = 0.0;
+      for (int k = 0; k <= i; ++k) acc += M[i + k * LD] * vec[k];
+      yv[i] = acc;
+    }
+  } else {
+    trsm_rows16(S, dinv, a);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[(16 * w + lr) + (size_t)(16 * kb + lk + 4 * r) * NB] = a[kb][r];
+  }
+}
+
+// grid = (mcap*(mcap+1)/2 + mcap, fronts in level, n_frames); mcap >= nt-1-c of every front
+__global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ frames, int level,
+                                                 int c, int mcap) {
+  __shared__ double Bl[TILE];
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  if (c >= f.npt) return;
+  const int m = f.nt - 1 - c;
+  const int ntri = mcap * (mcap + 1) / 2;
+  int t = blockIdx.x;
+  if (t < ntri) {
+    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    while (a * (a + 1) / 2 > t) --a;
+    const int b = t - a * (a + 1) / 2;
+    const int da = a + 1, db = b + 1;
+    if (da > m) return;
+    const double* Lr = ftile(fd, f, c + da, c);
+    const double* Ls = ftile(fd, f, c + db, c);
+    double* Ct = ftile(fd, f, c + da, c + db);
+    double breg[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
+    double areg[16];
+    load_a_frags(Lr, areg);
+    double4_t acc[4];
+    load_c_frags(Ct, acc);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+    __syncthreads();
+    tile_ABt_regs<true>(areg, Bl, acc);
+    store_c_frags(Ct, acc);
+  } else {
+    const int db = t - ntri + 1;
+    if (db > m) return;
+    __shared__ double y[NB];
+    __shared__ double part[4][NB];
+    const double* Ls = ftile(fd, f, c + db, c);
+    double* vecs = fd.fvec + f.vec_off;
+    if (threadIdx.x < NB) y[threadIdx.x] = vecs[(size_t)c * NB + threadIdx.x];
+    __syncthreads();
+    const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 16 * q; k < 16 * q + 16; ++k) acc += Ls[i + k * NB] * y[k];
+    part[q][i] = acc;
+    __syncthreads();
+    if (threadIdx.x < NB)
+      vecs[(size_t)(c + db) * NB + i] -= part[0][i] + part[1][i] + part[2][i] + part[3][i];
+  }
+}
+
+// Add the Schur complement (and forward-eliminated rhs) of every front of the level whose
+// which_child == which into its parent.  One wave per boundary node pair (bi >= bj).
+// grid = (ceil(max pairs / 4), fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_extend_add(const FrameDev* __restrict__ frames, int level,
+                                                     int which) {
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  if (f.parent < 0 || f.which_child != which) return;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int npairs = f.nb * (f.nb + 1) / 2;
+  if (t >= npairs) return;
+  int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  while (bi * (bi + 1) / 2 > t) --bi;
+  const int bj = t - bi * (bi + 1) / 2;
+  const NDFront& pf = fd.fronts[f.parent];
+  const int* em = fd.nd_eamap + f.eamap_off;
+  const int pi = nd_base(pf, em[bi]), pj = nd_base(pf, em[bj]);
+  const int ci = f.n1p + 7 * bi, cj = f.n1p + 7 * bj;
+  const int l = threadIdx.x & 63;
+  if (l < 49) {
+    const int ca = l / 7, cb = l % 7;
+    if (bi != bj || ca >= cb)
+      *front_entry(fd, pf, pi + ca, pj + cb) += *front_entry(fd, f, ci + ca, cj + cb);
+  } else if (bi == bj && l < 56) {
+    const int c = l - 49;
+    fd.fvec[pf.vec_off + pi + c] += fd.fvec[f.vec_off + ci + c];
+  }
+}
+
+// Back substitution, part 1: y_c -= sum over boundary tiles r of L(r,c)^T x_r, where x of
+// the boundary nodes is read from the global solution (their fronts are done already).
+// grid = (max npt, fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_fback_prep(const FrameDev* __restrict__ frames, int level) {
+  extern __shared__ double xb[];   // n2p doubles
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  const int c = blockIdx.x;
+  if (c >= f.npt || f.nb == 0) return;
+  const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
+  for (int i = threadIdx.x; i < f.n2p; i += blockDim.x)
+    xb[i] = (i < 7 * f.nb) ? fd.delta[7 * nodes[i / 7] + i % 7] : 0.0;
+  __syncthreads();
+  const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
+  double acc = 0.0;
+  for (int r = f.npt; r < f.nt; ++r) {
+    const double* Lt = ftile(fd, f, r, c);
+    const double* xr = xb + (size_t)(r - f.npt) * NB;
+#pragma unroll
+    for (int mrow = 16 * q; mrow < 16 * q + 16; ++mrow) acc += Lt[mrow + n * NB] * xr[mrow];
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (q == 0) fd.fvec[f.vec_off + (size_t)c * NB + n] -= acc;
+}
+
+// Back substitution, part 2, pivot tile column c = npt-1-step of every front of the level:
+// x_c = L_cc^-T y_c, y_(c-d) -= L(c,c-d)^T x_c; block 0 scatters x_c to the global solution.
+// grid = (max npt, fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_fbacksub(const FrameDev* __restrict__ frames, int level,
+                                                   int step) {
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  const int c = f.npt - 1 - step;
+  if (c < 0) return;
+  const int d = blockIdx.x;
+  if (d > c) return;
+  __shared__ double y[NB];
+  __shared__ double x[NB];
+  __shared__ double part[4][NB];
+  double* vecs = fd.fvec + f.vec_off;
+  const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+  if (threadIdx.x < NB) y[threadIdx.x] = vecs[(size_t)c * NB + threadIdx.x];
+  __syncthreads();
+  {
+    const int k = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 16 * q; i < 16 * q + 16; ++i) acc += linv[i + k * NB] * y[i];
+    part[q][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < NB) x[k] = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+    __syncthreads();
+  }
+  if (d == 0) {
+    if (threadIdx.x < NB) {
+      const int i = c * NB + threadIdx.x;
+      if (i < f.n1) {
+        const int node = fd.nd_nodes[f.nodes_off + i / 7];
+        fd.delta[7 * node + i % 7] = x[threadIdx.x];
+      }
+    }
+  } else {
+    const double* Lt = ftile(fd, f, c, c - d);
+    const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int mrow = 16 * q; mrow < 16 * q + 16; ++mrow) acc += Lt[mrow + n * NB] * x[mrow];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (q == 0) vecs[(size_t)(c - d) * NB + n] -= acc;
+  }
+}
+
+// ---- host launchers --------------------------------------------------------------------
+void launch_front_assemble(const FrameDev* fr, int n_frames, int max_blocks, hipStream_t st) {
+  if (max_blocks <= 0) return;
+  hipLaunchKernelGGL(k_front_assemble, dim3((max_blocks + 3) / 4, n_frames), dim3(256), 0, st, fr);
+}
+
+void launch_reg_grad_nd(const FrameDev* fr, int n_frames, int maxJKe, int use_arap, double lam_a,
+                        int use_rot, double lam_r, hipStream_t st) {
+  if (maxJKe <= 0 || (!use_arap && !use_rot)) return;
+  hipLaunchKernelGGL(k_reg_grad_nd, dim3((maxJKe + 255) / 256, n_frames), dim3(256), 0, st, fr, use_arap,
+                     lam_a, use_rot, lam_r);
+}
+
+void launch_front_load_rhs(const FrameDev* fr, int n_frames, int maxP, hipStream_t st) {
+  hipLaunchKernelGGL(k_front_load_rhs, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, fr);
+}
+
+void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
+  hipLaunchKernelGGL(k_iter_begin_nd, dim3(64, n_frames), dim3(256), 0, st, fr);
+}
+
+// Level schedule shared by all slots of a batch (they may have different plans: the host
+// passes, per level, the maxima over the batch; blocks beyond a front's own size exit).
+void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv, int n_levels,
+                        double u_override, hipStream_t st) {
+  const size_t lds = PANEL_LDS_DOUBLES * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  for (int l = 0; l < n_levels; ++l) {
+    const NDLevelSched& s = lv[l];
+    if (s.n_fronts <= 0) continue;
+    for (int c = 0; c < s.max_npt; ++c) {
+      const int mcap = s.max_nt - 1 - c;
+      hipLaunchKernelGGL(k_fpanel, dim3(mcap + 1, s.n_fronts, n_frames), dim3(256), lds, st, fr,
+                         l, c, u_override);
+      const int ntr = mcap * (mcap + 1) / 2 + mcap;
+      if (ntr > 0)
+        hipLaunchKernelGGL(k_ftrail, dim3(ntr, s.n_fronts, n_frames), dim3(256), 0, st, fr, l,
+                           c, mcap);
+    }
+    // push the Schur complements of this level into the parents (next level); two passes so
+    // that the two children of a parent never write the same entry concurrently
+    if (s.max_pairs > 0) {
+      const dim3 g((s.max_pairs + 3) / 4, s.n_fronts, n_frames);
+      hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, fr, l, 0);
+      hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, fr, l, 1);
+    }
+  }
+  for (int l = n_levels - 1; l >= 0; --l) {
+    const NDLevelSched& s = lv[l];
+    if (s.n_fronts <= 0 || s.max_npt <= 0) continue;
+    if (s.max_n2p > 0)
+      hipLaunchKernelGGL(k_fback_prep, dim3(s.max_npt, s.n_fronts, n_frames), dim3(256),
+                         (size_t)s.max_n2p * sizeof(double), st, fr, l);
+    for (int e = 0; e < s.max_npt; ++e)
+      hipLaunchKernelGGL(k_fbacksub, dim3(s.max_npt, s.n_fronts, n_frames), dim3(256), 0, st, fr,
+                         l, e);
+  }
+}

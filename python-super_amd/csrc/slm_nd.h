@@ -1,0 +1,73 @@
+// slm_nd.h -- nested-dissection multifrontal Cholesky of the damped normal equations
+// (replaces the dense torch.linalg.cholesky / cholesky_solve of reference super/LM.py:37-51).
+//
+// The coupling graph of the ED nodes is geometric (surfel KNN tuples + node KNN), so a
+// recursive coordinate bisection of the node positions gives small vertex separators.
+// Elimination follows the separator tree bottom-up; every tree node ("front") is a DENSE
+// partial factorisation [F11 F21^T; F21 F22]: factor the n1 pivot variables, push the
+// Schur complement F22 - L21 L21^T to the parent (extend-add).  All fronts of one tree
+// level are independent and are processed by the same launches (blockIdx.y = front,
+// blockIdx.z = frame slot), on the same 64x64 f64-MFMA tile kernels as the band solver.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+
+#define SLM_ND_LEAF 32   // stop bisecting below this many nodes
+
+// One front, device + host view.  Local node positions: [0,nv) pivots (elimination order),
+// [nv, nv+nb) boundary (ancestor separator nodes, elimination order).  Scalar layout:
+// pivots at 7*pos, padded with identity rows to n1p (multiple of 64); boundary at
+// n1p + 7*(pos-nv), padded to n2p.  Tiles (64x64, column-major inside) of the lower
+// triangle, packed by tile column: tile(r,c) = c*nt - c*(c-1)/2 + (r-c).
+struct NDFront {
+  int32_t nv, nb;        // pivot / boundary node counts
+  int32_t n1, n1p;       // 7*nv and its 64-padding
+  int32_t n2p;           // padded boundary scalars
+  int32_t nt, npt;       // tiles per side, pivot tile columns
+  int32_t parent;        // front index of the parent or -1
+  int32_t which_child;   // 0/1: index among the parent's children (extend-add pass)
+  int32_t depth;
+  int32_t nodes_off;     // into nodes[]: nv pivot node ids then nb boundary node ids
+  int32_t eamap_off;     // into eamap[]: boundary index -> local node position in the parent
+  int64_t tile_off;      // into the slot's front tile storage (doubles)
+  int64_t vec_off;       // into the slot's front vector storage (doubles), length nt*64
+  int64_t linv_off;      // into the slot's diagonal-inverse storage (doubles), npt tiles
+};
+
+// destination of a 7x7 node-pair block inside a front
+struct NDDest {
+  int32_t front;   // front index
+  int32_t prow;    // local node position of the later-eliminated node (row)
+  int32_t pcol;    // local node position of the earlier-eliminated node (column)
+  int32_t transpose;  // 1: the block given as (a,b) with a >= b by id lands transposed
+};
+
+// per-level launch bounds (maxima over the slots of a batch)
+struct NDLevelSched {
+  int32_t n_fronts;    // fronts in the level
+  int32_t max_npt;     // pivot tile columns
+  int32_t max_nt;      // tiles per side
+  int32_t max_pairs;   // boundary node pairs nb*(nb+1)/2 (extend-add)
+  int32_t max_n2p;     // padded boundary scalars
+};
+
+struct NDPlanHost {
+  std::vector<NDFront> fronts;        // processing order: deepest level first
+  std::vector<int32_t> level_start;   // fronts[level_start[l] .. level_start[l+1]) are independent
+  std::vector<int32_t> nodes;
+  std::vector<int32_t> eamap;
+  std::vector<int32_t> node_front;    // (J) front that eliminates the node
+  std::vector<int32_t> node_pos;      // (J) its local pivot position
+  std::vector<NDDest> block_dest;     // per data-term block (order of blk_key)
+  std::vector<NDDest> pair_dest;      // per (j, slot) ARAP pair, J*K_ED
+  int64_t tile_doubles = 0, vec_doubles = 0, linv_doubles = 0;
+  int32_t max_nt = 0, max_npt = 0, max_level_fronts = 0;
+  std::vector<NDLevelSched> sched;    // one entry per level
+  double flops = 0.0;
+};
+
+// Host symbolic analysis.  pairs: unique coupled node pairs key = a*J + b (a >= b) of the data
+// term; ed_knn: (J,K_ED); pts: (J,3).  Returns false when the graph cannot be handled.
+bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, const uint32_t* pairs,
+                   int n_pairs, NDPlanHost& out);

@@ -1,0 +1,290 @@
+// slm_nd_host.hip -- host-side symbolic analysis for the nested-dissection multifrontal
+// solver (see slm_nd.h).  Runs once per frame inside slm_bind_frame on a node graph of
+// J ~ 10^3 vertices (milliseconds); everything numeric runs on the device.
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#include "slm_nd.h"
+
+namespace {
+
+struct TreeNode {
+  std::vector<int> vars;
+  int child[2] = {-1, -1};
+  int parent = -1;
+  int depth = 0;
+};
+
+struct Builder {
+  int J;
+  const float* pts;
+  std::vector<std::vector<int>> adj;
+  std::vector<TreeNode> tree;
+  std::vector<char> side;   // scratch: 1 = A, 2 = B
+
+  int dissect(std::vector<int>& nodes, int depth) {
+    const int id = (int)tree.size();
+    tree.emplace_back();
+    tree[id].depth = depth;
+    if ((int)nodes.size() <= SLM_ND_LEAF) {
+      tree[id].vars = nodes;
+      return id;
+    }
+    // widest coordinate axis, median split
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int v : nodes)
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = std::min(lo[a], pts[3 * v + a]);
+        hi[a] = std::max(hi[a], pts[3 * v + a]);
+      }
+    int ax = 0;
+    for (int a = 1; a < 3; ++a)
+      if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+    std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) {
+      return pts[3 * x + ax] < pts[3 * y + ax];
+    });
+    const size_t half = nodes.size() / 2;
+    for (size_t i = 0; i < nodes.size(); ++i) side[nodes[i]] = i < half ? 1 : 2;
+    // vertex separator: the nodes of one side that touch the other side (smaller choice)
+    std::vector<int> SA, SB;
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      const int v = nodes[i];
+      const char other = side[v] == 1 ? 2 : 1;
+      bool touches = false;
+      for (int w : adj[v])
+        if (side[w] == other) { touches = true; break; }
+      if (touches) (side[v] == 1 ? SA : SB).push_back(v);
+    }
+    const std::vector<int>& S = SA.size() <= SB.size() ? SA : SB;
+    for (int v : S) side[v] = 3;
+    std::vector<int> A, B;
+    for (int v : nodes) {
+      if (side[v] == 1) A.push_back(v);
+      else if (side[v] == 2) B.push_back(v);
+    }
+    std::vector<int> Sv = S;
+    for (int v : nodes) side[v] = 0;
+    if (A.empty() || B.empty()) {   // could not split: dense leaf
+      tree[id].vars = nodes;
+      return id;
+    }
+    std::sort(Sv.begin(), Sv.end());
+    tree[id].vars = Sv;
+    const int ca = dissect(A, depth + 1);
+    const int cb = dissect(B, depth + 1);
+    tree[id].child[0] = ca;
+    tree[id].child[1] = cb;
+    tree[ca].parent = id;
+    tree[cb].parent = id;
+    return id;
+  }
+};
+
+inline int round64(int x) { return (x + 63) / 64 * 64; }
+
+}  // namespace
+
+bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, const uint32_t* pairs,
+                   int n_pairs, NDPlanHost& out) {
+  if (J < 1) return false;
+  Builder b;
+  b.J = J;
+  b.pts = pts;
+  b.adj.assign(J, {});
+  b.side.assign(J, 0);
+  auto add_edge = [&](int x, int y) {
+    if (x == y || x < 0 || y < 0 || x >= J || y >= J) return;
+    b.adj[x].push_back(y);
+    b.adj[y].push_back(x);
+  };
+  for (int i = 0; i < n_pairs; ++i) add_edge((int)(pairs[i] / (uint32_t)J), (int)(pairs[i] % (uint32_t)J));
+  for (int j = 0; j < J; ++j)
+    for (int s = 0; s < K_ED; ++s) add_edge(j, ed_knn[j * K_ED + s]);
+  for (auto& a : b.adj) {
+    std::sort(a.begin(), a.end());
+    a.erase(std::unique(a.begin(), a.end()), a.end());
+  }
+  // the graph may be disconnected: dissect() only needs the node list
+  std::vector<int> all(J);
+  std::iota(all.begin(), all.end(), 0);
+  const int root = b.dissect(all, 0);
+  (void)root;
+  const int T = (int)b.tree.size();
+
+  // ---- elimination order: post-order over the separator tree ----------------------
+  std::vector<int> post;   // tree node ids, children before parents
+  {
+    std::vector<std::pair<int, int>> st;
+    st.push_back({0, 0});
+    while (!st.empty()) {
+      auto& top = st.back();
+      const int id = top.first;
+      if (top.second < 2 && b.tree[id].child[top.second] >= 0) {
+        const int c = b.tree[id].child[top.second];
+        ++top.second;
+        st.push_back({c, 0});
+      } else if (top.second < 2 && b.tree[id].child[top.second] < 0) {
+        ++top.second;
+      } else {
+        post.push_back(id);
+        st.pop_back();
+      }
+    }
+  }
+  std::vector<int> order(J, -1), node_tree(J, -1);
+  int cnt = 0;
+  for (int id : post)
+    for (int v : b.tree[id].vars) {
+      order[v] = cnt++;
+      node_tree[v] = id;
+    }
+  if (cnt != J) return false;
+
+  // ---- boundaries, bottom-up -----------------------------------------------------------
+  std::vector<std::vector<int>> bnd(T);
+  std::vector<char> mark(J, 0);
+  for (int id : post) {
+    std::vector<int> acc;
+    auto push = [&](int w) {
+      if (!mark[w]) { mark[w] = 1; acc.push_back(w); }
+    };
+    int my_max = -1;
+    for (int v : b.tree[id].vars) my_max = std::max(my_max, order[v]);
+    for (int v : b.tree[id].vars)
+      for (int w : b.adj[v])
+        if (order[w] > my_max) push(w);
+    for (int c = 0; c < 2; ++c)
+      if (b.tree[id].child[c] >= 0)
+        for (int w : bnd[b.tree[id].child[c]])
+          if (node_tree[w] != id) push(w);
+    for (int w : acc) mark[w] = 0;
+    std::sort(acc.begin(), acc.end(), [&](int x, int y) { return order[x] < order[y]; });
+    bnd[id] = acc;
+  }
+
+  // ---- fronts in processing order: deepest level first ------------------------------------
+  int max_depth = 0;
+  for (auto& t : b.tree) max_depth = std::max(max_depth, t.depth);
+  std::vector<int> proc;   // tree ids
+  out.level_start.clear();
+  for (int d = max_depth; d >= 0; --d) {
+    out.level_start.push_back((int)proc.size());
+    for (int id = 0; id < T; ++id)
+      if (b.tree[id].depth == d) proc.push_back(id);
+  }
+  out.level_start.push_back((int)proc.size());
+  std::vector<int> front_of_tree(T, -1);
+  for (int i = 0; i < (int)proc.size(); ++i) front_of_tree[proc[i]] = i;
+
+  out.fronts.assign(T, NDFront());
+  out.nodes.clear();
+  out.eamap.clear();
+  out.node_front.assign(J, -1);
+  out.node_pos.assign(J, -1);
+  out.tile_doubles = out.vec_doubles = out.linv_doubles = 0;
+  out.max_nt = out.max_npt = out.max_level_fronts = 0;
+  out.flops = 0.0;
+  std::vector<std::unordered_map<int, int>> local_pos(T);   // node -> local position in its front
+  for (int i = 0; i < T; ++i) {
+    const int id = proc[i];
+    TreeNode& t = b.tree[id];
+    // pivots in elimination order
+    std::sort(t.vars.begin(), t.vars.end(), [&](int x, int y) { return order[x] < order[y]; });
+    NDFront& f = out.fronts[i];
+    f.nv = (int)t.vars.size();
+    f.nb = (int)bnd[id].size();
+    f.n1 = 7 * f.nv;
+    f.n1p = round64(f.n1);
+    f.n2p = round64(7 * f.nb);
+    f.nt = (f.n1p + f.n2p) / 64;
+    f.npt = f.n1p / 64;
+    f.depth = t.depth;
+    f.parent = t.parent >= 0 ? front_of_tree[t.parent] : -1;
+    f.which_child = 0;
+    if (t.parent >= 0 && b.tree[t.parent].child[1] == id) f.which_child = 1;
+    f.nodes_off = (int)out.nodes.size();
+    int p = 0;
+    for (int v : t.vars) {
+      out.nodes.push_back(v);
+      out.node_front[v] = i;
+      out.node_pos[v] = p;
+      local_pos[id][v] = p++;
+    }
+    for (int v : bnd[id]) {
+      out.nodes.push_back(v);
+      local_pos[id][v] = p++;
+    }
+    f.tile_off = out.tile_doubles;
+    out.tile_doubles += (int64_t)f.nt * (f.nt + 1) / 2 * 4096;
+    f.vec_off = out.vec_doubles;
+    out.vec_doubles += (int64_t)f.nt * 64;
+    f.linv_off = out.linv_doubles;
+    out.linv_doubles += (int64_t)f.npt * 4096;
+    out.max_nt = std::max(out.max_nt, f.nt);
+    out.max_npt = std::max(out.max_npt, f.npt);
+    const double n1 = f.n1p, n2 = f.n2p;
+    out.flops += n1 * n1 * n1 / 3.0 + n1 * n1 * n2 + n1 * n2 * n2;
+  }
+  out.sched.clear();
+  for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
+    NDLevelSched sc{0, 0, 0, 0, 0};
+    sc.n_fronts = out.level_start[l + 1] - out.level_start[l];
+    for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
+      const NDFront& f = out.fronts[i];
+      sc.max_npt = std::max(sc.max_npt, f.npt);
+      sc.max_nt = std::max(sc.max_nt, f.nt);
+      sc.max_pairs = std::max(sc.max_pairs, f.parent >= 0 ? f.nb * (f.nb + 1) / 2 : 0);
+      sc.max_n2p = std::max(sc.max_n2p, f.n2p);
+    }
+    out.sched.push_back(sc);
+    out.max_level_fronts = std::max(out.max_level_fronts, sc.n_fronts);
+  }
+  // extend-add maps: boundary index of a child -> local node position in the parent
+  for (int i = 0; i < T; ++i) {
+    const int id = proc[i];
+    NDFront& f = out.fronts[i];
+    f.eamap_off = (int)out.eamap.size();
+    if (b.tree[id].parent < 0) {
+      if (f.nb != 0) return false;   // the root cannot have a boundary
+      continue;
+    }
+    auto& lp = local_pos[b.tree[id].parent];
+    for (int v : bnd[id]) {
+      auto it = lp.find(v);
+      if (it == lp.end()) return false;   // boundary must be covered by the parent front
+      out.eamap.push_back(it->second);
+    }
+  }
+
+  // ---- destinations of the assembled blocks -------------------------------------------------
+  auto dest_of = [&](int a, int bnode, NDDest& d) -> bool {   // block given as (a,b), a >= b by id
+    const int e = order[a] < order[bnode] ? a : bnode;          // earlier eliminated -> column
+    const int l = (e == a) ? bnode : a;
+    const int tid = node_tree[e];
+    auto& lp = local_pos[tid];
+    auto it = lp.find(l);
+    if (it == lp.end()) return false;
+    d.front = front_of_tree[tid];
+    d.pcol = lp[e];
+    d.prow = it->second;
+    d.transpose = (e == a && a != bnode) ? 1 : 0;
+    return true;
+  };
+  out.block_dest.resize(n_pairs);
+  for (int i = 0; i < n_pairs; ++i) {
+    const int a = (int)(pairs[i] / (uint32_t)J), bb = (int)(pairs[i] % (uint32_t)J);
+    if (!dest_of(a, bb, out.block_dest[i])) return false;
+  }
+  out.pair_dest.resize((size_t)J * K_ED);
+  for (int j = 0; j < J; ++j)
+    for (int s = 0; s < K_ED; ++s) {
+      const int k = ed_knn[j * K_ED + s];
+      const int a = std::max(j, k), bb = std::min(j, k);
+      if (!dest_of(a, bb, out.pair_dest[(size_t)j * K_ED + s])) return false;
+    }
+  return true;
+}

@@ -99,6 +99,7 @@ class LM_Solver():
             int(bool(o.mesh_rot))
         c.max_frames = self.max_frames
         c.data_path = int(getattr(o, "slm_data_path", 0))
+        c.solver_path = int(getattr(o, "slm_solver_path", 0))
         c.w_data = float(getattr(o, "sf_point_plane_weight", 1.0))
         c.w_arap = float(getattr(o, "mesh_arap_weight", 10.0))
         c.w_rot = float(getattr(o, "mesh_rot_weight", 1.0))

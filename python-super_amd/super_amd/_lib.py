@@ -26,7 +26,7 @@ EXPORTS = [
 class SlmConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int32), ("phase_test", C.c_int32), ("use_data", C.c_int32),
                 ("use_arap", C.c_int32), ("use_rot", C.c_int32), ("max_frames", C.c_int32),
-                ("data_path", C.c_int32), ("reserved", C.c_int32),
+                ("data_path", C.c_int32), ("solver_path", C.c_int32),
                 ("w_data", C.c_double), ("w_arap", C.c_double), ("w_rot", C.c_double),
                 ("u0", C.c_double), ("v", C.c_double), ("minimal_loss0", C.c_double)]
 

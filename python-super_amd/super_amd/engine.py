@@ -70,13 +70,14 @@ class Engine:
 
     def __init__(self, device, max_frames=1, num_iterations=10, phase_test=True, use_data=True,
                  use_arap=True, use_rot=True, w_data=1.0, w_arap=10.0, w_rot=1.0, u0=10.0, v=7.5,
-                 minimal_loss0=1e10, data_path=0):
+                 minimal_loss0=1e10, data_path=0, solver_path=0):
         self.lib = _lib.load()
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         cfg = SlmConfig(num_iterations=num_iterations, phase_test=int(phase_test),
                         use_data=int(use_data), use_arap=int(use_arap), use_rot=int(use_rot),
-                        max_frames=max_frames, data_path=data_path, w_data=w_data, w_arap=w_arap, w_rot=w_rot, u0=u0,
+                        max_frames=max_frames, data_path=data_path, solver_path=solver_path,
+                        w_data=w_data, w_arap=w_arap, w_rot=w_rot, u0=u0,
                         v=v, minimal_loss0=minimal_loss0)
         self.cfg = cfg
         self.h = C.c_void_p()

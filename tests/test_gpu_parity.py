@@ -181,3 +181,33 @@ def test_atomic_cross_check_path_agrees():
     scale = np.abs(outs[0][0]).max()
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-12 * scale)
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
+def test_nd_multifrontal_solve_matches_band_and_numpy(name):
+    """slm_solve through the nested-dissection multifrontal path, the band path, and a dense
+    NumPy solve of the assembled system agree."""
+    import torch
+    from super_amd import _lib
+    from super_amd.LM import LM_Solver, _dev_ptr, _stream_ptr
+    g, sc, opt = load_golden(name)
+    sf, inputs, new_data = torch_frame(sc)
+    beta = torch.from_numpy(g["b1_beta"]).cuda()
+    P = 7 * sc.J
+    sols = {}
+    for path in (0, 1):
+        o = ref_opt(opt)
+        o.slm_solver_path = path
+        lm = LM_Solver(o)
+        jtj, jtl = lm.prepareCostTerm(sf, inputs, new_data, beta, grad=True)   # binds + sets beta
+        h = lm._handle()
+        st = _stream_ptr(beta.device)
+        delta = torch.zeros(P, dtype=torch.float64, device="cuda")
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(lm.lib.slm_solve(h, 0, 0.37, _dev_ptr(delta), _dev_ptr(status), st), "slm_solve")
+        assert int(status.item()) == 0
+        sols[path] = delta.cpu().numpy()
+        A = jtj.cpu().numpy() + 0.37 * np.eye(P)
+        ref = np.linalg.solve(A, jtl.cpu().numpy().reshape(-1))
+        np.testing.assert_allclose(sols[path], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(sols[0], sols[1], rtol=0, atol=1e-9)
