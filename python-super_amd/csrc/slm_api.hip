@@ -62,6 +62,8 @@ struct Slot {
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
   // nested-dissection plan: host copy + device mirrors (grow-only)
   NDPlanHost nd;
+  uint64_t nd_hash = 0;         // hash of the coupled-pair list + node KNN the cached plan was built from
+  bool nd_valid = false;
   std::vector<uint32_t> h_pairs;
   std::vector<int32_t> h_knn;
   std::vector<float> h_pts;
@@ -253,7 +255,20 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     HIPCHK(hipMemcpyAsync(sl.h_knn.data(), f->ed_knn_idx, sizeof(int32_t) * sl.h_knn.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(sl.h_pts.data(), f->ed_points, sizeof(float) * sl.h_pts.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), sl.h_pairs.data(), h.n_blocks, sl.nd)) {
+    // the symbolic plan depends only on the coupling graph: reuse it while the graph is unchanged
+    uint64_t hash = 1469598103934665603ull;
+    auto mix = [&](const void* ptr, size_t bytes) {
+      const uint32_t* w = static_cast<const uint32_t*>(ptr);
+      for (size_t i = 0; i < bytes / 4; ++i) hash = (hash ^ w[i]) * 1099511628211ull;
+    };
+    const int32_t dims[2] = {f->J, f->K_ED};
+    mix(dims, sizeof(dims));
+    mix(sl.h_pairs.data(), sizeof(uint32_t) * sl.h_pairs.size());
+    mix(sl.h_knn.data(), sizeof(int32_t) * sl.h_knn.size());
+    if (sl.nd_valid && sl.nd_hash == hash && (int)sl.nd.block_dest.size() == h.n_blocks) {
+      h.nd_ready = 1;   // device mirrors of the plan are still in place (pointers kept in h)
+    } else if (nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), sl.h_pairs.data(), h.n_blocks, sl.nd)) {
+      sl.nd_valid = false;
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J;
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
@@ -287,6 +302,10 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.fvec = sl.fvec;
       h.flinv = sl.flinv;
       h.nd_ready = 1;
+      sl.nd_hash = hash;
+      sl.nd_valid = true;
+    } else {
+      sl.nd_valid = false;
     }
   }
   h.bound = 1;

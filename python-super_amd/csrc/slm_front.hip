@@ -259,6 +259,88 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   }
 }
 
+// Split form of k_fpanel for levels with many fronts x frames (the fused form factors the
+// diagonal tile redundantly in every block of the tile column, which is the right trade only
+// while the launch is latency-bound):
+//   k_fpotrf  one block per front: factor, full inverse -> flinv, forward substitution
+//   k_ftrsm   block d >= 1: L(c+d,c) = A(c+d,c) L_cc^-T as one tile product with L_cc^-1
+// grid = (1, fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ frames, int level, int c,
+                                                 double u_override) {
+  extern __shared__ double lds[];
+  double* S = lds;
+  double* M = lds + TILE;
+  double* dinv = lds + 2 * TILE;
+  double* wt = dinv + 4 * 256;
+  double* vec = wt + 4 * 256;
+  int* s_ok = reinterpret_cast<int*>(vec + NB);
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  if (c >= f.npt) return;
+  const double u = (u_override >= 0.0) ? u_override : fd.st->u;
+  double* yv = fd.fvec + f.vec_off + (size_t)c * NB;
+  if (threadIdx.x < NB) vec[threadIdx.x] = yv[threadIdx.x];
+  {
+    const double* src = ftile(fd, f, c, c);
+    double v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = src[threadIdx.x + 256 * t];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = threadIdx.x + 256 * t;
+      const int i = e % NB, k = e / NB;
+      double x = (i >= k) ? v[t] : 0.0;
+      if (i == k) x = (c * NB + i < f.n1) ? x + u : 1.0;
+      S[i + k * LD] = x;
+    }
+  }
+  __syncthreads();
+  const bool ok = potrf64(S, dinv, s_ok, fd, false);
+  if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
+  inverse_assemble64(S, M, dinv, wt);
+  double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+  for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];
+  if (threadIdx.x < NB) {
+    const int i = threadIdx.x;
+    double acc = 0.0;
+    for (int k = 0; k <= i; ++k) acc += M[i + k * LD] * vec[k];
+    yv[i] = acc;
+  }
+}
+
+// grid = (max tiles below, fronts in level, n_frames): block d-1 -> tile (c+d, c)
+__global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ frames, int level, int c) {
+  __shared__ double Bl[TILE];
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  if (c >= f.npt) return;
+  const int d = blockIdx.x + 1;
+  if (c + d >= f.nt) return;
+  double* At = ftile(fd, f, c + d, c);
+  const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+  double breg[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) breg[e] = linv[threadIdx.x + 256 * e];
+  double areg[16];
+  load_a_frags(At, areg);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+  __syncthreads();
+  double4_t acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+  tile_ABt_regs<false>(areg, Bl, acc);   // A (L^-1)^T
+  store_c_frags(At, acc);
+}
+
 // grid = (mcap*(mcap+1)/2 + mcap, fronts in level, n_frames); mcap >= nt-1-c of every front
 __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ frames, int level,
                                                  int c, int mcap) {
@@ -316,10 +398,13 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 }
 
 // Add the Schur complement (and forward-eliminated rhs) of every front of the level whose
-// which_child == which into its parent.  One wave per boundary node pair (bi >= bj).
-// grid = (ceil(max pairs / 4), fronts in level, n_frames)
+// which_child == which into its parent.  One block per 64x64 tile (tr >= tc) of the child's
+// boundary part; the child -> parent scalar index maps of the tile's rows and columns are
+// built once per block in LDS (node map eamap, 7 scalars per node).
+// grid = (max boundary tile pairs, fronts in level, n_frames)
 __global__ void __launch_bounds__(256) k_extend_add(const FrameDev* __restrict__ frames, int level,
                                                      int which) {
+  __shared__ int rmap[NB], cmap[NB];
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   if (level >= fd.n_levels) return;
@@ -327,25 +412,38 @@ __global__ void __launch_bounds__(256) k_extend_add(const FrameDev* __restrict__
   if (fi >= fd.level_start[level + 1]) return;
   const NDFront& f = fd.fronts[fi];
   if (f.parent < 0 || f.which_child != which) return;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int npairs = f.nb * (f.nb + 1) / 2;
-  if (t >= npairs) return;
-  int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-  while (bi * (bi + 1) / 2 > t) --bi;
-  const int bj = t - bi * (bi + 1) / 2;
+  const int nbt = f.nt - f.npt;                 // boundary tiles per side
+  const int t = blockIdx.x;
+  if (t >= nbt * (nbt + 1) / 2) return;
+  int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  while (tr * (tr + 1) / 2 > t) --tr;
+  const int tc = t - tr * (tr + 1) / 2;
   const NDFront& pf = fd.fronts[f.parent];
   const int* em = fd.nd_eamap + f.eamap_off;
-  const int pi = nd_base(pf, em[bi]), pj = nd_base(pf, em[bj]);
-  const int ci = f.n1p + 7 * bi, cj = f.n1p + 7 * bj;
-  const int l = threadIdx.x & 63;
-  if (l < 49) {
-    const int ca = l / 7, cb = l % 7;
-    if (bi != bj || ca >= cb)
-      *front_entry(fd, pf, pi + ca, pj + cb) += *front_entry(fd, f, ci + ca, cj + cb);
-  } else if (bi == bj && l < 56) {
-    const int c = l - 49;
-    fd.fvec[pf.vec_off + pi + c] += fd.fvec[f.vec_off + ci + c];
+  const int n2 = 7 * f.nb;
+  if (threadIdx.x < 2 * NB) {
+    const bool is_row = threadIdx.x < NB;
+    const int i = (is_row ? tr : tc) * NB + (threadIdx.x & 63);   // child boundary scalar index
+    const int m = (i < n2) ? nd_base(pf, em[i / 7]) + i % 7 : -1;
+    if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
+  }
+  __syncthreads();
+  const double* src = ftile(fd, f, f.npt + tr, f.npt + tc);
+  double v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) v[e] = src[threadIdx.x + 256 * e];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int idx = threadIdx.x + 256 * e;
+    const int i = idx & 63, j = idx >> 6;
+    const int pr = rmap[i], pc = cmap[j];
+    if (pr >= 0 && pc >= 0 && (tr > tc || i >= j)) *front_entry(fd, pf, pr, pc) += v[e];
+  }
+  // rhs: diagonal tiles carry their rows' vector entries
+  if (tr == tc && threadIdx.x < NB) {
+    const int pr = rmap[threadIdx.x];
+    if (pr >= 0) fd.fvec[pf.vec_off + pr] += fd.fvec[f.vec_off + (size_t)(f.npt + tr) * NB + threadIdx.x];
   }
 }
 
@@ -460,6 +558,7 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_fpotrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   for (int l = 0; l < n_levels; ++l) {
@@ -467,8 +566,17 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     if (s.n_fronts <= 0) continue;
     for (int c = 0; c < s.max_npt; ++c) {
       const int mcap = s.max_nt - 1 - c;
-      hipLaunchKernelGGL(k_fpanel, dim3(mcap + 1, s.n_fronts, n_frames), dim3(256), lds, st, fr,
-                         l, c, u_override);
+      // fused panel while the launch is small (latency-bound); split once the redundant
+      // factorisations would take more than ~2 blocks per CU
+      if ((long)(mcap + 1) * s.n_fronts * n_frames <= 512) {
+        hipLaunchKernelGGL(k_fpanel, dim3(mcap + 1, s.n_fronts, n_frames), dim3(256), lds, st, fr,
+                           l, c, u_override);
+      } else {
+        hipLaunchKernelGGL(k_fpotrf, dim3(1, s.n_fronts, n_frames), dim3(256), lds, st, fr, l, c,
+                           u_override);
+        if (mcap > 0)
+          hipLaunchKernelGGL(k_ftrsm, dim3(mcap, s.n_fronts, n_frames), dim3(256), 0, st, fr, l, c);
+      }
       const int ntr = mcap * (mcap + 1) / 2 + mcap;
       if (ntr > 0)
         hipLaunchKernelGGL(k_ftrail, dim3(ntr, s.n_fronts, n_frames), dim3(256), 0, st, fr, l,
@@ -476,8 +584,9 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     }
     // push the Schur complements of this level into the parents (next level); two passes so
     // that the two children of a parent never write the same entry concurrently
-    if (s.max_pairs > 0) {
-      const dim3 g((s.max_pairs + 3) / 4, s.n_fronts, n_frames);
+    if (s.max_n2p > 0 && l + 1 < n_levels) {
+      const int nbt = s.max_n2p / 64;
+      const dim3 g(nbt * (nbt + 1) / 2, s.n_fronts, n_frames);
       hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, fr, l, 0);
       hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, fr, l, 1);
     }
