@@ -14,6 +14,8 @@
 //                   the runs that contain both nodes (inverted index built once per frame
 //                   by slm_prep.hip) and stores them into the lower band -- each band
 //                   entry is written by exactly one lane, bitwise reproducible.
+#include <cstdlib>
+
 #include "slm_data.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -21,7 +23,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define ROW_STRIDE 33   // doubles per surfel row in LDS (33: conflict-free 64-bit writes)
 
 // grid = (ceil(max n_pos / 256), n_frames), 256 threads = 4 waves, one 64-position chunk each
-__global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ frames, double lam) {
+// dbg (diagnostic build only): bit0 skip slab stores, bit1 skip MFMA, bit2 skip surfel evaluation
+__global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ frames, double lam,
+                                                    int dbg) {
   __shared__ double rows[4][64 * ROW_STRIDE];
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
@@ -35,7 +39,12 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
   SurfelEval ev;
   ev.match = false;
   const bool live = fd.s_idx[4 * pos] >= 0;
-  if (live) eval_surfel_at<true>(fd, fd.s_pts, fd.s_idx, fd.s_w, lam, fd.beta, nullptr, pos, ev);
+#ifdef SLM_STAMPS
+  if (live && !(dbg & 4))
+#else
+  if (live)
+#endif
+    eval_surfel_at<true>(fd, fd.s_pts, fd.s_idx, fd.s_w, lam, fd.beta, nullptr, pos, ev);
   const unsigned long long mm = __ballot(ev.match);
   if (l == 0 && mm) atomicAdd(&fd.st->m_grad, __popcll(mm));
 
@@ -66,6 +75,9 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
 
   auto flush = [&](int run) {
     double* out = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+#ifdef SLM_STAMPS
+    if (!(dbg & 1))
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       out[r * 64 + l] = g00[r];
@@ -100,6 +112,9 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
     if (run < 0) continue;
     const double* rp = &rows[w][(4 * g + lq) * ROW_STRIDE];
     const double a0 = rp[lc], a1 = rp[16 + lc];
+#ifdef SLM_STAMPS
+    if (dbg & 2) { g00[0] += a0; g11[0] += a1; continue; }
+#endif
     g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g00, 0, 0, 0);
     g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g10, 0, 0, 0);
     g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
@@ -137,7 +152,12 @@ __global__ void __launch_bounds__(256) k_band_assemble(const FrameDev* __restric
 
 void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, hipStream_t st) {
   if (max_pos <= 0) return;
-  hipLaunchKernelGGL(k_data_gram, dim3((max_pos + 255) / 256, n_frames), dim3(256), 0, st, frames_dev, lam);
+  int dbg = 0;
+#ifdef SLM_STAMPS
+  if (const char* e = getenv("SLM_DBG")) dbg = atoi(e);
+#endif
+  hipLaunchKernelGGL(k_data_gram, dim3((max_pos + 255) / 256, n_frames), dim3(256), 0, st, frames_dev, lam,
+                     dbg);
 }
 
 void launch_band_assemble(const FrameDev* frames_dev, int n_frames, int max_blocks, hipStream_t st) {

@@ -9,6 +9,8 @@
 // -> for every level, root first: k_fback_prep, k_fbacksub(step)...   back substitution,
 //    each front scatters its pivots' solution into delta.
 // Grid convention: blockIdx.y = front within the level, blockIdx.z = frame slot.
+#include <algorithm>
+
 #include "slm_tile.h"
 
 __device__ __forceinline__ int nd_base(const NDFront& f, int p) {
@@ -210,6 +212,8 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   const double u = (u_override >= 0.0) ? u_override : fd.st->u;
 
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  const bool stamp = (c == 1 && blockIdx.z == 0 && blockIdx.y == 0 && d == 1 && level == fd.n_levels - 1);
+  SLM_STAMP(fd, stamp, 0);
   double* At = ftile(fd, f, c + d, c);
   double* yv = fd.fvec + f.vec_off + (size_t)c * NB;
   double4_t a[4];
@@ -237,7 +241,9 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
     }
   }
   __syncthreads();
-  const bool ok = potrf64(S, dinv, s_ok, fd, false);
+  SLM_STAMP(fd, stamp, 1);
+  const bool ok = potrf64(S, dinv, s_ok, fd, stamp);
+  SLM_STAMP(fd, stamp, 14);
 
   if (d == 0) {
     if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
@@ -257,6 +263,7 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
 #pragma unroll
       for (int r = 0; r < 4; ++r) At[(16 * w + lr) + (size_t)(16 * kb + lk + 4 * r) * NB] = a[kb][r];
   }
+  SLM_STAMP(fd, stamp, 15);
 }
 
 // Split form of k_fpanel for levels with many fronts x frames (the fused form factors the
@@ -341,9 +348,14 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
   store_c_frags(At, acc);
 }
 
-// grid = (mcap*(mcap+1)/2 + mcap, fronts in level, n_frames); mcap >= nt-1-c of every front
+// Trailing update of tile column c, restricted to the PIVOT tile columns that are still to be
+// factored (s < npt): A(r,s) -= L(r,c) L(s,c)^T for c < s < npt, s <= r < nt, plus the rhs
+// rows b_r -= L(r,c) y_c for all r > c.  The boundary x boundary block is updated once per
+// front by k_fschur with the whole pivot block as the inner dimension.
+// Block index t: columns b = s-c = 1..bcap, rows a = r-c = b..mcap, then mcap rhs blocks.
+// grid = (ntile_cap + mcap, fronts in level, n_frames)
 __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ frames, int level,
-                                                 int c, int mcap) {
+                                                 int c, int mcap, int bcap, int ntile_cap) {
   __shared__ double Bl[TILE];
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
@@ -353,15 +365,15 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
   const int m = f.nt - 1 - c;
-  const int ntri = mcap * (mcap + 1) / 2;
   int t = blockIdx.x;
-  if (t < ntri) {
-    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= t) ++a;
-    while (a * (a + 1) / 2 > t) --a;
-    const int b = t - a * (a + 1) / 2;
-    const int da = a + 1, db = b + 1;
-    if (da > m) return;
+  if (t < ntile_cap) {
+    int db = 1;
+    while (db <= bcap && t >= mcap - db + 1) {
+      t -= mcap - db + 1;
+      ++db;
+    }
+    const int da = db + t;
+    if (da > m || c + db >= f.npt) return;
     const double* Lr = ftile(fd, f, c + da, c);
     const double* Ls = ftile(fd, f, c + db, c);
     double* Ct = ftile(fd, f, c + da, c + db);
@@ -378,7 +390,7 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
     tile_ABt_regs<true>(areg, Bl, acc);
     store_c_frags(Ct, acc);
   } else {
-    const int db = t - ntri + 1;
+    const int db = t - ntile_cap + 1;
     if (db > m) return;
     __shared__ double y[NB];
     __shared__ double part[4][NB];
@@ -395,6 +407,55 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
     if (threadIdx.x < NB)
       vecs[(size_t)(c + db) * NB + i] -= part[0][i] + part[1][i] + part[2][i] + part[3][i];
   }
+}
+
+// Schur complement of a front in one pass: U(r,s) -= sum_{c < npt} L(r,c) L(s,c)^T for the
+// boundary tiles npt <= s <= r < nt.  The U tile is read and written once; the next pivot
+// column's operands are fetched while the current one is on the MFMA.
+// grid = (max boundary tile pairs, fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ frames, int level) {
+  __shared__ double Bl[2][TILE];
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  const int nbt = f.nt - f.npt;
+  const int t = blockIdx.x;
+  if (f.npt == 0 || t >= nbt * (nbt + 1) / 2) return;
+  int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  while (tr * (tr + 1) / 2 > t) --tr;
+  const int tc = t - tr * (tr + 1) / 2;
+  const int r = f.npt + tr, sc = f.npt + tc;
+  double* Ct = ftile(fd, f, r, sc);
+  double4_t acc[4];
+  load_c_frags(Ct, acc);
+  double breg[16], areg[16];
+  {
+    const double* Ls = ftile(fd, f, sc, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
+    load_a_frags(ftile(fd, f, r, 0), areg);
+  }
+  for (int c = 0; c < f.npt; ++c) {
+    double* B = Bl[c & 1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) B[threadIdx.x + 256 * e] = breg[e];
+    double acur[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acur[e] = areg[e];
+    if (c + 1 < f.npt) {   // prefetch the next pivot column
+      const double* Ls = ftile(fd, f, sc, c + 1);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
+      load_a_frags(ftile(fd, f, r, c + 1), areg);
+    }
+    __syncthreads();   // B[c&1] complete; the buffer written two steps ago is free again
+    tile_ABt_regs<true>(acur, B, acc);
+  }
+  store_c_frags(Ct, acc);
 }
 
 // Add the Schur complement (and forward-eliminated rhs) of every front of the level whose
@@ -577,10 +638,16 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
         if (mcap > 0)
           hipLaunchKernelGGL(k_ftrsm, dim3(mcap, s.n_fronts, n_frames), dim3(256), 0, st, fr, l, c);
       }
-      const int ntr = mcap * (mcap + 1) / 2 + mcap;
-      if (ntr > 0)
-        hipLaunchKernelGGL(k_ftrail, dim3(ntr, s.n_fronts, n_frames), dim3(256), 0, st, fr, l,
-                           c, mcap);
+      const int bcap = std::min(mcap, s.max_npt - 1 - c);
+      int ntile = 0;
+      for (int b = 1; b <= bcap; ++b) ntile += mcap - b + 1;
+      if (ntile + mcap > 0)
+        hipLaunchKernelGGL(k_ftrail, dim3(ntile + mcap, s.n_fronts, n_frames), dim3(256), 0, st, fr, l,
+                           c, mcap, bcap, ntile);
+    }
+    if (s.max_n2p > 0 && s.max_npt > 0) {
+      const int nbt = s.max_n2p / 64;
+      hipLaunchKernelGGL(k_fschur, dim3(nbt * (nbt + 1) / 2, s.n_fronts, n_frames), dim3(256), 0, st, fr, l);
     }
     // push the Schur complements of this level into the parents (next level); two passes so
     // that the two children of a parent never write the same entry concurrently

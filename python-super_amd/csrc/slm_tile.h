@@ -98,20 +98,34 @@ __device__ __forceinline__ bool diag16(double* Sd, double* Dinv) {
   }
   bool ok = true;
   double pv = 1.0;   // lane with (l & 15) == j keeps pivot j
+  // The reciprocal of pivot j+1 is computed on the VALU while the rank-1 MFMAs of step j are
+  // still in flight: p_{j+1} = S[j+1][j+1] - S[j][j+1]^2 / p_j, formed exactly like the
+  // MFMA forms it (fma of the rounded A entry), from registers that step j-1 has completed.
+  double p = readlane_d(S[0], 0);
+  double rinv = rcp_nr(p);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int q = j & 3, r = j >> 2;
     const double v = S[r];
-    const double p = readlane_d(v, 16 * q + j);
     ok = ok && (p > 0.0);
-    const double rinv = rcp_nr(p);
     pv = (lc == j) ? p : pv;
-    const bool mine = (lq == q);
-    const double a = (mine && lc != j) ? -v * rinv : 0.0;
-    const double bs = mine ? v : 0.0;
-    const double bm = mine ? M[r] : 0.0;
+    // Only the A operand is masked: k-slots other than q (and row j itself) carry a zero A
+    // entry, so whatever (finite) B value sits in those slots contributes nothing.
+    const double a = (l != 16 * q + j && lq == q) ? -v * rinv : 0.0;
+    const double bs = v;
+    const double bm = M[r];
+    double p_next = 1.0, rinv_next = 1.0;
+    if (j + 1 < 16) {
+      const int q1 = (j + 1) & 3, r1 = (j + 1) >> 2;
+      const double x = readlane_d(v, 16 * q + (j + 1));           // S[j][j+1]
+      const double d = readlane_d(S[r1], 16 * q1 + (j + 1));      // S[j+1][j+1] before this step
+      p_next = fma(-x * rinv, x, d);
+      rinv_next = rcp_nr(p_next);
+    }
     S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs, S, 0, 0, 0);
     M = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bm, M, 0, 0, 0);
+    p = p_next;
+    rinv = rinv_next;
   }
   const double rsv = rsq_nr(pv);   // lane l: 1/sqrt(pivot (l & 15))
 #pragma unroll
