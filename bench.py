@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C4", "tiny"])
     ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the frames of a GPU over this many solver handles / HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event phase timing")
     return ap.parse_args()
@@ -92,6 +94,25 @@ def cpu_baseline(dims, seed):
             "seconds": dt}
 
 
+def cpu_baseline_autograd(dims, seed):
+    """The reference's DEFAULT optimiser (GraphFit: autograd + Adam, BASELINE configs[0]) as
+    restated in oracle/graphfit_oracle.py (PyTorch CPU, float64): one full frame = 10 Adam
+    iterations of point-plane + ARAP + Rot on one frame."""
+    import torch
+    from oracle import graphfit_oracle as gfo
+    from super_amd import synth
+    sc = synth.make_scene(seed=seed, **dims)
+    pb = gfo.Problem(sc)
+    opt = gfo.default_opt(optimizer="Adam")
+    t0 = time.perf_counter()
+    gfo.graphfit(pb, opt)
+    dt = time.perf_counter() - t0
+    return {"value": opt.num_optimize_iterations / dt, "unit": "Adam it/s", "cores": int(torch.get_num_threads()),
+            "kind": "port", "ms_per_frame": 1e3 * dt,
+            "sample": f"10 Adam iterations (one frame) of the autograd path on one {sc.N}-surfel / "
+                      f"{sc.J}-node frame, PyTorch-CPU float64, {dt:.1f} s"}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -125,7 +146,12 @@ def main():
     pristine = [DeviceFrame.from_scene(sc, device) for sc in scenes]
     work = [DeviceFrame.from_scene(sc, device) for sc in scenes]   # updated in place per step
     N, J = scenes[0].N, scenes[0].J
-    eng = Engine(device, max_frames=B, num_iterations=iters)
+    S = max(1, min(a.streams, B))
+    assert B % S == 0, "--frames-per-gpu must be divisible by --streams"
+    Bs = B // S
+    engs = [Engine(device, max_frames=Bs, num_iterations=iters) for _ in range(S)]
+    streams = [torch.cuda.Stream(device) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(device)]
+    eng = engs[0]
     betas = [torch.empty((J, 7), dtype=torch.float64, device=device) for _ in range(B)]
     gathered = [None]
     local = torch.empty((B, J, 7), dtype=torch.float64, device=device)
@@ -136,12 +162,21 @@ def main():
             w.sf_norms.copy_(p.sf_norms)
             w.ed_points.copy_(p.ed_points)
             w.ed_norms.copy_(p.ed_norms)
-        for i, w in enumerate(work):
-            eng.bind(i, w)                               # loss_term.prepare (LM.py:93-94)
-        eng.run(B)                                       # LM_Solver.LM         (LM.py:95-117)
-        for i in range(B):
-            eng.beta(i, betas[i])
-            eng.apply_update(i, betas[i])                # Surfels.update      (nodes.py:193-223)
+        if S > 1:
+            main = torch.cuda.current_stream(device)
+            for st in streams:
+                st.wait_stream(main)
+        for k, (e, st) in enumerate(zip(engs, streams)):
+            with torch.cuda.stream(st):
+                for i in range(Bs):
+                    e.bind(i, work[k * Bs + i])          # loss_term.prepare (LM.py:93-94)
+                e.run(Bs)                                # LM_Solver.LM         (LM.py:95-117)
+                for i in range(Bs):
+                    e.beta(i, betas[k * Bs + i])
+                    e.apply_update(i, betas[k * Bs + i])  # Surfels.update   (nodes.py:193-223)
+        if S > 1:
+            for st in streams:
+                torch.cuda.current_stream(device).wait_stream(st)
         if world > 1:                                    # end-of-frame exchange
             torch.stack(betas, out=local)
             gathered[0] = all_gather_betas(local, world * B)
@@ -155,14 +190,24 @@ def main():
         step()
     fence()
     if not a.no_profile:
-        eng.profile(True)
+        for e in engs:
+            e.profile(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = eng.profile_read() if not a.no_profile else None
-    eng.profile(False)
+    prof = None
+    if not a.no_profile:
+        for e in engs:
+            pr = e.profile_read()
+            if prof is None:
+                prof = pr
+            else:
+                for k2, v2 in pr.items():
+                    prof[k2]["ms"] += v2["ms"]
+                    prof[k2]["count"] += v2["count"]
+            e.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,7 +231,8 @@ def main():
             "config": {"workload": f"{a.workload}: {N} surfels / {J} ED nodes / KNN=4, "
                                    f"point-to-plane + ARAP + Rot, {iters} LM iterations + "
                                    f"Surfels.update per frame",
-                       "frames_per_gpu": B, "global_frames": world * B, "image": [dims["H"], dims["W"]],
+                       "frames_per_gpu": B, "streams_per_gpu": S, "global_frames": world * B,
+                       "image": [dims["H"], dims["W"]],
                        "storage": "f32/i32 in HBM, f64 arithmetic and solve",
                        "parallelism": f"frames sharded over {world} GPU(s), beta all-gather"},
             "lm_iterations_ok_frame0": n_ok,
@@ -194,19 +240,19 @@ def main():
         }
         if prof is not None:
             g = prof["data_grad"]
-            per_launch_bytes = B * (72.0 * N + 3165.0 * J)     # grad pass, f32/i32
+            per_launch_bytes = Bs * (72.0 * N + 3165.0 * J)    # grad pass, f32/i32
             avg_s = g["ms"] / max(g["count"], 1) * 1e-3
             ach = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
             out["roofline"] = {"kernel": "k_data_gram", "bound": "hbm", "achieved": ach,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic("k_data_gram", a.workload, B),
+                               "traffic": pmc_traffic("k_data_gram", a.workload, Bs),
                                "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
                                "algorithmic_bytes_per_launch": per_launch_bytes}
             nt = (7 * J + NB - 1) // NB
             lo = np.min(scenes[0].sf_knn_idx, axis=1)
             hi = np.max(scenes[0].sf_knn_idx, axis=1)
             wb = int(((7 * hi + 6) // NB - (7 * lo) // NB).max())
-            flops = B * nt * (wb * (wb + 1) / 2 + wb) * 2.0 * NB ** 3   # SYRK + TRSM tiles
+            flops = Bs * nt * (wb * (wb + 1) / 2 + wb) * 2.0 * NB ** 3   # SYRK + TRSM tiles
             s = prof["solve"]
             savg = s["ms"] / max(s["count"], 1) * 1e-3
             tf = flops / savg / 1e12 if savg > 0 else 0.0
@@ -217,6 +263,7 @@ def main():
             out["phase_ms_per_iteration"] = {k: v["ms"] / max(v["count"], 1) for k, v in prof.items()}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, seed=0)
+            out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,169 @@
+"""ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A float64 PyTorch-CPU restatement of the reference's DEFAULT per-frame optimiser, the
+autograd path ``GraphFit`` (``super/deform_mesh.py:198-230,251-379`` with the loss terms of
+``super/loss.py:293-401,458-473,502-505``): skin the stable surfels with the local warps,
+apply the global row T_g, evaluate face / ARAP / Rot / point-to-plane losses, backprop,
+scale the global row's gradient by 1/J, step SGD(momentum 0.9) or Adam.  This is the path
+BASELINE.json names as the reported CPU baseline (``configs[0]``); ``bench.py`` times it on
+the host cores, and it is the parity reference for the hand-derived-gradient HIP version.
+
+Pinned against the reference itself by ``tests/golden/make_golden.py`` (``gf_*`` arrays in
+the fixtures): per-term losses and d(loss)/d(deform_verts) at iteration 0, and the final
+``deform_verts`` after 10 iterations of SGD and of Adam.  Only ``tests/`` and ``bench.py``'s
+``cpu_baseline`` leg import this module.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+F64 = torch.float64
+
+
+def _t(a, dt=F64):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+
+
+def qrot(q, x):
+    """R(q)x for an un-normalised quaternion, broadcasting (super/utils.py:49-54)."""
+    w, v = q[..., 0:1], q[..., 1:4]
+    c = torch.cross(v.expand_as(x), x, dim=-1)
+    return x + 2.0 * w * c + 2.0 * torch.cross(v.expand_as(x), c, dim=-1)
+
+
+class Problem:
+    """Tensors GraphFit reads from ``src`` (Surfels), ``trg`` (Data) and ``inputs``."""
+
+    def __init__(self, sc, stable=None):
+        st = np.ones(sc.N, bool) if stable is None else np.asarray(stable, bool)
+        self.J = sc.J
+        self.p = _t(sc.sf_points)[st]
+        self.idx = _t(sc.sf_knn_idx, torch.long)[st]
+        self.w = _t(sc.sf_knn_w)[st]
+        self.g = _t(sc.ed_points)
+        self.e_idx = _t(sc.ed_knn_idx, torch.long)
+        self.e_w = _t(sc.ed_knn_w)
+        self.tri = _t(sc.ed_triangles, torch.long) if sc.ed_triangles is not None else None
+        self.tri_area = _t(sc.ed_triangle_areas) if sc.ed_triangle_areas is not None else None
+        self.o = _t(sc.tgt_points)
+        self.n = _t(sc.tgt_norms)
+        self.index_map = _t(sc.index_map, torch.long)
+        self.H, self.W = sc.H, sc.W
+        K = sc.K
+        self.fx, self.fy, self.cx, self.cy = (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
+                                               float(K[1, 2]))
+
+
+def deform(pb: Problem, dv):
+    """``deform_source`` (deform_mesh.py:198-230): local skinning then the global row.
+    Returns the deformed node positions (J,3) and surfel points (N,3)."""
+    gk = pb.g[pb.idx]                                    # (N,K,3)
+    bk = dv[:-1][pb.idx]                                 # (N,K,7)
+    t = qrot(bk[..., 0:4], pb.p[:, None, :] - gk) + bk[..., 4:7] + gk
+    sf = (pb.w[..., None] * t).sum(1)
+    qg, bg = dv[-1:, 0:4], dv[-1:, 4:7]
+    verts = qrot(qg, pb.g + dv[:-1, 4:7]) + bg
+    sf = qrot(qg, sf) + bg
+    return verts, sf
+
+
+def point_plane(pb: Problem, sf):
+    """``DataLoss.autograd_forward`` with ``loss_type='point-plane'`` (loss.py:293-366):
+    margin-1 validity on ROUNDED projections, 4 taps all mapped (zero fill), weights
+    differentiable through (u,v), sum of (n.(p-o))^2."""
+    Z = sf[:, 2] + 1e-8
+    u_ = sf[:, 0] * pb.fx / Z + pb.cx
+    v_ = sf[:, 1] * pb.fy / Z + pb.cy
+    ur, vr = torch.round(u_).long(), torch.round(v_).long()
+    ok = (vr >= 1) & (vr < pb.H - 2) & (ur >= 1) & (ur < pb.W - 2)
+    u, v, P = u_[ok], v_[ok], sf[ok]
+    fv, cv, fu, cu = torch.floor(v), torch.ceil(v), torch.floor(u), torch.ceil(u)
+    nb = torch.stack([fv, fv, cv, cv], -1)
+    mb = torch.stack([fu, cu, fu, cu], -1)
+    rows = pb.index_map[nb.long(), mb.long()]            # (M,4)
+    tap_ok = (rows >= 0).all(-1)
+    feat = torch.cat([pb.o, pb.n], -1)
+    U = torch.zeros(rows.shape + (6,), dtype=F64)
+    U[rows >= 0] = feat[rows[rows >= 0]]
+    an = torch.clamp(1 - torch.abs(nb - v[:, None]), min=0)[..., None]
+    am = torch.clamp(1 - torch.abs(mb - u[:, None]), min=0)[..., None]
+    out = (U * an * am).sum(-2)
+    o, n = out[:, 0:3], out[:, 3:6]
+    r = (n[tap_ok] * (P[tap_ok] - o[tap_ok])).sum(-1)
+    return (r ** 2).sum(), int(tap_ok.sum())
+
+
+def arap(pb: Problem, dv_local):
+    """``ARAPLoss.autograd_forward`` (loss.py:458-473): weighted by the node KNN weights."""
+    d = pb.g[:, None, :] - pb.g[pb.e_idx]
+    bk = dv_local[pb.e_idx]
+    # quirk kept: the reference subtracts the float32-ROUNDED edge vector (loss.py:468)
+    r = qrot(bk[..., 0:4], d) + bk[..., 4:7] - d.float().double() - dv_local[:, None, 4:7]
+    return (pb.e_w * (r ** 2).sum(-1)).sum()
+
+
+def rot(dv):
+    """``RotLoss.autograd_forward`` over all J+1 rows (loss.py:502-505)."""
+    return ((1.0 - (dv[:, 0:4] ** 2).sum(-1)) ** 2).sum()
+
+
+def face(pb: Problem, verts):
+    """Face term (deform_mesh.py:51-60)."""
+    c = torch.cross(verts[pb.tri[1]] - verts[pb.tri[0]], verts[pb.tri[2]] - verts[pb.tri[0]], dim=1)
+    a = 0.5 * torch.sqrt((c ** 2).sum(1) + 1e-13)
+    return ((a - pb.tri_area) ** 2).sum()
+
+
+def default_opt(**kw):
+    o = SimpleNamespace(sf_point_plane=True, sf_point_plane_weight=1.0, mesh_arap=True,
+                        mesh_arap_weight=10.0, mesh_rot=True, mesh_rot_weight=1.0, mesh_face=False,
+                        mesh_face_weight=1.0, num_optimize_iterations=10, optimizer="SGD",
+                        learning_rate=5e-5)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def total_loss(pb: Problem, dv, opt):
+    """``get_losses`` (deform_mesh.py:25-196) for the geometric terms; returns (loss, dict)."""
+    verts, sf = deform(pb, dv)
+    terms = {}
+    if opt.mesh_face:
+        terms["face_losses"] = opt.mesh_face_weight * face(pb, verts)
+    if opt.mesh_arap:
+        terms["arap_loss"] = opt.mesh_arap_weight * arap(pb, dv[:-1])
+    if opt.mesh_rot:
+        terms["rot_loss"] = opt.mesh_rot_weight * rot(dv)
+    if opt.sf_point_plane:
+        pp, m = point_plane(pb, sf)
+        terms["point_plane_loss"] = opt.sf_point_plane_weight * pp
+        terms["_matched"] = m
+    loss = sum(v for k, v in terms.items() if not k.startswith("_"))
+    return loss, terms
+
+
+def graphfit(pb: Problem, opt, trace=None):
+    """``deform_superedg`` (deform_mesh.py:251-379): identity init of (J+1,7), Niter steps of
+    SGD(momentum .9) / Adam at lr = opt.learning_rate with the global row's gradient / J."""
+    dv = torch.zeros((pb.J + 1, 7), dtype=F64)
+    dv[:, 0] = 1.0
+    dv.requires_grad_(True)
+    if opt.optimizer == "SGD":
+        optim = torch.optim.SGD([dv], lr=opt.learning_rate, momentum=0.9)
+    elif opt.optimizer == "Adam":
+        optim = torch.optim.Adam([dv], lr=opt.learning_rate)
+    else:
+        raise ValueError(opt.optimizer)
+    for it in range(opt.num_optimize_iterations):
+        optim.zero_grad()
+        loss, terms = total_loss(pb, dv, opt)
+        loss.backward()
+        dv.grad[-1] = dv.grad[-1] / pb.J
+        if trace is not None:
+            trace.append(dict(it=it, loss=float(loss), grad=dv.grad.detach().clone().numpy(),
+                              terms={k: (float(v) if torch.is_tensor(v) else v) for k, v in terms.items()}))
+        optim.step()
+    return dv.detach().numpy()

@@ -142,6 +142,8 @@ class Scene:
     tgt_norms: np.ndarray         # (T,3) f32
     index_map: np.ndarray         # (H,W) i64, -1 invalid
     valid: np.ndarray             # (H*W,) bool
+    ed_triangles: np.ndarray = None       # (3,Tr) i64 node-grid triangles (graph_encoder.py:11-67 schema)
+    ed_triangle_areas: np.ndarray = None  # (Tr,) f32
     meta: dict = field(default_factory=dict)
 
     @property
@@ -207,6 +209,14 @@ def make_scene(N=50_000, J=512, H=480, W=640, seed=0, n_neighbors=4, n_ed_neighb
     ed_radii = _f32(dd[:, 1:].mean(axis=1))
     ed_knn_w = _f32(softmax_exp_weights(dd[:, 1:], ed_radii.astype(np.float64)[:, None]))
 
+    # ---- grid triangles (two per grid cell) and their rest areas (face term) ----------
+    gi = np.arange(gh * gw).reshape(gh, gw)
+    t0 = np.stack([gi[:-1, :-1], gi[:-1, 1:], gi[1:, :-1]], axis=0).reshape(3, -1)
+    t1 = np.stack([gi[:-1, 1:], gi[1:, 1:], gi[1:, :-1]], axis=0).reshape(3, -1)
+    ed_triangles = np.concatenate([t0, t1], axis=1).astype(np.int64)
+    cr = np.cross(e64[ed_triangles[1]] - e64[ed_triangles[0]], e64[ed_triangles[2]] - e64[ed_triangles[0]])
+    ed_triangle_areas = _f32(0.5 * np.sqrt((cr ** 2).sum(1) + 1e-13))
+
     # ---- surfel -> node KNN + weights ---------------------------------------------
     ds, sf_knn_idx = _knn(sf_points.astype(np.float64), e64, n_neighbors)
     sf_knn_w = _f32(softmax_exp_weights(ds, ed_radii.astype(np.float64)[sf_knn_idx]))
@@ -217,6 +227,7 @@ def make_scene(N=50_000, J=512, H=480, W=640, seed=0, n_neighbors=4, n_ed_neighb
                  ed_knn_idx=np.ascontiguousarray(ed_knn_idx, dtype=np.int64), ed_knn_w=ed_knn_w,
                  tgt_points=tgt_points, tgt_norms=tgt_norms, index_map=index_map,
                  valid=valid_map.reshape(-1).copy(),
+                 ed_triangles=ed_triangles, ed_triangle_areas=ed_triangle_areas,
                  meta=dict(N=N, J=J, H=H, W=W, seed=seed, grid=(gh, gw), phi=phi, dphi=dphi))
 
 

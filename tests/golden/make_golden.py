@@ -168,6 +168,42 @@ def capture_knn(ref, sc, opt):
                 knn_ed_w=_np(sf.ED_nodes.knn_w))
 
 
+def capture_graphfit(ref, sc, okw):
+    """Reference autograd path (GraphFit): iteration-0 losses and gradient (after the 1/J
+    scaling of the global row), final deform_verts for SGD and Adam; with and without the
+    face term."""
+    out = {}
+    for tag, extra in (("sgd", dict(optimizer="SGD")), ("adam", dict(optimizer="Adam")),
+                       ("sgdface", dict(optimizer="SGD", mesh_face=True))):
+        kw = dict(okw)
+        kw.update(extra)
+        opt = ref_shim.ref_opt(**kw)
+        src, inputs, trg, models = ref_shim.graphfit_frame(sc)
+        gf = ref.deform_mesh.GraphFit(opt)
+        rec = {}
+        orig = gf.get_losses
+
+        def wrapped(deform_verts, *a, **k):
+            loss, losses = orig(deform_verts, *a, **k)
+            if "loss0" not in rec:
+                rec["loss0"] = float(loss)
+                rec["terms0"] = {n: float(v) for n, v in losses.items()}
+                g, = torch.autograd.grad(loss, deform_verts, retain_graph=True)
+                g = g.clone()
+                g[-1] = g[-1] / src.ED_nodes.num
+                rec["grad0"] = _np(g)
+            return loss, losses
+
+        gf.get_losses = wrapped
+        dv = gf(inputs, src, trg, models)
+        out[f"gf_{tag}_final"] = _np(dv)
+        out[f"gf_{tag}_loss0"] = rec["loss0"]
+        out[f"gf_{tag}_grad0"] = rec["grad0"]
+        for n, v in rec["terms0"].items():
+            out[f"gf_{tag}_term_{n}"] = v
+    return out
+
+
 def main():
     ref = ref_shim.install()
     for name, (skw, okw, store_jtj) in SCENES.items():
@@ -206,6 +242,9 @@ def main():
         g.update(capture_lm(ref, solver, sf, inputs, new_data))
         g.update(capture_update(ref, sc, opt, g["lm_beta"]))
         g.update(capture_knn(ref, sc, opt))
+        g["in_ed_triangles"], g["in_ed_triangle_areas"] = sc.ed_triangles, sc.ed_triangle_areas
+        if name in ("s60x80_j48", "s60x80_j48_reject"):
+            g.update(capture_graphfit(ref, sc, okw))
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **g)
         print(f"{name}: N={sc.N} J={sc.J} M(b0)={len(g['b0_match'])} "

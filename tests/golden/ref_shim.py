@@ -105,8 +105,9 @@ def install():
     import super.utils as ref_utils      # noqa: E402
     import super.nodes as ref_nodes      # noqa: E402
     import utils.utils as ref_uutils     # noqa: E402
+    import super.deform_mesh as ref_dm    # noqa: E402
     return SimpleNamespace(LM=ref_LM, loss=ref_loss, utils=ref_utils, nodes=ref_nodes,
-                           uutils=ref_uutils)
+                           uutils=ref_uutils, deform_mesh=ref_dm)
 
 
 def torch_frame(sc, frame_id=1):
@@ -127,11 +128,29 @@ def torch_frame(sc, frame_id=1):
     return sf, inputs, new_data
 
 
+def graphfit_frame(sc, stable=None):
+    """``src`` / ``trg`` / ``models`` objects for the reference's GraphFit (autograd path)."""
+    sf, inputs, new_data = torch_frame(sc)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+    sf.isStable = torch.ones(sc.N, dtype=torch.bool) if stable is None else t(stable, torch.bool)
+    sf.colors = torch.zeros(sc.N, 3)
+    sf.time = 0
+    sf.summary_writer = _SummaryWriter()
+    sf.ED_nodes.triangles = t(sc.ed_triangles, torch.long)
+    sf.ED_nodes.triangles_areas = t(sc.ed_triangle_areas)
+    new_data.time = 1
+    models = SimpleNamespace(renderer=lambda inputs, data, rad=None: torch.zeros(sc.H, sc.W, 3))
+    return sf, inputs, new_data, models
+
+
 def ref_opt(**kw):
     o = SimpleNamespace(sf_point_plane=True, sf_point_plane_weight=1.0, mesh_arap=True,
                         mesh_arap_weight=10.0, mesh_rot=True, mesh_rot_weight=1.0,
                         num_optimize_iterations=10, phase="test", use_derived_gradient=True,
-                        num_neighbors=4, num_ED_neighbors=4, method="super")
+                        num_neighbors=4, num_ED_neighbors=4, method="super", optimizer="SGD",
+                        learning_rate=5e-5, mesh_face=False, mesh_face_weight=1.0, sf_corr=False,
+                        sf_corr_match_renderimg=False, deform_udpate_method="super_edg",
+                        renderer_rad=0.0002, depth_model="monodepth2", save_sample_freq=1000000)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
