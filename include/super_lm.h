@@ -193,6 +193,62 @@ int slm_knn_weights(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* i
                     const float* dist, const float* node_radii, float* w_out,
                     uint8_t* stable_io, void* stream);
 
+/* =====================================================================================
+ * The reference's DEFAULT per-frame optimiser (no --use_derived_gradient): GraphFit,
+ * autograd + SGD(momentum 0.9) / Adam over (J+1,7) rows, last row = global transform T_g.
+ *   slm_gf_create / destroy   <- GraphFit.__init__                  super/deform_mesh.py:11-17
+ *   slm_gf_bind_frame         <- arguments of GraphFit.forward      super/deform_mesh.py:232-247
+ *   slm_gf_run                <- GraphFit.deform_superedg           super/deform_mesh.py:251-379
+ *   slm_gf_loss_grad          <- deform_source + get_losses + backward (one evaluation)
+ *                                                                    super/deform_mesh.py:25-230
+ *   slm_apply_update_gf       <- Surfels.update, autograd variant   super/nodes.py:193-223
+ * The gradients that the reference obtains by autograd are hand-derived here (2 J^T r per
+ * term, chained through the global row); results are checked against the autograd oracle.
+ * ===================================================================================== */
+typedef struct slm_gf slm_gf; /* opaque */
+
+typedef struct slm_gf_config {
+  int32_t num_iterations;  /* opt.num_optimize_iterations (10) */
+  int32_t optimizer;       /* 0 = "SGD" (momentum 0.9, the reference default), 1 = "Adam" */
+  int32_t use_data;        /* opt.sf_point_plane */
+  int32_t use_arap;        /* opt.mesh_arap (weighted by the node KNN weights on this path) */
+  int32_t use_rot;         /* opt.mesh_rot (all J+1 rows) */
+  int32_t use_face;        /* opt.mesh_face */
+  int32_t max_frames;
+  int32_t reserved;
+  double w_data, w_arap, w_rot, w_face; /* opt.*_weight */
+  double lr;               /* opt.learning_rate (5e-5) */
+} slm_gf_config;
+
+typedef struct slm_gf_frame {
+  slm_frame base;                 /* same fields as the LM path (tgt_valid is not read here) */
+  const uint8_t* sf_stable;       /* device (N) sf.isStable, or NULL = all stable */
+  const float* ed_knn_w;          /* device (J,K_ED) sf.ED_nodes.knn_w */
+  const int32_t* ed_triangles;    /* device (3,Tr) sf.ED_nodes.triangles, or NULL */
+  const float* ed_triangle_areas; /* device (Tr)   sf.ED_nodes.triangles_areas */
+  int32_t n_triangles;
+  int32_t pad;
+} slm_gf_frame;
+
+int slm_gf_create(const slm_gf_config* cfg, slm_gf** out);
+int slm_gf_destroy(slm_gf* g);
+/* Binds device pointers to `slot` and resets deform_verts to identity, optimiser state to 0. */
+int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* frame, void* stream);
+/* num_iterations optimiser steps for slots [0,n_frames), entirely on the device. */
+int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream);
+/* Copies deform_verts ((J+1)*7 doubles) of the slot into caller device memory. */
+int slm_gf_get_deform(slm_gf* g, int32_t slot, double* out_device, void* stream);
+/* One loss + gradient evaluation at dv_device ((J+1)*7): terms_device[0..3] = face, arap,
+ * rot, point_plane losses (already weighted), terms_device[4] = matched surfels;
+ * grad_device ((J+1)*7) = d(sum)/d(dv) with the global row divided by J like the reference. */
+int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv_device, double* terms_device,
+                     double* grad_device, void* stream);
+/* Surfels.update for this path: deform_device is (J+1,7); the global row's translation is
+ * added to points / nodes and its rotation applied to the normals (super/nodes.py:204-222). */
+int slm_apply_update_gf(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
+                        const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
+                        float* ed_norms, const double* deform_device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,9 @@ static int fail(int code, const char* msg) {
   return code;
 }
 
+// other translation units (slm_gf.hip) report through the same slm_last_error()
+void slm_set_error_text(const char* msg) { g_err = msg; }
+
 namespace {
 constexpr int kLossBlocks = 512;   // data-loss partial sums per slot
 constexpr int kRegBlocksMax = 64;

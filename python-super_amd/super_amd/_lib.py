@@ -19,7 +19,8 @@ EXPORTS = [
     "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame",
     "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
-    "slm_knn_weights",
+    "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
+    "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
 ]
 
 
@@ -38,6 +39,20 @@ class SlmFrame(C.Structure):
                 ("sf_points", C.c_void_p), ("sf_knn_idx", C.c_void_p), ("sf_knn_w", C.c_void_p),
                 ("ed_points", C.c_void_p), ("ed_knn_idx", C.c_void_p), ("tgt_points", C.c_void_p),
                 ("tgt_norms", C.c_void_p), ("index_map", C.c_void_p), ("tgt_valid", C.c_void_p)]
+
+
+class SlmGfConfig(C.Structure):
+    _fields_ = [("num_iterations", C.c_int32), ("optimizer", C.c_int32), ("use_data", C.c_int32),
+                ("use_arap", C.c_int32), ("use_rot", C.c_int32), ("use_face", C.c_int32),
+                ("max_frames", C.c_int32), ("reserved", C.c_int32),
+                ("w_data", C.c_double), ("w_arap", C.c_double), ("w_rot", C.c_double),
+                ("w_face", C.c_double), ("lr", C.c_double)]
+
+
+class SlmGfFrame(C.Structure):
+    _fields_ = [("base", SlmFrame), ("sf_stable", C.c_void_p), ("ed_knn_w", C.c_void_p),
+                ("ed_triangles", C.c_void_p), ("ed_triangle_areas", C.c_void_p),
+                ("n_triangles", C.c_int32), ("pad", C.c_int32)]
 
 
 class SlmIterRecord(C.Structure):
@@ -88,6 +103,13 @@ def load():
         "slm_apply_update": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
         "slm_knn": [i32, i32, i32, i32, vp, vp, vp, vp, vp],
         "slm_knn_weights": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
+        "slm_gf_create": [C.POINTER(SlmGfConfig), C.POINTER(vp)],
+        "slm_gf_destroy": [vp],
+        "slm_gf_bind_frame": [vp, i32, C.POINTER(SlmGfFrame), vp],
+        "slm_gf_run": [vp, i32, vp],
+        "slm_gf_get_deform": [vp, i32, vp, vp],
+        "slm_gf_loss_grad": [vp, i32, vp, vp, vp, vp],
+        "slm_apply_update_gf": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -1,0 +1,126 @@
+"""Host-side mirror of the reference's default per-frame optimiser ``GraphFit``
+(``super/deform_mesh.py:10-379``) over libsuper_lm.so.
+
+Same constructor and ``forward(inputs, src, trg, models)`` surface as the reference class,
+so ``SuPer.__init__`` / ``SuPer.fusion`` (``super/super.py:20-21,70``) can use it unchanged:
+
+    self.graph_fit = GraphFit(self.opt)
+    deform_param = self.graph_fit(inputs, self.sf, sfdata, models)   # (J+1,7) float64
+
+Supported loss flags: ``sf_point_plane``, ``mesh_arap``, ``mesh_rot``, ``mesh_face`` with their
+weights, ``optimizer`` in {"SGD", "Adam"}, ``learning_rate``, ``num_optimize_iterations``.  The
+Semantic-SuPer terms, ``sf_corr`` and the (unused) render loss raise ``NotImplementedError``.
+The renderer call the reference makes every iteration (deform_mesh.py:294-298) only feeds the
+render / correspondence losses and is not needed here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SlmGfConfig, SlmGfFrame
+from .LM import BoundFrame, _as, _dev_ptr, _stream_ptr
+
+
+class GraphFit:
+    def __init__(self, opt, max_frames=1):
+        self.opt = opt
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SuperLMError("no HIP device visible: super_amd has no CPU fallback")
+        for flag in ("sf_corr", "render_loss", "sf_bn_morph", "sf_hard_seg_point_plane",
+                     "sf_soft_seg_point_plane"):
+            if getattr(opt, flag, False):
+                raise NotImplementedError(f"super_amd.GraphFit: opt.{flag} is not supported yet")
+        self.valid_margin = 1
+        self.optim = opt.optimizer
+        self.Niter = opt.num_optimize_iterations
+        if self.optim not in ("SGD", "Adam"):
+            raise NotImplementedError(f"optimizer {self.optim!r}")
+        self.max_frames = max_frames
+        cfg = SlmGfConfig()
+        cfg.num_iterations = int(self.Niter)
+        cfg.optimizer = 0 if self.optim == "SGD" else 1
+        cfg.use_data = int(bool(opt.sf_point_plane))
+        cfg.use_arap = int(bool(opt.mesh_arap))
+        cfg.use_rot = int(bool(opt.mesh_rot))
+        cfg.use_face = int(bool(getattr(opt, "mesh_face", False)))
+        cfg.max_frames = max_frames
+        cfg.w_data = float(getattr(opt, "sf_point_plane_weight", 1.0))
+        cfg.w_arap = float(getattr(opt, "mesh_arap_weight", 10.0))
+        cfg.w_rot = float(getattr(opt, "mesh_rot_weight", 1.0))
+        cfg.w_face = float(getattr(opt, "mesh_face_weight", 1.0))
+        cfg.lr = float(opt.learning_rate)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _lib.check(self.lib.slm_gf_create(C.byref(cfg), C.byref(self.h)), "slm_gf_create")
+        self._keep = [None] * max_frames
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.slm_gf_destroy(self.h)
+        except Exception:
+            pass
+
+    def _bind(self, slot, inputs, src, trg):
+        new_data = trg
+        if not hasattr(trg, "valid"):            # not read on this path
+            trg = type("T", (), {})()
+            trg.points, trg.norms, trg.index_map = new_data.points, new_data.norms, new_data.index_map
+            trg.valid = torch.zeros(new_data.index_map.numel(), dtype=torch.bool,
+                                    device=new_data.points.device)
+        bf = BoundFrame(src, inputs, trg)
+        dev = bf.device
+        ed = src.ED_nodes
+        fr = SlmGfFrame()
+        fr.base = bf.c
+        keep = [bf]
+        stable = getattr(src, "isStable", None)
+        if stable is not None:
+            st8 = _as(stable, torch.uint8, dev)
+            keep.append(st8)
+            fr.sf_stable = _dev_ptr(st8)
+        w = _as(ed.knn_w, torch.float32, dev)
+        keep.append(w)
+        fr.ed_knn_w = _dev_ptr(w)
+        if self.cfg.use_face:
+            tri = _as(ed.triangles, torch.int32, dev)
+            area = _as(ed.triangles_areas, torch.float32, dev)
+            keep += [tri, area]
+            fr.ed_triangles, fr.ed_triangle_areas = _dev_ptr(tri), _dev_ptr(area)
+            fr.n_triangles = int(tri.shape[1])
+        _lib.check(self.lib.slm_gf_bind_frame(self.h, slot, C.byref(fr), _stream_ptr(dev)),
+                   "slm_gf_bind_frame")
+        self._keep[slot] = keep
+        return bf
+
+    def forward(self, inputs, src, trg, models=None):
+        """(reference ``deform_mesh.py:232-247``) returns deform_verts (J+1,7) float64."""
+        if getattr(self.opt, "deform_udpate_method", "super_edg") != "super_edg":
+            raise NotImplementedError("only deform_udpate_method == 'super_edg'")
+        bf = self._bind(0, inputs, src, trg)
+        st = _stream_ptr(bf.device)
+        _lib.check(self.lib.slm_gf_run(self.h, 1, st), "slm_gf_run")
+        out = torch.empty((bf.J + 1, 7), dtype=torch.float64, device=bf.device)
+        _lib.check(self.lib.slm_gf_get_deform(self.h, 0, _dev_ptr(out), st), "slm_gf_get_deform")
+        return out
+
+    __call__ = forward
+
+    def loss_and_grad(self, inputs, src, trg, deform_verts):
+        """One evaluation of ``deform_source`` + ``get_losses`` + backward at ``deform_verts``:
+        returns (dict of weighted loss terms, matched count, gradient (J+1,7) with the global
+        row divided by J)."""
+        bf = self._bind(0, inputs, src, trg)
+        st = _stream_ptr(bf.device)
+        dv = _as(deform_verts, torch.float64, bf.device)
+        terms = torch.zeros(5, dtype=torch.float64, device=bf.device)
+        grad = torch.zeros((bf.J + 1, 7), dtype=torch.float64, device=bf.device)
+        _lib.check(self.lib.slm_gf_loss_grad(self.h, 0, _dev_ptr(dv), _dev_ptr(terms), _dev_ptr(grad), st),
+                   "slm_gf_loss_grad")
+        t = terms.cpu().tolist()
+        return (dict(face_losses=t[0], arap_loss=t[1], rot_loss=t[2], point_plane_loss=t[3]), int(t[4]),
+                grad)

@@ -74,8 +74,9 @@ def update_sfed_knn(sf):
 
 
 def update(sf, deform):
-    """Apply the solved warp (LM variant: no global row): skin surfel points, blend and
-    normalise surfel normals, translate nodes, rotate node normals."""
+    """Apply the solved warp: skin surfel points, blend and normalise surfel normals, translate
+    nodes, rotate node normals.  ``deform`` is (J,7) on the LM path
+    (``opt.use_derived_gradient``) and (J+1,7) with the global row T_g on the autograd path."""
     if deform is None:
         return
     lib = _lib.load()
@@ -87,7 +88,12 @@ def update(sf, deform):
     idx = _as(sf.knn_indices, torch.int32, dev)
     w = _as(sf.knn_w, f32, dev)
     beta = _as(deform, torch.float64, dev)
-    _lib.check(lib.slm_apply_update(pts.shape[0], epts.shape[0], idx.shape[1], _dev_ptr(pts),
+    fn = lib.slm_apply_update
+    if beta.shape[0] == epts.shape[0] + 1:
+        fn = lib.slm_apply_update_gf
+    elif beta.shape[0] != epts.shape[0]:
+        raise ValueError("deform must have J or J+1 rows")
+    _lib.check(fn(pts.shape[0], epts.shape[0], idx.shape[1], _dev_ptr(pts),
                                     _dev_ptr(nrm), _dev_ptr(idx), _dev_ptr(w), _dev_ptr(epts),
                                     _dev_ptr(enrm), _dev_ptr(beta), _stream_ptr(dev)),
                "slm_apply_update")

@@ -197,6 +197,12 @@ def capture_graphfit(ref, sc, okw):
         gf.get_losses = wrapped
         dv = gf(inputs, src, trg, models)
         out[f"gf_{tag}_final"] = _np(dv)
+        if tag == "sgd":   # Surfels.update, autograd variant (global row), on the reference
+            sfu, _, _ = ref_shim.torch_frame(sc)
+            sfu.opt = ref_shim.ref_opt(use_derived_gradient=False)
+            ref.nodes.Surfels.update(sfu, dv.detach())
+            out["gf_upd_points"], out["gf_upd_norms"] = _np(sfu.points), _np(sfu.norms)
+            out["gf_upd_ed_points"], out["gf_upd_ed_norms"] = _np(sfu.ED_nodes.points), _np(sfu.ED_nodes.norms)
         out[f"gf_{tag}_loss0"] = rec["loss0"]
         out[f"gf_{tag}_grad0"] = rec["grad0"]
         for n, v in rec["terms0"].items():

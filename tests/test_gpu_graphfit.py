@@ -1,0 +1,94 @@
+"""HIP GraphFit (autograd path with hand-derived gradients) vs the reference's goldens and
+the PyTorch-CPU oracle, through the C ABI.  Needs an MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from helpers import load_golden, ref_opt, torch_frame
+from oracle import graphfit_oracle as gfo
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("s60x80_j48", "sgd"), ("s60x80_j48", "adam"), ("s60x80_j48", "sgdface"),
+         ("s60x80_j48_reject", "sgd"), ("s60x80_j48_reject", "adam")]
+
+
+def _opt(tag, **kw):
+    o = gfo.default_opt(optimizer="Adam" if tag == "adam" else "SGD", mesh_face=(tag == "sgdface"), **kw)
+    o.deform_udpate_method = "super_edg"
+    return o
+
+
+def _frame(sc):
+    import torch
+    sf, inputs, new_data = torch_frame(sc)
+    sf.ED_nodes.triangles = torch.from_numpy(sc.ed_triangles).cuda()
+    sf.ED_nodes.triangles_areas = torch.from_numpy(sc.ed_triangle_areas).cuda().double()
+    return sf, inputs, new_data
+
+
+@pytest.mark.parametrize("name,tag", CASES)
+def test_loss_and_gradient_at_identity_match_reference(name, tag):
+    import torch
+    from super_amd.deform_mesh import GraphFit
+    g, sc, _ = load_golden(name)
+    sf, inputs, new_data = _frame(sc)
+    gf = GraphFit(_opt(tag))
+    dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64, device="cuda")
+    dv[:, 0] = 1.0
+    terms, matched, grad = gf.loss_and_grad(inputs, sf, new_data, dv)
+    for k, v in terms.items():
+        key = f"gf_{tag}_term_{k}"
+        if key in g.files:
+            np.testing.assert_allclose(v, float(g[key]), rtol=1e-9, atol=1e-15)
+    assert abs(sum(terms.values()) - float(g[f"gf_{tag}_loss0"])) <= 1e-9 * abs(float(g[f"gf_{tag}_loss0"]))
+    ref = g[f"gf_{tag}_grad0"]
+    np.testing.assert_allclose(grad.cpu().numpy(), ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    assert matched > 0
+
+
+@pytest.mark.parametrize("name,tag", CASES)
+def test_final_deform_verts_match_reference(name, tag):
+    from super_amd.deform_mesh import GraphFit
+    g, sc, _ = load_golden(name)
+    sf, inputs, new_data = _frame(sc)
+    dv = GraphFit(_opt(tag))(inputs, sf, new_data, None).cpu().numpy()
+    np.testing.assert_allclose(dv, g[f"gf_{tag}_final"], rtol=0, atol=1e-9)   # north_star bar: 1e-4
+
+
+def test_gradient_at_random_point_vs_autograd_oracle():
+    """Away from identity (global row active, face term on) against torch autograd."""
+    import torch
+    from super_amd import synth
+    from super_amd.deform_mesh import GraphFit
+    sc = synth.make_scene(N=3000, J=48, H=60, W=80, seed=21, src_border=5, tgt_border=3, tgt_holes=0.01)
+    rng = np.random.default_rng(3)
+    dv0 = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (sc.J + 1, 1))
+    dv0 += np.concatenate([rng.normal(0, 0.01, (sc.J + 1, 4)), rng.normal(0, 0.003, (sc.J + 1, 3))], axis=1)
+    opt = _opt("sgdface")
+    stable = rng.uniform(size=sc.N) > 0.1
+    pb = gfo.Problem(sc, stable=stable)
+    dvt = torch.from_numpy(dv0.copy()).requires_grad_(True)
+    loss, terms = gfo.total_loss(pb, dvt, opt)
+    gref, = torch.autograd.grad(loss, dvt)
+    gref = gref.clone()
+    gref[-1] /= sc.J
+    sf, inputs, new_data = _frame(sc)
+    sf.isStable = torch.from_numpy(stable).cuda()
+    t, matched, grad = GraphFit(opt).loss_and_grad(inputs, sf, new_data, torch.from_numpy(dv0).cuda())
+    assert matched == terms["_matched"]
+    np.testing.assert_allclose(sum(t.values()), float(loss.detach()), rtol=1e-10)
+    np.testing.assert_allclose(grad.cpu().numpy(), gref.numpy(), rtol=0,
+                               atol=1e-9 * max(1.0, float(gref.abs().max())))
+
+
+def test_update_autograd_variant_matches_reference():
+    import torch
+    from super_amd import nodes
+    g, sc, opt = load_golden("s60x80_j48")
+    sf, _, _ = torch_frame(sc)
+    sf.opt = ref_opt(opt)
+    sf.opt.use_derived_gradient = False
+    nodes.update(sf, torch.from_numpy(g["gf_sgd_final"]).cuda())
+    for mine, key in ((sf.points, "gf_upd_points"), (sf.norms, "gf_upd_norms"),
+                      (sf.ED_nodes.points, "gf_upd_ed_points"), (sf.ED_nodes.norms, "gf_upd_ed_norms")):
+        np.testing.assert_allclose(mine.cpu().numpy(), g[key], rtol=0, atol=2e-7)
