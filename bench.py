@@ -128,11 +128,19 @@ def main():
                              "--master-addr 127.0.0.1 bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    device = torch.device("cuda", local_rank)
+    # Test knobs (single-GPU boxes only): BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # BENCH_DIST_BACKEND=gloo exchanges through host memory, so the multi-rank control flow
+    # can be exercised where RCCL cannot run.  The driver's runs use neither.
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from super_amd import synth
     from super_amd.dist import all_gather_betas
@@ -179,7 +187,10 @@ def main():
                 torch.cuda.current_stream(device).wait_stream(st)
         if world > 1:                                    # end-of-frame exchange
             torch.stack(betas, out=local)
-            gathered[0] = all_gather_betas(local, world * B)
+            if backend == "nccl":
+                gathered[0] = all_gather_betas(local, world * B)
+            else:
+                gathered[0] = all_gather_betas(local.cpu(), world * B)
 
     def fence():
         if world > 1:
@@ -209,7 +220,7 @@ def main():
                     prof[k2]["count"] += v2["count"]
             e.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
