@@ -348,6 +348,195 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
   store_c_frags(At, acc);
 }
 
+// ---------------------------------------------------------------------------------------
+// Compact form for levels whose fronts have few pivot tile columns (npt <= 4: the leaf side
+// of the tree, where there are many fronts): two launches per level instead of three per
+// tile column.
+//   k_fL11  one workgroup per front factors the whole pivot block L11 (all npt tile columns:
+//           tile Cholesky + inverse, row solves and trailing updates inside the block, forward
+//           substitution of the pivot rows), looping over its tiles through LDS / L2;
+//   k_fL21  one workgroup per boundary row tile r solves its whole row against L11:
+//           X_c = (A(r,c) - sum_{c'<c} X_c' L(c,c')^T) L_cc^-T, results chained in registers
+//           (accumulator layout == next A-fragment layout), rhs row updated at the end.
+// grid k_fL11 = (1, fronts in level, n_frames); k_fL21 = (max boundary tiles, fronts, frames)
+#define L11_LDS_DOUBLES (3 * TILE + 8 * 256 + 2 * NB + 8)
+
+__global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frames, int level,
+                                               double u_override) {
+  extern __shared__ double lds[];
+  double* S = lds;
+  double* M = lds + TILE;
+  double* Bl = lds + 2 * TILE;
+  double* dinv = lds + 3 * TILE;
+  double* wt = dinv + 4 * 256;
+  double* vec = wt + 4 * 256;      // NB: rhs tile in / y tile out
+  double* part = vec + NB;         // NB scratch
+  int* s_ok = reinterpret_cast<int*>(part + NB);
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  if (f.npt == 0) return;
+  const double u = (u_override >= 0.0) ? u_override : fd.st->u;
+  double* vecs = fd.fvec + f.vec_off;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+
+  for (int c = 0; c < f.npt; ++c) {
+    // ---- diagonal tile: factor + inverse + forward substitution of rhs tile c ----
+    {
+      const double* src = ftile(fd, f, c, c);
+      double v[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = src[threadIdx.x + 256 * t];
+      if (threadIdx.x < NB) vec[threadIdx.x] = vecs[(size_t)c * NB + threadIdx.x];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int e = threadIdx.x + 256 * t;
+        const int i = e % NB, k = e / NB;
+        double x = (i >= k) ? v[t] : 0.0;
+        if (i == k) x = (c * NB + i < f.n1) ? x + u : 1.0;
+        S[i + k * LD] = x;
+      }
+    }
+    __syncthreads();
+    const bool ok = potrf64(S, dinv, s_ok, fd, false);
+    if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
+    inverse_assemble64(S, M, dinv, wt);
+    {
+      double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+      for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];
+      if (threadIdx.x < NB) {
+        const int i = threadIdx.x;
+        double acc = 0.0;
+        for (int k = 0; k <= i; ++k) acc += M[i + k * LD] * vec[k];
+        part[i] = acc;
+      }
+      __syncthreads();
+      if (threadIdx.x < NB) {
+        vec[threadIdx.x] = part[threadIdx.x];                       // y_c
+        vecs[(size_t)c * NB + threadIdx.x] = part[threadIdx.x];
+      }
+      __syncthreads();
+    }
+    // ---- row solves inside the pivot block: L(r,c) = A(r,c) L_cc^-T, rhs_r -= L(r,c) y_c ----
+    for (int r = c + 1; r < f.npt; ++r) {
+      double* At = ftile(fd, f, r, c);
+      double areg[16];
+      load_a_frags(At, areg);
+      double4_t acc[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+      tile_ABt_regs<false>(areg, M, acc);
+      store_c_frags(At, acc);
+      // rhs rows of this wave: sum_col L[row][col] y[col], reduced over the 4 lk lanes
+      double sacc = 0.0;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sacc += acc[ni][rr] * vec[16 * ni + lk + 4 * rr];
+      sacc += __shfl_xor(sacc, 16, 64);
+      sacc += __shfl_xor(sacc, 32, 64);
+      if (lk == 0) vecs[(size_t)r * NB + 16 * w + lr] -= sacc;
+    }
+    __syncthreads();   // L(r,c) tiles visible to the whole workgroup
+    // ---- trailing update inside the pivot block: A(r,s) -= L(r,c) L(s,c)^T ----
+    for (int sc = c + 1; sc < f.npt; ++sc) {
+      const double* Ls = ftile(fd, f, sc, c);
+      double breg[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
+      __syncthreads();   // previous users of Bl are done
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+      __syncthreads();
+      for (int r = sc; r < f.npt; ++r) {
+        double* Ct = ftile(fd, f, r, sc);
+        double areg[16];
+        load_a_frags(ftile(fd, f, r, c), areg);
+        double4_t acc[4];
+        load_c_frags(Ct, acc);
+        tile_ABt_regs<true>(areg, Bl, acc);
+        store_c_frags(Ct, acc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frames, int level) {
+  __shared__ double Bl[TILE];
+  __shared__ double yv[NB];
+  const FrameDev& fd = frames[blockIdx.z];
+  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (level >= fd.n_levels) return;
+  const int fi = fd.level_start[level] + blockIdx.y;
+  if (fi >= fd.level_start[level + 1]) return;
+  const NDFront& f = fd.fronts[fi];
+  const int r = f.npt + blockIdx.x;
+  if (f.npt == 0 || r >= f.nt) return;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+  double* vecs = fd.fvec + f.vec_off;
+  double x[4][16];     // X_c in A-fragment layout: x[c][4*ni + rr] == acc[ni][rr]
+  double rhs_acc = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < f.npt) {
+      double* At = ftile(fd, f, r, c);
+      double4_t acc[4];
+      load_c_frags(At, acc);
+      // acc -= X_c' L(c,c')^T for the earlier pivot columns
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) {
+        if (cp < c) {
+          const double* Lt = ftile(fd, f, c, cp);
+          double breg[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) breg[e] = Lt[threadIdx.x + 256 * e];
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+          __syncthreads();
+          tile_ABt_regs<true>(x[cp], Bl, acc);
+        }
+      }
+      // X_c = acc L_cc^-T
+      {
+        const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+        double breg[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) breg[e] = linv[threadIdx.x + 256 * e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+        if (threadIdx.x < NB) yv[threadIdx.x] = vecs[(size_t)c * NB + threadIdx.x];
+        __syncthreads();
+        double areg[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) areg[4 * ni + rr] = acc[ni][rr];
+        double4_t xa[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+        tile_ABt_regs<false>(areg, Bl, xa);
+        store_c_frags(At, xa);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            x[c][4 * ni + rr] = xa[ni][rr];
+            rhs_acc += xa[ni][rr] * yv[16 * ni + lk + 4 * rr];
+          }
+      }
+    }
+  }
+  rhs_acc += __shfl_xor(rhs_acc, 16, 64);
+  rhs_acc += __shfl_xor(rhs_acc, 32, 64);
+  if (lk == 0) vecs[(size_t)r * NB + 16 * w + lr] -= rhs_acc;
+}
+
 // Trailing update of tile column c, restricted to the PIVOT tile columns that are still to be
 // factored (s < npt): A(r,s) -= L(r,c) L(s,c)^T for c < s < npt, s <= r < nt, plus the rhs
 // rows b_r -= L(r,c) y_c for all r > c.  The boundary x boundary block is updated once per
@@ -616,8 +805,10 @@ void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
 void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv, int n_levels,
                         double u_override, hipStream_t st) {
   const size_t lds = PANEL_LDS_DOUBLES * sizeof(double);
+  const size_t lds11 = L11_LDS_DOUBLES * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_fL11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11);
     (void)hipFuncSetAttribute((const void*)k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k_fpotrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
@@ -625,7 +816,13 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
   for (int l = 0; l < n_levels; ++l) {
     const NDLevelSched& s = lv[l];
     if (s.n_fronts <= 0) continue;
-    for (int c = 0; c < s.max_npt; ++c) {
+    const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= 16;
+    if (compact) {
+      hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, l, u_override);
+      if (s.max_n2p > 0)
+        hipLaunchKernelGGL(k_fL21, dim3(s.max_n2p / 64, s.n_fronts, n_frames), dim3(256), 0, st, fr, l);
+    }
+    for (int c = 0; !compact && c < s.max_npt; ++c) {
       const int mcap = s.max_nt - 1 - c;
       // fused panel while the launch is small (latency-bound); split once the redundant
       // factorisations would take more than ~2 blocks per CU
