@@ -179,8 +179,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_ED_neighbors must be in 1..8");
   if (f->N < 0 || f->J < 1 || f->H < 2 || f->W < 2 || f->T < 0)
     return fail(SLM_ERR_INVALID, "slm_bind_frame: bad sizes");
-  if (!f->sf_points || !f->sf_knn_idx || !f->sf_knn_w || !f->ed_points || !f->ed_knn_idx ||
-      !f->tgt_points || !f->tgt_norms || !f->index_map || !f->tgt_valid)
+  if ((f->N > 0 && (!f->sf_points || !f->sf_knn_idx || !f->sf_knn_w)) || !f->ed_points || !f->ed_knn_idx ||
+      (f->T > 0 && (!f->tgt_points || !f->tgt_norms)) || !f->index_map || !f->tgt_valid)
     return fail(SLM_ERR_INVALID, "slm_bind_frame: null device pointer");
   hipStream_t st = (hipStream_t)stream;
   Slot& sl = s->slots[slot];
