@@ -27,6 +27,9 @@ void launch_band_to_dense(const FrameDev*, int, double*, hipStream_t);
 void launch_dense_to_band(const FrameDev*, const double*, const double*, hipStream_t);
 void launch_init_slot(const FrameDev*, int, int, const slm_config&, hipStream_t);
 void launch_iter_begin(const FrameDev*, int, hipStream_t);
+void launch_pack_nodes(const FrameDev*, int, int, hipStream_t);
+void launch_make_trial(const FrameDev*, int, int, hipStream_t);
+void launch_pack_target(int, const float*, const float*, float4*, hipStream_t);
 void launch_accept(const FrameDev*, int, int, int, hipStream_t);
 void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
@@ -61,7 +64,7 @@ constexpr int kRegBlocksMax = 64;
 
 struct Slot {
   FrameDev h{};                 // host mirror of the device descriptor
-  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0;
+  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0, cap_npk = 0, cap_tpn = 0;
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
   // nested-dissection plan: host copy + device mirrors (grow-only)
   NDPlanHost nd;
@@ -151,6 +154,8 @@ int slm_destroy(slm_solver* s) {
     if (h.loss_part) (void)hipFree(h.loss_part);
     if (h.st) (void)hipFree(h.st);
     if (h.rec) (void)hipFree(h.rec);
+    if (h.node_pk) (void)hipFree(h.node_pk);
+    if (h.tgt_pn) (void)hipFree(h.tgt_pn);
     plan_free(sl.plan);
     if (sl.d_fronts) (void)hipFree(sl.d_fronts);
     if (sl.d_ints) (void)hipFree(sl.d_ints);
@@ -202,6 +207,14 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   h.n_loss_part = s->cfg.use_data ? kLossBlocks : 0;
   size_t cap_dummy;
   HIPCHK(grow(h.beta, sl.cap_beta, (size_t)P));
+  {
+    size_t c = sl.cap_npk;
+    HIPCHK(grow(h.node_pk, c, (size_t)2 * SLM_NPK * f->J));
+    sl.cap_npk = c;
+    h.node_pk_try = h.node_pk + (size_t)SLM_NPK * f->J;
+    HIPCHK(grow(h.tgt_pn, sl.cap_tpn, (size_t)2 * (f->T > 0 ? f->T : 1)));
+    launch_pack_target(f->T, f->tgt_points, f->tgt_norms, h.tgt_pn, st);
+  }
   {
     size_t need = (size_t)nt * SLM_NB, c1 = sl.cap_vec, c2 = sl.cap_vec;
     HIPCHK(grow(h.delta, c1, need));
@@ -472,6 +485,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     mark();
     if (d.nd) launch_front_solve(fr, n_frames, d.sched.data(), (int)d.sched.size(), -1.0, st);
     else launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
+    if (c.use_data) launch_make_trial(fr, n_frames, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
     mark();
     if (c.use_data) launch_data_loss(fr, n_frames, kLossBlocks, c.w_data, 1, st);
     mark();
@@ -533,6 +547,7 @@ int slm_set_beta(slm_solver* s, int32_t slot, const double* in, void* stream) {
   // fresh LM state (u0, minimal_loss0, records), then the caller's beta
   launch_init_slot(s->frames_dev, slot, h.f.J, s->cfg, st);
   HIPCHK(hipMemcpyAsync(h.beta, in, sizeof(double) * h.P, hipMemcpyDeviceToDevice, st));
+  launch_pack_nodes(s->frames_dev, slot, h.f.J, st);
   return SLM_OK;
 }
 

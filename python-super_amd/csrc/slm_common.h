@@ -41,6 +41,10 @@ struct FrameDev {
   int32_t pad2;
   LMState* st;
   slm_iter_record* rec;  // (num_iterations)
+  // packed gather tables of the per-surfel evaluation (16-byte loads instead of scalar ones)
+  double* node_pk;       // (J,10): beta[0..6], {g.x,g.y} as two floats, {g.z,0} as two floats, pad
+  double* node_pk_try;   // same at the trial point beta + delta (loss pass of the LM loop)
+  float4* tgt_pn;        // (T,2): target point xyz0, target normal xyz0
   unsigned long long* dbg;  // diagnostic builds only (-DSLM_STAMPS): in-kernel s_memtime stamps
   // ---- tuple-sorted data-term assembly (slm_prep.hip / slm_data_v1.hip) ----
   int32_t v1_ready;      // 1 when the structures below are valid for this frame
@@ -147,6 +151,17 @@ __device__ __forceinline__ double* band_entry(const FrameDev& fd, int i, int j) 
   int tr = i / SLM_NB, tc = j / SLM_NB;
   size_t tile = (size_t)tc * (fd.wb + 1) + (tr - tc);
   return fd.band + tile * (SLM_NB * SLM_NB) + (i - tr * SLM_NB) + (size_t)(j - tc * SLM_NB) * SLM_NB;
+}
+
+#define SLM_NPK 10   // doubles per node in node_pk
+
+__device__ __forceinline__ void pack_node(double* dst, const double bb[7], const float* g) {
+#pragma unroll
+  for (int c = 0; c < 7; ++c) dst[c] = bb[c];
+  float2 gxy = make_float2(g[0], g[1]), gz = make_float2(g[2], 0.f);
+  dst[7] = __builtin_bit_cast(double, gxy);
+  dst[8] = __builtin_bit_cast(double, gz);
+  dst[9] = 0.0;
 }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {

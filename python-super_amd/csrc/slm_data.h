@@ -15,13 +15,13 @@ struct SurfelEval {
   int taps[4];         // target rows of the four bilinear taps (-1 invalid)
 };
 
-// beta may be offset by delta (trial point beta + delta of the LM loss pass).
+// npk: packed node table (fd.node_pk at beta, fd.node_pk_try at the trial point beta + delta).
 // sf_pts / sf_idx / sf_w: the surfel streams to read (caller order or tuple-sorted copies).
 template <bool GRAD>
 __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* __restrict__ sf_pts,
                                                const int* __restrict__ sf_idx,
                                                const float* __restrict__ sf_w, double lam,
-                                               const double* beta, const double* delta, int i,
+                                               const double* __restrict__ npk, int i,
                                                SurfelEval& out) {
   const slm_frame& f = fd.f;
   const d3 p = {(double)sf_pts[3 * i], (double)sf_pts[3 * i + 1], (double)sf_pts[3 * i + 2]};
@@ -36,17 +36,11 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     out.id[k] = id[k];
-    const double* b = beta + 7 * id[k];
-    double bb[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) bb[c] = b[c];
-    if (delta) {
-      const double* dl = delta + 7 * id[k];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) bb[c] += dl[c];
-    }
-    d3 g = {(double)f.ed_points[3 * id[k]], (double)f.ed_points[3 * id[k] + 1],
-            (double)f.ed_points[3 * id[k] + 2]};
+    const double2* nq = reinterpret_cast<const double2*>(npk + (size_t)SLM_NPK * id[k]);
+    const double2 n0 = nq[0], n1 = nq[1], n2 = nq[2], n3 = nq[3], n4 = nq[4];
+    const double bb[7] = {n0.x, n0.y, n1.x, n1.y, n2.x, n2.y, n3.x};
+    const float2 gxy = __builtin_bit_cast(float2, n3.y), gz = __builtin_bit_cast(float2, n4.x);
+    d3 g = {(double)gxy.x, (double)gxy.y, (double)gz.x};
     qw[k] = bb[0];
     qv[k] = {bb[1], bb[2], bb[3]};
     dk[k] = p - g;
@@ -94,10 +88,9 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* 
   for (int t = 0; t < 4; ++t) {
     const double dn = nn[t] - v_, dm = mm[t] - u_;
     const double an = fmax(1.0 - fabs(dn), 0.0), am = fmax(1.0 - fabs(dm), 0.0);
-    const float* tp = f.tgt_points + 3 * (size_t)rows[t];
-    const float* tn = f.tgt_norms + 3 * (size_t)rows[t];
-    const d3 P = {(double)tp[0], (double)tp[1], (double)tp[2]};
-    const d3 Nn = {(double)tn[0], (double)tn[1], (double)tn[2]};
+    const float4 tp = fd.tgt_pn[2 * (size_t)rows[t]], tn = fd.tgt_pn[2 * (size_t)rows[t] + 1];
+    const d3 P = {(double)tp.x, (double)tp.y, (double)tp.z};
+    const d3 Nn = {(double)tn.x, (double)tn.y, (double)tn.z};
     const double wv = an * am;
     o = {o.x + P.x * wv, o.y + P.y * wv, o.z + P.z * wv};
     n = {n.x + Nn.x * wv, n.y + Nn.y * wv, n.z + Nn.z * wv};
@@ -142,7 +135,7 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* 
 }
 
 template <bool GRAD>
-__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* beta,
-                                            const double* delta, int i, SurfelEval& out) {
-  eval_surfel_at<GRAD>(fd, fd.f.sf_points, fd.f.sf_knn_idx, fd.f.sf_knn_w, lam, beta, delta, i, out);
+__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* npk, int i,
+                                            SurfelEval& out) {
+  eval_surfel_at<GRAD>(fd, fd.f.sf_points, fd.f.sf_knn_idx, fd.f.sf_knn_w, lam, npk, i, out);
 }

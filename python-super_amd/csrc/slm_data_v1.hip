@@ -8,12 +8,12 @@
 //                   groups of 4 surfels on the f64 MFMA:  G += row^T row  (32 x 32 as the
 //                   three 16x16 tiles 00, 10, 11).  G[28][0..27] = J^T r and G[28][28] =
 //                   sum r^2 ride along for free.  One G per (tuple, chunk) run goes to
-//                   the slab with plain coalesced stores; -J^T r goes to rhs (f64 atomics,
-//                   28 per run).
+//                   the slab with plain coalesced stores (no atomics at all).
 //   k_band_assemble one wave per coupled node pair (a >= b): sums the 7x7 sub-blocks of
 //                   the runs that contain both nodes (inverted index built once per frame
-//                   by slm_prep.hip) and stores them into the lower band -- each band
-//                   entry is written by exactly one lane, bitwise reproducible.
+//                   by slm_prep.hip) and stores them into the lower band; the diagonal
+//                   pair (a,a) also sums row 28 of its runs into jtl.  Every band / jtl
+//                   entry is written by exactly one lane: bitwise reproducible.
 #include <cstdlib>
 
 #include "slm_data.h"
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
 #else
   if (live)
 #endif
-    eval_surfel_at<true>(fd, fd.s_pts, fd.s_idx, fd.s_w, lam, fd.beta, nullptr, pos, ev);
+    eval_surfel_at<true>(fd, fd.s_pts, fd.s_idx, fd.s_w, lam, fd.node_pk, pos, ev);
   const unsigned long long mm = __ballot(ev.match);
   if (l == 0 && mm) atomicAdd(&fd.st->m_grad, __popcll(mm));
 
@@ -84,19 +84,7 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
       out[256 + r * 64 + l] = g10[r];
       out[512 + r * 64 + l] = g11[r];
     }
-    // jtl = -J^T r : row 28 of G = reg 3 of lanes 0..15 (tile 10: cols 0..15, tile 11: cols 16..27)
-    if (l < 16) {
-      const int4 nd = *reinterpret_cast<const int4*>(fd.run_nodes + 4 * run);
-      const int nodes[4] = {nd.x, nd.y, nd.z, nd.w};
-      {
-        const int e = l;
-        atomic_add_f64(fd.rhs + 7 * nodes[e / 7] + e % 7, -g10[3]);
-      }
-      if (l < 12) {
-        const int e = 16 + l;
-        atomic_add_f64(fd.rhs + 7 * nodes[e / 7] + e % 7, -g11[3]);
-      }
-    }
+    // row 28 of G (= J^T r, sum r^2) travels in the slab; k_*_assemble turns it into jtl
   };
 
 #pragma unroll 1
@@ -140,14 +128,18 @@ __global__ void __launch_bounds__(256) k_band_assemble(const FrameDev* __restric
   const int a = (int)(key / (unsigned)fd.f.J), b = (int)(key % (unsigned)fd.f.J);
   const int ca = l / 7, cb = l % 7;
   const bool act = (l < 49) && (a != b || ca >= cb);   // lower triangle only on diagonal blocks
+  const bool jt = (a == b) && l >= 49 && l < 56;       // diagonal block: lanes 49..55 build jtl of node a
   const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
   double acc = 0.0;
   for (int s = s0; s < s1; ++s) {
     const int pl = fd.blk_entry[s];
     const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
-    if (act) acc += gram_at(fd.slab + (size_t)run * SLM_SLAB_STRIDE, 7 * pa + ca, 7 * pb + cb);
+    const double* G = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+    if (act) acc += gram_at(G, 7 * pa + ca, 7 * pb + cb);
+    else if (jt) acc += gram_at(G, 28, 7 * pa + (l - 49));     // (J^T r) of node a in this run
   }
   if (act) *band_entry(fd, 7 * a + ca, 7 * b + cb) = acc;
+  else if (jt) fd.rhs[7 * a + (l - 49)] = -acc;               // jtl = -J^T r, one writer per entry
 }
 
 void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, hipStream_t st) {

@@ -14,6 +14,8 @@ __global__ void __launch_bounds__(256) k_init_slot(const FrameDev* __restrict__ 
     b[0] = 1.0;
 #pragma unroll
     for (int c = 1; c < 7; ++c) b[c] = 0.0;
+    const double ident[7] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    pack_node(fd.node_pk + (size_t)SLM_NPK * t, ident, fd.f.ed_points + 3 * t);
   }
   if (t < num_iterations) {
     slm_iter_record r;
@@ -116,8 +118,45 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
   }
   __syncthreads();
   if (s_accept) {
-    for (int e = threadIdx.x; e < fd.P; e += blockDim.x) fd.beta[e] += fd.delta[e];
+    for (int e = threadIdx.x; e < fd.P; e += blockDim.x) {
+      const double b = fd.beta[e] + fd.delta[e];
+      fd.beta[e] = b;
+      fd.node_pk[(size_t)SLM_NPK * (e / 7) + e % 7] = b;
+    }
   }
+}
+
+// node_pk <- beta (after slm_set_beta); grid = (ceil(J/256), 1)
+__global__ void __launch_bounds__(256) k_pack_nodes(const FrameDev* __restrict__ frames, int slot) {
+  const FrameDev& fd = frames[slot];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= fd.f.J) return;
+  double bb[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c];
+  pack_node(fd.node_pk + (size_t)SLM_NPK * j, bb, fd.f.ed_points + 3 * j);
+}
+
+// node_pk_try <- beta + delta: the trial point of the loss pass; grid = (ceil(maxJ/256), n_frames)
+__global__ void __launch_bounds__(256) k_make_trial(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= fd.f.J) return;
+  double bb[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c] + fd.delta[7 * j + c];
+  pack_node(fd.node_pk_try + (size_t)SLM_NPK * j, bb, fd.f.ed_points + 3 * j);
+}
+
+// target points + normals -> interleaved float4 pairs; grid = (ceil(T/256))
+__global__ void __launch_bounds__(256) k_pack_target(int T, const float* __restrict__ pts,
+                                                      const float* __restrict__ nrm,
+                                                      float4* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  out[2 * (size_t)t] = make_float4(pts[3 * t], pts[3 * t + 1], pts[3 * t + 2], 0.f);
+  out[2 * (size_t)t + 1] = make_float4(nrm[3 * t], nrm[3 * t + 1], nrm[3 * t + 2], 0.f);
 }
 
 // Reduce loss partials into out[0..3] = data, arap, rot, matched count (slm_loss).
@@ -316,6 +355,18 @@ void launch_init_slot(const FrameDev* frames_dev, int slot, int J, const slm_con
   if (n < 1) n = 1;
   hipLaunchKernelGGL(k_init_slot, dim3((n + 255) / 256), dim3(256), 0, st, frames_dev, slot, cfg.u0,
                      cfg.v, cfg.minimal_loss0, cfg.num_iterations);
+}
+
+void launch_pack_nodes(const FrameDev* frames_dev, int slot, int J, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_nodes, dim3((J + 255) / 256), dim3(256), 0, st, frames_dev, slot);
+}
+
+void launch_make_trial(const FrameDev* frames_dev, int n_frames, int maxJ, hipStream_t st) {
+  hipLaunchKernelGGL(k_make_trial, dim3((maxJ + 255) / 256, n_frames), dim3(256), 0, st, frames_dev);
+}
+
+void launch_pack_target(int T, const float* pts, const float* nrm, float4* out, hipStream_t st) {
+  if (T > 0) hipLaunchKernelGGL(k_pack_target, dim3((T + 255) / 256), dim3(256), 0, st, T, pts, nrm, out);
 }
 
 void launch_iter_begin(const FrameDev* frames_dev, int n_frames, hipStream_t st) {
