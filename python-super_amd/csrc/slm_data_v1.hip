@@ -20,12 +20,15 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-#define ROW_STRIDE 33   // doubles per surfel row in LDS (33: conflict-free 64-bit writes)
+#define ROW_STRIDE 17   // doubles per surfel half-row in LDS (odd: conflict-free 64-bit writes)
 
 // grid = (ceil(max n_pos / 256), n_frames), 256 threads = 4 waves, one 64-position chunk each
 // dbg (diagnostic build only): bit0 skip slab stores, bit1 skip MFMA, bit2 skip surfel evaluation
-__global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ frames, double lam,
-                                                    int dbg) {
+// The 32-entry rows pass through LDS in two halves of 16 entries (8.7 KB per wave instead of
+// 17 KB: three to four workgroups per CU instead of two); the first half's MFMA operands wait
+// in 16 registers per lane.
+__global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict__ frames, double lam,
+                                                       int dbg) {
   __shared__ double rows[4][64 * ROW_STRIDE];
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
@@ -48,27 +51,44 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
   const unsigned long long mm = __ballot(ev.match);
   if (l == 0 && mm) atomicAdd(&fd.st->m_grad, __popcll(mm));
 
+  // canonical slot of neighbour k = number of neighbour ids smaller than id[k]
+  int slot[4];
 #pragma unroll
-  for (int e = 0; e < 32; ++e) myrow[e] = 0.0;
-  if (ev.match) {
-    // canonical slot of neighbour k = number of neighbour ids smaller than id[k]
+  for (int k = 0; k < 4; ++k) {
+    slot[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int slot = 0;
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) slot += (ev.id[k2] < ev.id[k]) ? 1 : 0;
-#pragma unroll
-      for (int c = 0; c < 7; ++c) myrow[7 * slot + c] = ev.row[7 * k + c];
-    }
-    myrow[28] = ev.r;
+    for (int k2 = 0; k2 < 4; ++k2) slot[k] += (ev.id[k2] < ev.id[k]) ? 1 : 0;
   }
-  // the operands below are read by other lanes of the same wave
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int lc = l & 15, lq = l >> 4;
+  double a0[16];   // first-half operands of the 16 groups: rows[4g + lq][lc]
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) myrow[e] = 0.0;
+    if (ev.match) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+          const int e = 7 * slot[k] + c - 16 * half;
+          if (e >= 0 && e < 16) myrow[e] = ev.row[7 * k + c];
+        }
+      if (half == 1) myrow[28 - 16] = ev.r;
+    }
+    // the operands below are read by other lanes of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (half == 0) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) a0[g] = rows[w][(4 * g + lq) * ROW_STRIDE + lc];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
 
   // ---- Gram accumulation per run ---------------------------------------------------
-  const int lc = l & 15, lq = l >> 4;
   const int my_run = fd.grp_run[(base >> 2) + lc];   // lane (l & 15) holds the run of group (l & 15)
   double4_t g00 = {0, 0, 0, 0}, g10 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
   int cur = -1;
@@ -87,7 +107,7 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
     // row 28 of G (= J^T r, sum r^2) travels in the slab; k_*_assemble turns it into jtl
   };
 
-#pragma unroll 1
+#pragma unroll
   for (int g = 0; g < 16; ++g) {
     const int run = __builtin_amdgcn_readlane(my_run, g);
     if (run != cur) {
@@ -98,13 +118,12 @@ __global__ void __launch_bounds__(256) k_data_gram(const FrameDev* __restrict__ 
       cur = run;
     }
     if (run < 0) continue;
-    const double* rp = &rows[w][(4 * g + lq) * ROW_STRIDE];
-    const double a0 = rp[lc], a1 = rp[16 + lc];
+    const double a1 = rows[w][(4 * g + lq) * ROW_STRIDE + lc];
 #ifdef SLM_STAMPS
-    if (dbg & 2) { g00[0] += a0; g11[0] += a1; continue; }
+    if (dbg & 2) { g00[0] += a0[g]; g11[0] += a1; continue; }
 #endif
-    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g00, 0, 0, 0);
-    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0, g10, 0, 0, 0);
+    g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[g], a0[g], g00, 0, 0, 0);
+    g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0[g], g10, 0, 0, 0);
     g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
   }
   if (cur >= 0) flush(cur);
