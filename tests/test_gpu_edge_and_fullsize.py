@@ -229,3 +229,46 @@ def test_c2_knn_sorted_and_update_identity(c2):
     np.testing.assert_allclose(p.cpu().numpy(), c2.sf_points, rtol=0, atol=2e-7)
     np.testing.assert_allclose(g.cpu().numpy(), c2.ed_points, rtol=0, atol=0)
     np.testing.assert_allclose(np.linalg.norm(nr.cpu().numpy(), axis=1), 1.0, atol=1e-6)
+
+
+def test_three_frame_tracking_loop_matches_oracle_pipeline():
+    """The per-frame sequence SuPer.fusion runs (super/super.py:66-73 plus the KNN refresh):
+    LM -> Surfels.update -> update_ed / update_sfed_knn -> next frame, three frames in a row,
+    HIP mirrors vs the NumPy oracle doing the same sequence."""
+    import torch
+    from super_amd import nodes, synth
+    from super_amd.LM import LM_Solver
+    base = synth.make_scene(N=3000, J=48, H=60, W=80, seed=51, src_border=6, tgt_border=3, dphi=0.05)
+    targets = [synth.make_scene(N=3000, J=48, H=60, W=80, seed=51, src_border=6, tgt_border=3,
+                                dphi=0.05 * (k + 1)) for k in range(3)]
+    opt = orc.default_opt(num_optimize_iterations=5)
+    # ---- oracle pipeline (f64, positions re-rounded to f32 after every update like the HIP path)
+    f32r = lambda a: a.astype(np.float32).astype(np.float64)
+    P, Nn = base.f64("sf_points"), base.f64("sf_norms")
+    G, Gn, R = base.f64("ed_points"), base.f64("ed_norms"), base.f64("ed_radii")
+    idx, w = base.sf_knn_idx.copy(), base.f64("sf_knn_w")
+    eidx = base.ed_knn_idx.copy()
+    # ---- HIP pipeline
+    sf, inputs, _ = torch_frame(base)
+    sf.opt = ref_opt(opt)
+    lm = LM_Solver(sf.opt)
+    for k, tg in enumerate(targets):
+        fr = orc.Frame(sf_points=P, sf_knn_idx=idx, sf_knn_w=w, ed_points=G, ed_knn_idx=eidx,
+                       tgt_points=tg.f64("tgt_points"), tgt_norms=tg.f64("tgt_norms"),
+                       index_map=tg.index_map, valid=tg.valid, K=tg.K, H=tg.H, W=tg.W)
+        beta_o = orc.lm(fr, opt)
+        P, Nn, G, Gn = (f32r(x) for x in orc.apply_update(P, Nn, idx, w, G, Gn, beta_o))
+        eidx, _, _ = orc.node_knn(G, R, 4)
+        idx, w, _, _ = orc.surfel_knn(P, G, R, 4)
+        w = f32r(w)
+
+        _, _, new_data = torch_frame(tg)
+        beta_h = lm.LM(sf, inputs, new_data)
+        np.testing.assert_allclose(beta_h.cpu().numpy(), beta_o, rtol=0, atol=1e-4, err_msg=f"frame {k}")
+        nodes.update(sf, beta_h)
+        nodes.update_ed(sf)
+        nodes.update_sfed_knn(sf)
+        sf.ED_nodes.num = base.J
+        np.testing.assert_allclose(sf.points.cpu().numpy(), P, rtol=0, atol=5e-6)
+        np.testing.assert_array_equal(sf.knn_indices.cpu().numpy(), idx)
+        np.testing.assert_array_equal(sf.ED_nodes.knn_indices.cpu().numpy(), eidx)
