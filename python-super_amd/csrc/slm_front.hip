@@ -111,14 +111,18 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = t / Ke, slot = t % Ke;
   if (j >= fd.f.J) return;
-  // diagonal block of node v: entries (x,y), x >= y
-  auto diag_add = [&](int v, int x, int y, double val) {
-    const NDFront& f = fd.fronts[fd.node_front[v]];
-    const int b = nd_base(f, fd.node_pos[v]);
-    atomic_add_f64(front_entry(fd, f, b + x, b + y), val);
-  };
+  // front / base of node j's diagonal block, resolved once
+  const NDFront fj = fd.fronts[fd.node_front[j]];
+  const int bj0 = nd_base(fj, fd.node_pos[j]);
   if (use_arap) {
     const int k = fd.f.ed_knn_idx[j * Ke + slot];
+    const NDFront fk = fd.fronts[fd.node_front[k]];
+    const int bk0 = nd_base(fk, fd.node_pos[k]);
+    const NDDest pd = fd.pair_dest[j * Ke + slot];   // block (max(j,k), min(j,k))
+    const NDFront fp = fd.fronts[pd.front];
+    const int prb = nd_base(fp, pd.prow), pcb = nd_base(fp, pd.pcol);
+    // is node k the ROW node of the stored (lower) cross block?
+    const bool k_is_row = ((k > j) != (pd.transpose != 0));
     const float* g = fd.f.ed_points;
     const d3 d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
                   (double)g[3 * j + 2] - (double)g[3 * k + 2]};
@@ -130,27 +134,40 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
                          lam_a * (tt.z + bk[6] - d.z - bj[6])};
     double Jq[3][4];
     quat_jac(bk[0], {bk[1], bk[2], bk[3]}, d, Jq);
-    const NDDest pd = fd.pair_dest[j * Ke + slot];   // block (max(j,k), min(j,k))
-    const bool k_is_a = k > j;                        // is node k the block's row node "a"?
+    const double l2 = lam_a * lam_a;
+    // The three residual rows c share their node-k quaternion columns: sum over c first.
+    //   K block (7x7 lower):  qq[a][b] = l2 sum_c Jq[c][a]Jq[c][b];  (4+c, a) = l2 Jq[c][a];  (4+c,4+c) = l2
+    //   cross block k-j:      (k a, j 4+c) = -l2 Jq[c][a];  (k 4+c, j 4+c) = -l2
+    //   J block:              (4+c, 4+c) = l2
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double gr = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gr += Jq[c][a] * r[c];
+      atomic_add_f64(fd.rhs + 7 * k + a, -lam_a * gr);
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double q = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q += Jq[c][a] * Jq[c][b];
+        atomic_add_f64(front_entry(fd, fk, bk0 + a, bk0 + b), l2 * q);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      // row c: node-k entries (components 0..3 and 4+c), node-j entry (component 4+c)
-      const int kc[5] = {0, 1, 2, 3, 4 + c};
-      const double kv[5] = {lam_a * Jq[c][0], lam_a * Jq[c][1], lam_a * Jq[c][2], lam_a * Jq[c][3], lam_a};
-      const int jc = 4 + c;
-      const double jv = -lam_a;
+      atomic_add_f64(fd.rhs + 7 * k + 4 + c, -lam_a * r[c]);
+      atomic_add_f64(fd.rhs + 7 * j + 4 + c, lam_a * r[c]);
+      atomic_add_f64(front_entry(fd, fk, bk0 + 4 + c, bk0 + 4 + c), l2);
+      atomic_add_f64(front_entry(fd, fj, bj0 + 4 + c, bj0 + 4 + c), l2);
 #pragma unroll
-      for (int a = 0; a < 5; ++a) {
-        atomic_add_f64(fd.rhs + 7 * k + kc[a], -kv[a] * r[c]);
-#pragma unroll
-        for (int b = 0; b <= a; ++b) diag_add(k, kc[a], kc[b], kv[a] * kv[b]);   // kc ascending
-        // cross block entry between (k, kc[a]) and (j, jc)
-        const double cv = kv[a] * jv;
-        if (k_is_a) atomic_add_f64(dest_entry(fd, pd, kc[a], jc), cv);
-        else atomic_add_f64(dest_entry(fd, pd, jc, kc[a]), cv);
+      for (int a = 0; a < 4; ++a) {
+        atomic_add_f64(front_entry(fd, fk, bk0 + 4 + c, bk0 + a), l2 * Jq[c][a]);
+        const double cv = -l2 * Jq[c][a];                       // between (k, a) and (j, 4+c)
+        if (k_is_row) atomic_add_f64(front_entry(fd, fp, prb + a, pcb + 4 + c), cv);
+        else atomic_add_f64(front_entry(fd, fp, prb + 4 + c, pcb + a), cv);
       }
-      atomic_add_f64(fd.rhs + 7 * j + jc, -jv * r[c]);
-      diag_add(j, jc, jc, jv * jv);
+      // between (k, 4+c) and (j, 4+c): same component on both sides
+      atomic_add_f64(front_entry(fd, fp, prb + 4 + c, pcb + 4 + c), -l2);
     }
   }
   if (use_rot && slot == 0) {
@@ -165,7 +182,7 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
     for (int a = 0; a < 4; ++a) {
       atomic_add_f64(fd.rhs + 7 * j + a, (double)jtr[a]);
 #pragma unroll
-      for (int b = 0; b <= a; ++b) diag_add(j, a, b, (double)jtj[a][b]);
+      for (int b = 0; b <= a; ++b) atomic_add_f64(front_entry(fd, fj, bj0 + a, bj0 + b), (double)jtj[a][b]);
     }
   }
 }
