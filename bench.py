@@ -259,18 +259,19 @@ def main():
                                "traffic": pmc_traffic("k_data_gram", a.workload, Bs),
                                "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
                                "algorithmic_bytes_per_launch": per_launch_bytes}
-            nt = (7 * J + NB - 1) // NB
-            lo = np.min(scenes[0].sf_knn_idx, axis=1)
-            hi = np.max(scenes[0].sf_knn_idx, axis=1)
-            wb = int(((7 * hi + 6) // NB - (7 * lo) // NB).max())
-            flops = Bs * nt * (wb * (wb + 1) / 2 + wb) * 2.0 * NB ** 3   # SYRK + TRSM tiles
+            info = eng.plan_info(0)
+            flops = Bs * info["factor_flops"]          # padded dense-front FLOPs of one factorisation
             s = prof["solve"]
             savg = s["ms"] / max(s["count"], 1) * 1e-3
             tf = flops / savg / 1e12 if savg > 0 else 0.0
-            out["roofline_solver"] = {"phase": "banded Cholesky factor+solve (all launches)",
+            out["roofline_solver"] = {"phase": f"{info['solver']} Cholesky factor + substitutions "
+                                               "(all launches of one LM iteration)",
                                       "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS,
                                       "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
-                                      "avg_phase_ms": savg * 1e3, "tile_cols": nt, "tile_halfband": wb}
+                                      "avg_phase_ms": savg * 1e3, "factor_gflop_per_frame": info["factor_flops"] / 1e9,
+                                      "fronts": int(info["fronts"]), "levels": int(info["levels"])}
+            out["plan"] = {k: (int(v) if isinstance(v, float) and k not in ("factor_flops", "factor_bytes") else v)
+                           for k, v in info.items()}
             out["phase_ms_per_iteration"] = {k: v["ms"] / max(v["count"], 1) for k, v in prof.items()}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, seed=0)

@@ -498,6 +498,31 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
   return SLM_OK;
 }
 
+int slm_get_plan_info(slm_solver* s, int32_t slot, double* out) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  if (!out) return fail(SLM_ERR_INVALID, "slm_get_plan_info: null output");
+  const Slot& sl = s->slots[slot];
+  const FrameDev& h = sl.h;
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  if (h.nd_ready) {
+    out[0] = 0.0;
+    out[1] = (double)sl.nd.fronts.size();
+    out[2] = (double)sl.nd.level_start.size() - 1.0;
+    out[3] = sl.nd.flops;
+    out[4] = 8.0 * (double)sl.nd.tile_doubles;
+  } else {
+    out[0] = 1.0;
+    const double w = (double)h.wb * SLM_NB;
+    out[3] = (double)h.P * w * w;
+    out[4] = 8.0 * (double)h.nt * (h.wb + 1) * SLM_NB * SLM_NB;
+  }
+  out[5] = h.n_tuples;
+  out[6] = h.n_runs;
+  out[7] = h.n_blocks;
+  return SLM_OK;
+}
+
 int slm_profile_enable(slm_solver* s, int32_t on) {
   if (!s) return fail(SLM_ERR_INVALID, "slm_profile_enable: null solver");
   s->profile = on != 0;

@@ -17,7 +17,7 @@ PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 
 EXPORTS = [
     "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame",
-    "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
+    "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_plan_info", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
     "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -91,6 +91,7 @@ def load():
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],
+        "slm_get_plan_info": [vp, i32, C.POINTER(C.c_double)],
         "slm_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
         "slm_get_beta": [vp, i32, vp, vp],
         "slm_set_beta": [vp, i32, vp, vp],

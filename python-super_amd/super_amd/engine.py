@@ -130,6 +130,14 @@ class Engine:
         return [dict(loss=r.loss, u=r.u, accepted=bool(r.accepted), status=int(r.status),
                      M_grad=int(r.M_grad), M_loss=int(r.M_loss)) for r in arr[:n]]
 
+    def plan_info(self, slot: int = 0):
+        out = (C.c_double * 8)()
+        _lib.check(self.lib.slm_get_plan_info(self.h, slot, out), "slm_get_plan_info")
+        keys = ("solver", "fronts", "levels", "factor_flops", "factor_bytes", "tuples", "runs", "pairs")
+        d = {k: out[i] for i, k in enumerate(keys)}
+        d["solver"] = "nested-dissection multifrontal" if d["solver"] == 0 else "band"
+        return d
+
     def profile(self, on: bool):
         _lib.check(self.lib.slm_profile_enable(self.h, int(on)), "slm_profile_enable")
 
