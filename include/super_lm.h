@@ -64,8 +64,9 @@ typedef struct slm_config {
   int32_t use_arap;         /* opt.mesh_arap */
   int32_t use_rot;          /* opt.mesh_rot */
   int32_t max_frames;       /* number of slots (>= 1) */
-  int32_t data_path;        /* 0 = tuple-sorted MFMA assembly (default); 1 = per-entry f64 atomics
-                               (simple cross-check path, also used when J >= 65536) */
+  int32_t data_path;        /* 0 = tuple-sorted MFMA assembly, node-pair blocks merged per workgroup in
+                               LDS (default); 1 = per-entry f64 atomics (simple cross-check path, also
+                               used when J >= 65536); 2 = MFMA assembly with one Gram per run in HBM */
   int32_t solver_path;      /* 0 = nested-dissection multifrontal Cholesky (default, needs data_path 0);
                                1 = block-banded Cholesky */
   double w_data;            /* opt.sf_point_plane_weight (1.0) */
@@ -130,10 +131,11 @@ int slm_set_beta(slm_solver* s, int32_t slot, const double* beta_in_device, void
 int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int32_t max_records,
                     void* stream);
 
-/* Host-side facts about the slot's per-frame plan (after slm_bind_frame), info_out[8]:
+/* Host-side facts about the slot's per-frame plan (after slm_bind_frame), info_out[10]:
  * [0] solver in use (0 nested dissection, 1 band), [1] fronts, [2] tree levels,
  * [3] FLOPs of one factorisation (padded dense fronts, or P*w^2 for the band),
- * [4] factor storage bytes, [5] distinct KNN tuples, [6] Gram runs, [7] coupled node pairs. */
+ * [4] factor storage bytes, [5] distinct KNN tuples, [6] Gram runs, [7] coupled node pairs,
+ * [8] workgroup-merged (workgroup, pair) records (0: one Gram per run in HBM), [9] padded positions. */
 int slm_get_plan_info(slm_solver* s, int32_t slot, double* info_out);
 
 /* -- phase timing (bench.py roofline leg) ----------------------------------------- */

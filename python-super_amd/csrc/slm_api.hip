@@ -12,7 +12,7 @@
 void launch_data_grad(const FrameDev*, int, int, double, hipStream_t);
 void launch_data_loss(const FrameDev*, int, int, double, int, hipStream_t);
 void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
-void launch_data_gram(const FrameDev*, int, int, double, hipStream_t);
+void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_assemble(const FrameDev*, int, int, hipStream_t);
@@ -241,7 +241,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   }
   // tuple-sorted data-term assembly plan (DataLoss.prepare analogue)
   h.v1_ready = 0;
-  if (s->cfg.use_data && s->cfg.data_path == 0 && f->J < 65536 && f->N > 0) {
+  if (s->cfg.use_data && s->cfg.data_path != 1 && f->J < 65536 && f->N > 0) {
     V1Sizes sz;
     HIPCHK(prep_v1(s->prep, *f, sl.plan, &sz, st));
     if (sz.n_tuples > 0) {
@@ -259,6 +259,18 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.blk_start = sl.plan.blk_start;
       h.blk_entry = sl.plan.blk_entry;
       h.v1_ready = 1;
+      // workgroup-merged records (default); data_path 2 keeps the per-run slab
+      h.v2_ready = 0;
+      if (s->cfg.data_path == 0 && sz.n_wblk > 0 && sz.max_wblk_per_wg <= SLM_LB_MAX) {
+        h.n_wblk = sz.n_wblk;
+        h.wg_first = sl.plan.wg_first;
+        h.wg_last = sl.plan.wg_last;
+        h.run_lidx = sl.plan.run_lidx;
+        h.wgslab = sl.plan.wgslab;
+        h.blk2_start = sl.plan.blk2_start;
+        h.blk2_entry = sl.plan.blk2_entry;
+        h.v2_ready = 1;
+      }
     }
   }
   // nested-dissection plan (symbolic analysis on the host from the coupled-pair list)
@@ -348,6 +360,7 @@ struct BatchDims {
   int maxN = 0, maxJKe = 0, nt_max = 0, wb_cap = 0, n_reg_part = 0;
   int max_pos = 0, max_blocks = 0, maxP = 0;
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
+  int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
   bool nd = true;   // every slot of the batch has a nested-dissection plan
   std::vector<NDLevelSched> sched;   // per-level launch bounds over the batch
 };
@@ -362,6 +375,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.max_pos = std::max(d.max_pos, h.n_pos);
     d.max_blocks = std::max(d.max_blocks, h.n_blocks);
     d.v1 = d.v1 && h.v1_ready;
+    if (h.v1_ready) d.gram_variants |= h.v2_ready ? 1 : 2;
     d.nd = d.nd && h.nd_ready;
     d.maxP = std::max(d.maxP, h.P);
   }
@@ -395,7 +409,7 @@ hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims&
   }
   launch_iter_begin_nd(fr, n, st);
   if (s->cfg.use_data) {
-    launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, st);
+    launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
   }
   launch_reg_grad_nd(fr, n, d.maxJKe, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
@@ -407,7 +421,7 @@ void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims&
   launch_iter_begin(fr, n, st);
   if (s->cfg.use_data) {
     if (d.v1) {
-      launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, st);
+      launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
       launch_band_assemble(fr, n, d.max_blocks, st);
     } else {
       launch_data_grad(fr, n, d.maxN, s->cfg.w_data, st);
@@ -470,7 +484,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     }
     mark();
     if (c.use_data) {
-      if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, st);
+      if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, d.gram_variants, st);
       else launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
     }
     mark();
@@ -504,7 +518,7 @@ int slm_get_plan_info(slm_solver* s, int32_t slot, double* out) {
   if (!out) return fail(SLM_ERR_INVALID, "slm_get_plan_info: null output");
   const Slot& sl = s->slots[slot];
   const FrameDev& h = sl.h;
-  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  for (int i = 0; i < 10; ++i) out[i] = 0.0;
   if (h.nd_ready) {
     out[0] = 0.0;
     out[1] = (double)sl.nd.fronts.size();
@@ -520,6 +534,8 @@ int slm_get_plan_info(slm_solver* s, int32_t slot, double* out) {
   out[5] = h.n_tuples;
   out[6] = h.n_runs;
   out[7] = h.n_blocks;
+  out[8] = h.v1_ready && h.v2_ready ? h.n_wblk : 0;
+  out[9] = h.n_pos;
   return SLM_OK;
 }
 

@@ -62,6 +62,17 @@ struct FrameDev {
   int32_t* blk_key;      // (n_blocks) a*J + b
   int32_t* blk_start;    // (n_blocks+1) CSR offsets into blk_entry
   int32_t* blk_entry;    // run*16 + pa*4 + pb
+  // ---- workgroup-merged Gram blocks (v2): the 4 waves of a workgroup add their runs' 7x7
+  //      blocks into LDS accumulators keyed by node pair; one 56-double record per
+  //      (workgroup, node pair) goes to HBM instead of one 768-double Gram per run ----
+  int32_t v2_ready;
+  int32_t n_wblk;          // (workgroup, pair) records
+  const int32_t* wg_first; // (n_wg) first record of each workgroup
+  const int32_t* wg_last;  // (n_wg) last record (first-1 if none)
+  const uint8_t* run_lidx; // (n_runs,10) local record index of the run's 10 node pairs
+  double* wgslab;          // (n_wblk, 56): 49 block entries (row-major ca,cb) + 7 entries of -J^T r
+  const int32_t* blk2_start;  // (n_blocks+1) CSR over blk2_entry, same pair order as blk_key
+  const int32_t* blk2_entry;  // record ids
   // ---- nested-dissection multifrontal solver (slm_nd_host.hip / slm_front.hip) ----
   int32_t nd_ready;      // 1 when the plan below is valid for this frame
   int32_t n_fronts;
@@ -80,6 +91,8 @@ struct FrameDev {
   double* flinv;               // inverses of the diagonal Cholesky blocks of the fronts
 };
 #define SLM_SLAB_STRIDE 768
+#define SLM_WREC 56          // doubles per (workgroup, pair) record
+#define SLM_LB_MAX 96        // records a workgroup can hold in LDS
 
 // In-kernel stamps exist only in the diagnostic build; the shipped library executes none.
 #ifdef SLM_STAMPS

@@ -27,14 +27,30 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // The 32-entry rows pass through LDS in two halves of 16 entries (8.7 KB per wave instead of
 // 17 KB: three to four workgroups per CU instead of two); the first half's MFMA operands wait
 // in 16 registers per lane.
+//
+// MERGE (default): the workgroup's 4 waves add the 7x7 node-pair blocks of their runs (and the
+// 7-entry J^T r pieces of the diagonal pairs) into LDS records keyed by node pair (ds_add_f64),
+// and the workgroup writes one 56-double record per distinct pair -- about 4x fewer HBM bytes
+// than one 768-double Gram per run, and the assemble kernels read contiguous records.
+template <bool MERGE>
 __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict__ frames, double lam,
                                                        int dbg) {
   __shared__ double rows[4][64 * ROW_STRIDE];
+  __shared__ double recs[MERGE ? SLM_LB_MAX * SLM_WREC : 1];
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
+  if (MERGE != (fd.v2_ready != 0)) return;   // the host launches both variants when slots differ
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int base = (blockIdx.x * 4 + w) * 64;
-  if (base >= fd.n_pos) return;
+  if (blockIdx.x * 256 >= fd.n_pos) return;
+  int rec0 = 0, nrec = 0;
+  if (MERGE) {
+    rec0 = fd.wg_first[blockIdx.x];
+    nrec = fd.wg_last[blockIdx.x] - rec0 + 1;
+    for (int i = threadIdx.x; i < nrec * SLM_WREC; i += 256) recs[i] = 0.0;
+    __syncthreads();
+  }
+  if (base < fd.n_pos) {
   const int pos = base + l;
   double* myrow = &rows[w][l * ROW_STRIDE];
 
@@ -94,17 +110,38 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   int cur = -1;
 
   auto flush = [&](int run) {
-    double* out = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
 #ifdef SLM_STAMPS
-    if (!(dbg & 1))
+    if (dbg & 1) return;
 #endif
+    if (MERGE) {
+      // accumulator element (tile, r) of lane l is G[i][j], i = 4r + lq (+16), j = lc (+16)
+      const int lv = fd.run_lidx[10 * run + (l < 10 ? l : 0)];   // record of each of the 10 node pairs
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      out[r * 64 + l] = g00[r];
-      out[256 + r * 64 + l] = g10[r];
-      out[512 + r * 64 + l] = g11[r];
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * r + lq + (t >= 1 ? 16 : 0), j = lc + (t == 2 ? 16 : 0);
+          const double v = t == 0 ? g00[r] : (t == 1 ? g10[r] : g11[r]);
+          const int pa = (i * 37) >> 8, pb = (j * 37) >> 8;   // i / 7 for i < 32
+          const int ca = i - 7 * pa, cb = j - 7 * pb;
+          const bool jrow = (i == 28);
+          const bool act = j < 28 && (jrow || (i < 28 && i >= j));
+          // row 28 (J^T r) goes to the diagonal record of node slot pb, entries 49..55
+          int ps = jrow ? (pb * (pb + 1) / 2 + pb) : (pa * (pa + 1) / 2 + pb);
+          ps = act ? ps : 0;
+          const int rec = __shfl(lv, ps);
+          if (act) unsafeAtomicAdd(&recs[rec * SLM_WREC + (jrow ? 49 + cb : 7 * ca + cb)], v);
+        }
+    } else {
+      double* out = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        out[r * 64 + l] = g00[r];
+        out[256 + r * 64 + l] = g10[r];
+        out[512 + r * 64 + l] = g11[r];
+      }
+      // row 28 of G (= J^T r, sum r^2) travels in the slab; k_*_assemble turns it into jtl
     }
-    // row 28 of G (= J^T r, sum r^2) travels in the slab; k_*_assemble turns it into jtl
   };
 
 #pragma unroll
@@ -127,6 +164,12 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
     g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
   }
   if (cur >= 0) flush(cur);
+  }   // wave has positions
+  if (MERGE) {
+    __syncthreads();
+    double* out = fd.wgslab + (size_t)rec0 * SLM_WREC;
+    for (int i = threadIdx.x; i < nrec * SLM_WREC; i += 256) out[i] = recs[i];
+  }
 }
 
 // G[i][j], i >= j, from a slab entry (tiles 00, 10, 11; 16x16 row-major each)
@@ -148,27 +191,36 @@ __global__ void __launch_bounds__(256) k_band_assemble(const FrameDev* __restric
   const int ca = l / 7, cb = l % 7;
   const bool act = (l < 49) && (a != b || ca >= cb);   // lower triangle only on diagonal blocks
   const bool jt = (a == b) && l >= 49 && l < 56;       // diagonal block: lanes 49..55 build jtl of node a
-  const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
   double acc = 0.0;
-  for (int s = s0; s < s1; ++s) {
-    const int pl = fd.blk_entry[s];
-    const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
-    const double* G = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
-    if (act) acc += gram_at(G, 7 * pa + ca, 7 * pb + cb);
-    else if (jt) acc += gram_at(G, 28, 7 * pa + (l - 49));     // (J^T r) of node a in this run
+  if (fd.v2_ready) {
+    const int s0 = fd.blk2_start[bi], s1 = fd.blk2_start[bi + 1];
+    if (l < SLM_WREC)
+      for (int s = s0; s < s1; ++s) acc += fd.wgslab[(size_t)fd.blk2_entry[s] * SLM_WREC + l];
+  } else {
+    const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
+    for (int s = s0; s < s1; ++s) {
+      const int pl = fd.blk_entry[s];
+      const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
+      const double* G = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+      if (act) acc += gram_at(G, 7 * pa + ca, 7 * pb + cb);
+      else if (jt) acc += gram_at(G, 28, 7 * pa + (l - 49));     // (J^T r) of node a in this run
+    }
   }
   if (act) *band_entry(fd, 7 * a + ca, 7 * b + cb) = acc;
   else if (jt) fd.rhs[7 * a + (l - 49)] = -acc;               // jtl = -J^T r, one writer per entry
 }
 
-void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, hipStream_t st) {
+// variants: bit0 = some slot uses the workgroup-merged records, bit1 = some slot uses the per-run slab
+void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, int variants,
+                      hipStream_t st) {
   if (max_pos <= 0) return;
   int dbg = 0;
 #ifdef SLM_STAMPS
   if (const char* e = getenv("SLM_DBG")) dbg = atoi(e);
 #endif
-  hipLaunchKernelGGL(k_data_gram, dim3((max_pos + 255) / 256, n_frames), dim3(256), 0, st, frames_dev, lam,
-                     dbg);
+  const dim3 grid((max_pos + 255) / 256, n_frames);
+  if (variants & 1) hipLaunchKernelGGL(k_data_gram<true>, grid, dim3(256), 0, st, frames_dev, lam, dbg);
+  if (variants & 2) hipLaunchKernelGGL(k_data_gram<false>, grid, dim3(256), 0, st, frames_dev, lam, dbg);
 }
 
 void launch_band_assemble(const FrameDev* frames_dev, int n_frames, int max_blocks, hipStream_t st) {

@@ -54,14 +54,21 @@ __global__ void __launch_bounds__(256) k_front_assemble(const FrameDev* __restri
   const bool diag = d.prow == d.pcol;
   const bool act = (l < 49) && (!diag || ca >= cb);
   const bool jt = diag && l >= 49 && l < 56;   // diagonal pair: lanes 49..55 build jtl of the node
-  const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
   double acc = 0.0;
-  for (int s = s0; s < s1; ++s) {
-    const int pl = fd.blk_entry[s];
-    const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
-    const double* G = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
-    if (act) acc += gram_at(G, 7 * pa + ca, 7 * pb + cb);
-    else if (jt) acc += gram_at(G, 28, 7 * pa + (l - 49));
+  if (fd.v2_ready) {
+    // one 56-double record per (workgroup, pair): 49 block entries + 7 entries of J^T r
+    const int s0 = fd.blk2_start[bi], s1 = fd.blk2_start[bi + 1];
+    if (l < SLM_WREC)
+      for (int s = s0; s < s1; ++s) acc += fd.wgslab[(size_t)fd.blk2_entry[s] * SLM_WREC + l];
+  } else {
+    const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
+    for (int s = s0; s < s1; ++s) {
+      const int pl = fd.blk_entry[s];
+      const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
+      const double* G = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+      if (act) acc += gram_at(G, 7 * pa + ca, 7 * pb + cb);
+      else if (jt) acc += gram_at(G, 28, 7 * pa + (l - 49));
+    }
   }
   if (act) *dest_entry(fd, d, ca, cb) = acc;
   else if (jt) {

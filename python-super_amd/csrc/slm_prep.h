@@ -19,12 +19,21 @@ struct V1Plan {
   int32_t* blk_key = nullptr;
   int32_t* blk_start = nullptr;
   int32_t* blk_entry = nullptr;
+  int32_t* run_chunk = nullptr;   // (n_runs) 64-position chunk of each run
+  int32_t* wg_first = nullptr;
+  int32_t* wg_last = nullptr;
+  uint8_t* run_lidx = nullptr;
+  double* wgslab = nullptr;
+  int32_t* blk2_start = nullptr;
+  int32_t* blk2_entry = nullptr;
+  size_t cap_rchunk = 0, cap_wg = 0, cap_lidx = 0, cap_wgslab = 0, cap_b2start = 0, cap_b2entry = 0;
   size_t cap_pts = 0, cap_idx = 0, cap_w = 0, cap_grp = 0, cap_runs = 0, cap_slab = 0, cap_bkey = 0,
          cap_bstart = 0, cap_bentry = 0;
 };
 
 struct V1Sizes {
   int n_tuples, n_pos, n_runs, n_blocks;
+  int n_wblk, max_wblk_per_wg;   // v2 records; v2 is usable when max_wblk_per_wg <= SLM_LB_MAX
 };
 
 PrepBuffers* prep_create();

@@ -14,6 +14,7 @@
 //      contributions, by a second sort + run-length encode
 // rocPRIM is used only for these once-per-frame sorts/scans (plumbing); every kernel on
 // the per-iteration path is hand-written.
+#include <algorithm>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -73,7 +74,8 @@ __global__ void __launch_bounds__(256) k_fill_sorted(
     const unsigned long long* __restrict__ tkeys, const int* __restrict__ tcount,
     const int* __restrict__ tstart, const int* __restrict__ pstart, const int* __restrict__ rstart,
     const int* __restrict__ sids, float* __restrict__ s_pts, int* __restrict__ s_idx,
-    float* __restrict__ s_w, int* __restrict__ grp_run, int* __restrict__ run_nodes) {
+    float* __restrict__ s_w, int* __restrict__ grp_run, int* __restrict__ run_nodes,
+    int* __restrict__ run_chunk) {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= n_pos_bound) return;
   const int nt = scal[0], ptot = scal[1];
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(256) k_fill_sorted(
       int4 nodes = make_int4((int)(k >> 48) & 0xFFFF, (int)(k >> 32) & 0xFFFF, (int)(k >> 16) & 0xFFFF,
                              (int)k & 0xFFFF);
       *reinterpret_cast<int4*>(run_nodes + 4 * run) = nodes;
+      run_chunk[run] = pos >> 6;
     }
   }
   *reinterpret_cast<int4*>(s_idx + 4 * pos) = idv;
@@ -147,6 +150,83 @@ __global__ void k_totals2(int* __restrict__ scal, const unsigned* __restrict__ u
   scal[3] = nb;
 }
 
+// ---- v2: (workgroup, pair) records ------------------------------------------------------
+// key = (workgroup << 32) | (a*J + b), payload = run*16 + pa*4 + pb; workgroup = chunk / 4
+__global__ void __launch_bounds__(256) k_pairs2(int n_runs_bound, const int* __restrict__ scal, int J,
+                                                 const int* __restrict__ run_nodes,
+                                                 const int* __restrict__ run_chunk,
+                                                 unsigned long long* __restrict__ keys,
+                                                 int* __restrict__ vals) {
+  const int rr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rr >= n_runs_bound) return;
+  const bool live = rr < scal[2];
+  int n[4] = {0, 0, 0, 0};
+  unsigned long long wg = 0;
+  if (live) {
+    const int4 v = *reinterpret_cast<const int4*>(run_nodes + 4 * rr);
+    n[0] = v.x; n[1] = v.y; n[2] = v.z; n[3] = v.w;
+    wg = (unsigned long long)(run_chunk[rr] >> 2);
+  }
+  int e = 0;
+#pragma unroll
+  for (int pa = 0; pa < 4; ++pa)
+#pragma unroll
+    for (int pb = 0; pb <= pa; ++pb, ++e) {
+      keys[10 * rr + e] = live ? ((wg << 32) | (unsigned)(n[pa] * J + n[pb])) : ~0ull;
+      vals[10 * rr + e] = rr * 16 + pa * 4 + pb;
+    }
+}
+
+// per unique (workgroup, pair) record u: first/last record of its workgroup, max records per
+// workgroup, and the pair key / record id for the final pair -> records index
+__global__ void __launch_bounds__(256) k_wg_bounds(int nwb_bound, int* __restrict__ scal,
+                                                    const unsigned long long* __restrict__ wkeys,
+                                                    int* __restrict__ wg_first, int* __restrict__ wg_last,
+                                                    unsigned* __restrict__ pk, int* __restrict__ pv) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nwb_bound) return;
+  const int nu = scal[5];
+  const bool live = u < nu && wkeys[u] != ~0ull;
+  pk[u] = live ? (unsigned)(wkeys[u] & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+  pv[u] = u;
+  if (!live) return;
+  const int wg = (int)(wkeys[u] >> 32);
+  if (u == 0 || (int)(wkeys[u - 1] >> 32) != wg) wg_first[wg] = u;
+  const bool last = (u + 1 >= nu) || wkeys[u + 1] == ~0ull || (int)(wkeys[u + 1] >> 32) != wg;
+  if (last) wg_last[wg] = u;
+  atomicAdd(&scal[6], 1);   // live records
+}
+
+__global__ void __launch_bounds__(256) k_wg_max(int n_wg, const int* __restrict__ wg_first,
+                                                 const int* __restrict__ wg_last, int* __restrict__ scal) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_wg) return;
+  const int c = wg_last[g] - wg_first[g] + 1;
+  if (c > 0) atomicMax(&scal[7], c);
+}
+
+// local record index of every (run, pair slot)
+__global__ void __launch_bounds__(256) k_run_lidx(int nwb_bound, const int* __restrict__ scal,
+                                                   const unsigned long long* __restrict__ wkeys,
+                                                   const int* __restrict__ wstart, const int* __restrict__ wcount,
+                                                   const int* __restrict__ svals, const int* __restrict__ wg_first,
+                                                   uint8_t* __restrict__ run_lidx) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nwb_bound || u >= scal[5] || wkeys[u] == ~0ull) return;
+  const int wg = (int)(wkeys[u] >> 32);
+  const int lidx = u - wg_first[wg];
+  for (int e = wstart[u]; e < wstart[u] + wcount[u]; ++e) {
+    const int pl = svals[e];
+    const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
+    run_lidx[10 * run + pa * (pa + 1) / 2 + pb] = (uint8_t)(lidx < 255 ? lidx : 255);
+  }
+}
+
+// blk2_start[n_blocks] = number of live records (end of the last live pair)
+__global__ void k_totals3(const int* __restrict__ scal, int* __restrict__ blk2_start) {
+  blk2_start[scal[3]] = scal[6];
+}
+
 template <typename T>
 hipError_t grow_raw(T*& p, size_t& cap, size_t need) {
   if (need <= cap) return hipSuccess;
@@ -175,6 +255,11 @@ struct PrepBuffers {
   unsigned *pkeys = nullptr, *spkeys = nullptr, *ukeys = nullptr;
   int *pvals = nullptr, *bcount = nullptr;
   size_t cap_e = 0;
+  unsigned long long *wkeys = nullptr, *swkeys = nullptr, *uwkeys = nullptr;
+  int *wvals = nullptr, *swvals = nullptr, *wcount = nullptr, *wstart = nullptr, *pv2 = nullptr, *spv2 = nullptr,
+      *b2count = nullptr;
+  unsigned *pk2 = nullptr, *spk2 = nullptr, *upk2 = nullptr;
+  size_t cap_w = 0;
   void* tmp = nullptr;
   size_t cap_tmp = 0;
   int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique
@@ -194,7 +279,9 @@ PrepBuffers* prep_create() {
 void prep_destroy(PrepBuffers* p) {
   if (!p) return;
   void* ptrs[] = {p->keys, p->skeys, p->tkeys, p->ids, p->sids, p->tcount, p->tstart, p->pc, p->pstart,
-                  p->nruns, p->rstart, p->pkeys, p->spkeys, p->ukeys, p->pvals, p->bcount, p->tmp, p->scal};
+                  p->nruns, p->rstart, p->pkeys, p->spkeys, p->ukeys, p->pvals, p->bcount, p->tmp, p->scal,
+                  p->wkeys, p->swkeys, p->uwkeys, p->wvals, p->swvals, p->wcount, p->wstart, p->pv2, p->spv2,
+                  p->b2count, p->pk2, p->spk2, p->upk2};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->scal_host) (void)hipHostFree(p->scal_host);
@@ -218,7 +305,8 @@ static hipError_t ensure_tmp(PrepBuffers* p, size_t bytes) {
 
 void plan_free(V1Plan& plan) {
   void* ptrs[] = {plan.s_pts, plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes, plan.slab, plan.blk_key,
-                  plan.blk_start, plan.blk_entry};
+                  plan.blk_start, plan.blk_entry, plan.run_chunk, plan.wg_first, plan.wg_last, plan.run_lidx,
+                  plan.wgslab, plan.blk2_start, plan.blk2_entry};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   plan = V1Plan();
@@ -227,6 +315,7 @@ void plan_free(V1Plan& plan) {
 hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* out, hipStream_t st) {
   const size_t N = (size_t)f.N;
   out->n_tuples = out->n_pos = out->n_runs = out->n_blocks = 0;
+  out->n_wblk = out->max_wblk_per_wg = 0;
   if (N == 0) return hipSuccess;
   // ---- phase A: tuples ----------------------------------------------------------
   if (N > p->cap_n) {
@@ -279,6 +368,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   PCHK(grow_raw(plan.s_w, plan.cap_w, 4 * pos_bound));
   PCHK(grow_raw(plan.grp_run, plan.cap_grp, pos_bound / 4));
   PCHK(grow_raw(plan.run_nodes, plan.cap_runs, 4 * runs_bound));
+  PCHK(grow_raw(plan.run_chunk, plan.cap_rchunk, runs_bound));
   PCHK(grow_raw(plan.slab, plan.cap_slab, (size_t)SLM_SLAB_STRIDE * runs_bound));
   PCHK(grow_raw(plan.blk_key, plan.cap_bkey, n_entries));
   PCHK(grow_raw(plan.blk_start, plan.cap_bstart, n_entries + 1));
@@ -296,7 +386,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   hipLaunchKernelGGL(k_totals, dim3(1), dim3(1), 0, st, p->scal, p->pstart, p->pc, p->rstart, p->nruns);
   hipLaunchKernelGGL(k_fill_sorted, dim3((pos_bound + 255) / 256), blk, 0, st, (int)pos_bound, p->scal, f,
                      p->tkeys, p->tcount, p->tstart, p->pstart, p->rstart, p->sids, plan.s_pts,
-                     plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes);
+                     plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes, plan.run_chunk);
   hipLaunchKernelGGL(k_pairs, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
                      plan.run_nodes, p->pkeys, p->pvals);
   size_t b3 = 0, b4 = 0, b5 = 0;
@@ -315,11 +405,71 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   PCHK(rocprim::exclusive_scan(p->tmp, b5, p->bcount, plan.blk_start, 0, n_entries, rocprim::plus<int>(), st));
   PCHK(hipMemcpyAsync(plan.blk_key, p->ukeys, sizeof(unsigned) * n_entries, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_totals2, dim3(1), dim3(1), 0, st, p->scal, p->ukeys, plan.blk_start, (int)n_entries);
-  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  // ---- phase C: (workgroup, pair) records for the LDS-merged Gram path -------------------
+  const size_t n_wg = pos_bound / 256 + 1;
+  if (n_entries > p->cap_w) {
+    size_t c;
+    c = p->cap_w; PCHK(grow_raw(p->wkeys, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->swkeys, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->uwkeys, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->wvals, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->swvals, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->wcount, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->wstart, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->pv2, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->spv2, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->b2count, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->pk2, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->spk2, c, n_entries));
+    c = p->cap_w; PCHK(grow_raw(p->upk2, c, n_entries));
+    p->cap_w = c;
+  }
+  {
+    size_t c1 = plan.cap_wg, c2 = plan.cap_wg;
+    PCHK(grow_raw(plan.wg_first, c1, n_wg));
+    PCHK(grow_raw(plan.wg_last, c2, n_wg));
+    plan.cap_wg = c1 < c2 ? c1 : c2;
+  }
+  PCHK(grow_raw(plan.run_lidx, plan.cap_lidx, 10 * runs_bound));
+  PCHK(grow_raw(plan.blk2_start, plan.cap_b2start, n_entries + 1));
+  PCHK(grow_raw(plan.blk2_entry, plan.cap_b2entry, n_entries));
+  PCHK(hipMemsetAsync(p->scal + 5, 0, 3 * sizeof(int), st));
+  PCHK(hipMemsetAsync(plan.wg_first, 0, n_wg * sizeof(int), st));
+  PCHK(hipMemsetAsync(plan.wg_last, 0xFF, n_wg * sizeof(int), st));   // -1
+  hipLaunchKernelGGL(k_pairs2, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
+                     plan.run_nodes, plan.run_chunk, p->wkeys, p->wvals);
+  size_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+  PCHK(rocprim::radix_sort_pairs(nullptr, c1, p->wkeys, p->swkeys, p->wvals, p->swvals, n_entries, 0, 64, st));
+  PCHK(rocprim::run_length_encode(nullptr, c2, p->swkeys, n_entries, p->uwkeys, p->wcount, p->scal + 5, st));
+  PCHK(rocprim::exclusive_scan(nullptr, c3, p->wcount, p->wstart, 0, n_entries, rocprim::plus<int>(), st));
+  PCHK(rocprim::radix_sort_pairs(nullptr, c4, p->pk2, p->spk2, p->pv2, plan.blk2_entry, n_entries, 0, 32, st));
+  PCHK(rocprim::run_length_encode(nullptr, c5, p->spk2, n_entries, p->upk2, p->b2count, p->scal + 4, st));
+  size_t cm = std::max(std::max(c1, c2), std::max(std::max(c3, c4), c5));
+  PCHK(ensure_tmp(p, cm));
+  PCHK(rocprim::radix_sort_pairs(p->tmp, c1, p->wkeys, p->swkeys, p->wvals, p->swvals, n_entries, 0, 64, st));
+  PCHK(rocprim::run_length_encode(p->tmp, c2, p->swkeys, n_entries, p->uwkeys, p->wcount, p->scal + 5, st));
+  PCHK(rocprim::exclusive_scan(p->tmp, c3, p->wcount, p->wstart, 0, n_entries, rocprim::plus<int>(), st));
+  const dim3 ge((n_entries + 255) / 256);
+  hipLaunchKernelGGL(k_wg_bounds, ge, blk, 0, st, (int)n_entries, p->scal, p->uwkeys, plan.wg_first, plan.wg_last,
+                     p->pk2, p->pv2);
+  hipLaunchKernelGGL(k_wg_max, dim3((n_wg + 255) / 256), blk, 0, st, (int)n_wg, plan.wg_first, plan.wg_last,
+                     p->scal);
+  hipLaunchKernelGGL(k_run_lidx, ge, blk, 0, st, (int)n_entries, p->scal, p->uwkeys, p->wstart, p->wcount,
+                     p->swvals, plan.wg_first, plan.run_lidx);
+  // pair -> records: same pair order as blk_key (both are the ascending unique pair keys)
+  PCHK(rocprim::radix_sort_pairs(p->tmp, c4, p->pk2, p->spk2, p->pv2, plan.blk2_entry, n_entries, 0, 32, st));
+  PCHK(rocprim::run_length_encode(p->tmp, c5, p->spk2, n_entries, p->upk2, p->b2count, p->scal + 4, st));
+  PCHK(rocprim::exclusive_scan(p->tmp, c3, p->b2count, plan.blk2_start, 0, n_entries, rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(k_totals3, dim3(1), dim3(1), 0, st, p->scal, plan.blk2_start);
+
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
   out->n_tuples = p->scal_host[0];
   out->n_pos = (p->scal_host[1] + 63) / 64 * 64;
   out->n_runs = p->scal_host[2];
   out->n_blocks = p->scal_host[3];
+  out->n_wblk = p->scal_host[6];
+  out->max_wblk_per_wg = p->scal_host[7];
+  PCHK(grow_raw(plan.wgslab, plan.cap_wgslab, (size_t)SLM_WREC * (out->n_wblk + 1)));
   return hipGetLastError();
 }

@@ -187,7 +187,7 @@ def test_c2_assembly_paths_agree_and_match_oracle_terms(c2):
         [rng.normal(0, 0.01, (c2.J, 4)), rng.normal(0, 0.002, (c2.J, 3))], axis=1)
     bt = torch.from_numpy(beta).cuda()
     out = []
-    for dp in (0, 1):
+    for dp in (0, 1, 2):
         e = _engine(data_path=dp, solver_path=1)
         e.bind(0, _dframe(c2))
         _lib.check(e.lib.slm_set_beta(e.h, 0, bt.data_ptr(), e.stream), "set_beta")
@@ -201,7 +201,8 @@ def test_c2_assembly_paths_agree_and_match_oracle_terms(c2):
             t = orc.data_term(orc.Frame.from_scene(c2), beta, 1.0)
             np.testing.assert_array_equal(np.nonzero(m.cpu().numpy())[0], t.match)
             np.testing.assert_allclose(r.cpu().numpy()[t.match], t.r, rtol=0, atol=1e-10)
-    np.testing.assert_allclose(out[0], out[1], rtol=0, atol=1e-9 * max(1.0, np.abs(out[1]).max()))
+    for k in (1, 2):
+        np.testing.assert_allclose(out[0], out[k], rtol=0, atol=1e-9 * max(1.0, np.abs(out[k]).max()))
 
 
 def test_c2_knn_sorted_and_update_identity(c2):

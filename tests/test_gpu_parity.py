@@ -164,14 +164,14 @@ def test_mid_size_vs_oracle(N, J):
 
 
 def test_atomic_cross_check_path_agrees():
-    """data_path=1 (per-entry f64 atomics) and the default tuple-sorted MFMA assembly give
-    the same normal equations."""
+    """data_path=1 (per-entry f64 atomics), data_path=2 (one Gram per run in HBM) and the default
+    tuple-sorted MFMA assembly with workgroup-merged records give the same normal equations."""
     import torch
     g, sc, opt = load_golden("s120x160_j108")
     sf, inputs, new_data = torch_frame(sc)
     beta = torch.from_numpy(g["b1_beta"]).cuda()
     outs = []
-    for path in (0, 1):
+    for path in (0, 1, 2):
         o = ref_opt(opt)
         o.slm_data_path = path
         from super_amd.LM import LM_Solver
@@ -179,8 +179,9 @@ def test_atomic_cross_check_path_agrees():
         jtj, jtl = lm.prepareCostTerm(sf, inputs, new_data, beta, grad=True)
         outs.append((jtj.cpu().numpy(), jtl.cpu().numpy()))
     scale = np.abs(outs[0][0]).max()
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-12 * scale)
-    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-11)
+    for k in (1, 2):
+        np.testing.assert_allclose(outs[0][0], outs[k][0], rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(outs[0][1], outs[k][1], rtol=0, atol=1e-11)
 
 
 @pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
