@@ -223,9 +223,17 @@ typedef struct slm_gf_config {
   int32_t use_rot;         /* opt.mesh_rot (all J+1 rows) */
   int32_t use_face;        /* opt.mesh_face */
   int32_t max_frames;
+  int32_t seg_mode;        /* point-plane semantic weight: 0 none, 1 opt.sf_hard_seg_point_plane,
+                              2 opt.sf_soft_seg_point_plane (either implies the point-plane term,
+                              super/deform_mesh.py:76-92; needs slm_gf_bind_semantic) */
+  int32_t use_bn_morph;    /* opt.sf_bn_morph (needs slm_gf_bind_semantic) */
   int32_t reserved;
   double w_data, w_arap, w_rot, w_face; /* opt.*_weight */
   double lr;               /* opt.learning_rate (5e-5) */
+  double w_bn_morph;       /* opt.sf_bn_morph_weight (0.1) */
+  double pp_max;           /* > 0: drop squared point-plane residuals >= pp_max (2e-5 when
+                              opt.depth_model == "raft_stereo", super/deform_mesh.py:97;
+                              ignored with seg_mode != 0 like the reference) */
 } slm_gf_config;
 
 typedef struct slm_gf_frame {
@@ -238,16 +246,41 @@ typedef struct slm_gf_frame {
   int32_t pad;
 } slm_gf_frame;
 
+#define SLM_MAX_CLASSES 4
+/* Semantic-SuPer inputs of one frame (super/deform_mesh.py:76-92,126-194, super/loss.py:346-399). */
+typedef struct slm_gf_semantic {
+  int32_t num_classes;        /* opt.num_classes, 1..SLM_MAX_CLASSES */
+  int32_t pad;
+  const int32_t* sf_seg;      /* device (N)     src.seg        (indexed like sf_points) */
+  const float* sf_seg_conf;   /* device (N,C)   src.seg_conf */
+  const float* tgt_seg_conf;  /* device (T,C)   trg.seg_conf */
+  const float* img_seg_conf;  /* device (C,H,W) inputs[("seg_conf",0)][0] */
+  const int32_t* img_seg;     /* device (H,W)   inputs[("seg",0)][0,0] */
+} slm_gf_semantic;
+
 int slm_gf_create(const slm_gf_config* cfg, slm_gf** out);
 int slm_gf_destroy(slm_gf* g);
 /* Binds device pointers to `slot` and resets deform_verts to identity, optimiser state to 0. */
 int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* frame, void* stream);
+/* After slm_gf_bind_frame: binds the semantic inputs of the slot and extracts, per class, the
+ * class-boundary pixels of img_seg in row-major order (find_edge_region with kernel 3 +
+ * margin test, utils/utils.py:276-301, super/deform_mesh.py:149-165).  edge_counts_host, if not
+ * NULL, receives num_classes counts (synchronises `stream`). */
+int slm_gf_bind_semantic(slm_gf* g, int32_t slot, const slm_gf_semantic* sem, int32_t* edge_counts_host,
+                         void* stream);
+/* Copies the slot's boundary pixels of `class_id` ((x,y) float pairs, row-major pixel order) to
+ * device memory `xy_out_device` (capacity max_points pairs). */
+int slm_gf_get_edge_points(slm_gf* g, int32_t slot, int32_t class_id, float* xy_out_device,
+                           int32_t max_points, void* stream);
 /* num_iterations optimiser steps for slots [0,n_frames), entirely on the device. */
 int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream);
 /* Copies deform_verts ((J+1)*7 doubles) of the slot into caller device memory. */
 int slm_gf_get_deform(slm_gf* g, int32_t slot, double* out_device, void* stream);
-/* One loss + gradient evaluation at dv_device ((J+1)*7): terms_device[0..3] = face, arap,
- * rot, point_plane losses (already weighted), terms_device[4] = matched surfels;
+/* One loss + gradient evaluation at dv_device ((J+1)*7): terms_device[8]: [0..3] = face, arap,
+ * rot, point_plane losses (already weighted), [4] = point-plane residuals kept, [5] = boundary
+ * morphing loss (weighted; NaN when candidates exist but none passes the > 15 test, like the
+ * reference's mean over an empty tensor), [6] = surfels kept by the morphing term,
+ * [7] = 1 when some class contributed to it (the loss key exists in the reference);
  * grad_device ((J+1)*7) = d(sum)/d(dv) with the global row divided by J like the reference. */
 int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv_device, double* terms_device,
                      double* grad_device, void* stream);

@@ -4,13 +4,17 @@ A float64 PyTorch-CPU restatement of the reference's DEFAULT per-frame optimiser
 autograd path ``GraphFit`` (``super/deform_mesh.py:198-230,251-379`` with the loss terms of
 ``super/loss.py:293-401,458-473,502-505``): skin the stable surfels with the local warps,
 apply the global row T_g, evaluate face / ARAP / Rot / point-to-plane losses, backprop,
-scale the global row's gradient by 1/J, step SGD(momentum 0.9) or Adam.  This is the path
+scale the global row's gradient by 1/J, step SGD(momentum 0.9) or Adam; plus the
+Semantic-SuPer terms of the same function: the hard / soft segmentation weight on the
+point-to-plane residuals (``loss.py:346-399``), the optional ``max`` clip (``loss.py:369-370``)
+and the semantic-boundary morphing term (``deform_mesh.py:126-194``).  This is the path
 BASELINE.json names as the reported CPU baseline (``configs[0]``); ``bench.py`` times it on
 the host cores, and it is the parity reference for the hand-derived-gradient HIP version.
 
 Pinned against the reference itself by ``tests/golden/make_golden.py`` (``gf_*`` arrays in
 the fixtures): per-term losses and d(loss)/d(deform_verts) at iteration 0, and the final
-``deform_verts`` after 10 iterations of SGD and of Adam.  Only ``tests/`` and ``bench.py``'s
+``deform_verts`` after 10 iterations of SGD and of Adam; ``s60x80_j48_semantic`` pins the
+semantic terms the same way.  Only ``tests/`` and ``bench.py``'s
 ``cpu_baseline`` leg import this module.
 """
 from __future__ import annotations
@@ -19,6 +23,7 @@ from types import SimpleNamespace
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 F64 = torch.float64
 
@@ -55,6 +60,14 @@ class Problem:
         K = sc.K
         self.fx, self.fy, self.cx, self.cy = (float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
                                                float(K[1, 2]))
+        self.C = int(getattr(sc, "num_classes", 0) or 0)
+        if self.C:
+            self.sf_seg = _t(sc.sf_seg, torch.long)[st]            # src.seg[isStable]
+            self.sf_seg_conf = _t(sc.sf_seg_conf)[st]              # src.seg_conf[isStable]
+            self.tgt_seg_conf = _t(sc.tgt_seg_conf)                # trg.seg_conf (T,C)
+            self.img_seg_conf = _t(sc.img_seg_conf)[None]          # inputs[("seg_conf",0)] (1,C,H,W)
+            self.img_seg = _t(sc.img_seg, torch.long)              # inputs[("seg",0)][0,0]
+            self.edge_pts = None
 
 
 def deform(pb: Problem, dv):
@@ -70,10 +83,23 @@ def deform(pb: Problem, dv):
     return verts, sf
 
 
-def point_plane(pb: Problem, sf):
-    """``DataLoss.autograd_forward`` with ``loss_type='point-plane'`` (loss.py:293-366):
+def kld(P, Q, eps=1e-13):
+    """``KLD`` (utils/utils.py:244-250)."""
+    return (P * (P / (Q + eps) + eps).log()).sum(-1)
+
+
+def jsd(P, Q, eps=1e-13):
+    """``JSD`` (utils/utils.py:252-254)."""
+    M = 0.5 * (P + Q)
+    return 0.5 * (kld(P, M, eps) + kld(Q, M, eps))
+
+
+def point_plane(pb: Problem, sf, seg_mode=None, pp_max=None):
+    """``DataLoss.autograd_forward`` with ``loss_type='point-plane'`` (loss.py:293-401):
     margin-1 validity on ROUNDED projections, 4 taps all mapped (zero fill), weights
-    differentiable through (u,v), sum of (n.(p-o))^2."""
+    differentiable through (u,v), sum of (n.(p-o))^2.  ``seg_mode`` 'soft' / 'hard' multiplies
+    each squared residual by the detached semantic weight (loss.py:379-399); ``pp_max`` drops
+    squared residuals >= max (loss.py:369-370, only without segmentation)."""
     Z = sf[:, 2] + 1e-8
     u_ = sf[:, 0] * pb.fx / Z + pb.cx
     v_ = sf[:, 1] * pb.fy / Z + pb.cy
@@ -85,15 +111,85 @@ def point_plane(pb: Problem, sf):
     mb = torch.stack([fu, cu, fu, cu], -1)
     rows = pb.index_map[nb.long(), mb.long()]            # (M,4)
     tap_ok = (rows >= 0).all(-1)
-    feat = torch.cat([pb.o, pb.n], -1)
-    U = torch.zeros(rows.shape + (6,), dtype=F64)
+    feats = [pb.o, pb.n] + ([pb.tgt_seg_conf] if seg_mode else [])
+    feat = torch.cat(feats, -1)
+    U = torch.zeros(rows.shape + (feat.shape[-1],), dtype=F64)
     U[rows >= 0] = feat[rows[rows >= 0]]
     an = torch.clamp(1 - torch.abs(nb - v[:, None]), min=0)[..., None]
     am = torch.clamp(1 - torch.abs(mb - u[:, None]), min=0)[..., None]
     out = (U * an * am).sum(-2)
     o, n = out[:, 0:3], out[:, 3:6]
-    r = (n[tap_ok] * (P[tap_ok] - o[tap_ok])).sum(-1)
-    return (r ** 2).sum(), int(tap_ok.sum())
+    losses = (n[tap_ok] * (P[tap_ok] - o[tap_ok])).sum(-1) ** 2
+    if seg_mode:
+        with torch.no_grad():
+            tconf = out[:, 6:].softmax(1)                   # trg.seg_conf is softmaxed AGAIN (loss.py:357)
+            if seg_mode == "soft":
+                wgt = torch.exp(-0.1 * jsd(pb.sf_seg_conf[ok], tconf))
+            else:
+                wgt = (pb.sf_seg[ok] == torch.argmax(tconf, dim=1)).to(F64)
+        losses = losses * wgt[tap_ok]
+    elif pp_max is not None:
+        losses = losses[losses < pp_max]
+    return losses.sum(), int(losses.numel())
+
+
+def edge_points(img_seg, num_classes, kernel=3, margin=1):
+    """Per class, the (x,y) pixels of that class with a pixel of another class in their
+    kernel x kernel neighbourhood, image border of ``kernel`` px dropped, row-major order
+    (``find_edge_region`` utils/utils.py:276-301 as called at deform_mesh.py:149-165)."""
+    seg = np.asarray(img_seg)
+    H, W = seg.shape
+    r = kernel // 2
+    out = []
+    for c in range(num_classes):
+        m = seg == c
+        other = np.pad(~m, r, constant_values=False)      # zero padding: outside is not "other"
+        near = np.zeros((H, W), bool)
+        for dy in range(kernel):
+            for dx in range(kernel):
+                near |= other[dy:dy + H, dx:dx + W]
+        e = near & m
+        e[:kernel] = e[-kernel:] = False
+        e[:, :kernel] = e[:, -kernel:] = False
+        ey, ex = np.nonzero(e)
+        keep = (ex >= margin) & (ex < W - 1 - margin) & (ey >= margin) & (ey < H - 1 - margin)
+        out.append(torch.from_numpy(np.stack([ex[keep], ey[keep]], 1).astype(np.float64)).reshape(-1, 2))
+    return out
+
+
+def bn_morph(pb: Problem, sf):
+    """Semantic-boundary morphing term (deform_mesh.py:126-194): surfels whose class differs
+    from the class of the pixel they project to are pulled towards the 2 nearest boundary pixels
+    of their own class; mean over the surfels whose mean squared distance exceeds 15.
+    Returns None when no class contributes a list entry, else the (possibly NaN) mean."""
+    Z = sf[:, 2] + 1e-8
+    x = sf[:, 0] * pb.fx / Z + pb.cx
+    y = sf[:, 1] * pb.fy / Z + pb.cy
+    grid = torch.stack([x, y], 1)
+    sg = torch.stack([x / pb.W * 2 - 1, y / pb.H * 2 - 1], 1)
+    with torch.no_grad():
+        new_seg = F.grid_sample(pb.img_seg_conf, sg[None, :, None, :].detach(), align_corners=False
+                                )[0, :, :, 0].argmax(0)
+    val = (new_seg != pb.sf_seg) & (sg[:, 0] > -1) & (sg[:, 0] < 1) & (sg[:, 1] > -1) & (sg[:, 1] < 1)
+    if pb.edge_pts is None:
+        pb.edge_pts = edge_points(pb.img_seg.numpy(), pb.C)
+    parts = []
+    for c in range(pb.C):
+        cm = (pb.sf_seg == c) & val
+        E = pb.edge_pts[c]
+        if not bool(cm.any()) or len(E) == 0:
+            continue
+        g = grid[cm]
+        d2 = ((g[:, None, :] - E[None, :, :]) ** 2).sum(-1)
+        order = torch.argsort(d2.detach(), dim=1, stable=True)[:, :2]
+        kd = torch.sqrt(torch.gather(d2.detach(), 1, order))
+        dte = torch.minimum(torch.minimum(g.min(1).values, pb.W - g[:, 0]), pb.H - g[:, 1])
+        ok = ~torch.any(kd > dte[:, None], dim=1)
+        li = ((E[order][ok] - g[ok][:, None, :]) ** 2).sum(2).mean(1)
+        parts.append(li[li > 15])
+    if not parts:
+        return None
+    return torch.cat(parts).mean()
 
 
 def arap(pb: Problem, dv_local):
@@ -121,7 +217,8 @@ def default_opt(**kw):
     o = SimpleNamespace(sf_point_plane=True, sf_point_plane_weight=1.0, mesh_arap=True,
                         mesh_arap_weight=10.0, mesh_rot=True, mesh_rot_weight=1.0, mesh_face=False,
                         mesh_face_weight=1.0, num_optimize_iterations=10, optimizer="SGD",
-                        learning_rate=5e-5)
+                        learning_rate=5e-5, sf_soft_seg_point_plane=False, sf_hard_seg_point_plane=False,
+                        sf_bn_morph=False, sf_bn_morph_weight=1.0, depth_model="monodepth2")
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -137,10 +234,18 @@ def total_loss(pb: Problem, dv, opt):
         terms["arap_loss"] = opt.mesh_arap_weight * arap(pb, dv[:-1])
     if opt.mesh_rot:
         terms["rot_loss"] = opt.mesh_rot_weight * rot(dv)
-    if opt.sf_point_plane:
-        pp, m = point_plane(pb, sf)
+    soft = getattr(opt, "sf_soft_seg_point_plane", False)
+    hard = getattr(opt, "sf_hard_seg_point_plane", False)
+    if opt.sf_point_plane or soft or hard:
+        seg_mode = "soft" if soft else ("hard" if hard else None)     # soft wins (loss.py:384)
+        pp_max = 2e-5 if (seg_mode is None and getattr(opt, "depth_model", "") == "raft_stereo") else None
+        pp, m = point_plane(pb, sf, seg_mode, pp_max)
         terms["point_plane_loss"] = opt.sf_point_plane_weight * pp
         terms["_matched"] = m
+    if getattr(opt, "sf_bn_morph", False):
+        bm = bn_morph(pb, sf)
+        if bm is not None:
+            terms["sf_bn_morph_loss"] = opt.sf_bn_morph_weight * bm
     loss = sum(v for k, v in terms.items() if not k.startswith("_"))
     return loss, terms
 

@@ -1,0 +1,64 @@
+// slm_gf.h -- state shared by the GraphFit kernels (slm_gf.hip) and the Semantic-SuPer
+// kernels (slm_sem.hip).
+#pragma once
+#include "slm_data.h"
+
+struct GfSlot {
+  slm_gf_frame f;
+  int32_t bound;
+  int32_t step;          // optimiser steps done
+  double* dv;            // (J+1,7)
+  double* grad;          // (J+1,7)
+  double* m1;            // momentum buffer / Adam exp_avg
+  double* m2;            // Adam exp_avg_sq
+  double* terms;         // [0..3] face, arap, rot, point-plane; [4] residuals kept;
+                         // [5] morphing loss sum (weighted mean after k_gf_finish), [6] kept, [7] candidates
+  // ---- Semantic-SuPer (slm_gf_bind_semantic) ----
+  slm_gf_semantic sem;
+  int32_t sem_bound;
+  int32_t edge_off[SLM_MAX_CLASSES + 1];   // class c owns edge_xy[edge_off[c] .. edge_off[c+1])
+  float2* edge_xy;       // boundary pixels (x,y), per class, row-major pixel order
+  double2* morph_g;      // (N) d(loss_i)/d(x,y) of the morphing term, 0 when not kept
+};
+
+// R(q)^T c for an un-normalised quaternion = R(conj q) c
+__device__ __forceinline__ d3 quat_apply_t(double w, d3 v, d3 c) {
+  return quat_apply(w, {-v.x, -v.y, -v.z}, c);
+}
+
+// deformed surfel i: T(p) = sum_k w_k [R(q_k)(p-g_k) + b_k + g_k], P = R(q_g) T + b_g
+// (deform_source, super/deform_mesh.py:198-221)
+struct GfSkin {
+  int id[4];
+  double w[4], qw[4];
+  d3 qv[4], dk[4], T, P;
+  double gw;
+  d3 gv;
+};
+
+__device__ __forceinline__ void gf_skin(const GfSlot& s, int i, GfSkin& k) {
+  const slm_frame& f = s.f.base;
+  const d3 p = {(double)f.sf_points[3 * i], (double)f.sf_points[3 * i + 1], (double)f.sf_points[3 * i + 2]};
+  const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
+  const float4 wf = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
+  k.id[0] = ids.x; k.id[1] = ids.y; k.id[2] = ids.z; k.id[3] = ids.w;
+  k.w[0] = (double)wf.x; k.w[1] = (double)wf.y; k.w[2] = (double)wf.z; k.w[3] = (double)wf.w;
+  k.T = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const double* b = s.dv + 7 * k.id[a];
+    const d3 g = {(double)f.ed_points[3 * k.id[a]], (double)f.ed_points[3 * k.id[a] + 1],
+                  (double)f.ed_points[3 * k.id[a] + 2]};
+    k.qw[a] = b[0];
+    k.qv[a] = {b[1], b[2], b[3]};
+    k.dk[a] = p - g;
+    d3 t = quat_apply(k.qw[a], k.qv[a], k.dk[a]);
+    t = {t.x + b[4] + g.x, t.y + b[5] + g.y, t.z + b[6] + g.z};
+    k.T = {k.T.x + k.w[a] * t.x, k.T.y + k.w[a] * t.y, k.T.z + k.w[a] * t.z};
+  }
+  const double* bgl = s.dv + 7 * f.J;
+  k.gw = bgl[0];
+  k.gv = {bgl[1], bgl[2], bgl[3]};
+  k.P = quat_apply(k.gw, k.gv, k.T);
+  k.P = {k.P.x + bgl[4], k.P.y + bgl[5], k.P.z + bgl[6]};
+}

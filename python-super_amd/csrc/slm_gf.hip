@@ -14,34 +14,22 @@
 #include <string>
 #include <vector>
 
-#include "slm_data.h"
-
-struct GfSlot {
-  slm_gf_frame f;
-  int32_t bound;
-  int32_t step;          // optimiser steps done
-  double* dv;            // (J+1,7)
-  double* grad;          // (J+1,7)
-  double* m1;            // momentum buffer / Adam exp_avg
-  double* m2;            // Adam exp_avg_sq
-  double* terms;         // [0..3] face, arap, rot, point-plane; [4] matched
-};
-
-// R(q)^T c for an un-normalised quaternion = R(conj q) c
-__device__ __forceinline__ d3 quat_apply_t(double w, d3 v, d3 c) {
-  return quat_apply(w, {-v.x, -v.y, -v.z}, c);
-}
+#include "slm_sem.h"
 
 __global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
   GfSlot& s = slots[blockIdx.y];
   if (!s.bound) return;
   const int n = (s.f.base.J + 1) * 7;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) s.grad[e] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x < 5) s.terms[threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < 8) s.terms[threadIdx.x] = 0.0;
 }
 
 // grid = (ceil(maxN/256), n_frames)
-__global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, double lam) {
+// seg_mode: 0 none, 1 hard, 2 soft semantic weight on the squared residual (loss.py:379-399);
+// pp_max > 0 (and no seg_mode): squared residuals >= pp_max are dropped (loss.py:369-370);
+// use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
+__global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode,
+                                                  double pp_max, int use_morph, double w_morph) {
   __shared__ double sm[16];
   GfSlot& s = slots[blockIdx.y];
   if (!s.bound) return;
@@ -50,38 +38,21 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, dou
   const int J = f.J;
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0;
   if (i < f.N && (!s.f.sf_stable || s.f.sf_stable[i])) {
-    const d3 p = {(double)f.sf_points[3 * i], (double)f.sf_points[3 * i + 1], (double)f.sf_points[3 * i + 2]};
-    const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
-    const float4 wf = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
-    const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-    const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
-    double qw[4];
-    d3 qv[4], dk[4], T = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double* b = s.dv + 7 * id[k];
-      const d3 g = {(double)f.ed_points[3 * id[k]], (double)f.ed_points[3 * id[k] + 1],
-                    (double)f.ed_points[3 * id[k] + 2]};
-      qw[k] = b[0];
-      qv[k] = {b[1], b[2], b[3]};
-      dk[k] = p - g;
-      d3 t = quat_apply(qw[k], qv[k], dk[k]);
-      t = {t.x + b[4] + g.x, t.y + b[5] + g.y, t.z + b[6] + g.z};
-      T = {T.x + w[k] * t.x, T.y + w[k] * t.y, T.z + w[k] * t.z};
-    }
-    const double* bgl = s.dv + 7 * J;
-    const double gw = bgl[0];
-    const d3 gv = {bgl[1], bgl[2], bgl[3]};
-    d3 P = quat_apply(gw, gv, T);
-    P = {P.x + bgl[4], P.y + bgl[5], P.z + bgl[6]};
-
+    GfSkin k;
+    gf_skin(s, i, k);
+    const d3 P = k.P;
     const double fx = (double)f.fx, fy = (double)f.fy, cx = (double)f.cx, cy = (double)f.cy;
     const double Ze = P.z + 1e-8;
+    // the forward divides by Z + 1e-8, and so does its derivative
+    const d3 Pi0 = {fx / Ze, 0.0, -fx * P.x / (Ze * Ze)};
+    const d3 Pi1 = {0.0, fy / Ze, -fy * P.y / (Ze * Ze)};
+    d3 gP = {0, 0, 0};   // dL/dP of this surfel
+    bool any = false;
     const double u_ = P.x * fx / Ze + cx, v_ = P.y * fy / Ze + cy;
     const double ur = rint(u_), vr = rint(v_);
     const int H = f.H, W = f.W;
     // valid_margin = 1 (loss.py:306-309)
-    if (vr >= 1.0 && vr < (double)(H - 2) && ur >= 1.0 && ur < (double)(W - 2)) {
+    if (use_pp && vr >= 1.0 && vr < (double)(H - 2) && ur >= 1.0 && ur < (double)(W - 2)) {
       const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
       const double nn[4] = {fv, fv, cv, cv}, mm[4] = {fu, cu, fu, cu};
       int rows[4];
@@ -93,6 +64,8 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, dou
       }
       if (all_ok) {
         d3 o = {0, 0, 0}, n = {0, 0, 0}, dou = {0, 0, 0}, dov = {0, 0, 0}, dnu = {0, 0, 0}, dnv = {0, 0, 0};
+        double conf[SLM_MAX_CLASSES] = {0, 0, 0, 0};
+        const int C = (seg_mode && s.sem_bound) ? s.sem.num_classes : 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const double dn = nn[t] - v_, dm = mm[t] - u_;
@@ -112,39 +85,87 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, dou
           dov = {dov.x + Pt.x * gvv, dov.y + Pt.y * gvv, dov.z + Pt.z * gvv};
           dnu = {dnu.x + Nt.x * gu, dnu.y + Nt.y * gu, dnu.z + Nt.z * gu};
           dnv = {dnv.x + Nt.x * gvv, dnv.y + Nt.y * gvv, dnv.z + Nt.z * gvv};
+          for (int c = 0; c < C; ++c) conf[c] += (double)s.sem.tgt_seg_conf[(size_t)rows[t] * C + c] * wv;
         }
         const d3 e = P - o;
         const double r = dot(n, e);
-        loss = lam * r * r;
-        cnt = 1.0;
-        // c = dr/dP ; the forward divides by Z + 1e-8, and so does its derivative
-        const d3 Pi0 = {fx / Ze, 0.0, -fx * P.x / (Ze * Ze)};
-        const d3 Pi1 = {0.0, fy / Ze, -fy * P.y / (Ze * Ze)};
-        const double s0 = dot(e, dnu) - dot(n, dou), s1 = dot(e, dnv) - dot(n, dov);
-        const d3 c = {n.x + s0 * Pi0.x + s1 * Pi1.x, n.y + s0 * Pi0.y + s1 * Pi1.y,
-                      n.z + s0 * Pi0.z + s1 * Pi1.z};
-        const double G = 2.0 * lam * r;
-        double jq[4];
-        quat_jac_row(gw, gv, T, c, jq);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) gq[a] = G * jq[a];
-        gb[0] = G * c.x;
-        gb[1] = G * c.y;
-        gb[2] = G * c.z;
-        const d3 cl = quat_apply_t(gw, gv, c);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          quat_jac_row(qw[k], qv[k], dk[k], cl, jq);
-          const double Gw = G * w[k];
-          double* gr = s.grad + 7 * id[k];
-          atomic_add_f64(gr + 0, Gw * jq[0]);
-          atomic_add_f64(gr + 1, Gw * jq[1]);
-          atomic_add_f64(gr + 2, Gw * jq[2]);
-          atomic_add_f64(gr + 3, Gw * jq[3]);
-          atomic_add_f64(gr + 4, Gw * cl.x);
-          atomic_add_f64(gr + 5, Gw * cl.y);
-          atomic_add_f64(gr + 6, Gw * cl.z);
+        double wgt = 1.0;
+        bool keep = true;
+        if (C > 0) {
+          // sampled trg.seg_conf is softmaxed again (loss.py:357); weights are detached
+          double mx = conf[0];
+          int am = 0;
+          for (int c = 1; c < C; ++c)
+            if (conf[c] > mx) {
+              mx = conf[c];
+              am = c;
+            }
+          if (seg_mode == 1) {
+            wgt = (s.sem.sf_seg[i] == am) ? 1.0 : 0.0;
+          } else {
+            double q[SLM_MAX_CLASSES], den = 0.0;
+            for (int c = 0; c < C; ++c) {
+              q[c] = exp(conf[c] - mx);
+              den += q[c];
+            }
+            // JSD(P, Q) = (KL(P|M) + KL(Q|M)) / 2, KL(P|Q) = sum P log(P / (Q + eps) + eps)  (utils.py:244-254)
+            const double eps = 1e-13;
+            double k1 = 0.0, k2 = 0.0;
+            for (int c = 0; c < C; ++c) {
+              const double pc = (double)s.sem.sf_seg_conf[(size_t)i * C + c], qc = q[c] / den;
+              const double m = 0.5 * (pc + qc);
+              k1 += pc * log(pc / (m + eps) + eps);
+              k2 += qc * log(qc / (m + eps) + eps);
+            }
+            wgt = exp(-0.1 * (0.5 * (k1 + k2)));
+          }
+        } else if (pp_max > 0.0) {
+          keep = (r * r) < pp_max;
         }
+        if (keep) {
+          loss = lam * wgt * r * r;
+          cnt = 1.0;
+          // c = dr/dP
+          const double s0 = dot(e, dnu) - dot(n, dou), s1 = dot(e, dnv) - dot(n, dov);
+          const double G = 2.0 * lam * wgt * r;
+          gP = {G * (n.x + s0 * Pi0.x + s1 * Pi1.x), G * (n.y + s0 * Pi0.y + s1 * Pi1.y),
+                G * (n.z + s0 * Pi0.z + s1 * Pi1.z)};
+          any = true;
+        }
+      }
+    }
+    if (use_morph && s.sem_bound) {
+      // mean over the kept surfels (count from k_gf_morph, earlier in the stream)
+      const double2 mg = s.morph_g[i];
+      const double kept = s.terms[6];
+      if (kept > 0.0 && (mg.x != 0.0 || mg.y != 0.0)) {
+        const double sc = w_morph / kept;
+        gP = {gP.x + sc * (mg.x * Pi0.x + mg.y * Pi1.x), gP.y + sc * (mg.x * Pi0.y + mg.y * Pi1.y),
+              gP.z + sc * (mg.x * Pi0.z + mg.y * Pi1.z)};
+        any = true;
+      }
+    }
+    if (any) {
+      double jq[4];
+      quat_jac_row(k.gw, k.gv, k.T, gP, jq);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) gq[a] = jq[a];
+      gb[0] = gP.x;
+      gb[1] = gP.y;
+      gb[2] = gP.z;
+      const d3 cl = quat_apply_t(k.gw, k.gv, gP);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        quat_jac_row(k.qw[a], k.qv[a], k.dk[a], cl, jq);
+        const double wk = k.w[a];
+        double* gr = s.grad + 7 * k.id[a];
+        atomic_add_f64(gr + 0, wk * jq[0]);
+        atomic_add_f64(gr + 1, wk * jq[1]);
+        atomic_add_f64(gr + 2, wk * jq[2]);
+        atomic_add_f64(gr + 3, wk * jq[3]);
+        atomic_add_f64(gr + 4, wk * cl.x);
+        atomic_add_f64(gr + 5, wk * cl.y);
+        atomic_add_f64(gr + 6, wk * cl.z);
       }
     }
   }
@@ -266,12 +287,17 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
 }
 
 // grad[J] /= J, then torch.optim.SGD(momentum=0.9) or torch.optim.Adam step (float64).
+// Also turns the morphing term's sum into the reference's weighted mean (NaN over an empty set).
 __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int optimizer, double lr,
-                                                  int apply) {
+                                                  int apply, int use_morph, double w_morph) {
   GfSlot& s = slots[blockIdx.y];
   if (!s.bound) return;
   const int J = s.f.base.J, n = (J + 1) * 7;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0 && use_morph) {
+    const double kept = s.terms[6];
+    s.terms[5] = s.terms[7] != 0.0 ? (kept > 0.0 ? w_morph * s.terms[5] / kept : nan("")) : 0.0;
+  }
   if (e >= n) return;
   double g = s.grad[e];
   if (e >= 7 * J) {
@@ -380,6 +406,7 @@ struct slm_gf {
   slm_gf_config cfg{};
   std::vector<GfSlot> host;
   std::vector<size_t> cap;
+  std::vector<SemScratch> sem;
   GfSlot* dev = nullptr;
 };
 
@@ -400,8 +427,11 @@ static int gf_fail(int code, const char* msg) {
 static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
   const slm_gf_config& c = g->cfg;
   hipLaunchKernelGGL(k_gf_zero, dim3(32, n), dim3(256), 0, st, slots);
-  if (c.use_data && maxN > 0)
-    hipLaunchKernelGGL(k_gf_data, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, c.w_data);
+  const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
+  if (c.use_bn_morph) launch_gf_morph(slots, n, maxN, st);
+  if ((use_pp || c.use_bn_morph) && maxN > 0)
+    hipLaunchKernelGGL(k_gf_data, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
+                       c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph);
   if ((c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
     hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
                        c.use_rot, c.w_rot, c.use_face, c.w_face);
@@ -410,13 +440,15 @@ static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxRe
 extern "C" {
 
 int slm_gf_create(const slm_gf_config* cfg, slm_gf** out) {
-  if (!cfg || !out || cfg->max_frames < 1 || cfg->num_iterations < 0 || (cfg->optimizer != 0 && cfg->optimizer != 1))
+  if (!cfg || !out || cfg->max_frames < 1 || cfg->num_iterations < 0 || (cfg->optimizer != 0 && cfg->optimizer != 1) ||
+      cfg->seg_mode < 0 || cfg->seg_mode > 2)
     return gf_fail(SLM_ERR_INVALID, "slm_gf_create: bad argument");
   if (slm_device_count() < 1) return gf_fail(SLM_ERR_NO_DEVICE, "slm_gf_create: no HIP device visible");
   slm_gf* g = new slm_gf();
   g->cfg = *cfg;
   g->host.assign(cfg->max_frames, GfSlot{});
   g->cap.assign(cfg->max_frames, 0);
+  g->sem.assign(cfg->max_frames, SemScratch());
   hipError_t e = hipMalloc((void**)&g->dev, sizeof(GfSlot) * cfg->max_frames);
   if (e == hipSuccess) e = hipMemset(g->dev, 0, sizeof(GfSlot) * cfg->max_frames);
   if (e != hipSuccess) {
@@ -433,6 +465,7 @@ int slm_gf_destroy(slm_gf* g) {
   for (GfSlot& s : g->host) {
     if (s.dv) (void)hipFree(s.dv);   // dv | grad | m1 | m2 | terms are one allocation
   }
+  for (SemScratch& sc : g->sem) sem_free(sc);
   if (g->dev) (void)hipFree(g->dev);
   delete g;
   return SLM_OK;
@@ -465,10 +498,58 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* fr, void* str
   s.f = *fr;
   s.bound = 1;
   s.step = 0;
+  s.sem_bound = 0;   // semantic inputs belong to the frame: bind them again
   GFCHK(hipMemcpyAsync(g->dev + slot, &s, sizeof(GfSlot), hipMemcpyHostToDevice, st));
   GFCHK(hipStreamSynchronize(st));
   hipLaunchKernelGGL(k_gf_init, dim3((n + 255) / 256), dim3(256), 0, st, g->dev, slot);
   GFCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_gf_bind_semantic(slm_gf* g, int32_t slot, const slm_gf_semantic* sem, int32_t* edge_counts_host,
+                         void* stream) {
+  if (!g || !sem) return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_semantic: null argument");
+  if (slot < 0 || slot >= (int)g->host.size()) return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_semantic: bad slot");
+  GfSlot& s = g->host[slot];
+  if (!s.bound) return gf_fail(SLM_ERR_UNBOUND, "slm_gf_bind_semantic: slm_gf_bind_frame first");
+  if (sem->num_classes < 1 || sem->num_classes > SLM_MAX_CLASSES)
+    return gf_fail(SLM_ERR_UNSUPPORTED, "slm_gf_bind_semantic: num_classes must be 1..4");
+  const slm_frame& f = s.f.base;
+  const bool need_pp = g->cfg.seg_mode != 0, need_morph = g->cfg.use_bn_morph != 0;
+  if ((f.N > 0 && !sem->sf_seg) || (need_pp && ((f.N > 0 && !sem->sf_seg_conf) || (f.T > 0 && !sem->tgt_seg_conf))) ||
+      (need_morph && (!sem->img_seg_conf || !sem->img_seg)))
+    return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_semantic: null device pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SemScratch& sc = g->sem[slot];
+  s.sem = *sem;
+  for (int c = 0; c <= SLM_MAX_CLASSES; ++c) s.edge_off[c] = 0;
+  if (need_morph) {
+    GFCHK(sem_extract_edges(sc, *sem, f.H, f.W, s.edge_off, st));
+    GFCHK(sem_ensure_morph(sc, f.N));
+  }
+  s.edge_xy = sc.edge_xy;
+  s.morph_g = sc.morph_g;
+  s.sem_bound = 1;
+  if (edge_counts_host)
+    for (int c = 0; c < sem->num_classes; ++c) edge_counts_host[c] = s.edge_off[c + 1] - s.edge_off[c];
+  GFCHK(hipMemcpyAsync(g->dev + slot, &s, sizeof(GfSlot), hipMemcpyHostToDevice, st));
+  GFCHK(hipStreamSynchronize(st));
+  return SLM_OK;
+}
+
+int slm_gf_get_edge_points(slm_gf* g, int32_t slot, int32_t class_id, float* xy_out, int32_t max_points,
+                           void* stream) {
+  if (!g || slot < 0 || slot >= (int)g->host.size() || !xy_out)
+    return gf_fail(SLM_ERR_INVALID, "slm_gf_get_edge_points: bad argument");
+  const GfSlot& s = g->host[slot];
+  if (!s.bound || !s.sem_bound) return gf_fail(SLM_ERR_UNBOUND, "slm_gf_get_edge_points: no semantic inputs bound");
+  if (class_id < 0 || class_id >= s.sem.num_classes)
+    return gf_fail(SLM_ERR_INVALID, "slm_gf_get_edge_points: bad class");
+  const int n = s.edge_off[class_id + 1] - s.edge_off[class_id];
+  if (n > max_points) return gf_fail(SLM_ERR_INVALID, "slm_gf_get_edge_points: output too small");
+  if (n > 0)
+    GFCHK(hipMemcpyAsync(xy_out, s.edge_xy + s.edge_off[class_id], sizeof(float2) * n, hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream));
   return SLM_OK;
 }
 
@@ -479,6 +560,8 @@ static int gf_dims(slm_gf* g, int first, int n, int* maxN, int* maxReg, int* max
   for (int i = first; i < first + n; ++i) {
     const GfSlot& s = g->host[i];
     if (!s.bound) return gf_fail(SLM_ERR_UNBOUND, "slm_gf: slot used before slm_gf_bind_frame");
+    if ((g->cfg.seg_mode || g->cfg.use_bn_morph) && !s.sem_bound)
+      return gf_fail(SLM_ERR_UNBOUND, "slm_gf: semantic terms enabled but slm_gf_bind_semantic was not called");
     *maxN = std::max(*maxN, s.f.base.N);
     int reg = std::max(s.f.base.J * s.f.base.K_ED, s.f.base.J + 1);
     if (g->cfg.use_face) reg = std::max(reg, s.f.n_triangles);
@@ -496,7 +579,7 @@ int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream) {
   for (int it = 0; it < g->cfg.num_iterations; ++it) {
     gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st);
     hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev,
-                       g->cfg.optimizer, g->cfg.lr, 1);
+                       g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
     hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
   }
   GFCHK(hipGetLastError());
@@ -522,8 +605,8 @@ int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv, double* terms, d
   GFCHK(hipMemcpyAsync(s.dv, dv, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   gf_enqueue_eval(g, g->dev + slot, 1, maxN, maxReg, st);
   hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, 1), dim3(256), 0, st, g->dev + slot, g->cfg.optimizer,
-                     g->cfg.lr, 0);
-  if (terms) GFCHK(hipMemcpyAsync(terms, s.terms, sizeof(double) * 5, hipMemcpyDeviceToDevice, st));
+                     g->cfg.lr, 0, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
+  if (terms) GFCHK(hipMemcpyAsync(terms, s.terms, sizeof(double) * 8, hipMemcpyDeviceToDevice, st));
   if (grad) GFCHK(hipMemcpyAsync(grad, s.grad, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   GFCHK(hipGetLastError());
   return SLM_OK;

@@ -20,6 +20,7 @@ EXPORTS = [
     "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_plan_info", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
     "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
+    "slm_gf_bind_semantic", "slm_gf_get_edge_points",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
 ]
 
@@ -44,15 +45,23 @@ class SlmFrame(C.Structure):
 class SlmGfConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int32), ("optimizer", C.c_int32), ("use_data", C.c_int32),
                 ("use_arap", C.c_int32), ("use_rot", C.c_int32), ("use_face", C.c_int32),
-                ("max_frames", C.c_int32), ("reserved", C.c_int32),
+                ("max_frames", C.c_int32), ("seg_mode", C.c_int32), ("use_bn_morph", C.c_int32),
+                ("reserved", C.c_int32),
                 ("w_data", C.c_double), ("w_arap", C.c_double), ("w_rot", C.c_double),
-                ("w_face", C.c_double), ("lr", C.c_double)]
+                ("w_face", C.c_double), ("lr", C.c_double), ("w_bn_morph", C.c_double),
+                ("pp_max", C.c_double)]
 
 
 class SlmGfFrame(C.Structure):
     _fields_ = [("base", SlmFrame), ("sf_stable", C.c_void_p), ("ed_knn_w", C.c_void_p),
                 ("ed_triangles", C.c_void_p), ("ed_triangle_areas", C.c_void_p),
                 ("n_triangles", C.c_int32), ("pad", C.c_int32)]
+
+
+class SlmGfSemantic(C.Structure):
+    _fields_ = [("num_classes", C.c_int32), ("pad", C.c_int32), ("sf_seg", C.c_void_p),
+                ("sf_seg_conf", C.c_void_p), ("tgt_seg_conf", C.c_void_p),
+                ("img_seg_conf", C.c_void_p), ("img_seg", C.c_void_p)]
 
 
 class SlmIterRecord(C.Structure):
@@ -108,6 +117,8 @@ def load():
         "slm_gf_destroy": [vp],
         "slm_gf_bind_frame": [vp, i32, C.POINTER(SlmGfFrame), vp],
         "slm_gf_run": [vp, i32, vp],
+        "slm_gf_bind_semantic": [vp, i32, C.POINTER(SlmGfSemantic), C.POINTER(C.c_int32), vp],
+        "slm_gf_get_edge_points": [vp, i32, i32, vp, i32, vp],
         "slm_gf_get_deform": [vp, i32, vp, vp],
         "slm_gf_loss_grad": [vp, i32, vp, vp, vp, vp],
         "slm_apply_update_gf": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],

@@ -8,8 +8,11 @@ so ``SuPer.__init__`` / ``SuPer.fusion`` (``super/super.py:20-21,70``) can use i
     deform_param = self.graph_fit(inputs, self.sf, sfdata, models)   # (J+1,7) float64
 
 Supported loss flags: ``sf_point_plane``, ``mesh_arap``, ``mesh_rot``, ``mesh_face`` with their
-weights, ``optimizer`` in {"SGD", "Adam"}, ``learning_rate``, ``num_optimize_iterations``.  The
-Semantic-SuPer terms, ``sf_corr`` and the (unused) render loss raise ``NotImplementedError``.
+weights, the Semantic-SuPer terms ``sf_soft_seg_point_plane`` / ``sf_hard_seg_point_plane`` /
+``sf_bn_morph`` (+ ``sf_bn_morph_weight``, ``num_classes``), the ``max`` clip of the point-plane
+term that ``depth_model == "raft_stereo"`` switches on, ``optimizer`` in {"SGD", "Adam"},
+``learning_rate``, ``num_optimize_iterations``.  ``sf_corr`` (needs the optical-flow network) and
+the (unused) render loss raise ``NotImplementedError``.
 The renderer call the reference makes every iteration (deform_mesh.py:294-298) only feeds the
 render / correspondence losses and is not needed here.
 """
@@ -20,7 +23,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import SlmGfConfig, SlmGfFrame
+from ._lib import SlmGfConfig, SlmGfFrame, SlmGfSemantic
 from .LM import BoundFrame, _as, _dev_ptr, _stream_ptr
 
 
@@ -30,8 +33,7 @@ class GraphFit:
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.SuperLMError("no HIP device visible: super_amd has no CPU fallback")
-        for flag in ("sf_corr", "render_loss", "sf_bn_morph", "sf_hard_seg_point_plane",
-                     "sf_soft_seg_point_plane"):
+        for flag in ("sf_corr", "render_loss"):
             if getattr(opt, flag, False):
                 raise NotImplementedError(f"super_amd.GraphFit: opt.{flag} is not supported yet")
         self.valid_margin = 1
@@ -53,6 +55,15 @@ class GraphFit:
         cfg.w_rot = float(getattr(opt, "mesh_rot_weight", 1.0))
         cfg.w_face = float(getattr(opt, "mesh_face_weight", 1.0))
         cfg.lr = float(opt.learning_rate)
+        # Semantic-SuPer (deform_mesh.py:76-99,126-194): soft wins over hard (loss.py:384)
+        soft = bool(getattr(opt, "sf_soft_seg_point_plane", False))
+        hard = bool(getattr(opt, "sf_hard_seg_point_plane", False))
+        cfg.seg_mode = 2 if soft else (1 if hard else 0)
+        cfg.use_bn_morph = int(bool(getattr(opt, "sf_bn_morph", False)))
+        cfg.w_bn_morph = float(getattr(opt, "sf_bn_morph_weight", 0.1))
+        cfg.pp_max = 2e-5 if getattr(opt, "depth_model", None) == "raft_stereo" else 0.0
+        self.semantic = bool(cfg.seg_mode or cfg.use_bn_morph)
+        self.edge_counts = None
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib.slm_gf_create(C.byref(cfg), C.byref(self.h)), "slm_gf_create")
@@ -94,6 +105,36 @@ class GraphFit:
             fr.n_triangles = int(tri.shape[1])
         _lib.check(self.lib.slm_gf_bind_frame(self.h, slot, C.byref(fr), _stream_ptr(dev)),
                    "slm_gf_bind_frame")
+        if self.semantic:
+            # src.seg / src.seg_conf (deform_mesh.py:262-264), trg.seg_conf (loss.py:350),
+            # inputs[("seg_conf",0)] / inputs[("seg",0)] (deform_mesh.py:136,149)
+            sem = SlmGfSemantic()
+            nc = int(getattr(self.opt, "num_classes", src.seg_conf.shape[1]))
+            sem.num_classes = nc
+            seg = _as(src.seg, torch.int32, dev)
+            keep.append(seg)
+            sem.sf_seg = _dev_ptr(seg)
+            if self.cfg.seg_mode:
+                sconf = _as(src.seg_conf, torch.float32, dev)
+                tconf = _as(new_data.seg_conf, torch.float32, dev)
+                if sconf.shape[1] != nc or tconf.shape[1] != nc:
+                    raise ValueError("seg_conf must have opt.num_classes columns")
+                keep += [sconf, tconf]
+                sem.sf_seg_conf, sem.tgt_seg_conf = _dev_ptr(sconf), _dev_ptr(tconf)
+            if self.cfg.use_bn_morph:
+                iconf = _as(inputs[("seg_conf", 0)][0], torch.float32, dev)
+                iseg = inputs[("seg", 0)]
+                if iseg.shape[1] > 1:                      # find_edge_region: argmax over channels
+                    iseg = torch.argmax(iseg, dim=1, keepdim=True)
+                iseg = _as(iseg[0, 0], torch.int32, dev)
+                if iconf.shape[0] != nc:
+                    raise ValueError('inputs[("seg_conf",0)] must have opt.num_classes channels')
+                keep += [iconf, iseg]
+                sem.img_seg_conf, sem.img_seg = _dev_ptr(iconf), _dev_ptr(iseg)
+            counts = (C.c_int32 * 4)()
+            _lib.check(self.lib.slm_gf_bind_semantic(self.h, slot, C.byref(sem), counts, _stream_ptr(dev)),
+                       "slm_gf_bind_semantic")
+            self.edge_counts = list(counts)[:nc]
         self._keep[slot] = keep
         return bf
 
@@ -117,10 +158,23 @@ class GraphFit:
         bf = self._bind(0, inputs, src, trg)
         st = _stream_ptr(bf.device)
         dv = _as(deform_verts, torch.float64, bf.device)
-        terms = torch.zeros(5, dtype=torch.float64, device=bf.device)
+        terms = torch.zeros(8, dtype=torch.float64, device=bf.device)
         grad = torch.zeros((bf.J + 1, 7), dtype=torch.float64, device=bf.device)
         _lib.check(self.lib.slm_gf_loss_grad(self.h, 0, _dev_ptr(dv), _dev_ptr(terms), _dev_ptr(grad), st),
                    "slm_gf_loss_grad")
         t = terms.cpu().tolist()
-        return (dict(face_losses=t[0], arap_loss=t[1], rot_loss=t[2], point_plane_loss=t[3]), int(t[4]),
-                grad)
+        d = dict(face_losses=t[0], arap_loss=t[1], rot_loss=t[2], point_plane_loss=t[3])
+        if self.cfg.use_bn_morph and t[7] != 0.0:       # the reference only adds the key when a class contributes
+            d["sf_bn_morph_loss"] = t[5]
+        self.last_bn_morph_kept = int(t[6])
+        return d, int(t[4]), grad
+
+    def edge_points(self, class_id):
+        """Boundary pixels (x,y) of ``class_id`` extracted at the last bind (``self.edge_pts`` of the
+        reference, deform_mesh.py:145-165), float32 (E,2) on the device."""
+        n = self.edge_counts[class_id]
+        dev = self._keep[0][0].device
+        out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.slm_gf_get_edge_points(self.h, 0, class_id, _dev_ptr(out), n, _stream_ptr(dev)),
+                   "slm_gf_get_edge_points")
+        return out

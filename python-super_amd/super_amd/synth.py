@@ -144,6 +144,13 @@ class Scene:
     valid: np.ndarray             # (H*W,) bool
     ed_triangles: np.ndarray = None       # (3,Tr) i64 node-grid triangles (graph_encoder.py:11-67 schema)
     ed_triangle_areas: np.ndarray = None  # (Tr,) f32
+    # Semantic-SuPer inputs (make_scene(semantic=True)); data_loader.py:319-331,455-457,494-496
+    num_classes: int = 0
+    img_seg_conf: np.ndarray = None       # (C,H,W) f32  inputs[("seg_conf",0)][0]
+    img_seg: np.ndarray = None            # (H,W) i64    inputs[("seg",0)][0,0]
+    tgt_seg_conf: np.ndarray = None       # (T,C) f32    trg.seg_conf (per-pixel softmax of img_seg_conf)
+    sf_seg: np.ndarray = None             # (N,) i64     src.seg
+    sf_seg_conf: np.ndarray = None        # (N,C) f32    src.seg_conf
     meta: dict = field(default_factory=dict)
 
     @property
@@ -162,9 +169,37 @@ class Scene:
         return getattr(self, name).astype(np.float64)
 
 
+def _box_mean(x, k):
+    """k x k mean filter over the last two axes, borders averaged over the in-image part
+    (``nn.AvgPool2d(k, 1, k//2, count_include_pad=False)``, data_loader.py:322)."""
+    r = k // 2
+    H, W = x.shape[-2:]
+    c = np.zeros(x.shape[:-2] + (H + 1, W + 1))
+    c[..., 1:, 1:] = x.cumsum(-2).cumsum(-1)
+    y0, y1 = np.clip(np.arange(H) - r, 0, H), np.clip(np.arange(H) + r + 1, 0, H)
+    x0, x1 = np.clip(np.arange(W) - r, 0, W), np.clip(np.arange(W) + r + 1, 0, W)
+    tot = (c[..., y1[:, None], x1[None, :]] - c[..., y0[:, None], x1[None, :]]
+           - c[..., y1[:, None], x0[None, :]] + c[..., y0[:, None], x0[None, :]])
+    return tot / ((y1 - y0)[:, None] * (x1 - x0)[None, :])
+
+
+def _softmax(x, axis):
+    e = np.exp(x - x.max(axis=axis, keepdims=True))
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def _class_logits(u, v, H, W, C, shift):
+    """Logits +-4 of C wavy vertical class bands, shifted ``shift`` px to the right."""
+    b = np.zeros(np.shape(u), np.int64)
+    for c in range(1, C):
+        b += (u - shift) >= c * W / C + 0.05 * W * np.sin(2.0 * np.pi * 1.5 * v / H + c)
+    return np.where(np.arange(C).reshape((C,) + (1,) * np.ndim(u)) == b[None], 4.0, -4.0)
+
+
 def make_scene(N=50_000, J=512, H=480, W=640, seed=0, n_neighbors=4, n_ed_neighbors=4,
                phi=0.3, dphi=0.15, src_border=10, tgt_border=4, jitter=0.35,
-               depth_noise=1e-4, tgt_holes=0.0) -> Scene:
+               depth_noise=1e-4, tgt_holes=0.0, semantic=False, num_classes=3, seg_shift=6.0,
+               seg_smooth=5) -> Scene:
     """Build the seeded synthetic frame pair described in the module docstring."""
     rng = np.random.default_rng(seed)
     K = intrinsics() if (H, W) == (480, 640) else _scaled_intrinsics(H, W)
@@ -221,7 +256,21 @@ def make_scene(N=50_000, J=512, H=480, W=640, seed=0, n_neighbors=4, n_ed_neighb
     ds, sf_knn_idx = _knn(sf_points.astype(np.float64), e64, n_neighbors)
     sf_knn_w = _f32(softmax_exp_weights(ds, ed_radii.astype(np.float64)[sf_knn_idx]))
 
-    return Scene(H=H, W=W, K=K, sf_points=sf_points, sf_norms=sf_norms,
+    sem = {}
+    if semantic:
+        # class bands: the target image is the source segmentation moved seg_shift px
+        C = num_classes
+        img_conf = _f32(_box_mean(_class_logits(uu, vv, H, W, C, seg_shift), seg_smooth))
+        src_conf = _box_mean(_class_logits(uu, vv, H, W, C, 0.0), seg_smooth)
+        pv = np.clip(np.rint(sv).astype(np.int64), 0, H - 1)
+        pu = np.clip(np.rint(su).astype(np.int64), 0, W - 1)
+        sf_conf = _f32(_softmax(src_conf[:, pv, pu].T, 1))
+        sem = dict(num_classes=C, img_seg_conf=img_conf,
+                   img_seg=np.argmax(img_conf, axis=0).astype(np.int64),
+                   tgt_seg_conf=_f32(_softmax(img_conf.astype(np.float64), 0).transpose(1, 2, 0)[valid_map]),
+                   sf_seg=np.argmax(sf_conf, axis=1).astype(np.int64), sf_seg_conf=sf_conf)
+
+    return Scene(**sem, H=H, W=W, K=K, sf_points=sf_points, sf_norms=sf_norms,
                  sf_knn_idx=np.ascontiguousarray(sf_knn_idx, dtype=np.int64), sf_knn_w=sf_knn_w,
                  ed_points=ed_points, ed_norms=ed_norms, ed_radii=ed_radii,
                  ed_knn_idx=np.ascontiguousarray(ed_knn_idx, dtype=np.int64), ed_knn_w=ed_knn_w,

@@ -1,6 +1,6 @@
 """Generate golden vectors by running the REFERENCE itself (build container only).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [scene names ...]
 
 imports the unmodified reference hot-path modules from ``/root/reference``
 through ``ref_shim`` and records, for small seeded synthetic scenes
@@ -44,6 +44,27 @@ SCENES = {
     # large motion (dphi) so that some LM steps are rejected
     "s60x80_j48_reject": (dict(N=1500, J=48, H=60, W=80, seed=4, src_border=5, tgt_border=2,
                                dphi=0.9), dict(), False),
+    # Semantic-SuPer: 3 wavy class bands, target segmentation moved 6 px (configs[4] terms)
+    "s60x80_j48_semantic": (dict(N=1500, J=48, H=60, W=80, seed=5, src_border=5, tgt_border=2,
+                                 semantic=True), dict(), False),
+}
+
+# GraphFit variants recorded per scene: tag -> opt overrides
+GF_VARIANTS = {
+    "plain": (("sgd", dict(optimizer="SGD")), ("adam", dict(optimizer="Adam")),
+              ("sgdface", dict(optimizer="SGD", mesh_face=True))),
+    "semantic": (
+        # the configs[4] trio: soft-seg point-plane + face + boundary morphing
+        ("soft", dict(optimizer="SGD", sf_point_plane=False, sf_soft_seg_point_plane=True,
+                      sf_hard_seg_point_plane=False, mesh_face=True, sf_bn_morph=True)),
+        ("softadam", dict(optimizer="Adam", sf_point_plane=False, sf_soft_seg_point_plane=True,
+                          sf_hard_seg_point_plane=False, mesh_face=True, sf_bn_morph=True,
+                          learning_rate=1e-4)),
+        ("hard", dict(optimizer="SGD", sf_point_plane=False, sf_soft_seg_point_plane=False,
+                      sf_hard_seg_point_plane=True)),
+        ("morph", dict(optimizer="SGD", sf_point_plane=True, sf_bn_morph=True, sf_bn_morph_weight=1e-6)),
+        ("clip", dict(optimizer="SGD", depth_model="raft_stereo")),
+    ),
 }
 
 
@@ -168,16 +189,16 @@ def capture_knn(ref, sc, opt):
                 knn_ed_w=_np(sf.ED_nodes.knn_w))
 
 
-def capture_graphfit(ref, sc, okw):
+def capture_graphfit(ref, sc, okw, variants):
     """Reference autograd path (GraphFit): iteration-0 losses and gradient (after the 1/J
-    scaling of the global row), final deform_verts for SGD and Adam; with and without the
-    face term."""
+    scaling of the global row) and the final deform_verts, per option variant."""
     out = {}
-    for tag, extra in (("sgd", dict(optimizer="SGD")), ("adam", dict(optimizer="Adam")),
-                       ("sgdface", dict(optimizer="SGD", mesh_face=True))):
+    for tag, extra in variants:
         kw = dict(okw)
         kw.update(extra)
         opt = ref_shim.ref_opt(**kw)
+        if getattr(sc, "num_classes", 0):
+            opt.num_classes, opt.width, opt.height = sc.num_classes, sc.W, sc.H
         src, inputs, trg, models = ref_shim.graphfit_frame(sc)
         gf = ref.deform_mesh.GraphFit(opt)
         rec = {}
@@ -213,6 +234,8 @@ def capture_graphfit(ref, sc, okw):
 def main():
     ref = ref_shim.install()
     for name, (skw, okw, store_jtj) in SCENES.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         sc = synth.make_scene(**skw)
         opt = ref_shim.ref_opt(**okw)
         sf, inputs, new_data = ref_shim.torch_frame(sc)
@@ -250,7 +273,12 @@ def main():
         g.update(capture_knn(ref, sc, opt))
         g["in_ed_triangles"], g["in_ed_triangle_areas"] = sc.ed_triangles, sc.ed_triangle_areas
         if name in ("s60x80_j48", "s60x80_j48_reject"):
-            g.update(capture_graphfit(ref, sc, okw))
+            g.update(capture_graphfit(ref, sc, okw, GF_VARIANTS["plain"]))
+        if sc.num_classes:
+            for f in ("img_seg_conf", "img_seg", "tgt_seg_conf", "sf_seg", "sf_seg_conf"):
+                g["in_" + f] = getattr(sc, f)
+            g["in_num_classes"] = sc.num_classes
+            g.update(capture_graphfit(ref, sc, okw, GF_VARIANTS["semantic"]))
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **g)
         print(f"{name}: N={sc.N} J={sc.J} M(b0)={len(g['b0_match'])} "

@@ -139,6 +139,12 @@ def graphfit_frame(sc, stable=None):
     sf.ED_nodes.triangles = t(sc.ed_triangles, torch.long)
     sf.ED_nodes.triangles_areas = t(sc.ed_triangle_areas)
     new_data.time = 1
+    if getattr(sc, "num_classes", 0):      # Semantic-SuPer inputs (data_loader.py:319-331,455-457,494-496)
+        sf.seg = t(sc.sf_seg, torch.long)
+        sf.seg_conf = t(sc.sf_seg_conf)
+        new_data.seg_conf = t(sc.tgt_seg_conf)
+        inputs[("seg_conf", 0)] = t(sc.img_seg_conf)[None]
+        inputs[("seg", 0)] = t(sc.img_seg, torch.long)[None, None]
     models = SimpleNamespace(renderer=lambda inputs, data, rad=None: torch.zeros(sc.H, sc.W, 3))
     return sf, inputs, new_data, models
 
@@ -150,7 +156,9 @@ def ref_opt(**kw):
                         num_neighbors=4, num_ED_neighbors=4, method="super", optimizer="SGD",
                         learning_rate=5e-5, mesh_face=False, mesh_face_weight=1.0, sf_corr=False,
                         sf_corr_match_renderimg=False, deform_udpate_method="super_edg",
-                        renderer_rad=0.0002, depth_model="monodepth2", save_sample_freq=1000000)
+                        renderer_rad=0.0002, depth_model="monodepth2", save_sample_freq=1000000,
+                        sf_hard_seg_point_plane=False, sf_soft_seg_point_plane=False,
+                        sf_bn_morph=False, sf_bn_morph_weight=0.1, num_classes=3)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -53,3 +53,16 @@ def ref_opt(opt):
     o.num_neighbors = 4
     o.num_ED_neighbors = 4
     return o
+
+
+# option overrides of the Semantic-SuPer GraphFit variants recorded in s60x80_j48_semantic.npz
+# (same table as tests/golden/make_golden.py GF_VARIANTS["semantic"])
+GF_SEMANTIC_VARIANTS = {
+    "soft": dict(optimizer="SGD", sf_point_plane=False, sf_soft_seg_point_plane=True, mesh_face=True,
+                 sf_bn_morph=True, sf_bn_morph_weight=0.1),
+    "softadam": dict(optimizer="Adam", sf_point_plane=False, sf_soft_seg_point_plane=True, mesh_face=True,
+                     sf_bn_morph=True, sf_bn_morph_weight=0.1, learning_rate=1e-4),
+    "hard": dict(optimizer="SGD", sf_point_plane=False, sf_hard_seg_point_plane=True),
+    "morph": dict(optimizer="SGD", sf_point_plane=True, sf_bn_morph=True, sf_bn_morph_weight=1e-6),
+    "clip": dict(optimizer="SGD", depth_model="raft_stereo"),
+}

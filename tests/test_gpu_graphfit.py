@@ -3,16 +3,21 @@ the PyTorch-CPU oracle, through the C ABI.  Needs an MI355X (-m gpu)."""
 import numpy as np
 import pytest
 
-from helpers import load_golden, ref_opt, torch_frame
+from helpers import GF_SEMANTIC_VARIANTS, load_golden, ref_opt, torch_frame
 from oracle import graphfit_oracle as gfo
 
 pytestmark = pytest.mark.gpu
 
 CASES = [("s60x80_j48", "sgd"), ("s60x80_j48", "adam"), ("s60x80_j48", "sgdface"),
          ("s60x80_j48_reject", "sgd"), ("s60x80_j48_reject", "adam")]
+CASES += [("s60x80_j48_semantic", t) for t in GF_SEMANTIC_VARIANTS]   # Semantic-SuPer terms (configs[4])
 
 
 def _opt(tag, **kw):
+    if tag in GF_SEMANTIC_VARIANTS:
+        o = gfo.default_opt(**GF_SEMANTIC_VARIANTS[tag], **kw)
+        o.deform_udpate_method, o.num_classes = "super_edg", 3
+        return o
     o = gfo.default_opt(optimizer="Adam" if tag == "adam" else "SGD", mesh_face=(tag == "sgdface"), **kw)
     o.deform_udpate_method = "super_edg"
     return o
@@ -23,6 +28,12 @@ def _frame(sc):
     sf, inputs, new_data = torch_frame(sc)
     sf.ED_nodes.triangles = torch.from_numpy(sc.ed_triangles).cuda()
     sf.ED_nodes.triangles_areas = torch.from_numpy(sc.ed_triangle_areas).cuda().double()
+    if sc.num_classes:
+        sf.seg = torch.from_numpy(sc.sf_seg).cuda()
+        sf.seg_conf = torch.from_numpy(sc.sf_seg_conf).cuda().double()
+        new_data.seg_conf = torch.from_numpy(sc.tgt_seg_conf).cuda().double()
+        inputs[("seg_conf", 0)] = torch.from_numpy(sc.img_seg_conf).cuda().double()[None]
+        inputs[("seg", 0)] = torch.from_numpy(sc.img_seg).cuda()[None, None]
     return sf, inputs, new_data
 
 
@@ -53,6 +64,55 @@ def test_final_deform_verts_match_reference(name, tag):
     sf, inputs, new_data = _frame(sc)
     dv = GraphFit(_opt(tag))(inputs, sf, new_data, None).cpu().numpy()
     np.testing.assert_allclose(dv, g[f"gf_{tag}_final"], rtol=0, atol=1e-9)   # north_star bar: 1e-4
+
+
+def test_semantic_edge_points_match_find_edge_region():
+    """Class-boundary pixels extracted on the device == the oracle's restatement of
+    find_edge_region (bit-exact, same row-major order)."""
+    import torch
+    from super_amd.deform_mesh import GraphFit
+    g, sc, _ = load_golden("s60x80_j48_semantic")
+    sf, inputs, new_data = _frame(sc)
+    gf = GraphFit(_opt("soft"))
+    dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64, device="cuda")
+    dv[:, 0] = 1.0
+    gf.loss_and_grad(inputs, sf, new_data, dv)
+    ref = gfo.edge_points(sc.img_seg, 3)
+    assert gf.edge_counts == [len(e) for e in ref]
+    for c in range(3):
+        np.testing.assert_array_equal(gf.edge_points(c).cpu().numpy(), ref[c].numpy().astype(np.float32))
+
+
+@pytest.mark.parametrize("tag", ["soft", "hard", "morph"])
+def test_semantic_gradient_at_random_point_vs_autograd_oracle(tag):
+    """Semantic weights / morphing term away from identity, with unstable surfels, against
+    torch autograd on the oracle."""
+    import torch
+    from super_amd import synth
+    from super_amd.deform_mesh import GraphFit
+    sc = synth.make_scene(N=3000, J=48, H=60, W=80, seed=23, src_border=5, tgt_border=3, tgt_holes=0.01,
+                          semantic=True)
+    rng = np.random.default_rng(5)
+    dv0 = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (sc.J + 1, 1))
+    dv0 += np.concatenate([rng.normal(0, 0.01, (sc.J + 1, 4)), rng.normal(0, 0.003, (sc.J + 1, 3))], axis=1)
+    opt = _opt(tag)
+    stable = rng.uniform(size=sc.N) > 0.1
+    pb = gfo.Problem(sc, stable=stable)
+    dvt = torch.from_numpy(dv0.copy()).requires_grad_(True)
+    loss, terms = gfo.total_loss(pb, dvt, opt)
+    gref, = torch.autograd.grad(loss, dvt)
+    gref = gref.clone()
+    gref[-1] /= sc.J
+    sf, inputs, new_data = _frame(sc)
+    sf.isStable = torch.from_numpy(stable).cuda()
+    t, matched, grad = GraphFit(opt).loss_and_grad(inputs, sf, new_data, torch.from_numpy(dv0).cuda())
+    assert matched == terms["_matched"]
+    for k, v in t.items():
+        if k in terms:
+            np.testing.assert_allclose(v, float(terms[k].detach()), rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(sum(t.values()), float(loss.detach()), rtol=1e-9)
+    np.testing.assert_allclose(grad.cpu().numpy(), gref.numpy(), rtol=0,
+                               atol=1e-9 * max(1.0, float(gref.abs().max())))
 
 
 def test_gradient_at_random_point_vs_autograd_oracle():

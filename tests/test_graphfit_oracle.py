@@ -4,14 +4,17 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden
+from helpers import GF_SEMANTIC_VARIANTS, load_golden
 from oracle import graphfit_oracle as gfo
 
 CASES = [("s60x80_j48", "sgd"), ("s60x80_j48", "adam"), ("s60x80_j48", "sgdface"),
          ("s60x80_j48_reject", "sgd"), ("s60x80_j48_reject", "adam")]
+CASES += [("s60x80_j48_semantic", t) for t in GF_SEMANTIC_VARIANTS]   # Semantic-SuPer terms
 
 
 def _opt(tag):
+    if tag in GF_SEMANTIC_VARIANTS:
+        return gfo.default_opt(**GF_SEMANTIC_VARIANTS[tag])
     return gfo.default_opt(optimizer="Adam" if tag == "adam" else "SGD", mesh_face=(tag == "sgdface"))
 
 
@@ -40,3 +43,24 @@ def test_final_deform_verts(name, tag):
     dv = gfo.graphfit(gfo.Problem(sc), _opt(tag))
     np.testing.assert_allclose(dv, g[f"gf_{tag}_final"], rtol=0, atol=1e-10)
     assert np.abs(dv - np.eye(1, 7)).max() > 1e-7      # the optimiser moved
+
+
+def test_semantic_edge_points_and_weights_are_nontrivial():
+    """The semantic fixture exercises what it claims: every class has boundary pixels, the
+    soft weights are strictly inside (0,1), hard matching drops some residuals, the clip drops
+    some, and some (not all) mismatching surfels pass the > 15 test of the morphing term."""
+    g, sc, _ = load_golden("s60x80_j48_semantic")
+    pb = gfo.Problem(sc)
+    E = gfo.edge_points(pb.img_seg.numpy(), pb.C)
+    assert all(len(e) > 10 for e in E)
+    dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64)
+    dv[:, 0] = 1.0
+    _, sf = gfo.deform(pb, dv)
+    plain, m = gfo.point_plane(pb, sf)
+    soft, _ = gfo.point_plane(pb, sf, "soft")
+    hard, _ = gfo.point_plane(pb, sf, "hard")
+    clip, mc = gfo.point_plane(pb, sf, None, 2e-5)
+    assert 0.9 * float(plain) < float(soft) < float(plain)
+    assert 0 < float(hard) < float(plain)
+    assert 0 < mc < m
+    assert float(gfo.bn_morph(pb, sf)) > 15
