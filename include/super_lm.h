@@ -274,6 +274,24 @@ int slm_gf_get_edge_points(slm_gf* g, int32_t slot, int32_t class_id, float* xy_
                            int32_t max_points, void* stream);
 /* num_iterations optimiser steps for slots [0,n_frames), entirely on the device. */
 int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream);
+
+/* -- one large frame sharded over the GPUs of a node (BASELINE configs[4]) --
+ * After slm_gf_set_shard(rank, world) (before slm_gf_bind_frame) this context evaluates the
+ * surfels [N*rank/world, N*(rank+1)/world) of every slot; rank 0 also evaluates the node terms
+ * (ARAP / Rot / face).  The library holds no communicator: per optimiser iteration the caller runs
+ *     slm_gf_eval_morph   -> all-reduce(sum) of the partial state   (only with use_bn_morph: the
+ *                            global kept count scales the back-propagation)
+ *     slm_gf_eval_losses  -> all-reduce(sum) of the partial state   (gradient + loss terms)
+ *     slm_gf_step
+ * on every rank; the partial state is [(J+1)*7 gradient | 8 terms] doubles, moved with
+ * slm_gf_get_partial / slm_gf_set_partial (device to device) so that the collective runs on the
+ * caller's own buffer (torch.distributed all_reduce = RCCL over xGMI). */
+int slm_gf_set_shard(slm_gf* g, int32_t rank, int32_t world);
+int slm_gf_eval_morph(slm_gf* g, int32_t n_frames, void* stream);
+int slm_gf_eval_losses(slm_gf* g, int32_t n_frames, void* stream);
+int slm_gf_step(slm_gf* g, int32_t n_frames, void* stream);
+int slm_gf_get_partial(slm_gf* g, int32_t slot, double* out_device, void* stream);
+int slm_gf_set_partial(slm_gf* g, int32_t slot, const double* in_device, void* stream);
 /* Copies deform_verts ((J+1)*7 doubles) of the slot into caller device memory. */
 int slm_gf_get_deform(slm_gf* g, int32_t slot, double* out_device, void* stream);
 /* One loss + gradient evaluation at dv_device ((J+1)*7): terms_device[8]: [0..3] = face, arap,

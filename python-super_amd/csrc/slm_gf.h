@@ -7,6 +7,7 @@ struct GfSlot {
   slm_gf_frame f;
   int32_t bound;
   int32_t step;          // optimiser steps done
+  int32_t shard_lo, shard_hi;   // surfels [lo,hi) are evaluated by this rank (slm_gf_set_shard)
   double* dv;            // (J+1,7)
   double* grad;          // (J+1,7)
   double* m1;            // momentum buffer / Adam exp_avg

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int J = f.J;
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0;
-  if (i < f.N && (!s.f.sf_stable || s.f.sf_stable[i])) {
+  if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
     GfSkin k;
     gf_skin(s, i, k);
     const d3 P = k.P;
@@ -408,6 +408,7 @@ struct slm_gf {
   std::vector<size_t> cap;
   std::vector<SemScratch> sem;
   GfSlot* dev = nullptr;
+  int rank = 0, world = 1;   // surfel sharding of every slot (slm_gf_set_shard)
 };
 
 #define GFCHK(expr)                                                       \
@@ -424,17 +425,28 @@ static int gf_fail(int code, const char* msg) {
   return code;
 }
 
-static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
-  const slm_gf_config& c = g->cfg;
+// pass 1: zero the gradient / terms, then the morphing term's per-surfel pass (sum, count)
+static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStream_t st) {
   hipLaunchKernelGGL(k_gf_zero, dim3(32, n), dim3(256), 0, st, slots);
+  if (g->cfg.use_bn_morph) launch_gf_morph(slots, n, maxN, st);
+}
+
+// pass 2: point-plane (+ morphing back-propagation, needs the GLOBAL kept count in terms[6]) and
+// the node terms (on rank 0 only when the surfels are sharded: the caller sums the partials)
+static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
+  const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
-  if (c.use_bn_morph) launch_gf_morph(slots, n, maxN, st);
   if ((use_pp || c.use_bn_morph) && maxN > 0)
     hipLaunchKernelGGL(k_gf_data, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
                        c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph);
-  if ((c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
+  if (g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
     hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
                        c.use_rot, c.w_rot, c.use_face, c.w_face);
+}
+
+static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
+  gf_enqueue_morph(g, slots, n, maxN, st);
+  gf_enqueue_losses(g, slots, n, maxN, maxReg, st);
 }
 
 extern "C" {
@@ -499,6 +511,8 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* fr, void* str
   s.bound = 1;
   s.step = 0;
   s.sem_bound = 0;   // semantic inputs belong to the frame: bind them again
+  s.shard_lo = (int32_t)((int64_t)f.N * g->rank / g->world);
+  s.shard_hi = (int32_t)((int64_t)f.N * (g->rank + 1) / g->world);
   GFCHK(hipMemcpyAsync(g->dev + slot, &s, sizeof(GfSlot), hipMemcpyHostToDevice, st));
   GFCHK(hipStreamSynchronize(st));
   hipLaunchKernelGGL(k_gf_init, dim3((n + 255) / 256), dim3(256), 0, st, g->dev, slot);
@@ -571,10 +585,78 @@ static int gf_dims(slm_gf* g, int first, int n, int* maxN, int* maxReg, int* max
   return SLM_OK;
 }
 
+int slm_gf_set_shard(slm_gf* g, int32_t rank, int32_t world) {
+  if (!g || world < 1 || rank < 0 || rank >= world) return gf_fail(SLM_ERR_INVALID, "slm_gf_set_shard: bad rank/world");
+  g->rank = rank;
+  g->world = world;
+  for (GfSlot& s : g->host) s.bound = 0;   // shard bounds are fixed at bind time
+  hipError_t e = hipMemset(g->dev, 0, sizeof(GfSlot) * g->host.size());
+  if (e != hipSuccess) return gf_fail(SLM_ERR_HIP, hipGetErrorString(e));
+  return SLM_OK;
+}
+
+int slm_gf_eval_morph(slm_gf* g, int32_t n_frames, void* stream) {
+  int maxN, maxReg, maxP;
+  int rc = gf_dims(g, 0, n_frames, &maxN, &maxReg, &maxP);
+  if (rc) return rc;
+  gf_enqueue_morph(g, g->dev, n_frames, maxN, (hipStream_t)stream);
+  GFCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_gf_eval_losses(slm_gf* g, int32_t n_frames, void* stream) {
+  int maxN, maxReg, maxP;
+  int rc = gf_dims(g, 0, n_frames, &maxN, &maxReg, &maxP);
+  if (rc) return rc;
+  gf_enqueue_losses(g, g->dev, n_frames, maxN, maxReg, (hipStream_t)stream);
+  GFCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_gf_step(slm_gf* g, int32_t n_frames, void* stream) {
+  int maxN, maxReg, maxP;
+  int rc = gf_dims(g, 0, n_frames, &maxN, &maxReg, &maxP);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev, g->cfg.optimizer,
+                     g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
+  hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
+  GFCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_gf_get_partial(slm_gf* g, int32_t slot, double* out, void* stream) {
+  int maxN, maxReg, maxP;
+  int rc = gf_dims(g, slot, 1, &maxN, &maxReg, &maxP);
+  if (rc) return rc;
+  if (!out) return gf_fail(SLM_ERR_INVALID, "slm_gf_get_partial: null output");
+  const GfSlot& s = g->host[slot];
+  hipStream_t st = (hipStream_t)stream;
+  GFCHK(hipMemcpyAsync(out, s.grad, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
+  GFCHK(hipMemcpyAsync(out + maxP, s.terms, sizeof(double) * 8, hipMemcpyDeviceToDevice, st));
+  return SLM_OK;
+}
+
+int slm_gf_set_partial(slm_gf* g, int32_t slot, const double* in, void* stream) {
+  int maxN, maxReg, maxP;
+  int rc = gf_dims(g, slot, 1, &maxN, &maxReg, &maxP);
+  if (rc) return rc;
+  if (!in) return gf_fail(SLM_ERR_INVALID, "slm_gf_set_partial: null input");
+  const GfSlot& s = g->host[slot];
+  hipStream_t st = (hipStream_t)stream;
+  GFCHK(hipMemcpyAsync(s.grad, in, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
+  GFCHK(hipMemcpyAsync(s.terms, in + maxP, sizeof(double) * 8, hipMemcpyDeviceToDevice, st));
+  return SLM_OK;
+}
+
 int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream) {
   int maxN, maxReg, maxP;
   int rc = gf_dims(g, 0, n_frames, &maxN, &maxReg, &maxP);
   if (rc) return rc;
+  if (g->world > 1)
+    return gf_fail(SLM_ERR_UNSUPPORTED,
+                   "slm_gf_run: surfels are sharded; drive slm_gf_eval_morph / eval_losses / step with an "
+                   "all-reduce of slm_gf_get_partial between them");
   hipStream_t st = (hipStream_t)stream;
   for (int it = 0; it < g->cfg.num_iterations; ++it) {
     gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st);

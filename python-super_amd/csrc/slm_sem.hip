@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
   double li_sum = 0.0, kept = 0.0;
   if (i < f.N) {
     double2 g = make_double2(0.0, 0.0);
-    if (!s.f.sf_stable || s.f.sf_stable[i]) {
+    if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
       GfSkin k;
       gf_skin(s, i, k);
       const int H = f.H, W = f.W, C = s.sem.num_classes;

@@ -20,7 +20,8 @@ EXPORTS = [
     "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_plan_info", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
     "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
-    "slm_gf_bind_semantic", "slm_gf_get_edge_points",
+    "slm_gf_bind_semantic", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
+    "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
 ]
 
@@ -119,6 +120,12 @@ def load():
         "slm_gf_run": [vp, i32, vp],
         "slm_gf_bind_semantic": [vp, i32, C.POINTER(SlmGfSemantic), C.POINTER(C.c_int32), vp],
         "slm_gf_get_edge_points": [vp, i32, i32, vp, i32, vp],
+        "slm_gf_set_shard": [vp, i32, i32],
+        "slm_gf_eval_morph": [vp, i32, vp],
+        "slm_gf_eval_losses": [vp, i32, vp],
+        "slm_gf_step": [vp, i32, vp],
+        "slm_gf_get_partial": [vp, i32, vp, vp],
+        "slm_gf_set_partial": [vp, i32, vp, vp],
         "slm_gf_get_deform": [vp, i32, vp, vp],
         "slm_gf_loss_grad": [vp, i32, vp, vp, vp, vp],
         "slm_apply_update_gf": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],

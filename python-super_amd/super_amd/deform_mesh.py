@@ -28,7 +28,13 @@ from .LM import BoundFrame, _as, _dev_ptr, _stream_ptr
 
 
 class GraphFit:
-    def __init__(self, opt, max_frames=1):
+    """``GraphFit(opt)`` as in the reference.  ``rank`` / ``world`` (default: the
+    ``torch.distributed`` rank and world size when ``shard_surfels=True``) split the surfels of
+    one large frame over the GPUs of a node: every rank evaluates its block of surfels, the
+    partial gradient / loss sums are all-reduced (RCCL) twice per optimiser iteration and every
+    rank takes the same step (BASELINE configs[4])."""
+
+    def __init__(self, opt, max_frames=1, shard_surfels=False, rank=None, world=None, all_reduce=None):
         self.opt = opt
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -68,6 +74,15 @@ class GraphFit:
         self.h = C.c_void_p()
         _lib.check(self.lib.slm_gf_create(C.byref(cfg), C.byref(self.h)), "slm_gf_create")
         self._keep = [None] * max_frames
+        self.rank, self.world, self._all_reduce = 0, 1, all_reduce
+        if shard_surfels or world is not None:
+            import torch.distributed as dist
+            if world is None:
+                world, rank = dist.get_world_size(), dist.get_rank()
+            self.rank, self.world = int(rank), int(world)
+            if self._all_reduce is None:
+                self._all_reduce = lambda t: dist.all_reduce(t)     # sum, in place (RCCL on the GPU box)
+            _lib.check(self.lib.slm_gf_set_shard(self.h, self.rank, self.world), "slm_gf_set_shard")
 
     def __del__(self):
         try:
@@ -144,12 +159,57 @@ class GraphFit:
             raise NotImplementedError("only deform_udpate_method == 'super_edg'")
         bf = self._bind(0, inputs, src, trg)
         st = _stream_ptr(bf.device)
-        _lib.check(self.lib.slm_gf_run(self.h, 1, st), "slm_gf_run")
+        if self.world > 1:
+            part = torch.empty((bf.J + 1) * 7 + 8, dtype=torch.float64, device=bf.device)
+            for _ in range(int(self.Niter)):
+                self.eval_morph()
+                if self.cfg.use_bn_morph:
+                    self.exchange_partial(part)      # global kept count before the back-propagation
+                self.eval_losses()
+                self.exchange_partial(part)          # gradient + loss terms
+                self.step()
+        else:
+            _lib.check(self.lib.slm_gf_run(self.h, 1, st), "slm_gf_run")
         out = torch.empty((bf.J + 1, 7), dtype=torch.float64, device=bf.device)
         _lib.check(self.lib.slm_gf_get_deform(self.h, 0, _dev_ptr(out), st), "slm_gf_get_deform")
         return out
 
     __call__ = forward
+
+    # ---- stepwise evaluation (surfel-sharded frames; also usable with world == 1) -------------
+    def _st(self):
+        return _stream_ptr(self._keep[0][0].device)
+
+    def bind(self, inputs, src, trg):
+        return self._bind(0, inputs, src, trg)
+
+    def eval_morph(self):
+        _lib.check(self.lib.slm_gf_eval_morph(self.h, 1, self._st()), "slm_gf_eval_morph")
+
+    def eval_losses(self):
+        _lib.check(self.lib.slm_gf_eval_losses(self.h, 1, self._st()), "slm_gf_eval_losses")
+
+    def step(self):
+        _lib.check(self.lib.slm_gf_step(self.h, 1, self._st()), "slm_gf_step")
+
+    def get_partial(self, out):
+        _lib.check(self.lib.slm_gf_get_partial(self.h, 0, _dev_ptr(out), self._st()), "slm_gf_get_partial")
+        return out
+
+    def set_partial(self, buf):
+        _lib.check(self.lib.slm_gf_set_partial(self.h, 0, _dev_ptr(buf), self._st()), "slm_gf_set_partial")
+
+    def exchange_partial(self, buf):
+        """partial [(J+1)*7 gradient | 8 terms] -> sum over the ranks -> back into the slot."""
+        self.get_partial(buf)
+        self._all_reduce(buf)
+        self.set_partial(buf)
+
+    def deform_verts(self):
+        bf = self._keep[0][0]
+        out = torch.empty((bf.J + 1, 7), dtype=torch.float64, device=bf.device)
+        _lib.check(self.lib.slm_gf_get_deform(self.h, 0, _dev_ptr(out), self._st()), "slm_gf_get_deform")
+        return out
 
     def loss_and_grad(self, inputs, src, trg, deform_verts):
         """One evaluation of ``deform_source`` + ``get_losses`` + backward at ``deform_verts``:

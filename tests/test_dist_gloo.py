@@ -64,3 +64,58 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _shard_worker(rank, world, port, tmp):
+    for p in (ROOT, os.path.join(ROOT, "python-super_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import graphfit_oracle as gfo
+        from super_amd import synth
+        sc = synth.make_scene(N=900, J=20, H=48, W=64, seed=3, src_border=4, tgt_border=2, semantic=True)
+        # the exchange protocol of the surfel-sharded GraphFit (super_amd.deform_mesh.GraphFit.forward):
+        # rank r evaluates surfels [N r/W, N (r+1)/W), rank 0 also the node terms; sum all-reduce
+        lo, hi = sc.N * rank // world, sc.N * (rank + 1) // world
+        mask = np.zeros(sc.N, bool)
+        mask[lo:hi] = True
+        opt = gfo.default_opt(sf_point_plane=False, sf_soft_seg_point_plane=True, mesh_face=(rank == 0),
+                              mesh_arap=(rank == 0), mesh_rot=(rank == 0))
+        dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64)
+        dv[:, 0] = 1.0
+        dv[:, 1:] = 0.01 * torch.sin(torch.arange((sc.J + 1) * 6, dtype=torch.float64)).reshape(sc.J + 1, 6)
+        dv.requires_grad_(True)
+        loss, _ = gfo.total_loss(gfo.Problem(sc, stable=mask), dv, opt)
+        grad, = torch.autograd.grad(loss, dv)
+        part = torch.cat([grad.reshape(-1), loss.detach().reshape(1)])
+        dist.all_reduce(part)
+        np.save(os.path.join(tmp, f"shard{rank}.npy"), part.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_surfel_sharded_partials_sum_to_the_full_gradient(tmp_path):
+    """world_size-2 gloo run of the surfel-sharded exchange: per-rank partial gradient / loss
+    all-reduced == the unsharded evaluation (oracle arithmetic on CPU)."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")
+    np.testing.assert_array_equal(a, b)
+    for p in (ROOT, os.path.join(ROOT, "python-super_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import graphfit_oracle as gfo
+    from super_amd import synth
+    sc = synth.make_scene(N=900, J=20, H=48, W=64, seed=3, src_border=4, tgt_border=2, semantic=True)
+    opt = gfo.default_opt(sf_point_plane=False, sf_soft_seg_point_plane=True, mesh_face=True)
+    dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64)
+    dv[:, 0] = 1.0
+    dv[:, 1:] = 0.01 * torch.sin(torch.arange((sc.J + 1) * 6, dtype=torch.float64)).reshape(sc.J + 1, 6)
+    dv.requires_grad_(True)
+    loss, _ = gfo.total_loss(gfo.Problem(sc), dv, opt)
+    grad, = torch.autograd.grad(loss, dv)
+    ref = torch.cat([grad.reshape(-1), loss.detach().reshape(1)]).numpy()
+    np.testing.assert_allclose(a, ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))

@@ -273,3 +273,50 @@ def test_three_frame_tracking_loop_matches_oracle_pipeline():
         np.testing.assert_allclose(sf.points.cpu().numpy(), P, rtol=0, atol=5e-6)
         np.testing.assert_array_equal(sf.knn_indices.cpu().numpy(), idx)
         np.testing.assert_array_equal(sf.ED_nodes.knn_indices.cpu().numpy(), eidx)
+
+
+def test_c4_semantic_graphfit_matches_oracle():
+    """BASELINE configs[4] at full size (500k surfels / 4k nodes, 720x960, soft-seg point-plane +
+    face + boundary morphing): one loss/gradient evaluation away from identity and 3 optimiser
+    steps agree with the PyTorch-CPU oracle; the boundary pixels are bit-exact."""
+    import torch
+    from oracle import graphfit_oracle as gfo
+    from super_amd import synth
+    from super_amd.deform_mesh import GraphFit
+    from helpers import GF_SEMANTIC_VARIANTS, torch_frame
+    sc = synth.make_scene(seed=0, semantic=True, seg_smooth=11, **synth.WORKLOADS["C4"])
+    opt = gfo.default_opt(**GF_SEMANTIC_VARIANTS["soft"])
+    opt.deform_udpate_method, opt.num_classes, opt.num_optimize_iterations = "super_edg", 3, 3
+    sf, inputs, new_data = torch_frame(sc)
+    sf.ED_nodes.triangles = torch.from_numpy(sc.ed_triangles).cuda()
+    sf.ED_nodes.triangles_areas = torch.from_numpy(sc.ed_triangle_areas).cuda().double()
+    sf.seg = torch.from_numpy(sc.sf_seg).cuda()
+    sf.seg_conf = torch.from_numpy(sc.sf_seg_conf).cuda()
+    new_data.seg_conf = torch.from_numpy(sc.tgt_seg_conf).cuda()
+    inputs[("seg_conf", 0)] = torch.from_numpy(sc.img_seg_conf).cuda()[None]
+    inputs[("seg", 0)] = torch.from_numpy(sc.img_seg).cuda()[None, None]
+
+    rng = np.random.default_rng(11)
+    dv0 = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (sc.J + 1, 1))
+    dv0 += np.concatenate([rng.normal(0, 0.003, (sc.J + 1, 4)), rng.normal(0, 0.001, (sc.J + 1, 3))], axis=1)
+    pb = gfo.Problem(sc)
+    dvt = torch.from_numpy(dv0.copy()).requires_grad_(True)
+    loss, terms = gfo.total_loss(pb, dvt, opt)
+    gref, = torch.autograd.grad(loss, dvt)
+    gref = gref.clone()
+    gref[-1] /= sc.J
+    gf = GraphFit(opt)
+    t, matched, grad = gf.loss_and_grad(inputs, sf, new_data, torch.from_numpy(dv0).cuda())
+    assert matched == terms["_matched"]
+    assert gf.edge_counts == [len(e) for e in pb.edge_pts]
+    for c in range(3):
+        np.testing.assert_array_equal(gf.edge_points(c).cpu().numpy(), pb.edge_pts[c].numpy().astype(np.float32))
+    assert gf.last_bn_morph_kept > 100
+    for k, v in t.items():
+        np.testing.assert_allclose(v, float(terms[k].detach()), rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(grad.cpu().numpy(), gref.numpy(), rtol=0,
+                               atol=1e-9 * max(1.0, float(gref.abs().max())))
+    # 3 SGD steps from identity: tolerance 1e-4 is the north_star bar; f64 everywhere gives far less
+    dv = gf(inputs, sf, new_data, None).cpu().numpy()
+    ref = gfo.graphfit(gfo.Problem(sc), opt)
+    np.testing.assert_allclose(dv, ref, rtol=0, atol=1e-9)

@@ -152,3 +152,40 @@ def test_update_autograd_variant_matches_reference():
     for mine, key in ((sf.points, "gf_upd_points"), (sf.norms, "gf_upd_norms"),
                       (sf.ED_nodes.points, "gf_upd_ed_points"), (sf.ED_nodes.norms, "gf_upd_ed_norms")):
         np.testing.assert_allclose(mine.cpu().numpy(), g[key], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("tag,world", [("soft", 2), ("sgd", 3), ("morph", 4)])
+def test_surfel_sharded_ranks_reproduce_the_single_gpu_solve(tag, world):
+    """One frame split over `world` ranks (all on this GPU, the all-reduce emulated by summing
+    the ranks' partial buffers) takes the same optimiser steps as the unsharded solve."""
+    import torch
+    from super_amd.deform_mesh import GraphFit
+    name = "s60x80_j48_semantic" if tag in GF_SEMANTIC_VARIANTS else "s60x80_j48"
+    g, sc, _ = load_golden(name)
+    sf, inputs, new_data = _frame(sc)
+    opt = _opt(tag)
+    ranks = [GraphFit(opt, rank=r, world=world, all_reduce=lambda t: None) for r in range(world)]
+    for gf in ranks:
+        gf.bind(inputs, sf, new_data)
+    n = (sc.J + 1) * 7 + 8
+    bufs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in ranks]
+
+    def all_reduce():
+        tot = torch.stack([gf.get_partial(b) for gf, b in zip(ranks, bufs)]).sum(0)
+        for gf in ranks:
+            gf.set_partial(tot)
+
+    for _ in range(opt.num_optimize_iterations):
+        for gf in ranks:
+            gf.eval_morph()
+        if ranks[0].cfg.use_bn_morph:
+            all_reduce()
+        for gf in ranks:
+            gf.eval_losses()
+        all_reduce()
+        for gf in ranks:
+            gf.step()
+    dvs = [gf.deform_verts().cpu().numpy() for gf in ranks]
+    for d in dvs[1:]:
+        np.testing.assert_array_equal(d, dvs[0])           # every rank holds the same parameters
+    np.testing.assert_allclose(dvs[0], g[f"gf_{tag}_final"], rtol=0, atol=1e-9)
