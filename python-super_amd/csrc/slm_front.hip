@@ -4,12 +4,13 @@
 // inverted index, one writer per entry) -> k_reg_grad_nd (ARAP / Rot rows, f64 atomics)
 // -> k_front_load_rhs -> for every tree level, deepest first:
 //        for c < max pivot tile columns: k_fpanel(c), k_ftrail(c)   dense partial Cholesky
-//        k_extend_add(child 0), k_extend_add(child 1)   Schur complements -> parents (next level)
+//        k_fschur(child 0), k_fschur(child 1)   Schur complements added into the parents (next level)
 //    (the forward substitution rides along exactly as in the band solver)
 // -> for every level, root first: k_fback_prep, k_fbacksub(step)...   back substitution,
 //    each front scatters its pivots' solution into delta.
 // Grid convention: blockIdx.y = front within the level, blockIdx.z = frame slot.
 #include <algorithm>
+#include <cstdlib>
 
 #include "slm_tile.h"
 
@@ -32,6 +33,43 @@ __device__ __forceinline__ double* dest_entry(const FrameDev& fd, const NDDest& 
   const NDFront& f = fd.fronts[d.front];
   const int rb = nd_base(f, d.prow), cb = nd_base(f, d.pcol);
   return d.transpose ? front_entry(fd, f, rb + y, cb + x) : front_entry(fd, f, rb + x, cb + y);
+}
+
+
+// ---------------------------------------------------------------------------------
+// Workgroup -> (unit, front, frame) decoding.  The plain form is a 3-D grid.  The XCD-aware form
+// (used when a launch has >= 8 (front, frame) pairs) is a 1-D grid in which all units (tiles) of
+// a pair run on ONE XCD, back to back: blocks b and b+8 share an XCD and its 4 MiB L2, so block b
+// takes pair (b & 7) * chunk + (b >> 3) / n_units.  A front's operand tiles are then fetched from
+// HBM once per launch instead of once per consuming tile.
+struct WgMap {
+  int n_units, n_fronts, n_frames, xcd;
+};
+struct WgId {
+  int unit, front, frame;
+};
+__device__ __forceinline__ bool wg_decode(const WgMap& m, WgId& o) {
+  if (!m.xcd) {
+    o.unit = blockIdx.x;
+    o.front = blockIdx.y;
+    o.frame = blockIdx.z;
+    return true;
+  }
+  const int n_pairs = m.n_fronts * m.n_frames;
+  const int chunk = (n_pairs + 7) >> 3;
+  const int q = (blockIdx.x >> 3) / m.n_units;
+  const int pair = (blockIdx.x & 7) * chunk + q;
+  o.unit = (blockIdx.x >> 3) % m.n_units;
+  o.front = pair % m.n_fronts;
+  o.frame = pair / m.n_fronts;
+  return q < chunk && pair < n_pairs;
+}
+static inline WgMap make_map(int n_units, int n_fronts, int n_frames) {
+  return WgMap{n_units, n_fronts, n_frames, (n_fronts * n_frames >= 8) ? 1 : 0};
+}
+static inline dim3 map_grid(const WgMap& m) {
+  if (!m.xcd) return dim3(m.n_units, m.n_fronts, m.n_frames);
+  return dim3((unsigned)((m.n_fronts * m.n_frames + 7) / 8 * 8) * m.n_units);
 }
 
 // ---------------------------------------------------------------------------------
@@ -223,7 +261,7 @@ __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restric
 // Dense partial Cholesky of the fronts of one level, tile column c.
 // grid = (max tiles below + 1, fronts in level, n_frames)
 __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ frames, int level,
-                                                 int c, double u_override) {
+                                                 int c, double u_override, WgMap map) {
   extern __shared__ double lds[];
   double* S = lds;
   double* M = lds + TILE;
@@ -231,19 +269,21 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   double* wt = dinv + 4 * 256;
   double* vec = wt + 4 * 256;
   int* s_ok = reinterpret_cast<int*>(vec + NB);
-  const FrameDev& fd = frames[blockIdx.z];
+  WgId wg;
+  if (!wg_decode(map, wg)) return;
+  const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
+  const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
-  const int d = blockIdx.x;
+  const int d = wg.unit;
   if (c + d >= f.nt) return;
   const double u = (u_override >= 0.0) ? u_override : fd.st->u;
 
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
-  const bool stamp = (c == 1 && blockIdx.z == 0 && blockIdx.y == 0 && d == 1 && level == fd.n_levels - 1);
+  const bool stamp = (c == 1 && wg.frame == 0 && wg.front == 0 && d == 1 && level == fd.n_levels - 1);
   SLM_STAMP(fd, stamp, 0);
   double* At = ftile(fd, f, c + d, c);
   double* yv = fd.fvec + f.vec_off + (size_t)c * NB;
@@ -351,16 +391,18 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
 }
 
 // grid = (max tiles below, fronts in level, n_frames): block d-1 -> tile (c+d, c)
-__global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ frames, int level, int c) {
+__global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ frames, int level, int c, WgMap map) {
   __shared__ double Bl[TILE];
-  const FrameDev& fd = frames[blockIdx.z];
+  WgId wg;
+  if (!wg_decode(map, wg)) return;
+  const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
+  const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
-  const int d = blockIdx.x + 1;
+  const int d = wg.unit + 1;
   if (c + d >= f.nt) return;
   double* At = ftile(fd, f, c + d, c);
   const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
@@ -496,16 +538,18 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
   }
 }
 
-__global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frames, int level) {
+__global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frames, int level, WgMap map) {
   __shared__ double Bl[TILE];
   __shared__ double yv[NB];
-  const FrameDev& fd = frames[blockIdx.z];
+  WgId wg;
+  if (!wg_decode(map, wg)) return;
+  const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
+  const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
   const NDFront& f = fd.fronts[fi];
-  const int r = f.npt + blockIdx.x;
+  const int r = f.npt + wg.unit;
   if (f.npt == 0 || r >= f.nt) return;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   double* vecs = fd.fvec + f.vec_off;
@@ -575,17 +619,19 @@ __global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frame
 // Block index t: columns b = s-c = 1..bcap, rows a = r-c = b..mcap, then mcap rhs blocks.
 // grid = (ntile_cap + mcap, fronts in level, n_frames)
 __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ frames, int level,
-                                                 int c, int mcap, int bcap, int ntile_cap) {
+                                                 int c, int mcap, int bcap, int ntile_cap, WgMap map) {
   __shared__ double Bl[TILE];
-  const FrameDev& fd = frames[blockIdx.z];
+  WgId wg;
+  if (!wg_decode(map, wg)) return;
+  const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
+  const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
   const int m = f.nt - 1 - c;
-  int t = blockIdx.x;
+  int t = wg.unit;
   if (t < ntile_cap) {
     int db = 1;
     while (db <= bcap && t >= mcap - db + 1) {
@@ -630,30 +676,45 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 }
 
 // Schur complement of a front in one pass: U(r,s) -= sum_{c < npt} L(r,c) L(s,c)^T for the
-// boundary tiles npt <= s <= r < nt.  The U tile is read and written once; the next pivot
-// column's operands are fetched while the current one is on the MFMA.
+// boundary tiles npt <= s <= r < nt, fused with the extend-add: the updated tile never goes back
+// to the child front, it is added from the accumulators into the parent front through the
+// row / column index maps.  The next pivot column's operands are fetched while the current one
+// is on the MFMA.  `which` selects the children with that index (see launch_front_solve).
 // grid = (max boundary tile pairs, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ frames, int level) {
+__global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ frames, int level, int which,
+                                                 WgMap map) {
   __shared__ double Bl[2][TILE];
-  const FrameDev& fd = frames[blockIdx.z];
+  __shared__ int rmap[NB], cmap[NB];
+  WgId wg;
+  if (!wg_decode(map, wg)) return;
+  const int t = wg.unit;
+  const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
+  const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
   const NDFront& f = fd.fronts[fi];
+  if (f.parent < 0 || f.which_child != which) return;   // the root has no boundary
   const int nbt = f.nt - f.npt;
-  const int t = blockIdx.x;
-  if (f.npt == 0 || t >= nbt * (nbt + 1) / 2) return;
+  if (t >= nbt * (nbt + 1) / 2) return;
   int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
   while (tr * (tr + 1) / 2 > t) --tr;
   const int tc = t - tr * (tr + 1) / 2;
   const int r = f.npt + tr, sc = f.npt + tc;
-  double* Ct = ftile(fd, f, r, sc);
+  // child boundary scalar -> scalar index in the parent front (extend-add maps)
+  const NDFront& pf = fd.fronts[f.parent];
+  if (threadIdx.x < 2 * NB) {
+    const int* em = fd.nd_eamap + f.eamap_off;
+    const bool is_row = threadIdx.x < NB;
+    const int i = (is_row ? tr : tc) * NB + (threadIdx.x & 63);
+    const int m = (i < 7 * f.nb) ? nd_base(pf, em[i / 7]) + i % 7 : -1;
+    if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
+  }
   double4_t acc[4];
-  load_c_frags(Ct, acc);
+  load_c_frags(ftile(fd, f, r, sc), acc);
   double breg[16], areg[16];
-  {
+  if (f.npt > 0) {
     const double* Ls = ftile(fd, f, sc, 0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
@@ -675,51 +736,27 @@ __global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ fra
     __syncthreads();   // B[c&1] complete; the buffer written two steps ago is free again
     tile_ABt_regs<true>(acur, B, acc);
   }
-  store_c_frags(Ct, acc);
-}
-
-// Add the Schur complement (and forward-eliminated rhs) of every front of the level whose
-// which_child == which into its parent.  One block per 64x64 tile (tr >= tc) of the child's
-// boundary part; the child -> parent scalar index maps of the tile's rows and columns are
-// built once per block in LDS (node map eamap, 7 scalars per node).
-// grid = (max boundary tile pairs, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_extend_add(const FrameDev* __restrict__ frames, int level,
-                                                     int which) {
-  __shared__ int rmap[NB], cmap[NB];
-  const FrameDev& fd = frames[blockIdx.z];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
-  if (fi >= fd.level_start[level + 1]) return;
-  const NDFront& f = fd.fronts[fi];
-  if (f.parent < 0 || f.which_child != which) return;
-  const int nbt = f.nt - f.npt;                 // boundary tiles per side
-  const int t = blockIdx.x;
-  if (t >= nbt * (nbt + 1) / 2) return;
-  int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-  while (tr * (tr + 1) / 2 > t) --tr;
-  const int tc = t - tr * (tr + 1) / 2;
-  const NDFront& pf = fd.fronts[f.parent];
-  const int* em = fd.nd_eamap + f.eamap_off;
-  const int n2 = 7 * f.nb;
-  if (threadIdx.x < 2 * NB) {
-    const bool is_row = threadIdx.x < NB;
-    const int i = (is_row ? tr : tc) * NB + (threadIdx.x & 63);   // child boundary scalar index
-    const int m = (i < n2) ? nd_base(pf, em[i / 7]) + i % 7 : -1;
-    if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
-  }
+  __syncthreads();     // maps visible, all waves done with Bl
+  // extend-add: the tile goes through LDS so that every instruction updates 64 consecutive rows of
+  // one parent column (child rows map to parent rows in runs of 7 that are mostly adjacent)
+  store_c_frags(Bl[0], acc);
   __syncthreads();
-  const double* src = ftile(fd, f, f.npt + tr, f.npt + tc);
-  double v[16];
+  {
+    double* dst[16];
+    double cur[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) v[e] = src[threadIdx.x + 256 * e];
+    for (int e = 0; e < 16; ++e) {
+      const int idx = threadIdx.x + 256 * e;
+      const int i = idx & 63, j = idx >> 6;
+      const int pr = rmap[i], pc = cmap[j];
+      dst[e] = (pr >= 0 && pc >= 0 && (tr > tc || i >= j)) ? front_entry(fd, pf, pr, pc) : nullptr;
+    }
+    // all loads before the first store: the destinations are distinct but the compiler cannot know
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int idx = threadIdx.x + 256 * e;
-    const int i = idx & 63, j = idx >> 6;
-    const int pr = rmap[i], pc = cmap[j];
-    if (pr >= 0 && pc >= 0 && (tr > tc || i >= j)) *front_entry(fd, pf, pr, pc) += v[e];
+    for (int e = 0; e < 16; ++e) cur[e] = dst[e] ? *dst[e] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      if (dst[e]) *dst[e] = cur[e] + Bl[0][threadIdx.x + 256 * e];
   }
   // rhs: diagonal tiles carry their rows' vector entries
   if (tr == tc && threadIdx.x < NB) {
@@ -850,40 +887,42 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= 16;
     if (compact) {
       hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, l, u_override);
-      if (s.max_n2p > 0)
-        hipLaunchKernelGGL(k_fL21, dim3(s.max_n2p / 64, s.n_fronts, n_frames), dim3(256), 0, st, fr, l);
+      if (s.max_n2p > 0) {
+        const WgMap m = make_map(s.max_n2p / 64, s.n_fronts, n_frames);
+        hipLaunchKernelGGL(k_fL21, map_grid(m), dim3(256), 0, st, fr, l, m);
+      }
     }
     for (int c = 0; !compact && c < s.max_npt; ++c) {
       const int mcap = s.max_nt - 1 - c;
       // fused panel while the launch is small (latency-bound); split once the redundant
       // factorisations would take more than ~2 blocks per CU
       if ((long)(mcap + 1) * s.n_fronts * n_frames <= 512) {
-        hipLaunchKernelGGL(k_fpanel, dim3(mcap + 1, s.n_fronts, n_frames), dim3(256), lds, st, fr,
-                           l, c, u_override);
+        const WgMap m = make_map(mcap + 1, s.n_fronts, n_frames);
+        hipLaunchKernelGGL(k_fpanel, map_grid(m), dim3(256), lds, st, fr, l, c, u_override, m);
       } else {
         hipLaunchKernelGGL(k_fpotrf, dim3(1, s.n_fronts, n_frames), dim3(256), lds, st, fr, l, c,
                            u_override);
-        if (mcap > 0)
-          hipLaunchKernelGGL(k_ftrsm, dim3(mcap, s.n_fronts, n_frames), dim3(256), 0, st, fr, l, c);
+        if (mcap > 0) {
+          const WgMap m = make_map(mcap, s.n_fronts, n_frames);
+          hipLaunchKernelGGL(k_ftrsm, map_grid(m), dim3(256), 0, st, fr, l, c, m);
+        }
       }
       const int bcap = std::min(mcap, s.max_npt - 1 - c);
       int ntile = 0;
       for (int b = 1; b <= bcap; ++b) ntile += mcap - b + 1;
-      if (ntile + mcap > 0)
-        hipLaunchKernelGGL(k_ftrail, dim3(ntile + mcap, s.n_fronts, n_frames), dim3(256), 0, st, fr, l,
-                           c, mcap, bcap, ntile);
+      if (ntile + mcap > 0) {
+        const WgMap m = make_map(ntile + mcap, s.n_fronts, n_frames);
+        hipLaunchKernelGGL(k_ftrail, map_grid(m), dim3(256), 0, st, fr, l, c, mcap, bcap, ntile, m);
+      }
     }
-    if (s.max_n2p > 0 && s.max_npt > 0) {
-      const int nbt = s.max_n2p / 64;
-      hipLaunchKernelGGL(k_fschur, dim3(nbt * (nbt + 1) / 2, s.n_fronts, n_frames), dim3(256), 0, st, fr, l);
-    }
-    // push the Schur complements of this level into the parents (next level); two passes so
-    // that the two children of a parent never write the same entry concurrently
+    // Schur complements of this level, added straight into the parents (next level): one pass
+    // per child index so that the two children of a parent never update the same entry
+    // concurrently (plain read-modify-write, fixed order: bitwise reproducible)
     if (s.max_n2p > 0 && l + 1 < n_levels) {
       const int nbt = s.max_n2p / 64;
-      const dim3 g(nbt * (nbt + 1) / 2, s.n_fronts, n_frames);
-      hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, fr, l, 0);
-      hipLaunchKernelGGL(k_extend_add, g, dim3(256), 0, st, fr, l, 1);
+      const WgMap m = make_map(nbt * (nbt + 1) / 2, s.n_fronts, n_frames);
+      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, l, 0, m);
+      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, l, 1, m);
     }
   }
   for (int l = n_levels - 1; l >= 0; --l) {
