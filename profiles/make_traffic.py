@@ -18,7 +18,8 @@ import json
 def means(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        agg[name].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
@@ -37,6 +38,7 @@ def main():
         write_kib, _ = w[k]
         out["kernels"][k] = {
             "launches_sampled": n, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+            "traffic_bytes_all_launches": (2.0 * fetch_kib + write_kib) * 1024.0 * n,
             "traffic_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
             "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1"}
     json.dump(out, open(a.out, "w"), indent=1)

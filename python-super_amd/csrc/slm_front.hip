@@ -681,9 +681,9 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 // row / column index maps.  The next pivot column's operands are fetched while the current one
 // is on the MFMA.  `which` selects the children with that index (see launch_front_solve).
 // grid = (max boundary tile pairs, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ frames, int level, int which,
+__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, int level, int which,
                                                  WgMap map) {
-  __shared__ double Bl[2][TILE];
+  __shared__ double Bl[TILE];
   __shared__ int rmap[NB], cmap[NB];
   WgId wg;
   if (!wg_decode(map, wg)) return;
@@ -713,33 +713,56 @@ __global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ fra
   }
   double4_t acc[4];
   load_c_frags(ftile(fd, f, r, sc), acc);
-  double breg[16], areg[16];
+  // The B operand (L21 tile of block-row sc) passes through LDS in HALF tiles of 32 inner columns,
+  // double-buffered (2 x 16 KB): three workgroups per CU instead of two, and the next half is in
+  // flight while the current one is on the MFMA.
+  double breg[8], areg[16], acur[16];
+  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   if (f.npt > 0) {
     const double* Ls = ftile(fd, f, sc, 0);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
+    for (int e = 0; e < 8; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
     load_a_frags(ftile(fd, f, r, 0), areg);
   }
   for (int c = 0; c < f.npt; ++c) {
-    double* B = Bl[c & 1];
+    const double* Ls = ftile(fd, f, sc, c);
+    // ---- inner columns 0..31 ----
 #pragma unroll
-    for (int e = 0; e < 16; ++e) B[threadIdx.x + 256 * e] = breg[e];
-    double acur[16];
+    for (int e = 0; e < 8; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acur[e] = areg[e];
-    if (c + 1 < f.npt) {   // prefetch the next pivot column
-      const double* Ls = ftile(fd, f, sc, c + 1);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
-      load_a_frags(ftile(fd, f, r, c + 1), areg);
+    for (int e = 0; e < 8; ++e) breg[e] = Ls[TILE / 2 + threadIdx.x + 256 * e];
+    if (c + 1 < f.npt) load_a_frags(ftile(fd, f, r, c + 1), areg);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double av = -acur[ks];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[(16 * ni + lr) + (4 * ks + lk) * LD], av, acc[ni], 0, 0, 0);
     }
-    __syncthreads();   // B[c&1] complete; the buffer written two steps ago is free again
-    tile_ABt_regs<true>(acur, B, acc);
+    // ---- inner columns 32..63 ----
+#pragma unroll
+    for (int e = 0; e < 8; ++e) Bl[TILE / 2 + threadIdx.x + 256 * e] = breg[e];
+    if (c + 1 < f.npt) {
+      const double* Ln = ftile(fd, f, sc, c + 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) breg[e] = Ln[threadIdx.x + 256 * e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 8; ks < 16; ++ks) {
+      const double av = -acur[ks];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[(16 * ni + lr) + (4 * ks + lk) * LD], av, acc[ni], 0, 0, 0);
+    }
   }
   __syncthreads();     // maps visible, all waves done with Bl
   // extend-add: the tile goes through LDS so that every instruction updates 64 consecutive rows of
   // one parent column (child rows map to parent rows in runs of 7 that are mostly adjacent)
-  store_c_frags(Bl[0], acc);
+  store_c_frags(Bl, acc);
   __syncthreads();
   {
     double* dst[16];
@@ -756,7 +779,7 @@ __global__ void __launch_bounds__(256) k_fschur(const FrameDev* __restrict__ fra
     for (int e = 0; e < 16; ++e) cur[e] = dst[e] ? *dst[e] : 0.0;
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      if (dst[e]) *dst[e] = cur[e] + Bl[0][threadIdx.x + 256 * e];
+      if (dst[e]) *dst[e] = cur[e] + Bl[threadIdx.x + 256 * e];
   }
   // rhs: diagonal tiles carry their rows' vector entries
   if (tr == tc && threadIdx.x < NB) {
