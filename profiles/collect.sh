@@ -1,0 +1,17 @@
+#!/bin/bash
+# Collect the round's judged profiles on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
+# Writes under gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards (see README there).
+# rocprofv3 rules on this pool: the program itself after `--`; --pmc passes separate from --stats.
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+timeout 400 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err < /dev/null
+timeout 300 python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_b1.json 2> $R/gpurun_out/${TAG}_bench_b1.err < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
+find $R/gpurun_out/${TAG}_stats -name '*kernel_trace.csv' -delete
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1 < /dev/null
+  find $R/gpurun_out/${TAG}_pmc_$c -name '*kernel_trace.csv' -delete
+done
+ls $R/gpurun_out/${TAG}_stats/* $R/gpurun_out/${TAG}_pmc_FETCH_SIZE/* < /dev/null
