@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) k_panel(const FrameDev* __restrict__ fram
   load_diag_tile(fd, c, u, S);
   __syncthreads();
   SLM_STAMP(fd, stamp, 1);
-  const bool ok = potrf64(S, dinv, s_ok, fd, stamp);
+  const bool ok = potrf64(S, dinv, wt, s_ok, fd, stamp);
   SLM_STAMP(fd, stamp, 14);
 
   if (d == 0) {

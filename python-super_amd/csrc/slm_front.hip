@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   }
   __syncthreads();
   SLM_STAMP(fd, stamp, 1);
-  const bool ok = potrf64(S, dinv, s_ok, fd, stamp);
+  const bool ok = potrf64(S, dinv, wt, s_ok, fd, stamp);
   SLM_STAMP(fd, stamp, 14);
 
   if (d == 0) {
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
     }
   }
   __syncthreads();
-  const bool ok = potrf64(S, dinv, s_ok, fd, false);
+  const bool ok = potrf64(S, dinv, wt, s_ok, fd, false);
   if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
   inverse_assemble64(S, M, dinv, wt);
   double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
       }
     }
     __syncthreads();
-    const bool ok = potrf64(S, dinv, s_ok, fd, false);
+    const bool ok = potrf64(S, dinv, wt, s_ok, fd, false);
     if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
     inverse_assemble64(S, M, dinv, wt);
     {

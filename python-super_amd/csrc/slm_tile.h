@@ -76,18 +76,29 @@ __device__ __forceinline__ double readlane_d(double x, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// 16x16 diagonal block on ONE wave, register resident, rank-1 updates on the f64 MFMA.
-// The block S (full symmetric) and the running inverse M (starts as I) live in MFMA
-// accumulator layout: reg r of lane l <-> [row (l>>4)+4r][col l&15].  Pivot step j
-// (q = j&3, r = j>>2): row j of S already sits in register r of the 16 lanes of quarter
-// q, indexed by column -- exactly the k = q slot of both MFMA operands -- so
-//   S -= (v/p) v^T  and  M -= (v/p) M[j,:]
-// are one MFMA each with no cross-lane traffic; only the pivot p travels (v_readlane).
-// Row j is excluded from the update (its A-operand entry is zeroed), so on exit S holds
-// U = diag(p) L~^T (upper) and M holds L~^-1 (unit lower):
-//   L = U^T diag(p)^-1/2,  L^-1 = diag(p)^-1/2 L~^-1.
+// ~1 ulp reciprocal square root: v_rsq_f64 is good to ~1e-9, one Newton step squares that.
+__device__ __forceinline__ double rsq1(double p) {
+  const double r = __builtin_amdgcn_rsq(p);
+  return r * fma(-(0.5 * p) * r, r, 1.5);
+}
+
+// 16x16 diagonal block on ONE wave, register resident: blocked right-looking Cholesky with 4x4
+// pivot blocks, so that all four k-slots of v_mfma_f64_16x16x4_f64 carry a rank-1 term (on gfx950
+// an f64 MFMA issues in 70 cycles and does not overlap f64 VALU work: one MFMA per pivot, as in a
+// rank-1 formulation, costs 370 cycles per pivot; this costs 260, tests/micro/diag16_mb.hip).
+// The block S (full symmetric) and the running inverse M (starts as I) live in MFMA accumulator
+// layout: reg r of lane l <-> [row (l>>4)+4r][col l&15].  Block step b (rows 4b..4b+3 = register
+// b of the four lane quarters):
+//   * rows 4b..4b+3 of S and M go through LDS once (xch, 128 doubles owned by this wave): every
+//     lane reads the 4x4 pivot block P (broadcast) and the four entries S[i][4b..4b+3] of its
+//     row i = l&15 (resp. M[4b..4b+3][n] of its column);
+//   * every lane factors P = Lp Lp^T (10 entries, identical in all lanes) and forward-substitutes
+//     W[i][:] = S[i][blk] Lp^-T, Bm[:][n] = Lp^-1 M[blk][n]; lane (q,i) keeps W[i][q], Bm[q][i];
+//   * L[i][4b+q] = W and L^-1[4b+q][n] = Bm are final and go to Sd / Dinv;
+//   * S -= W W^T and M -= W Bm for the rows below the block: lane 16q+i holds A[i][k=q] = -W[i][q]
+//     and B[k=q][n=i] = W[i][q] (resp. Bm[q][i]) -- ONE MFMA each, no further data movement.
 // Writes L (lower, zeros above) to Sd (LDS, ld LD) and L^-1 to Dinv (16x16, ld 16).
-__device__ __forceinline__ bool diag16(double* Sd, double* Dinv) {
+__device__ __forceinline__ bool diag16(double* Sd, double* Dinv, double* xch) {
   const int l = threadIdx.x & 63, lc = l & 15, lq = l >> 4;
   double4_t S, M;
 #pragma unroll
@@ -97,45 +108,46 @@ __device__ __forceinline__ bool diag16(double* Sd, double* Dinv) {
     M[r] = (row == lc) ? 1.0 : 0.0;
   }
   bool ok = true;
-  double pv = 1.0;   // lane with (l & 15) == j keeps pivot j
-  // The reciprocal of pivot j+1 is computed on the VALU while the rank-1 MFMAs of step j are
-  // still in flight: p_{j+1} = S[j+1][j+1] - S[j][j+1]^2 / p_j, formed exactly like the
-  // MFMA forms it (fma of the rounded A entry), from registers that step j-1 has completed.
-  double p = readlane_d(S[0], 0);
-  double rinv = rcp_nr(p);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int q = j & 3, r = j >> 2;
-    const double v = S[r];
-    ok = ok && (p > 0.0);
-    pv = (lc == j) ? p : pv;
-    // Only the A operand is masked: k-slots other than q (and row j itself) carry a zero A
-    // entry, so whatever (finite) B value sits in those slots contributes nothing.
-    const double a = (l != 16 * q + j && lq == q) ? -v * rinv : 0.0;
-    const double bs = v;
-    const double bm = M[r];
-    double p_next = 1.0, rinv_next = 1.0;
-    if (j + 1 < 16) {
-      const int q1 = (j + 1) & 3, r1 = (j + 1) >> 2;
-      const double x = readlane_d(v, 16 * q + (j + 1));           // S[j][j+1]
-      const double d = readlane_d(S[r1], 16 * q1 + (j + 1));      // S[j+1][j+1] before this step
-      p_next = fma(-x * rinv, x, d);
-      rinv_next = rcp_nr(p_next);
+  for (int b = 0; b < 4; ++b) {
+    xch[l] = S[b];
+    xch[64 + l] = M[b];
+    wave_sync();
+    const double* ps = xch + 4 * b;     // P[q][q'] = xch[16q + 4b + q']
+    const double p00 = ps[0];
+    const double p10 = ps[16], p11 = ps[17];
+    const double p20 = ps[32], p21 = ps[33], p22 = ps[34];
+    const double p30 = ps[48], p31 = ps[49], p32 = ps[50], p33 = ps[51];
+    const double s0 = xch[lc], s1 = xch[16 + lc], s2 = xch[32 + lc], s3 = xch[48 + lc];
+    const double m0 = xch[64 + lc], m1 = xch[80 + lc], m2 = xch[96 + lc], m3 = xch[112 + lc];
+    // Cholesky of the pivot block
+    const double r0 = rsq1(p00);
+    const double l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+    const double d1 = fma(-l10, l10, p11);
+    const double r1 = rsq1(d1);
+    const double l21 = fma(-l20, l10, p21) * r1, l31 = fma(-l30, l10, p31) * r1;
+    const double d2 = fma(-l21, l21, fma(-l20, l20, p22));
+    const double r2 = rsq1(d2);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * r2;
+    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
+    const double r3 = rsq1(d3);
+    ok = ok && (p00 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d3 > 0.0);
+    // forward substitutions (every lane solves the four unknowns of its row / column)
+    const double w0 = s0 * r0, w1 = fma(-l10, w0, s1) * r1, w2 = fma(-l21, w1, fma(-l20, w0, s2)) * r2,
+                 w3 = fma(-l32, w2, fma(-l31, w1, fma(-l30, w0, s3))) * r3;
+    const double b0 = m0 * r0, b1 = fma(-l10, b0, m1) * r1, b2 = fma(-l21, b1, fma(-l20, b0, m2)) * r2,
+                 b3 = fma(-l32, b2, fma(-l31, b1, fma(-l30, b0, m3))) * r3;
+    const double W = lq == 0 ? w0 : (lq == 1 ? w1 : (lq == 2 ? w2 : w3));
+    const double Bm = lq == 0 ? b0 : (lq == 1 ? b1 : (lq == 2 ? b2 : b3));
+    const int col = 4 * b + lq;
+    Sd[lc + col * LD] = (lc >= col) ? W : 0.0;        // L[i][4b+q]; zero the strict upper part
+    Dinv[col + 16 * lc] = (lc <= col) ? Bm : 0.0;     // L^-1[4b+q][n]
+    if (b < 3) {
+      const double a = (lc > 4 * b + 3) ? -W : 0.0;   // rows of finished blocks stay as they are
+      S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W, S, 0, 0, 0);
+      M = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bm, M, 0, 0, 0);
+      wave_sync();                                    // xch is rewritten by the next block
     }
-    S = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs, S, 0, 0, 0);
-    M = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bm, M, 0, 0, 0);
-    p = p_next;
-    rinv = rinv_next;
-  }
-  const double rsv = rsq_nr(pv);   // lane l: 1/sqrt(pivot (l & 15))
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = lq + 4 * r;
-    const double rsr = __shfl(rsv, row, 64);
-    // U[row][lc] -> L[lc][row]; zero the strict upper part of L explicitly
-    if (lc >= row) Sd[lc + row * LD] = S[r] * rsr;
-    else Sd[lc + row * LD] = 0.0;
-    Dinv[row + 16 * lc] = (lc <= row) ? M[r] * rsr : 0.0;
   }
   wave_sync();
   return ok;
@@ -146,15 +158,17 @@ __device__ __forceinline__ bool diag16(double* Sd, double* Dinv) {
 // read) as L L^T and form L^-1, blocked by 16: the four diagonal blocks run on wave 0
 // (diag16), the panel / trailing / inverse-assembly products on the f64 MFMA across the
 // four waves.  On exit S = L (lower, zero above), dinv[kb] = inverse of diagonal block kb
-// (4 x 256 doubles).  256 threads.  Returns false (in every thread) when a pivot is <= 0 / NaN.
-__device__ __forceinline__ bool potrf64(double* S, double* dinv, int* s_ok, const FrameDev& fd,
+// (4 x 256 doubles); xch = 128 doubles of LDS scratch (may alias the scratch of
+// inverse_assemble64, which runs afterwards).  256 threads.  Returns false (in every thread) when
+// a pivot is <= 0 / NaN.
+__device__ __forceinline__ bool potrf64(double* S, double* dinv, double* xch, int* s_ok, const FrameDev& fd,
                                         bool stamp) {
   const int w = threadIdx.x >> 6;
   if (threadIdx.x == 0) *s_ok = 1;
   __syncthreads();
   for (int kb = 0; kb < 4; ++kb) {
     if (w == 0) {
-      const bool ok = diag16(S + kb * 16 * (LD + 1), dinv + kb * 256);
+      const bool ok = diag16(S + kb * 16 * (LD + 1), dinv + kb * 256, xch);
       if (!ok && (threadIdx.x & 63) == 0) *s_ok = 0;
     }
     SLM_STAMP(fd, stamp, 2 + 3 * kb);

@@ -27,6 +27,22 @@ __global__ void __launch_bounds__(64) k(double* out, unsigned long long* cyc, in
         a = fma(a, b, 1e-3);
       } else if (VAR == 5) {     // v_rcp_f64 dependent chain
         a = __builtin_amdgcn_rcp(a) + 1.0;
+      } else if (VAR == 7) {     // 10 x (2 v_readlane) feeding one dependent VALU op (pivot-block broadcast)
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+          int lo = __builtin_amdgcn_readlane(__double2loint(a), (3 * k + u) & 63);
+          int hi = __builtin_amdgcn_readlane(__double2hiint(a), (3 * k + u) & 63);
+          t += __hiloint2double(hi, lo);
+        }
+        a = a * 0.5 + t * 1e-3;
+      } else if (VAR == 8) {     // 4 f64 shuffles (8 ds_bpermute) feeding one dependent VALU op
+        const int l = threadIdx.x & 63;
+        double t = __shfl(a, l & 15, 64) + __shfl(a, 16 + (l & 15), 64) + __shfl(a, 32 + (l & 15), 64) + __shfl(a, 48 + (l & 15), 64);
+        a = a * 0.5 + t * 1e-3;
+      } else if (VAR == 9) {     // dependent v_rsq_f64 + 1 Newton step
+        const double r = __builtin_amdgcn_rsq(a);
+        a = r * fma(-(0.5 * a) * r, r, 1.5) + 1.0;
       } else if (VAR == 6) {     // readlane -> VALU chain
         int lo = __builtin_amdgcn_readlane(__double2loint(a), u);
         int hi = __builtin_amdgcn_readlane(__double2hiint(a), u);
@@ -55,5 +71,8 @@ int main() {
   run(k<4>, "dependent v_fma_f64", 1);
   run(k<5>, "dependent v_rcp_f64 + v_add_f64", 1);
   run(k<6>, "2 v_readlane + v_fma_f64 chain", 1);
+  run(k<7>, "20 v_readlane (10 doubles) + 10 adds + fma", 1);
+  run(k<8>, "4 f64 __shfl (8 ds_bpermute) + adds + fma", 1);
+  run(k<9>, "dependent v_rsq_f64 + 1 NR step + add", 1);
   return 0;
 }
