@@ -131,6 +131,43 @@ def cpu_baseline_autograd(dims, seed):
                       f"{sc.J}-node frame, PyTorch-CPU float64, {dt:.1f} s"}
 
 
+def next_row_timings(device):
+    """Untimed-region extras (rank 0, N=1): the widened rows of SURVEY.md 8(f), measured with torch
+    events on the stream the kernels run on.  f2 = depth_preprocessing at the SuPer image size."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from super_amd import synth
+    from super_amd.data_loader import depth_preprocessing
+    H, W = 480, 640
+    K = synth.intrinsics()
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    depth = torch.from_numpy((0.2 * synth._surface(uu, vv, H, W, 0.3)).astype(np.float32))[None, None].to(device)
+    color = torch.rand(1, 3, H, W, device=device) * 255.0
+    opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, depth_model="monodepth2",
+                          dilate_invalid_kernel=0, normal_model="naive", phase="test")
+    inputs = {"inv_K": torch.from_numpy(np.linalg.pinv(K))[None], "K": torch.from_numpy(K)[None],
+              ("color", 0): color, "divterm": 1.0 / (2 * 0.6 * 0.6), "filename": ["000001"]}
+    reps = 20
+    t = []
+    for i in range(reps + 3):
+        inputs[("depth", 0)] = depth.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        data, _ = depth_preprocessing(opt, None, inputs)
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            t.append(e0.elapsed_time(e1))
+    ms = sum(t) / len(t)
+    T = int(data.points.shape[0])
+    # algorithmic bytes: depth + colour in; points/normals/colours f32, radii f64, confs f32, index_map i32, valid u8 out
+    nbytes = H * W * (4 + 12) + T * (12 + 12 + 12 + 8 + 4) + H * W * (4 + 1)
+    return {"depth_preprocessing": {"ms_per_frame": ms, "image": [H, W], "valid_points": T,
+                                    "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / ms / 1e6,
+                                    "note": "mirror call incl. dtype conversions and the one host sync"}}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -294,6 +331,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, seed=0)
             out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)
+            out["next_rows"] = next_row_timings(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -308,6 +308,61 @@ int slm_apply_update_gf(int32_t N, int32_t J, int32_t K, float* sf_points, float
                         const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
                         float* ed_norms, const double* deform_device, void* stream);
 
+/* ===================================================================================
+ * "Next" row f2: depth map -> per-frame target `new_data`
+ *   slm_depth_*  <- depth_preprocessing  utils/data_loader.py:333-523 (+ getN :532-584,
+ *                   BackprojectDepth depth/monodepth2/layers.py:139-167, torch_dilate /
+ *                   find_edge_region utils/utils.py:152-157,276-301)
+ * Produces exactly what slm_bind_frame consumes (tgt_points, tgt_norms, index_map, tgt_valid)
+ * plus the other fields of the reference's Data object.  The optional SSIM confidence
+ * (opt.disable_ssim_conf == False, needs the stereo pair) is not built.
+ * =================================================================================== */
+typedef struct slm_depth slm_depth; /* opaque: scratch buffers for one image size */
+
+typedef struct slm_depth_config {
+  int32_t H, W;                  /* opt.height, opt.width */
+  int32_t data_mode;             /* 0 = opt.data "superv1", 1 = "superv2" */
+  int32_t raft_stereo;           /* opt.depth_model == "raft_stereo" (superv1 rules) */
+  int32_t dilate_invalid_kernel; /* opt.dilate_invalid_kernel (superv1) */
+  int32_t load_depth;            /* opt.load_depth (superv2) */
+  int32_t normal_model;          /* 0 = "naive", 1 = "8neighbors" */
+  int32_t num_classes;           /* opt.num_classes (with segmentation inputs), <= SLM_MAX_CLASSES */
+  int32_t n_del_classes;         /* len(opt.del_seg_classes) <= 3 */
+  int32_t del_classes[3];
+  float depth_width_range[2];    /* opt.depth_width_range (superv2 without load_depth) */
+  float inv_K[9];                /* inputs["inv_K"][0,:3,:3], row-major */
+  float fx, fy, cx, cy;          /* inputs["K"][0] */
+  double divterm;                /* inputs["divterm"] */
+} slm_depth_config;
+
+typedef struct slm_depth_inputs {   /* device pointers */
+  const float* depth;            /* (H,W)   inputs[("depth",0)][0,0] */
+  const float* color;            /* (3,H,W) inputs[("color",0)][0] */
+  const uint8_t* valid_mask;     /* (H,W) or NULL: the opt.load_valid_mask image (superv1) */
+  const int32_t* seg;            /* (H,W) or NULL: inputs[("seg",0)][0,0] */
+  const float* seg_conf;         /* (C,H,W) or NULL: inputs[("seg_conf",0)][0] */
+} slm_depth_inputs;
+
+typedef struct slm_depth_outputs {  /* device pointers; row capacity H*W; NULL = not wanted */
+  float* points;                 /* (T,3) data.points (the reference widens these float32 values to float64) */
+  float* norms;                  /* (T,3) data.norms */
+  float* colors;                 /* (T,3) data.colors */
+  double* radii;                 /* (T)   data.radii */
+  float* confs;                  /* (T)   data.confs */
+  int32_t* index_map;            /* (H,W) data.index_map, -1 invalid */
+  uint8_t* valid;                /* (H*W) data.valid */
+  int32_t* seg;                  /* (T)   data.seg */
+  double* seg_conf;              /* (T,C) data.seg_conf (per-pixel softmax) */
+  double* dist2edge;             /* (T)   data.dist2edge */
+  uint8_t* inval;                /* (H*W) the invalid-pixel map of step 1 (the reference NaNs depth / disp / pcd there) */
+} slm_depth_outputs;
+
+int slm_depth_create(int32_t H, int32_t W, slm_depth** out);
+int slm_depth_destroy(slm_depth* d);
+/* Runs the whole step on `stream`; *n_valid_host receives T (synchronises the stream). */
+int slm_depth_preprocess(slm_depth* d, const slm_depth_config* cfg, const slm_depth_inputs* in,
+                         const slm_depth_outputs* out, int32_t* n_valid_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ EXPORTS = [
     "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
     "slm_gf_bind_semantic", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
+    "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
 ]
 
@@ -63,6 +64,27 @@ class SlmGfSemantic(C.Structure):
     _fields_ = [("num_classes", C.c_int32), ("pad", C.c_int32), ("sf_seg", C.c_void_p),
                 ("sf_seg_conf", C.c_void_p), ("tgt_seg_conf", C.c_void_p),
                 ("img_seg_conf", C.c_void_p), ("img_seg", C.c_void_p)]
+
+
+class SlmDepthConfig(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("data_mode", C.c_int32), ("raft_stereo", C.c_int32),
+                ("dilate_invalid_kernel", C.c_int32), ("load_depth", C.c_int32), ("normal_model", C.c_int32),
+                ("num_classes", C.c_int32), ("n_del_classes", C.c_int32), ("del_classes", C.c_int32 * 3),
+                ("depth_width_range", C.c_float * 2), ("inv_K", C.c_float * 9),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("divterm", C.c_double)]
+
+
+class SlmDepthInputs(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("valid_mask", C.c_void_p),
+                ("seg", C.c_void_p), ("seg_conf", C.c_void_p)]
+
+
+class SlmDepthOutputs(C.Structure):
+    _fields_ = [("points", C.c_void_p), ("norms", C.c_void_p), ("colors", C.c_void_p),
+                ("radii", C.c_void_p), ("confs", C.c_void_p), ("index_map", C.c_void_p),
+                ("valid", C.c_void_p), ("seg", C.c_void_p), ("seg_conf", C.c_void_p),
+                ("dist2edge", C.c_void_p), ("inval", C.c_void_p)]
 
 
 class SlmIterRecord(C.Structure):
@@ -126,6 +148,10 @@ def load():
         "slm_gf_step": [vp, i32, vp],
         "slm_gf_get_partial": [vp, i32, vp, vp],
         "slm_gf_set_partial": [vp, i32, vp, vp],
+        "slm_depth_create": [i32, i32, C.POINTER(vp)],
+        "slm_depth_destroy": [vp],
+        "slm_depth_preprocess": [vp, C.POINTER(SlmDepthConfig), C.POINTER(SlmDepthInputs),
+                                 C.POINTER(SlmDepthOutputs), C.POINTER(C.c_int32), vp],
         "slm_gf_get_deform": [vp, i32, vp, vp],
         "slm_gf_loss_grad": [vp, i32, vp, vp, vp, vp],
         "slm_apply_update_gf": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],

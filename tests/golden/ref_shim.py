@@ -110,6 +110,35 @@ def install():
                            uutils=ref_uutils, deform_mesh=ref_dm)
 
 
+def install_data_loader():
+    """Additionally import the reference's ``utils.data_loader`` (for ``depth_preprocessing``,
+    SURVEY.md 8f row f2): stubs for the image / network modules it imports at module level."""
+    ref = install()
+
+    def mod(name, **attrs):
+        if name in sys.modules:
+            sys.modules[name].__dict__.update(attrs)
+            return sys.modules[name]
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    sk = mod("skimage")
+    sk.io = mod("skimage.io")
+    sk.metrics = mod("skimage.metrics", structural_similarity=None)
+    pil = mod("PIL")
+    pil.Image = mod("PIL.Image")
+    mod("depth.raft_core")
+    mod("depth.raft_core.utils")
+    mod("depth.raft_core.utils.utils", depth_to_point_cloud=None)
+    mod("seg")
+    mod("seg.inference", generate_mask=None)
+    import utils.data_loader as ref_dl   # noqa: E402
+    ref.data_loader = ref_dl
+    return ref
+
+
 def torch_frame(sc, frame_id=1):
     """Build the reference-side ``sf`` / ``inputs`` / ``new_data`` objects (f64/i64
     torch tensors) from a ``super_amd.synth.Scene``."""
