@@ -138,6 +138,33 @@ int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int3
  * [8] workgroup-merged (workgroup, pair) records (0: one Gram per run in HBM), [9] padded positions. */
 int slm_get_plan_info(slm_solver* s, int32_t slot, double* info_out);
 
+/* -- one LARGE frame sharded over the GPUs of a node ----------------
+ * After slm_set_shard(rank, world) (before slm_bind_frame; every rank binds the WHOLE frame so that
+ * all ranks build the same plan) a context evaluates only its share of the surfels: workgroups
+ * [n_wg*rank/world, ...) of the Jacobian pass and surfels [N*rank/world, ...) of the loss pass.
+ * The library holds no communicator; per LM iteration the caller runs on every rank
+ *     slm_lm_grad_local   zero, data-term Gram records of the share, per-pair partial sums
+ *       -> all-reduce(sum) of SLM_X_PAIR_BLOCKS   (coupled pairs x 56 doubles + matched count;
+ *                                                   7 MB at C2 = the block-sparse J^T J and J^T r)
+ *     slm_lm_solve        reduced blocks -> fronts, ARAP / Rot rows, factor + solve
+ *       -> broadcast of SLM_X_DELTA from rank 0   (keeps every rank on bit-identical parameters)
+ *     slm_lm_loss_local   trial point, data loss of the share, regularisation loss
+ *       -> all-reduce(sum) of SLM_X_DATA_LOSS     (1024 doubles)
+ *     slm_lm_accept       accept / reject, record
+ * with slm_lm_exchange_get / _set moving the buffers device to device to and from the caller's
+ * tensor (torch.distributed = RCCL over xGMI on the GPU box). */
+#define SLM_X_PAIR_BLOCKS 0
+#define SLM_X_DELTA 1
+#define SLM_X_DATA_LOSS 2
+int slm_set_shard(slm_solver* s, int32_t rank, int32_t world);
+int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream);
+int slm_lm_solve(slm_solver* s, int32_t n_frames, void* stream);
+int slm_lm_loss_local(slm_solver* s, int32_t n_frames, void* stream);
+int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream);
+int slm_lm_exchange_size(slm_solver* s, int32_t slot, int32_t what, int64_t* n_doubles);
+int slm_lm_exchange_get(slm_solver* s, int32_t slot, int32_t what, double* out_device, void* stream);
+int slm_lm_exchange_set(slm_solver* s, int32_t slot, int32_t what, const double* in_device, void* stream);
+
 /* -- phase timing (bench.py roofline leg) ----------------------------------------- */
 /* With profiling on, slm_run brackets each phase of every LM iteration with HIP events
  * recorded on the launch stream.  Phases: */

@@ -16,6 +16,8 @@ void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_assemble(const FrameDev*, int, int, hipStream_t);
+void launch_pair_reduce(const FrameDev*, int, int, hipStream_t);
+void launch_pair_scatter(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
@@ -77,6 +79,8 @@ struct Slot {
   int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos
   NDDest* d_dests = nullptr;    // block_dest | pair_dest
   double *ftiles = nullptr, *fvec = nullptr, *flinv = nullptr;
+  double* pairbuf = nullptr;   // sharded frames: per-pair sums to exchange
+  size_t cap_pairbuf = 0;
   size_t cap_fronts = 0, cap_ints = 0, cap_dests = 0, cap_ftiles = 0, cap_fvec = 0, cap_flinv = 0;
 };
 }  // namespace
@@ -91,6 +95,7 @@ struct slm_solver {
   FrameDev* frames_dev = nullptr;
   int* bw_dev = nullptr;
   int* bw_host = nullptr;       // pinned
+  int rank = 0, world = 1;      // surfel sharding of every frame (slm_set_shard)
 };
 
 template <typename T>
@@ -163,6 +168,7 @@ int slm_destroy(slm_solver* s) {
     if (sl.ftiles) (void)hipFree(sl.ftiles);
     if (sl.fvec) (void)hipFree(sl.fvec);
     if (sl.flinv) (void)hipFree(sl.flinv);
+    if (sl.pairbuf) (void)hipFree(sl.pairbuf);
   }
   prep_destroy(s->prep);
   for (auto& evs : s->ev_runs)
@@ -271,6 +277,25 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
         h.blk2_entry = sl.plan.blk2_entry;
         h.v2_ready = 1;
       }
+    }
+  }
+  // share of this rank when the frame is sharded over several GPUs (whole frame otherwise)
+  {
+    const int n_wg = (h.v1_ready ? h.n_pos + 255 : 0) / 256;
+    h.wg_lo = (int32_t)((int64_t)n_wg * s->rank / s->world);
+    h.wg_hi = (int32_t)((int64_t)n_wg * (s->rank + 1) / s->world);
+    h.sf_lo = (int32_t)((int64_t)f->N * s->rank / s->world);
+    h.sf_hi = (int32_t)((int64_t)f->N * (s->rank + 1) / s->world);
+    h.pairbuf = nullptr;
+    if (s->world > 1) {
+      if (!h.v1_ready)
+        return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: sharded frames need the tuple-sorted data path "
+                                         "(data_path 0, num_neighbors 4, J < 65536)");
+      HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + 2));
+      h.pairbuf = sl.pairbuf;
+      // records (or per-run Grams) of the other ranks' workgroups stay zero for the whole frame
+      if (h.v2_ready) HIPCHK(hipMemsetAsync(h.wgslab, 0, sizeof(double) * SLM_WREC * (size_t)h.n_wblk, st));
+      else HIPCHK(hipMemsetAsync(h.slab, 0, sizeof(double) * SLM_SLAB_STRIDE * (size_t)h.n_runs, st));
     }
   }
   // nested-dissection plan (symbolic analysis on the host from the coupled-pair list)
@@ -452,9 +477,143 @@ static hipEvent_t take_event(slm_solver* s) {
   return e;
 }
 
+// ---- one frame sharded over several GPUs ----------------------------------------------------
+int slm_set_shard(slm_solver* s, int32_t rank, int32_t world) {
+  if (!s || world < 1 || rank < 0 || rank >= world) return fail(SLM_ERR_INVALID, "slm_set_shard: bad rank/world");
+  if (world > 1 && (s->cfg.data_path != 0 || s->cfg.solver_path != 0))
+    return fail(SLM_ERR_UNSUPPORTED, "slm_set_shard: needs data_path 0 and solver_path 0");
+  s->rank = rank;
+  s->world = world;
+  for (Slot& sl : s->slots) sl.h.bound = 0;   // the shares are fixed at bind time
+  HIPCHK(hipMemset(s->frames_dev, 0, sizeof(FrameDev) * s->slots.size()));
+  return SLM_OK;
+}
+
+static int shard_dims(slm_solver* s, int n_frames, BatchDims& d) {
+  int rc = check_slots(s, 0, n_frames);
+  if (rc) return rc;
+  d = dims_of(s, 0, n_frames);
+  if (!d.nd || !d.v1)
+    return fail(SLM_ERR_UNSUPPORTED, "sharded LM step: every slot needs the tuple-sorted data path and the ND solver");
+  return SLM_OK;
+}
+
+int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
+  BatchDims d;
+  int rc = shard_dims(s, n_frames, d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const FrameDev* fr = s->frames_dev;
+  for (int i = 0; i < n_frames; ++i) {
+    Slot& sl = s->slots[i];
+    HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_doubles, st));
+    HIPCHK(hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st));
+  }
+  launch_iter_begin_nd(fr, n_frames, st);
+  if (s->cfg.use_data) {
+    launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st);
+    launch_pair_reduce(fr, n_frames, d.max_blocks, st);
+  }
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_lm_solve(slm_solver* s, int32_t n_frames, void* stream) {
+  BatchDims d;
+  int rc = shard_dims(s, n_frames, d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const FrameDev* fr = s->frames_dev;
+  const slm_config& c = s->cfg;
+  if (c.use_data) launch_pair_scatter(fr, n_frames, d.max_blocks, st);
+  launch_reg_grad_nd(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+  launch_front_load_rhs(fr, n_frames, d.maxP, st);
+  launch_front_solve(fr, n_frames, d.sched.data(), (int)d.sched.size(), -1.0, st);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_lm_loss_local(slm_solver* s, int32_t n_frames, void* stream) {
+  BatchDims d;
+  int rc = shard_dims(s, n_frames, d);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const FrameDev* fr = s->frames_dev;
+  const slm_config& c = s->cfg;
+  if (c.use_data) {
+    launch_make_trial(fr, n_frames, d.maxJKe, st);
+    launch_data_loss(fr, n_frames, kLossBlocks, c.w_data, 1, st);
+  }
+  if (d.n_reg_part > 0)
+    launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream) {
+  BatchDims d;
+  int rc = shard_dims(s, n_frames, d);
+  if (rc) return rc;
+  launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+static int exchange_buf(slm_solver* s, int slot, int what, double** p, int64_t* n) {
+  int rc = check_slots(s, slot, 1);
+  if (rc) return rc;
+  const FrameDev& h = s->slots[slot].h;
+  switch (what) {
+    case SLM_X_PAIR_BLOCKS:
+      if (!h.pairbuf) return fail(SLM_ERR_UNBOUND, "slm_lm_exchange: the slot was bound without slm_set_shard");
+      *p = h.pairbuf;
+      *n = (int64_t)h.n_blocks * SLM_WREC + 1;
+      return SLM_OK;
+    case SLM_X_DELTA:
+      *p = h.delta;
+      *n = h.P;
+      return SLM_OK;
+    case SLM_X_DATA_LOSS:
+      *p = h.loss_part;
+      *n = 2 * (int64_t)h.n_loss_part;
+      return SLM_OK;
+  }
+  return fail(SLM_ERR_INVALID, "slm_lm_exchange: unknown buffer");
+}
+
+int slm_lm_exchange_size(slm_solver* s, int32_t slot, int32_t what, int64_t* n_doubles) {
+  double* p;
+  if (!n_doubles) return fail(SLM_ERR_INVALID, "slm_lm_exchange_size: null output");
+  return exchange_buf(s, slot, what, &p, n_doubles);
+}
+
+int slm_lm_exchange_get(slm_solver* s, int32_t slot, int32_t what, double* out, void* stream) {
+  double* p;
+  int64_t n;
+  int rc = exchange_buf(s, slot, what, &p, &n);
+  if (rc) return rc;
+  if (!out) return fail(SLM_ERR_INVALID, "slm_lm_exchange_get: null output");
+  HIPCHK(hipMemcpyAsync(out, p, sizeof(double) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SLM_OK;
+}
+
+int slm_lm_exchange_set(slm_solver* s, int32_t slot, int32_t what, const double* in, void* stream) {
+  double* p;
+  int64_t n;
+  int rc = exchange_buf(s, slot, what, &p, &n);
+  if (rc) return rc;
+  if (!in) return fail(SLM_ERR_INVALID, "slm_lm_exchange_set: null input");
+  HIPCHK(hipMemcpyAsync(p, in, sizeof(double) * n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SLM_OK;
+}
+
 int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
   int rc = check_slots(s, 0, n_frames);
   if (rc) return rc;
+  if (s->world > 1)
+    return fail(SLM_ERR_UNSUPPORTED,
+                "slm_run: the frame is sharded; drive slm_lm_grad_local / slm_lm_solve / slm_lm_loss_local / "
+                "slm_lm_accept with the exchanges between them");
   hipStream_t st = (hipStream_t)stream;
   const BatchDims d = dims_of(s, 0, n_frames);
   const FrameDev* fr = s->frames_dev;

@@ -73,6 +73,12 @@ struct FrameDev {
   double* wgslab;          // (n_wblk, 56): 49 block entries (row-major ca,cb) + 7 entries of -J^T r
   const int32_t* blk2_start;  // (n_blocks+1) CSR over blk2_entry, same pair order as blk_key
   const int32_t* blk2_entry;  // record ids
+  // ---- one frame sharded over several GPUs (slm_set_shard): this rank evaluates the workgroups
+  //      [wg_lo, wg_hi) of the Jacobian pass and the surfels [sf_lo, sf_hi) of the loss pass; the
+  //      per-pair sums travel through pairbuf (n_blocks x 56 doubles + matched count) ----
+  int32_t wg_lo, wg_hi;
+  int32_t sf_lo, sf_hi;
+  double* pairbuf;
   // ---- nested-dissection multifrontal solver (slm_nd_host.hip / slm_front.hip) ----
   int32_t nd_ready;      // 1 when the plan below is valid for this frame
   int32_t n_fronts;

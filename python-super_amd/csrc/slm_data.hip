@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_data_loss(const FrameDev* __restrict__ 
   if (!fd.bound || fd.st->stopped) return;
   double acc = 0.0;
   int cnt = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fd.f.N; i += gridDim.x * blockDim.x) {
+  // [sf_lo, sf_hi) = all surfels unless the frame is sharded over several GPUs
+  for (int i = fd.sf_lo + blockIdx.x * blockDim.x + threadIdx.x; i < fd.sf_hi; i += gridDim.x * blockDim.x) {
     SurfelEval ev;
     eval_surfel<false>(fd, lam, use_delta ? fd.node_pk_try : fd.node_pk, i, ev);
     if (ev.match) {

@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int base = (blockIdx.x * 4 + w) * 64;
   if (blockIdx.x * 256 >= fd.n_pos) return;
+  if ((int)blockIdx.x < fd.wg_lo || (int)blockIdx.x >= fd.wg_hi) return;   // another rank's share
   int rec0 = 0, nrec = 0;
   if (MERGE) {
     rec0 = fd.wg_first[blockIdx.x];

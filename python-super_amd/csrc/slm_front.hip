@@ -115,6 +115,55 @@ __global__ void __launch_bounds__(256) k_front_assemble(const FrameDev* __restri
   }
 }
 
+// Sharded frames: the pair sums stop in pairbuf (k_pair_reduce), the caller all-reduces it over the
+// ranks, and k_pair_scatter places the reduced blocks.  Both are k_front_assemble cut in two.
+__global__ void __launch_bounds__(256) k_pair_reduce(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.v1_ready || !fd.nd_ready || fd.st->stopped) return;
+  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bi == 0 && (threadIdx.x & 63) == 0) fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC] = (double)fd.st->m_grad;
+  if (bi >= fd.n_blocks) return;
+  const int l = threadIdx.x & 63;
+  if (l >= SLM_WREC) return;
+  double acc = 0.0;
+  if (fd.v2_ready) {
+    for (int s = fd.blk2_start[bi]; s < fd.blk2_start[bi + 1]; ++s)
+      acc += fd.wgslab[(size_t)fd.blk2_entry[s] * SLM_WREC + l];
+  } else {   // one Gram per run in HBM (a workgroup would need more than SLM_LB_MAX records)
+    const int ca = l / 7, cb = l % 7;
+    for (int s = fd.blk_start[bi]; s < fd.blk_start[bi + 1]; ++s) {
+      const int pl = fd.blk_entry[s];
+      const int run = pl >> 4, pa = (pl >> 2) & 3, pb = pl & 3;
+      const double* G = fd.slab + (size_t)run * SLM_SLAB_STRIDE;
+      // entries 0..48: block (pa,pb) (the diagonal pair only needs ca >= cb, the rest is ignored by the
+      // scatter); entries 49..55: row 28 = J^T r of node slot pa (only used for diagonal pairs)
+      if (l < 49) acc += (pa != pb || ca >= cb) ? gram_at(G, 7 * pa + ca, 7 * pb + cb) : 0.0;
+      else acc += gram_at(G, 28, 7 * pa + (l - 49));
+    }
+  }
+  fd.pairbuf[(size_t)bi * SLM_WREC + l] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_pair_scatter(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.v1_ready || !fd.nd_ready || fd.st->stopped) return;
+  const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bi == 0 && (threadIdx.x & 63) == 0) fd.st->m_grad = (int)fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC];
+  if (bi >= fd.n_blocks) return;
+  const int l = threadIdx.x & 63;
+  if (l >= SLM_WREC) return;
+  const NDDest d = fd.block_dest[bi];
+  const int ca = l / 7, cb = l % 7;
+  const bool diag = d.prow == d.pcol;
+  const double acc = fd.pairbuf[(size_t)bi * SLM_WREC + l];
+  if (l < 49) {
+    if (!diag || ca >= cb) *dest_entry(fd, d, ca, cb) = acc;
+  } else if (diag) {
+    const unsigned key = (unsigned)fd.blk_key[bi];
+    fd.rhs[7 * (int)(key / (unsigned)fd.f.J) + (l - 49)] = -acc;   // jtl = -J^T r
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // ARAP + Rot Jacobian rows into the fronts (same maths as k_reg_grad, slm_reg.hip; reference
 // super/loss.py:408-455, 480-499).  One thread per (node j, neighbour slot).
@@ -871,6 +920,16 @@ __global__ void __launch_bounds__(256) k_fbacksub(const FrameDev* __restrict__ f
 }
 
 // ---- host launchers --------------------------------------------------------------------
+void launch_pair_reduce(const FrameDev* fr, int n_frames, int max_blocks, hipStream_t st) {
+  if (max_blocks <= 0) return;
+  hipLaunchKernelGGL(k_pair_reduce, dim3((max_blocks + 3) / 4, n_frames), dim3(256), 0, st, fr);
+}
+
+void launch_pair_scatter(const FrameDev* fr, int n_frames, int max_blocks, hipStream_t st) {
+  if (max_blocks <= 0) return;
+  hipLaunchKernelGGL(k_pair_scatter, dim3((max_blocks + 3) / 4, n_frames), dim3(256), 0, st, fr);
+}
+
 void launch_front_assemble(const FrameDev* fr, int n_frames, int max_blocks, hipStream_t st) {
   if (max_blocks <= 0) return;
   hipLaunchKernelGGL(k_front_assemble, dim3((max_blocks + 3) / 4, n_frames), dim3(256), 0, st, fr);

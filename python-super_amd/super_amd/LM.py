@@ -74,7 +74,12 @@ class BoundFrame:
 class LM_Solver():
     """Drop-in for ``super.LM.LM_Solver``; see module docstring."""
 
-    def __init__(self, opt, convs=None, max_frames=1):
+    def __init__(self, opt, convs=None, max_frames=1, shard_surfels=False, rank=None, world=None,
+                 all_reduce=None, broadcast=None):
+        """``LM_Solver(opt, convs)`` as in the reference.  ``shard_surfels=True`` (after
+        ``torch.distributed.init_process_group``) splits the surfels of ONE large frame over the GPUs
+        of a node: every rank evaluates its share, the block-sparse J^T J / J^T r sums and the loss are
+        all-reduced, every rank solves and takes rank 0's step."""
         self.opt = opt
         self.lib = _lib.load()                       # raises if the HIP library is missing
         self.device = torch.device("cuda", torch.cuda.current_device()) \
@@ -88,6 +93,17 @@ class LM_Solver():
         self._solvers = {}                           # (u, v, minimal_loss) -> handle
         self._bound = [None] * max_frames
         self.last_records = None
+        self.rank, self.world = 0, 1
+        self._all_reduce, self._broadcast = all_reduce, broadcast
+        if shard_surfels or world is not None:
+            import torch.distributed as dist
+            if world is None:
+                world, rank = dist.get_world_size(), dist.get_rank()
+            self.rank, self.world = int(rank), int(world)
+            if self._all_reduce is None:
+                self._all_reduce = lambda t: dist.all_reduce(t)          # sum, in place
+            if self._broadcast is None:
+                self._broadcast = lambda t: dist.broadcast(t, src=0)
 
     # ---- library handle --------------------------------------------------------------
     def _config(self, u, v, minimal_loss):
@@ -114,6 +130,8 @@ class LM_Solver():
             out = C.c_void_p()
             _lib.check(self.lib.slm_create(C.byref(cfg), C.byref(out)), "slm_create")
             h = out
+            if self.world > 1:
+                _lib.check(self.lib.slm_set_shard(h, self.rank, self.world), "slm_set_shard")
             self._solvers[key] = h
         return h
 
@@ -185,7 +203,10 @@ class LM_Solver():
         bfs = [self._bind(h, i, *fr) for i, fr in enumerate(frames)]
         dev = bfs[0].device
         st = _stream_ptr(dev)
-        _lib.check(self.lib.slm_run(h, n, st), "slm_run")
+        if self.world > 1:
+            self._run_sharded(h, n, dev)
+        else:
+            _lib.check(self.lib.slm_run(h, n, st), "slm_run")
         betas, self.last_records = [], []
         for i, (bf, fr) in enumerate(zip(bfs, frames)):
             beta = torch.empty((bf.J, 7), dtype=torch.float64, device=dev)
@@ -195,6 +216,37 @@ class LM_Solver():
             self.last_records.append(recs)
             self._report(fr[0], fr[1], recs)
         return betas
+
+    # ---- one frame sharded over several GPUs ------------------------------------------------
+    def exchange_buffer(self, h, slot, what, dev):
+        n = C.c_int64(0)
+        _lib.check(self.lib.slm_lm_exchange_size(h, slot, what, C.byref(n)), "slm_lm_exchange_size")
+        return torch.empty(n.value, dtype=torch.float64, device=dev)
+
+    def _exchange(self, h, n, what, op, bufs):
+        st = _stream_ptr(bufs[0].device)
+        for i in range(n):
+            _lib.check(self.lib.slm_lm_exchange_get(h, i, what, _dev_ptr(bufs[i]), st), "slm_lm_exchange_get")
+            op(bufs[i])
+            _lib.check(self.lib.slm_lm_exchange_set(h, i, what, _dev_ptr(bufs[i]), st), "slm_lm_exchange_set")
+
+    def _run_sharded(self, h, n, dev):
+        """The LM loop with the three exchanges per iteration (see include/super_lm.h)."""
+        st = _stream_ptr(dev)
+        lib = self.lib
+        pair = [self.exchange_buffer(h, i, _lib.SLM_X_PAIR_BLOCKS, dev) for i in range(n)]
+        delta = [self.exchange_buffer(h, i, _lib.SLM_X_DELTA, dev) for i in range(n)]
+        loss = [self.exchange_buffer(h, i, _lib.SLM_X_DATA_LOSS, dev) for i in range(n)]
+        for _ in range(int(self.opt.num_optimize_iterations)):
+            _lib.check(lib.slm_lm_grad_local(h, n, st), "slm_lm_grad_local")
+            if self.opt.sf_point_plane:
+                self._exchange(h, n, _lib.SLM_X_PAIR_BLOCKS, self._all_reduce, pair)
+            _lib.check(lib.slm_lm_solve(h, n, st), "slm_lm_solve")
+            self._exchange(h, n, _lib.SLM_X_DELTA, self._broadcast, delta)
+            _lib.check(lib.slm_lm_loss_local(h, n, st), "slm_lm_loss_local")
+            if self.opt.sf_point_plane:
+                self._exchange(h, n, _lib.SLM_X_DATA_LOSS, self._all_reduce, loss)
+            _lib.check(lib.slm_lm_accept(h, n, st), "slm_lm_accept")
 
     # ---- helpers -----------------------------------------------------------------------
     def records(self, h, slot, stream):

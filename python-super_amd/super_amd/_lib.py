@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG_ROOT, "lib", os.environ.get("SLM_LIB", "libsuper_lm
 
 SLM_OK = 0
 SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN = 0, 1, 2
+SLM_X_PAIR_BLOCKS, SLM_X_DELTA, SLM_X_DATA_LOSS = 0, 1, 2
 PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 
 EXPORTS = [
@@ -23,6 +24,8 @@ EXPORTS = [
     "slm_gf_bind_semantic", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
+    "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
+    "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
 ]
 
@@ -148,6 +151,14 @@ def load():
         "slm_gf_step": [vp, i32, vp],
         "slm_gf_get_partial": [vp, i32, vp, vp],
         "slm_gf_set_partial": [vp, i32, vp, vp],
+        "slm_set_shard": [vp, i32, i32],
+        "slm_lm_grad_local": [vp, i32, vp],
+        "slm_lm_solve": [vp, i32, vp],
+        "slm_lm_loss_local": [vp, i32, vp],
+        "slm_lm_accept": [vp, i32, vp],
+        "slm_lm_exchange_size": [vp, i32, i32, C.POINTER(C.c_int64)],
+        "slm_lm_exchange_get": [vp, i32, i32, vp, vp],
+        "slm_lm_exchange_set": [vp, i32, i32, vp, vp],
         "slm_depth_create": [i32, i32, C.POINTER(vp)],
         "slm_depth_destroy": [vp],
         "slm_depth_preprocess": [vp, C.POINTER(SlmDepthConfig), C.POINTER(SlmDepthInputs),

@@ -119,3 +119,65 @@ def test_surfel_sharded_partials_sum_to_the_full_gradient(tmp_path):
     grad, = torch.autograd.grad(loss, dv)
     ref = torch.cat([grad.reshape(-1), loss.detach().reshape(1)]).numpy()
     np.testing.assert_allclose(a, ref, rtol=0, atol=1e-12 * max(1.0, np.abs(ref).max()))
+
+
+def _lm_shard_worker(rank, world, port, tmp):
+    for p in (ROOT, os.path.join(ROOT, "python-super_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dataclasses
+        from oracle import lm_oracle as orc
+        from super_amd import synth
+        sc = synth.make_scene(N=900, J=20, H=48, W=64, seed=4, src_border=4, tgt_border=2)
+        fr = orc.Frame.from_scene(sc)
+        # the exchange of the surfel-sharded LM iteration (super_amd.LM.LM_Solver._run_sharded):
+        # data-term normal equations of the rank's surfels -> all-reduce; regularisers on every rank;
+        # every rank solves, delta is rank 0's; loss of the share -> all-reduce
+        lo, hi = sc.N * rank // world, sc.N * (rank + 1) // world
+        part = dataclasses.replace(fr, sf_points=fr.sf_points[lo:hi], sf_knn_idx=fr.sf_knn_idx[lo:hi],
+                                   sf_knn_w=fr.sf_knn_w[lo:hi])
+        beta = np.tile([1.0, 0, 0, 0, 0, 0, 0], (sc.J, 1))
+        data_only = orc.default_opt(mesh_arap=False, mesh_rot=False)
+        reg_only = orc.default_opt(sf_point_plane=False)
+        JtJ_d, jtl_d, M = orc.normal_equations(part, beta, data_only)
+        buf = torch.from_numpy(np.concatenate([JtJ_d.reshape(-1), jtl_d, [float(M)]]))
+        dist.all_reduce(buf)
+        P = 7 * sc.J
+        JtJ_r, jtl_r, _ = orc.normal_equations(fr, beta, reg_only)
+        JtJ = buf[:P * P].numpy().reshape(P, P) + JtJ_r
+        jtl = buf[P * P:P * P + P].numpy() + jtl_r
+        delta = torch.from_numpy(orc.solve_damped(JtJ, jtl, 10.0))
+        dist.broadcast(delta, src=0)
+        trial = beta + delta.numpy().reshape(sc.J, 7)
+        loss = torch.tensor([float((orc.data_term(part, trial, 1.0).r ** 2).sum())], dtype=torch.float64)
+        dist.all_reduce(loss)
+        np.save(os.path.join(tmp, f"lm{rank}.npy"), np.concatenate([delta.numpy().reshape(-1), loss.numpy(), [buf[-1].item()]]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_surfel_sharded_lm_exchange(tmp_path):
+    """world_size-2 gloo run of one surfel-sharded LM iteration (oracle arithmetic): all-reduced pair
+    sums + broadcast delta + all-reduced loss == the unsharded iteration."""
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    mp.spawn(_lm_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "lm0.npy"), np.load(tmp_path / "lm1.npy")
+    np.testing.assert_array_equal(a, b)
+    for p in (ROOT, os.path.join(ROOT, "python-super_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import lm_oracle as orc
+    from super_amd import synth
+    sc = synth.make_scene(N=900, J=20, H=48, W=64, seed=4, src_border=4, tgt_border=2)
+    fr = orc.Frame.from_scene(sc)
+    beta = np.tile([1.0, 0, 0, 0, 0, 0, 0], (sc.J, 1))
+    JtJ, jtl, M = orc.normal_equations(fr, beta, orc.default_opt())
+    delta = orc.solve_damped(JtJ, jtl, 10.0)
+    loss = float((orc.data_term(fr, beta + delta.reshape(sc.J, 7), 1.0).r ** 2).sum())
+    np.testing.assert_allclose(a[:-2], delta.reshape(-1), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(a[-2], loss, rtol=1e-10)
+    assert a[-1] == M

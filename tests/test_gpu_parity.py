@@ -212,3 +212,62 @@ def test_nd_multifrontal_solve_matches_band_and_numpy(name):
         ref = np.linalg.solve(A, jtl.cpu().numpy().reshape(-1))
         np.testing.assert_allclose(sols[path], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
     np.testing.assert_allclose(sols[0], sols[1], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,world", [("s60x80_j48", 2), ("s120x160_j108", 3), ("s60x80_j48_reject", 4)])
+def test_surfel_sharded_lm_reproduces_the_single_gpu_solve(name, world):
+    """One frame split over `world` ranks (one solver context each on this GPU; the all-reduce of
+    the J^T J / J^T r pair blocks and of the loss partials and the broadcast of delta are emulated by
+    combining the ranks' exchange buffers): same iterations, same accept flags, same beta."""
+    import ctypes as C
+    import torch
+    from super_amd import _lib
+    from super_amd.LM import LM_Solver, _dev_ptr, _stream_ptr
+    g, sc, opt = load_golden(name)
+    sf, inputs, new_data = torch_frame(sc)
+    o = ref_opt(opt)
+    ranks = [LM_Solver(o, rank=r, world=world, all_reduce=lambda t: None, broadcast=lambda t: None)
+             for r in range(world)]
+    hs = [lm._handle() for lm in ranks]
+    bfs = [lm._bind(h, 0, sf, inputs, new_data) for lm, h in zip(ranks, hs)]
+    dev = bfs[0].device
+    st = _stream_ptr(dev)
+    lib = ranks[0].lib
+
+    def exchange(what, combine):
+        bufs = [lm.exchange_buffer(h, 0, what, dev) for lm, h in zip(ranks, hs)]
+        for h, b in zip(hs, bufs):
+            _lib.check(lib.slm_lm_exchange_get(h, 0, what, _dev_ptr(b), st), "get")
+        out = combine(bufs)
+        for h in hs:
+            _lib.check(lib.slm_lm_exchange_set(h, 0, what, _dev_ptr(out), st), "set")
+
+    for _ in range(int(o.num_optimize_iterations)):
+        for h in hs:
+            _lib.check(lib.slm_lm_grad_local(h, 1, st), "grad_local")
+        if o.sf_point_plane:
+            exchange(_lib.SLM_X_PAIR_BLOCKS, lambda b: torch.stack(b).sum(0))
+        for h in hs:
+            _lib.check(lib.slm_lm_solve(h, 1, st), "solve")
+        exchange(_lib.SLM_X_DELTA, lambda b: b[0].clone())
+        for h in hs:
+            _lib.check(lib.slm_lm_loss_local(h, 1, st), "loss_local")
+        if o.sf_point_plane:
+            exchange(_lib.SLM_X_DATA_LOSS, lambda b: torch.stack(b).sum(0))
+        for h in hs:
+            _lib.check(lib.slm_lm_accept(h, 1, st), "accept")
+    betas = []
+    for lm, h, bf in zip(ranks, hs, bfs):
+        beta = torch.empty((bf.J, 7), dtype=torch.float64, device=dev)
+        _lib.check(lib.slm_get_beta(h, 0, _dev_ptr(beta), st), "get_beta")
+        betas.append(beta.cpu().numpy())
+    recs = [lm.records(h, 0, st) for lm, h in zip(ranks, hs)]
+    for b in betas[1:]:
+        np.testing.assert_array_equal(b, betas[0])                      # every rank: identical parameters
+    for r in recs[1:]:
+        assert [x["accepted"] for x in r] == [x["accepted"] for x in recs[0]]
+        assert [x["loss"] for x in r] == [x["loss"] for x in recs[0]]
+    np.testing.assert_allclose(betas[0], g["lm_beta"], rtol=0, atol=TOL_BETA)
+    np.testing.assert_allclose([x["loss"] for x in recs[0]], g["lm_loss"], rtol=1e-6)
+    assert [x["accepted"] for x in recs[0]] == [bool(a) for a in g["lm_accepted"]]
+    assert recs[0][0]["M_grad"] == len(g["b0_match"])
