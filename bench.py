@@ -163,9 +163,73 @@ def next_row_timings(device):
     T = int(data.points.shape[0])
     # algorithmic bytes: depth + colour in; points/normals/colours f32, radii f64, confs f32, index_map i32, valid u8 out
     nbytes = H * W * (4 + 12) + T * (12 + 12 + 12 + 8 + 4) + H * W * (4 + 1)
-    return {"depth_preprocessing": {"ms_per_frame": ms, "image": [H, W], "valid_points": T,
-                                    "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / ms / 1e6,
-                                    "note": "mirror call incl. dtype conversions and the one host sync"}}
+    out = {"depth_preprocessing": {"ms_per_frame": ms, "image": [H, W], "valid_points": T,
+                                   "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / ms / 1e6,
+                                   "note": "mirror call incl. dtype conversions and the one host sync"}}
+    out["surfel_fusion"] = fusion_timing(device)
+    return out
+
+
+def fusion_timing(device):
+    """f1 = fuseInputData + prepareStableIndexNSwapAllModel on the C2 surfel model (200k surfels,
+    2k nodes, 480x640 frame), C calls only (buffers prepared outside the timed region)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from super_amd import _lib, fusion, synth
+    sc = synth.make_scene(seed=0, **synth.WORKLOADS["C2"])
+    rng = np.random.default_rng(0)
+    n, T = sc.N, sc.T
+    t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    opt = SimpleNamespace(height=sc.H, width=sc.W, th_dist=0.006, th_cosine_ang=0.8, th_time_steps=30,
+                          disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
+                          disable_adding_new_surfels=False, disable_removing_unstable_surfels=False,
+                          phase="test", method="super", num_neighbors=4)
+    sf = SimpleNamespace(opt=opt, points=t64(sc.sf_points), norms=t64(sc.sf_norms),
+                         colors=t32(rng.uniform(0, 255, (n, 3))), radii=t64(rng.uniform(0.002, 0.004, n)),
+                         confs=t32(rng.uniform(0.2, 3.0, n)), time_stamp=t32(40.0 - rng.integers(0, 45, n)),
+                         isStable=torch.ones(n, dtype=torch.bool, device=device),
+                         knn_indices=torch.from_numpy(sc.sf_knn_idx).to(device), knn_w=t64(sc.sf_knn_w),
+                         ED_nodes=SimpleNamespace(points=t64(sc.ed_points), radii=t64(sc.ed_radii)),
+                         projdata=torch.zeros(n, 2, device=device))
+    inputs = {"K": torch.from_numpy(sc.K)[None], "time": 41}
+    frame = dict(points=t64(sc.tgt_points), norms=t64(sc.tgt_norms), colors=t32(rng.uniform(0, 255, (T, 3))),
+                 radii=t64(rng.uniform(0.002, 0.004, T)), confs=t32(rng.uniform(0.05, 1.0, T)),
+                 valid=torch.from_numpy(sc.valid).to(device).to(torch.uint8),
+                 index_map=torch.from_numpy(sc.index_map).to(device).to(torch.int32))
+    lib = _lib.load()
+    cfg = fusion._config(sf, inputs)
+    cap = n + T
+    h, _ = fusion._context(lib, cfg.H, cfg.W, cap, device)
+    fr = _lib.SlmNewFrame()
+    fr.T, fr.time = T, 41
+    for k, v in frame.items():
+        setattr(fr, k, v.data_ptr())
+    st = torch.cuda.current_stream(device).cuda_stream
+    t_fuse, t_swap, rows = [], [], (0, 0)
+    for i in range(8):
+        model = fusion._Model(sf, cap, device)               # fresh copy of the model (untimed)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        _lib.check(lib.slm_fuse_input_data(h, C.byref(cfg), C.byref(model.c), C.byref(fr), st), "fuse")
+        e[1].record()
+        n_fused = int(model.c.n)
+        _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), 41, st), "swap")
+        e[2].record()
+        torch.cuda.synchronize()
+        if i >= 2:
+            t_fuse.append(e[0].elapsed_time(e[1]))
+            t_swap.append(e[1].elapsed_time(e[2]))
+        rows = (n_fused, int(model.c.n))
+    # bytes: every surfel row read (+ written when fused), the frame rows, 16 layer maps written + read
+    row = 3 * 8 + 3 * 8 + 3 * 4 + 8 + 4 + 4 + 1 + 4 * 4 + 4 * 8 + 2 * 4
+    nbytes = 2 * rows[0] * row + T * (24 + 24 + 12 + 8 + 4) + 2 * 16 * sc.H * sc.W * 4
+    ms = sum(t_fuse) / len(t_fuse)
+    return {"fuse_ms_per_frame": ms, "swap_ms_per_frame": sum(t_swap) / len(t_swap), "surfels_in": n,
+            "surfels_after_fuse": rows[0], "surfels_after_swap": rows[1], "algorithmic_bytes": nbytes,
+            "achieved_GBps": nbytes / ms / 1e6, "note": "C calls with resident buffers; 3 count read-backs inside"}
 
 
 def main():

@@ -390,6 +390,68 @@ int slm_depth_destroy(slm_depth* d);
 int slm_depth_preprocess(slm_depth* d, const slm_depth_config* cfg, const slm_depth_inputs* in,
                          const slm_depth_outputs* out, int32_t* n_valid_host, void* stream);
 
+/* ===================================================================================
+ * "Next" row f1: surfel fusion, the step right after the solve every frame
+ *   slm_fuse_input_data   <- Surfels.fuseInputData                     super/nodes.py:268-541
+ *   slm_fuse_swap_stable  <- Surfels.prepareStableIndexNSwapAllModel   super/nodes.py:543-585
+ * for opt.method == "super" without tracked evaluation points.  Geometry is float64 like the
+ * reference's tensors, colours / confidences / time stamps float32.  Unpinned by the reference:
+ * the order of surfels with EQUAL confidence on one pixel (torch.sort(descending=True) is not
+ * stable); here the lower index comes first.
+ * =================================================================================== */
+typedef struct slm_fuse slm_fuse; /* opaque: sort / layer-map / compaction scratch */
+
+typedef struct slm_fuse_config {
+  int32_t H, W;                   /* opt.height, opt.width */
+  int32_t merge_new;              /* !opt.disable_merging_new_surfels */
+  int32_t merge_exist;            /* !opt.disable_merging_exist_surfels */
+  int32_t add_new;                /* !opt.disable_adding_new_surfels */
+  int32_t remove_unstable;        /* !opt.disable_removing_unstable_surfels */
+  int32_t phase_test;             /* opt.phase == "test": merged surfels get the frame's time stamp */
+  int32_t th_time_steps;          /* opt.th_time_steps (30) */
+  double th_dist;                 /* opt.th_dist (0.1) */
+  double th_cosine_ang;           /* opt.th_cosine_ang (0.4) */
+  float fx, fy, cx, cy;           /* inputs["K"][0] */
+} slm_fuse_config;
+
+typedef struct slm_surfel_model {  /* device pointers with room for `cap` rows; n rows in use */
+  int32_t n, cap;
+  double* points;                 /* (cap,3) sf.points */
+  double* norms;                  /* (cap,3) sf.norms */
+  float* colors;                  /* (cap,3) sf.colors */
+  double* radii;                  /* (cap)   sf.radii */
+  float* confs;                   /* (cap)   sf.confs */
+  float* time_stamp;              /* (cap)   sf.time_stamp */
+  uint8_t* is_stable;             /* (cap)   sf.isStable */
+  int32_t* knn_idx;               /* (cap,4) sf.knn_indices */
+  double* knn_w;                  /* (cap,4) sf.knn_w */
+  float* projdata;                /* (cap,2) sf.projdata */
+  int32_t J, pad;
+  const double* ed_points;        /* (J,3) sf.ED_nodes.points */
+  const double* ed_radii;         /* (J)   sf.ED_nodes.radii */
+} slm_surfel_model;
+
+typedef struct slm_new_frame {     /* sfdata from depth_preprocessing, device pointers */
+  int32_t T, time;                /* rows, sfdata.time */
+  const double* points;           /* (T,3) */
+  const double* norms;            /* (T,3) */
+  const float* colors;            /* (T,3) */
+  const double* radii;            /* (T) */
+  const float* confs;             /* (T) */
+  const uint8_t* valid;           /* (H*W) */
+  const int32_t* index_map;       /* (H,W), -1 invalid */
+} slm_new_frame;
+
+int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out);
+int slm_fuse_destroy(slm_fuse* f);
+/* Fuses the frame into the model in place; model->n (host struct) becomes the new row count.
+ * Synchronises `stream` (three count read-backs). */
+int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model,
+                        const slm_new_frame* frame, void* stream);
+/* Drops unstable / stale surfels (time = inputs["time"]); model->n becomes the new row count. */
+int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, int32_t time,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

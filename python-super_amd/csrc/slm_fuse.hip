@@ -1,0 +1,572 @@
+// slm_fuse.hip -- "next" row f1: surfel fusion after the solve (reference Surfels.fuseInputData and
+// prepareStableIndexNSwapAllModel, super/nodes.py:268-585, opt.method == "super").
+//
+//   k_fu_keys        project every surfel (pcd2depth, rounded), key = (pixel << 32) | ~confidence
+//   rocPRIM sort     stable radix sort by key: per pixel the surfels in descending confidence
+//   k_fu_layers      rank of a surfel inside its pixel (look-back <= 16) -> 16 layer maps
+//   k_fu_merge_new   one thread per pixel: the frame's point is fused into the first layer that passes
+//                    the distance / normal test, otherwise it becomes a candidate new surfel
+//   k_fu_merge_exist one thread per pixel: surfels sharing the pixel are fused pairwise in the
+//                    reference's (i, j) order, the absorbed ones are dropped
+//   k_fu_weights     skinning weights of every surfel at its fused position
+//   k_fu_candidates  4 nearest ED nodes + stability test of the candidate pixels
+//   rocPRIM scan     positions of the accepted candidates (row-major pixel order = sfdata order)
+//   k_fu_append      new rows;  k_fu_proj  float pixel coordinates of every surfel
+//   k_fu_keep / scan / k_fu_compact    drop unstable and stale surfels (swap)
+// Everything per pixel / per surfel is independent, so the reference's vectorised tensor
+// statements and these per-thread loops produce the same values (float32 confidence / colour
+// arithmetic and float64 geometry are kept operation by operation).
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include <string>
+
+#include "slm_common.h"
+
+void slm_set_error_text(const char* msg);   // slm_api.hip
+
+#define FU_LAYERS 16
+
+struct slm_fuse {
+  int H = 0, W = 0, cap = 0;
+  unsigned long long *keys = nullptr, *skeys = nullptr;
+  int32_t *ids = nullptr, *sids = nullptr;
+  int32_t* layers = nullptr;    // (FU_LAYERS, H*W) surfel id or -1
+  int32_t* flag = nullptr;      // per pixel / per surfel flags for the scans
+  int32_t* pos = nullptr;       // exclusive scan of flag
+  int32_t* cand_idx = nullptr;  // (H*W,4) nearest nodes of the candidate pixels
+  double* cand_w = nullptr;     // (H*W,4)
+  uint8_t* dead = nullptr;      // (cap) surfels to drop after the pairwise merges
+  int32_t* counters = nullptr;  // [0] layers in use
+  void* tmp = nullptr;
+  size_t cap_tmp = 0;
+  // compaction scratch (swap)
+  double *s_d3 = nullptr, *s_d1 = nullptr, *s_d4 = nullptr;
+  float *s_f3 = nullptr, *s_f1 = nullptr, *s_f2 = nullptr;
+  int32_t* s_i4 = nullptr;
+};
+
+namespace {
+
+#define FCHK(expr)                                                        \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess) {                                               \
+      slm_set_error_text((std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
+      return SLM_ERR_HIP;                                                 \
+    }                                                                     \
+  } while (0)
+
+int ffail(int code, const char* msg) {
+  slm_set_error_text(msg);
+  return code;
+}
+
+__device__ __forceinline__ void fu_project(const slm_fuse_config& c, const double* p, double& u_, double& v_) {
+  const double Z = p[2] + 1e-8;
+  u_ = p[0] * (double)c.fx / Z + (double)c.cx;
+  v_ = p[1] * (double)c.fy / Z + (double)c.cy;
+}
+
+// key of surfel i: (pixel << 32) | (0xFFFFFFFF - orderable(confidence)); unprojectable / unstable: ~0
+__global__ void __launch_bounds__(256) k_fu_keys(slm_fuse_config c, slm_surfel_model m, unsigned long long* __restrict__ keys,
+                                                  int32_t* __restrict__ ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  double u_, v_;
+  fu_project(c, m.points + 3 * (size_t)i, u_, v_);
+  const double ur = rint(u_), vr = rint(v_);
+  const bool ok = m.is_stable[i] && vr >= 0.0 && vr < (double)(c.H - 1) && ur >= 0.0 && ur < (double)(c.W - 1);
+  unsigned long long key = ~0ull;
+  if (ok) {
+    const unsigned pix = (unsigned)((int)vr * c.W + (int)ur);
+    unsigned b = __float_as_uint(m.confs[i]);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);       // monotone map float -> uint
+    key = ((unsigned long long)pix << 32) | (unsigned long long)(0xFFFFFFFFu - b);
+  }
+  keys[i] = key;
+  ids[i] = i;
+}
+
+// sorted element e: its rank inside the pixel (number of equal-pixel predecessors, <= 16 looked at)
+__global__ void __launch_bounds__(256) k_fu_layers(int n, int HW, const unsigned long long* __restrict__ skeys,
+                                                    const int32_t* __restrict__ sids, int32_t* __restrict__ layers,
+                                                    uint8_t* __restrict__ dead, int32_t* __restrict__ counters) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const unsigned long long k = skeys[e];
+  if (k == ~0ull) return;
+  const unsigned pix = (unsigned)(k >> 32);
+  int rank = 0;
+  while (rank < FU_LAYERS && e - rank - 1 >= 0 && (unsigned)(skeys[e - rank - 1] >> 32) == pix) ++rank;
+  if (rank < FU_LAYERS) {
+    layers[(size_t)rank * HW + pix] = sids[e];
+    atomicMax(&counters[0], rank + 1);
+  } else {
+    dead[sids[e]] = 1;    // beyond the 16 maps: dropped when surfels are merged (nodes.py:390-391)
+  }
+}
+
+struct FuRow {
+  double p[3], n[3], r;
+  float c[3], w;
+};
+
+__device__ __forceinline__ FuRow fu_load(const slm_surfel_model& m, int i) {
+  FuRow x;
+  for (int k = 0; k < 3; ++k) {
+    x.p[k] = m.points[3 * (size_t)i + k];
+    x.n[k] = m.norms[3 * (size_t)i + k];
+    x.c[k] = m.colors[3 * (size_t)i + k];
+  }
+  x.r = m.radii[i];
+  x.w = m.confs[i];
+  return x;
+}
+
+// merge_data (nodes.py:296-357) for one pair: `a` is the surfel that stays (row ia of the model)
+__device__ __forceinline__ bool fu_merge(const slm_fuse_config& c, const slm_surfel_model& m, int ia, const FuRow& a,
+                                         const FuRow& b, bool add_new, int time) {
+#pragma clang fp contract(off)
+  const double dx = a.p[0] - b.p[0], dy = a.p[1] - b.p[1], dz = a.p[2] - b.p[2];
+  const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+  const double cosang = a.n[0] * b.n[0] + a.n[1] * b.n[1] + a.n[2] * b.n[2];
+  if (!(dist < c.th_dist && cosang > c.th_cosine_ang)) return false;
+  const float wu = a.w + b.w;
+  const float w = a.w / wu, w2 = b.w / wu;
+  const double wd = (double)w, w2d = (double)w2;
+  m.radii[ia] = wd * a.r + w2d * b.r;
+  m.confs[ia] = wu;
+  double nn[3], s = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    m.points[3 * (size_t)ia + k] = wd * a.p[k] + w2d * b.p[k];
+    nn[k] = wd * a.n[k] + w2d * b.n[k];
+    s += nn[k] * nn[k];
+  }
+  const double den = fmax(sqrt(s), 1e-12);
+  for (int k = 0; k < 3; ++k) m.norms[3 * (size_t)ia + k] = nn[k] / den;
+  if (add_new) {
+    const float wn = w2 * 3.0f, ws = w + wn;
+    const float f1 = w / ws, f2 = wn / ws;
+    for (int k = 0; k < 3; ++k) m.colors[3 * (size_t)ia + k] = f1 * a.c[k] + f2 * b.c[k];
+  } else {
+    for (int k = 0; k < 3; ++k) m.colors[3 * (size_t)ia + k] = w * a.c[k] + w2 * b.c[k];
+  }
+  if (c.phase_test) m.time_stamp[ia] = (float)time;
+  return true;
+}
+
+// one thread per pixel: new point -> first matching layer, else candidate (flag = 1)
+__global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_surfel_model m, slm_new_frame fr,
+                                                       const int32_t* __restrict__ layers, int n_layers,
+                                                       int32_t* __restrict__ flag) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int HW = c.H * c.W;
+  if (pix >= HW) return;
+  int out = 0;
+  if (fr.valid[pix]) {
+    out = 1;
+    if (c.merge_new && n_layers > 0) {
+      const int t = fr.index_map[pix];
+      FuRow b;
+      for (int k = 0; k < 3; ++k) {
+        b.p[k] = fr.points[3 * (size_t)t + k];
+        b.n[k] = fr.norms[3 * (size_t)t + k];
+        b.c[k] = fr.colors[3 * (size_t)t + k];
+      }
+      b.r = fr.radii[t];
+      b.w = fr.confs[t];
+      for (int l = 0; l < n_layers; ++l) {
+        const int s = layers[(size_t)l * HW + pix];
+        if (s < 0) break;
+        const FuRow a = fu_load(m, s);
+        if (fu_merge(c, m, s, a, b, true, fr.time)) {
+          out = 0;
+          break;
+        }
+      }
+    } else {
+      out = 0;      // merging disabled or no surfel projects anywhere: add_valid stays None (nodes.py:404,471)
+    }
+  }
+  flag[pix] = out;
+}
+
+// one thread per pixel: pairwise fusion of the surfels that share the pixel (nodes.py:424-447)
+__global__ void __launch_bounds__(256) k_fu_merge_exist(slm_fuse_config c, slm_surfel_model m, int time,
+                                                         const int32_t* __restrict__ layers, int n_layers,
+                                                         uint8_t* __restrict__ dead) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int HW = c.H * c.W;
+  if (pix >= HW) return;
+  int id[FU_LAYERS];
+  unsigned present = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    id[l] = layers[(size_t)l * HW + pix];
+    if (id[l] >= 0) present |= 1u << l;
+  }
+  if (!(present & 2u)) return;   // fewer than two surfels here
+  for (int i = 0; i < n_layers; ++i) {
+    bool alive = (present >> i) & 1u;          // val_maps[i], then ANDed with every val_maps[j] in turn
+    for (int j = i + 1; j < n_layers && alive; ++j) {
+      alive = alive && ((present >> j) & 1u);
+      if (!alive) break;
+      const FuRow a = fu_load(m, id[i]), b = fu_load(m, id[j]);
+      if (fu_merge(c, m, id[i], a, b, false, time)) {
+        present &= ~(1u << j);                  // val_maps[j] loses the pixel for the later i loops
+        dead[id[j]] = 1;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fu_apply_dead(int n, const uint8_t* __restrict__ dead, uint8_t* __restrict__ stable) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && dead[i]) stable[i] = 0;
+}
+
+__device__ __forceinline__ void fu_softmax4(const double d[4], const double r[4], double w[4]) {
+  double e[4], mx = -1e300, s = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    e[k] = exp(-d[k] / r[k]);
+    mx = fmax(mx, e[k]);
+  }
+  for (int k = 0; k < 4; ++k) {
+    w[k] = exp(e[k] - mx);
+    s += w[k];
+  }
+  for (int k = 0; k < 4; ++k) w[k] /= s;
+}
+
+// knn_w = softmax(exp(-dist / radius)) at the current positions (nodes.py:466-469)
+__global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  double d[4], r[4], w[4];
+  for (int k = 0; k < 4; ++k) {
+    const int j = m.knn_idx[4 * (size_t)i + k];
+    double s = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double t = m.points[3 * (size_t)i + a] - m.ed_points[3 * (size_t)j + a];
+      s += t * t;
+    }
+    d[k] = sqrt(s);
+    r[k] = m.ed_radii[j];
+  }
+  fu_softmax4(d, r, w);
+  for (int k = 0; k < 4; ++k) m.knn_w[4 * (size_t)i + k] = w[k];
+}
+
+// candidate pixels: 4 nearest nodes (squared L2 ascending, lowest index first), stability test.
+// Node positions are staged through LDS in tiles of FU_TILE (broadcast reads), four distances per
+// step, and the sorted insertion only runs when one of them beats the current 4th best.
+#define FU_TILE 1024
+__global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_surfel_model m, slm_new_frame fr,
+                                                        int32_t* __restrict__ flag, int32_t* __restrict__ cand_idx,
+                                                        double* __restrict__ cand_w) {
+  __shared__ double nodes[3 * FU_TILE];
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = pix < c.H * c.W && flag[pix] != 0;
+  double px = 0.0, py = 0.0, pz = 0.0;
+  if (act) {
+    const int t = fr.index_map[pix];
+    px = fr.points[3 * (size_t)t];
+    py = fr.points[3 * (size_t)t + 1];
+    pz = fr.points[3 * (size_t)t + 2];
+  }
+  double bd[4] = {1e300, 1e300, 1e300, 1e300};
+  int bi[4] = {-1, -1, -1, -1};
+  for (int j0 = 0; j0 < m.J; j0 += FU_TILE) {
+    const int cnt = min(FU_TILE, m.J - j0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * cnt; e += blockDim.x) nodes[e] = m.ed_points[3 * (size_t)j0 + e];
+    __syncthreads();
+    if (!act) continue;
+    for (int jj = 0; jj < cnt; jj += 4) {
+      double d2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = jj + q < cnt ? jj + q : cnt - 1;     // tail: repeats the last node, rejected below
+        const double dx = px - nodes[3 * k], dy = py - nodes[3 * k + 1], dz = pz - nodes[3 * k + 2];
+        d2[q] = dx * dx + dy * dy + dz * dz;
+      }
+      if (fmin(fmin(d2[0], d2[1]), fmin(d2[2], d2[3])) < bd[3]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (jj + q < cnt && d2[q] < bd[3]) {
+            int k = 3;
+            while (k > 0 && d2[q] < bd[k - 1]) {
+              bd[k] = bd[k - 1];
+              bi[k] = bi[k - 1];
+              --k;
+            }
+            bd[k] = d2[q];
+            bi[k] = j0 + jj + q;
+          }
+        }
+      }
+    }
+  }
+  if (!act) return;
+  double d[4], r[4], w[4];
+  bool stable = false;
+  for (int k = 0; k < 4; ++k) {
+    d[k] = sqrt(bd[k]);
+    r[k] = m.ed_radii[bi[k]];
+    stable = stable || d[k] <= r[k];
+  }
+  if (!stable) {
+    flag[pix] = 0;       // too far from its nodes: not added (nodes.py:500)
+    return;
+  }
+  fu_softmax4(d, r, w);
+  for (int k = 0; k < 4; ++k) {
+    cand_idx[4 * (size_t)pix + k] = bi[k];
+    cand_w[4 * (size_t)pix + k] = w[k];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fu_append(slm_fuse_config c, slm_surfel_model m, slm_new_frame fr,
+                                                    const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
+                                                    const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_w) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= c.H * c.W || !flag[pix]) return;
+  const size_t o = (size_t)m.n + pos[pix];
+  if (o >= (size_t)m.cap) return;
+  const int t = fr.index_map[pix];
+  for (int k = 0; k < 3; ++k) {
+    m.points[3 * o + k] = fr.points[3 * (size_t)t + k];
+    m.norms[3 * o + k] = fr.norms[3 * (size_t)t + k];
+    m.colors[3 * o + k] = fr.colors[3 * (size_t)t + k];
+  }
+  m.radii[o] = fr.radii[t];
+  m.confs[o] = fr.confs[t];
+  m.time_stamp[o] = (float)fr.time;
+  m.is_stable[o] = 1;
+  for (int k = 0; k < 4; ++k) {
+    m.knn_idx[4 * o + k] = cand_idx[4 * (size_t)pix + k];
+    m.knn_w[4 * o + k] = cand_w[4 * (size_t)pix + k];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fu_proj(slm_fuse_config c, slm_surfel_model m, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double u_, v_;
+  fu_project(c, m.points + 3 * (size_t)i, u_, v_);
+  m.projdata[2 * (size_t)i] = (float)u_;
+  m.projdata[2 * (size_t)i + 1] = (float)v_;
+}
+
+__global__ void __launch_bounds__(256) k_fu_keep(slm_fuse_config c, slm_surfel_model m, int time, int32_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n) return;
+  const float age = (float)time - m.time_stamp[i];
+  flag[i] = (m.is_stable[i] && age < (float)c.th_time_steps) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_fu_compact(slm_surfel_model m, slm_fuse s, const int32_t* __restrict__ flag,
+                                                     const int32_t* __restrict__ pos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m.n || !flag[i]) return;
+  const size_t o = pos[i];
+  for (int k = 0; k < 3; ++k) {
+    s.s_d3[3 * o + k] = m.points[3 * (size_t)i + k];
+    s.s_d3[3 * ((size_t)m.cap + o) + k] = m.norms[3 * (size_t)i + k];
+    s.s_f3[3 * o + k] = m.colors[3 * (size_t)i + k];
+  }
+  s.s_d1[o] = m.radii[i];
+  s.s_f1[o] = m.confs[i];
+  s.s_f1[(size_t)m.cap + o] = m.time_stamp[i];
+  for (int k = 0; k < 4; ++k) {
+    s.s_i4[4 * o + k] = m.knn_idx[4 * (size_t)i + k];
+    s.s_d4[4 * o + k] = m.knn_w[4 * (size_t)i + k];
+  }
+  s.s_f2[2 * o] = m.projdata[2 * (size_t)i];
+  s.s_f2[2 * o + 1] = m.projdata[2 * (size_t)i + 1];
+}
+
+template <typename T>
+hipError_t falloc(T*& p, size_t n) {
+  return hipMalloc((void**)&p, n * sizeof(T));
+}
+
+hipError_t scan_flags(slm_fuse* f, int n, hipStream_t st) {
+  size_t bytes = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, bytes, f->flag, f->pos, 0, (size_t)n, rocprim::plus<int32_t>(), st);
+  if (e != hipSuccess) return e;
+  if (bytes > f->cap_tmp) {
+    if (f->tmp) (void)hipFree(f->tmp);
+    f->tmp = nullptr;
+    f->cap_tmp = 0;
+    e = hipMalloc(&f->tmp, bytes);
+    if (e != hipSuccess) return e;
+    f->cap_tmp = bytes;
+  }
+  return rocprim::exclusive_scan(f->tmp, bytes, f->flag, f->pos, 0, (size_t)n, rocprim::plus<int32_t>(), st);
+}
+
+// number of set flags among the first n entries (after scan_flags); synchronises the stream
+hipError_t count_flags(slm_fuse* f, int n, hipStream_t st, int* out) {
+  int32_t last[2] = {0, 0};
+  if (n > 0) {
+    hipError_t e = hipMemcpyAsync(&last[0], f->pos + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], f->flag + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipStreamSynchronize(st);
+  *out = last[0] + last[1];
+  return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out) {
+  if (!out || H < 8 || W < 8 || max_surfels < 1) return ffail(SLM_ERR_INVALID, "slm_fuse_create: bad argument");
+  if (slm_device_count() < 1) return ffail(SLM_ERR_NO_DEVICE, "slm_fuse_create: no HIP device visible");
+  slm_fuse* f = new slm_fuse();
+  f->H = H;
+  f->W = W;
+  f->cap = max_surfels;
+  const size_t HW = (size_t)H * W, cap = (size_t)max_surfels, nmax = HW > cap ? HW : cap;
+  hipError_t e = falloc(f->keys, cap);
+  if (e == hipSuccess) e = falloc(f->skeys, cap);
+  if (e == hipSuccess) e = falloc(f->ids, cap);
+  if (e == hipSuccess) e = falloc(f->sids, cap);
+  if (e == hipSuccess) e = falloc(f->layers, FU_LAYERS * HW);
+  if (e == hipSuccess) e = falloc(f->flag, nmax);
+  if (e == hipSuccess) e = falloc(f->pos, nmax);
+  if (e == hipSuccess) e = falloc(f->cand_idx, 4 * HW);
+  if (e == hipSuccess) e = falloc(f->cand_w, 4 * HW);
+  if (e == hipSuccess) e = falloc(f->dead, cap);
+  if (e == hipSuccess) e = falloc(f->counters, 4);
+  if (e == hipSuccess) e = falloc(f->s_d3, 6 * cap);
+  if (e == hipSuccess) e = falloc(f->s_d1, cap);
+  if (e == hipSuccess) e = falloc(f->s_d4, 4 * cap);
+  if (e == hipSuccess) e = falloc(f->s_f3, 3 * cap);
+  if (e == hipSuccess) e = falloc(f->s_f1, 2 * cap);
+  if (e == hipSuccess) e = falloc(f->s_f2, 2 * cap);
+  if (e == hipSuccess) e = falloc(f->s_i4, 4 * cap);
+  if (e != hipSuccess) {
+    slm_set_error_text((std::string("slm_fuse_create: ") + hipGetErrorString(e)).c_str());
+    slm_fuse_destroy(f);
+    return SLM_ERR_HIP;
+  }
+  *out = f;
+  return SLM_OK;
+}
+
+int slm_fuse_destroy(slm_fuse* f) {
+  if (!f) return SLM_OK;
+  void* ptrs[] = {f->keys, f->skeys, f->ids, f->sids, f->layers, f->flag, f->pos, f->cand_idx, f->cand_w, f->dead,
+                  f->counters, f->tmp, f->s_d3, f->s_d1, f->s_d4, f->s_f3, f->s_f1, f->s_f2, f->s_i4};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete f;
+  return SLM_OK;
+}
+
+static int fuse_check(slm_fuse* f, const slm_fuse_config* c, const slm_surfel_model* m) {
+  if (!f || !c || !m) return ffail(SLM_ERR_INVALID, "slm_fuse: null argument");
+  if (c->H != f->H || c->W != f->W) return ffail(SLM_ERR_INVALID, "slm_fuse: image size differs from slm_fuse_create");
+  if (m->n < 0 || m->cap > f->cap || m->n > m->cap) return ffail(SLM_ERR_INVALID, "slm_fuse: model rows exceed the capacity");
+  if (!m->points || !m->norms || !m->colors || !m->radii || !m->confs || !m->time_stamp || !m->is_stable ||
+      !m->knn_idx || !m->knn_w || !m->projdata || !m->ed_points || !m->ed_radii || m->J < 4)
+    return ffail(SLM_ERR_INVALID, "slm_fuse: null device pointer (or fewer than 4 ED nodes)");
+  return SLM_OK;
+}
+
+int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, const slm_new_frame* frame,
+                        void* stream) {
+  int rc = fuse_check(f, cfg, model);
+  if (rc) return rc;
+  if (!frame || !frame->valid || !frame->index_map ||
+      (frame->T > 0 && (!frame->points || !frame->norms || !frame->colors || !frame->radii || !frame->confs)))
+    return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: null frame pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const slm_fuse_config c = *cfg;
+  slm_surfel_model m = *model;
+  const int HW = c.H * c.W, n = m.n;
+  const dim3 blk(256), gp((HW + 255) / 256), gs((n + 255) / 256);
+  // 1. per-pixel confidence-ordered layers
+  FCHK(hipMemsetAsync(f->layers, 0xFF, sizeof(int32_t) * FU_LAYERS * (size_t)HW, st));
+  FCHK(hipMemsetAsync(f->dead, 0, (size_t)f->cap, st));
+  FCHK(hipMemsetAsync(f->counters, 0, sizeof(int32_t) * 4, st));
+  int n_layers = 0;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_fu_keys, gs, blk, 0, st, c, m, f->keys, f->ids);
+    size_t bytes = 0;
+    FCHK(rocprim::radix_sort_pairs(nullptr, bytes, f->keys, f->skeys, f->ids, f->sids, (size_t)n, 0, 64, st));
+    if (bytes > f->cap_tmp) {
+      if (f->tmp) FCHK(hipFree(f->tmp));
+      f->tmp = nullptr;
+      f->cap_tmp = 0;
+      FCHK(hipMalloc(&f->tmp, bytes));
+      f->cap_tmp = bytes;
+    }
+    FCHK(rocprim::radix_sort_pairs(f->tmp, bytes, f->keys, f->skeys, f->ids, f->sids, (size_t)n, 0, 64, st));
+    hipLaunchKernelGGL(k_fu_layers, gs, blk, 0, st, n, HW, f->skeys, f->sids, f->layers, f->dead, f->counters);
+    FCHK(hipMemcpyAsync(&n_layers, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FCHK(hipStreamSynchronize(st));
+  }
+  // 2. the frame's points into the layers; flag = candidate new surfel
+  hipLaunchKernelGGL(k_fu_merge_new, gp, blk, 0, st, c, m, *frame, f->layers, n_layers, f->flag);
+  // 3. surfels that share a pixel; drop the absorbed ones and those beyond the 16 maps
+  if (c.merge_exist && n_layers > 0) {
+    if (n_layers > 1)
+      hipLaunchKernelGGL(k_fu_merge_exist, gp, blk, 0, st, c, m, frame->time, f->layers, n_layers, f->dead);
+    hipLaunchKernelGGL(k_fu_apply_dead, gs, blk, 0, st, n, f->dead, m.is_stable);
+  }
+  // 4. skinning weights at the fused positions
+  if (n > 0) hipLaunchKernelGGL(k_fu_weights, gs, blk, 0, st, m);
+  // 5. unmatched points with a nearby node become new surfels, in row-major pixel (= sfdata) order
+  int n_new = 0;
+  if (c.add_new && c.merge_new && n_layers > 0) {
+    hipLaunchKernelGGL(k_fu_candidates, gp, blk, 0, st, c, m, *frame, f->flag, f->cand_idx, f->cand_w);
+    FCHK(scan_flags(f, HW, st));
+    FCHK(count_flags(f, HW, st, &n_new));
+    if (n + n_new > m.cap) return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: model capacity too small for the new surfels");
+    if (n_new > 0) hipLaunchKernelGGL(k_fu_append, gp, blk, 0, st, c, m, *frame, f->flag, f->pos, f->cand_idx, f->cand_w);
+  }
+  m.n = n + n_new;
+  if (m.n > 0) hipLaunchKernelGGL(k_fu_proj, dim3((m.n + 255) / 256), blk, 0, st, c, m, m.n);
+  FCHK(hipGetLastError());
+  model->n = m.n;
+  return SLM_OK;
+}
+
+int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, int32_t time, void* stream) {
+  int rc = fuse_check(f, cfg, model);
+  if (rc) return rc;
+  if (!cfg->remove_unstable || model->n == 0) return SLM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  slm_surfel_model m = *model;
+  const int n = m.n;
+  const dim3 blk(256), gs((n + 255) / 256);
+  hipLaunchKernelGGL(k_fu_keep, gs, blk, 0, st, *cfg, m, time, f->flag);
+  FCHK(scan_flags(f, n, st));
+  int kept = 0;
+  FCHK(count_flags(f, n, st, &kept));
+  slm_fuse scratch = *f;
+  hipLaunchKernelGGL(k_fu_compact, gs, blk, 0, st, m, scratch, f->flag, f->pos);
+  const size_t k = (size_t)kept, cap = (size_t)m.cap;
+  if (kept > 0) {
+    FCHK(hipMemcpyAsync(m.points, f->s_d3, sizeof(double) * 3 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.norms, f->s_d3 + 3 * cap, sizeof(double) * 3 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.colors, f->s_f3, sizeof(float) * 3 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.radii, f->s_d1, sizeof(double) * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.confs, f->s_f1, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.time_stamp, f->s_f1 + cap, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.knn_idx, f->s_i4, sizeof(int32_t) * 4 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.knn_w, f->s_d4, sizeof(double) * 4 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.projdata, f->s_f2, sizeof(float) * 2 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemsetAsync(m.is_stable, 1, k, st));
+  }
+  FCHK(hipGetLastError());
+  model->n = kept;
+  return SLM_OK;
+}
+
+}  // extern "C"

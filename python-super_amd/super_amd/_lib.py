@@ -24,6 +24,7 @@ EXPORTS = [
     "slm_gf_bind_semantic", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
+    "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -88,6 +89,27 @@ class SlmDepthOutputs(C.Structure):
                 ("radii", C.c_void_p), ("confs", C.c_void_p), ("index_map", C.c_void_p),
                 ("valid", C.c_void_p), ("seg", C.c_void_p), ("seg_conf", C.c_void_p),
                 ("dist2edge", C.c_void_p), ("inval", C.c_void_p)]
+
+
+class SlmFuseConfig(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("merge_new", C.c_int32), ("merge_exist", C.c_int32),
+                ("add_new", C.c_int32), ("remove_unstable", C.c_int32), ("phase_test", C.c_int32),
+                ("th_time_steps", C.c_int32), ("th_dist", C.c_double), ("th_cosine_ang", C.c_double),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class SlmSurfelModel(C.Structure):
+    _fields_ = [("n", C.c_int32), ("cap", C.c_int32), ("points", C.c_void_p), ("norms", C.c_void_p),
+                ("colors", C.c_void_p), ("radii", C.c_void_p), ("confs", C.c_void_p),
+                ("time_stamp", C.c_void_p), ("is_stable", C.c_void_p), ("knn_idx", C.c_void_p),
+                ("knn_w", C.c_void_p), ("projdata", C.c_void_p), ("J", C.c_int32), ("pad", C.c_int32),
+                ("ed_points", C.c_void_p), ("ed_radii", C.c_void_p)]
+
+
+class SlmNewFrame(C.Structure):
+    _fields_ = [("T", C.c_int32), ("time", C.c_int32), ("points", C.c_void_p), ("norms", C.c_void_p),
+                ("colors", C.c_void_p), ("radii", C.c_void_p), ("confs", C.c_void_p), ("valid", C.c_void_p),
+                ("index_map", C.c_void_p)]
 
 
 class SlmIterRecord(C.Structure):
@@ -159,6 +181,10 @@ def load():
         "slm_lm_exchange_size": [vp, i32, i32, C.POINTER(C.c_int64)],
         "slm_lm_exchange_get": [vp, i32, i32, vp, vp],
         "slm_lm_exchange_set": [vp, i32, i32, vp, vp],
+        "slm_fuse_create": [i32, i32, i32, C.POINTER(vp)],
+        "slm_fuse_destroy": [vp],
+        "slm_fuse_input_data": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), C.POINTER(SlmNewFrame), vp],
+        "slm_fuse_swap_stable": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), i32, vp],
         "slm_depth_create": [i32, i32, C.POINTER(vp)],
         "slm_depth_destroy": [vp],
         "slm_depth_preprocess": [vp, C.POINTER(SlmDepthConfig), C.POINTER(SlmDepthInputs),

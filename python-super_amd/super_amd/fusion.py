@@ -1,0 +1,132 @@
+"""Host-side mirrors of the reference's surfel fusion methods over
+libsuper_lm.so:
+
+* :func:`fuseInputData`                    <- ``Surfels.fuseInputData``                   (``super/nodes.py:268-541``)
+* :func:`prepareStableIndexNSwapAllModel`  <- ``Surfels.prepareStableIndexNSwapAllModel`` (``super/nodes.py:543-585``)
+
+Both take the reference's ``sf`` object (anything with the same attributes) and can be bound onto the
+reference class: ``Surfels.fuseInputData = super_amd.fusion.fuseInputData``.  Supported:
+``opt.method == "super"`` without tracked evaluation points (``opt.tracking_gt_file is None``), no
+segmentation fields; the logging / rendering calls at the end of the reference's swap are not
+part of the mirror.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SlmFuseConfig, SlmNewFrame, SlmSurfelModel
+from .LM import _as, _dev_ptr, _stream_ptr
+
+_ctx = {}
+
+
+def _context(lib, H, W, cap, dev):
+    key = (H, W, str(dev))
+    h, have = _ctx.get(key, (None, 0))
+    if h is None or have < cap:
+        if h is not None:
+            lib.slm_fuse_destroy(h)
+        h = C.c_void_p()
+        cap = int(cap * 1.25) + 1024
+        _lib.check(lib.slm_fuse_create(H, W, cap, C.byref(h)), "slm_fuse_create")
+        _ctx[key] = (h, cap)
+    return _ctx[key]
+
+
+def _config(sf, inputs):
+    o = sf.opt
+    if getattr(o, "method", "super") != "super" or getattr(sf, "hard_seg", False) or hasattr(sf, "seg"):
+        raise NotImplementedError("super_amd.fusion: only opt.method == 'super' without segmentation fields")
+    if getattr(sf, "evaluate_tracking", False):
+        raise NotImplementedError("super_amd.fusion: tracked evaluation points are not supported")
+    K = inputs["K"][0].detach().cpu().float()
+    c = SlmFuseConfig()
+    c.H, c.W = int(o.height), int(o.width)
+    c.merge_new = int(not o.disable_merging_new_surfels)
+    c.merge_exist = int(not o.disable_merging_exist_surfels)
+    c.add_new = int(not o.disable_adding_new_surfels)
+    c.remove_unstable = int(not o.disable_removing_unstable_surfels)
+    c.phase_test = int(o.phase == "test")
+    c.th_time_steps = int(o.th_time_steps)
+    c.th_dist, c.th_cosine_ang = float(o.th_dist), float(o.th_cosine_ang)
+    c.fx, c.fy, c.cx, c.cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+    return c
+
+
+class _Model:
+    """Device buffers with spare rows around the surfel arrays of ``sf``."""
+
+    FIELDS = (("points", torch.float64, 3), ("norms", torch.float64, 3), ("colors", torch.float32, 3),
+              ("radii", torch.float64, 0), ("confs", torch.float32, 0), ("time_stamp", torch.float32, 0),
+              ("isStable", torch.uint8, 0), ("knn_indices", torch.int32, 4), ("knn_w", torch.float64, 4),
+              ("projdata", torch.float32, 2))
+
+    def __init__(self, sf, cap, dev):
+        n = int(sf.points.shape[0])
+        self.n, self.cap, self.dev = n, cap, dev
+        self.buf = {}
+        for name, dt, width in self.FIELDS:
+            shape = (cap, width) if width else (cap,)
+            b = torch.zeros(shape, dtype=dt, device=dev)
+            src = getattr(sf, name, None)
+            if src is not None and src.shape[0] == n:
+                b[:n] = _as(src, dt, dev)
+            self.buf[name] = b
+        ed = sf.ED_nodes
+        self.ed_points = _as(ed.points, torch.float64, dev)
+        self.ed_radii = _as(ed.radii, torch.float64, dev)
+        m = SlmSurfelModel()
+        m.n, m.cap = n, cap
+        for cname, name in (("points", "points"), ("norms", "norms"), ("colors", "colors"), ("radii", "radii"),
+                            ("confs", "confs"), ("time_stamp", "time_stamp"), ("is_stable", "isStable"),
+                            ("knn_idx", "knn_indices"), ("knn_w", "knn_w"), ("projdata", "projdata")):
+            setattr(m, cname, _dev_ptr(self.buf[name]))
+        m.J = int(self.ed_points.shape[0])
+        m.ed_points, m.ed_radii = _dev_ptr(self.ed_points), _dev_ptr(self.ed_radii)
+        self.c = m
+
+    def write_back(self, sf):
+        n = int(self.c.n)
+        ref = {"points": torch.float64, "norms": torch.float64, "colors": torch.float32, "radii": torch.float64,
+               "confs": torch.float32, "time_stamp": torch.float32, "isStable": torch.bool,
+               "knn_indices": torch.long, "knn_w": torch.float64, "projdata": torch.float32}
+        for name, dt in ref.items():
+            setattr(sf, name, self.buf[name][:n].to(dt))
+
+
+def fuseInputData(sf, inputs, sfdata):
+    lib = _lib.load()
+    cfg = _config(sf, inputs)
+    dev = sf.points.device if sf.points.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    n, T = int(sf.points.shape[0]), int(sfdata.points.shape[0])
+    cap = n + T
+    h, _ = _context(lib, cfg.H, cfg.W, cap, dev)
+    model = _Model(sf, cap, dev)
+    fr = SlmNewFrame()
+    fr.T, fr.time = T, int(sfdata.time)
+    keep = dict(points=_as(sfdata.points, torch.float64, dev), norms=_as(sfdata.norms, torch.float64, dev),
+                colors=_as(sfdata.colors, torch.float32, dev), radii=_as(sfdata.radii, torch.float64, dev),
+                confs=_as(sfdata.confs, torch.float32, dev), valid=_as(sfdata.valid, torch.uint8, dev),
+                index_map=_as(sfdata.index_map, torch.int32, dev))
+    for k, v in keep.items():
+        setattr(fr, k, _dev_ptr(v))
+    sf.time = sfdata.time
+    _lib.check(lib.slm_fuse_input_data(h, C.byref(cfg), C.byref(model.c), C.byref(fr), _stream_ptr(dev)),
+               "slm_fuse_input_data")
+    model.write_back(sf)
+
+
+def prepareStableIndexNSwapAllModel(sf, inputs, sfdata):
+    lib = _lib.load()
+    cfg = _config(sf, inputs)
+    dev = sf.points.device if sf.points.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    n = int(sf.points.shape[0])
+    h, _ = _context(lib, cfg.H, cfg.W, n, dev)
+    model = _Model(sf, n, dev)
+    _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), int(inputs["time"]), _stream_ptr(dev)),
+               "slm_fuse_swap_stable")
+    model.write_back(sf)
+    sf.surfel_num = int(sf.isStable.count_nonzero())
