@@ -107,3 +107,90 @@ def test_fusion_full_size_matches_oracle():
                                                     "knn_indices", "knn_w", "projdata")}, "y_")
     w = sf.knn_w.cpu().numpy()
     np.testing.assert_allclose(w.sum(1), 1.0, rtol=0, atol=1e-12)
+
+
+def test_whole_frame_pipeline_depth_lm_update_fusion():
+    """SuPer.forward for two tracked frames with every stage on the device (super/super.py:39-77):
+    depth_preprocessing -> LM_Solver.LM -> Surfels.update -> fuseInputData ->
+    prepareStableIndexNSwapAllModel, chained through the mirrors on one `sf` object.  Each stage is
+    checked against its oracle evaluated on the state the stage actually received."""
+    import torch
+    from oracle import depth_oracle as dpo, fusion_oracle as fuo, lm_oracle as orc
+    from super_amd import fusion, nodes, synth
+    from super_amd.LM import LM_Solver
+    from super_amd.data_loader import depth_preprocessing
+    H, W = 60, 80
+    K = synth._scaled_intrinsics(H, W)
+    inv_K = np.linalg.pinv(K)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    rng = np.random.default_rng(8)
+    color = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
+    opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, depth_model="monodepth2",
+                          dilate_invalid_kernel=0, normal_model="naive", phase="test", method="super",
+                          sf_point_plane=True, mesh_arap=True, mesh_rot=True, sf_point_plane_weight=1.0,
+                          mesh_arap_weight=10.0, mesh_rot_weight=1.0, num_optimize_iterations=5,
+                          use_derived_gradient=True, num_neighbors=4, num_ED_neighbors=4,
+                          th_dist=0.02, th_cosine_ang=0.4, th_time_steps=30, disable_merging_new_surfels=False,
+                          disable_merging_exist_surfels=False, disable_adding_new_surfels=False,
+                          disable_removing_unstable_surfels=False)
+
+    def frame_inputs(k):
+        depth = synth._surface(uu, vv, H, W, 0.3 + 0.04 * k).astype(np.float32)
+        depth[:3] = 0.0
+        depth[:, :3] = 0.0            # a border without depth
+        return depth, {("depth", 0): torch.from_numpy(depth.copy())[None, None].cuda(), ("disp", 0): torch.zeros(1, 1, H, W).cuda(),
+                       "inv_K": torch.from_numpy(inv_K)[None], "K": torch.from_numpy(K)[None],
+                       ("color", 0): torch.from_numpy(color)[None].cuda(), "divterm": 1.0 / (2 * 0.6 * 0.6),
+                       "filename": ["%06d" % k], "time": k, "ID": torch.tensor([k])}
+
+    # ---- frame 0: the model starts as the first frame's points; nodes = every 7th valid pixel on a grid
+    _, inputs = frame_inputs(0)
+    data, inputs = depth_preprocessing(opt, None, inputs)
+    im = data.index_map.cpu().numpy()
+    node_rows = im[6:H - 6:7, 6:W - 6:7].reshape(-1)
+    node_rows = torch.from_numpy(node_rows[node_rows >= 0]).cuda()
+    ed = SimpleNamespace(points=data.points[node_rows].clone(), norms=data.norms[node_rows].clone())
+    ed.num, ed.param_num = int(ed.points.shape[0]), 7 * int(ed.points.shape[0])
+    d, _ = nodes.find_knn(ed.points, ed.points, k=5)
+    ed.radii = d[:, 1:].mean(1)
+    n0 = int(data.points.shape[0])
+    sf = SimpleNamespace(opt=opt, hard_seg=False, evaluate_tracking=False, ED_nodes=ed, points=data.points.clone(),
+                         norms=data.norms.clone(), colors=data.colors.clone(), radii=data.radii.clone(),
+                         confs=data.confs.clone(), time_stamp=torch.zeros(n0, device="cuda"),
+                         isStable=torch.ones(n0, dtype=torch.bool, device="cuda"), projdata=torch.zeros(n0, 2, device="cuda"),
+                         time=0)
+    nodes.update_ed(sf)
+    nodes.update_sfed_knn(sf)
+    lm = LM_Solver(opt)
+    oopt = orc.default_opt(num_optimize_iterations=5)
+    for k in (1, 2):
+        depth, inputs = frame_inputs(k)
+        data, inputs = depth_preprocessing(opt, None, inputs)
+        ref = dpo.depth_preprocessing(dpo.default_opt(height=H, width=W), depth, K, inv_K, color, inputs["divterm"])
+        np.testing.assert_array_equal(data.index_map.cpu().numpy(), ref["index_map"])
+        np.testing.assert_array_equal(data.points.cpu().numpy(), ref["points"])
+        # LM on the device vs the oracle on the float32-rounded state the HIP path streams
+        f32r = lambda t: t.cpu().numpy().astype(np.float32).astype(np.float64)
+        fr = orc.Frame(sf_points=f32r(sf.points), sf_knn_idx=sf.knn_indices.cpu().numpy(), sf_knn_w=f32r(sf.knn_w),
+                       ed_points=f32r(ed.points), ed_knn_idx=ed.knn_indices.cpu().numpy(), tgt_points=f32r(data.points),
+                       tgt_norms=f32r(data.norms), index_map=data.index_map.cpu().numpy(), valid=data.valid.cpu().numpy(),
+                       K=K, H=H, W=W)
+        beta = lm.LM(sf, inputs, data)
+        np.testing.assert_allclose(beta.cpu().numpy(), orc.lm(fr, oopt), rtol=0, atol=1e-4, err_msg=f"frame {k}")
+        nodes.update(sf, beta)
+        # fusion on the device vs the oracle on the same pre-fusion state
+        m = fuo.Model(*(getattr(sf, a).cpu().numpy() for a in ("points", "norms", "colors", "radii", "confs", "time_stamp",
+                                                               "isStable", "knn_indices", "knn_w")),
+                      ed.points.cpu().numpy(), ed.radii.cpu().numpy())
+        new = SimpleNamespace(**{a: getattr(data, a).cpu().numpy() for a in ("points", "norms", "colors", "radii", "confs", "valid")})
+        fopt = fuo.default_opt(height=H, width=W, th_dist=opt.th_dist)
+        fuo.fuse_input_data(m, fopt, K, new, k)
+        fuo.swap_stable(m, fopt, k)
+        n_before = int(sf.points.shape[0])
+        fusion.fuseInputData(sf, inputs, data)
+        fusion.prepareStableIndexNSwapAllModel(sf, inputs, data)
+        _check(sf, {"z_" + a: getattr(m, a) for a in ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable",
+                                                        "knn_indices", "knn_w", "projdata")}, "z_")
+        assert int(sf.points.shape[0]) >= n_before * 0.9 and bool(sf.isStable.all())
+        rec = lm.last_records[0]
+        assert rec[-1]["loss"] < rec[0]["loss"]
