@@ -452,6 +452,32 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
 int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, int32_t time,
                          void* stream);
 
+/* ===================================================================================
+ * "Next" row f3: ED-graph construction at frame 0
+ *   slm_graph_init  <- init_graph + DirectDeformGraph (grid_mesh)   super/graph_encoder.py:11-67,128-195
+ * Anchors on a pixel grid of step opt.mesh_step_size (row-major numbering), four edges and two
+ * triangles per grid cell (kept when all their vertices are valid anchors), node radius = mean
+ * length of the incident edges (isolated nodes get the mean of the others), triangle rest areas.
+ * Capacities: nodes <= ceil((H-1)/step) * ceil((W-1)/step), edges <= 4 * nodes, triangles <= 2 * nodes;
+ * edge_index / triangles are written row by row with row stride `cap_nodes * 4` / `cap_nodes * 2`.
+ * =================================================================================== */
+typedef struct slm_graph_outputs {  /* device pointers */
+  int32_t cap_nodes, pad;
+  double* points;                 /* (cap_nodes,3) graph.points */
+  double* norms;                  /* (cap_nodes,3) graph.norms */
+  double* radii;                  /* (cap_nodes)   graph.radii */
+  int32_t* edge_index;            /* (2, 4*cap_nodes) graph.edge_index */
+  double* edges_lens;             /* (4*cap_nodes)    graph.edges_lens */
+  int32_t* triangles;             /* (3, 2*cap_nodes) graph.triangles */
+  double* triangles_areas;        /* (2*cap_nodes)    graph.triangles_areas */
+} slm_graph_outputs;
+
+/* valid (H*W) = data.valid, index_map (H,W) = data.index_map, points / norms (T,3) = data.points /
+ * data.norms.  counts_host[3] = {nodes, edges, triangles}.  Synchronises `stream`. */
+int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t* valid, const int32_t* index_map,
+                   const double* points, const double* norms, const slm_graph_outputs* out,
+                   int32_t* counts_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ EXPORTS = [
     "slm_gf_bind_semantic", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
-    "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
+    "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -112,6 +112,12 @@ class SlmNewFrame(C.Structure):
                 ("index_map", C.c_void_p)]
 
 
+class SlmGraphOutputs(C.Structure):
+    _fields_ = [("cap_nodes", C.c_int32), ("pad", C.c_int32), ("points", C.c_void_p), ("norms", C.c_void_p),
+                ("radii", C.c_void_p), ("edge_index", C.c_void_p), ("edges_lens", C.c_void_p),
+                ("triangles", C.c_void_p), ("triangles_areas", C.c_void_p)]
+
+
 class SlmIterRecord(C.Structure):
     _fields_ = [("loss", C.c_double), ("u", C.c_double), ("accepted", C.c_int32),
                 ("status", C.c_int32), ("M_grad", C.c_int32), ("M_loss", C.c_int32)]
@@ -181,6 +187,7 @@ def load():
         "slm_lm_exchange_size": [vp, i32, i32, C.POINTER(C.c_int64)],
         "slm_lm_exchange_get": [vp, i32, i32, vp, vp],
         "slm_lm_exchange_set": [vp, i32, i32, vp, vp],
+        "slm_graph_init": [i32, i32, i32, vp, vp, vp, vp, C.POINTER(SlmGraphOutputs), C.POINTER(C.c_int32), vp],
         "slm_fuse_create": [i32, i32, i32, C.POINTER(vp)],
         "slm_fuse_destroy": [vp],
         "slm_fuse_input_data": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), C.POINTER(SlmNewFrame), vp],

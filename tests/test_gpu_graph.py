@@ -1,0 +1,54 @@
+"""HIP ED-graph construction vs the reference's goldens and the NumPy oracle,
+through the C ABI.  Needs an MI355X (-m gpu)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import graph_oracle as gro
+from test_graph_oracle import GOLD, VARIANTS
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(valid, index_map, points, norms, H, W, step):
+    import torch
+    from super_amd.graph_encoder import DirectDeformGraph
+    opt = SimpleNamespace(height=H, width=W, mesh_step_size=step, method="super")
+    data = SimpleNamespace(points=torch.from_numpy(points).cuda(), norms=torch.from_numpy(norms).cuda(),
+                           valid=torch.from_numpy(valid).cuda(), index_map=torch.from_numpy(index_map).cuda())
+    gr = DirectDeformGraph(opt)(None, data)
+    out = {k: getattr(gr, k).cpu().numpy() for k in ("points", "norms", "radii", "edge_index", "edges_lens", "triangles",
+                                                      "triangles_areas")}
+    out["num"] = gr.num
+    return out
+
+
+def _check(out, ref):
+    assert out["num"] == int(ref["num"])
+    np.testing.assert_array_equal(out["edge_index"], ref["edge_index"])
+    np.testing.assert_array_equal(out["triangles"], ref["triangles"])
+    np.testing.assert_array_equal(out["points"], ref["points"])
+    np.testing.assert_array_equal(out["norms"], ref["norms"])
+    np.testing.assert_allclose(out["edges_lens"], ref["edges_lens"], rtol=1e-14)
+    np.testing.assert_allclose(out["radii"], ref["radii"], rtol=1e-13)
+    np.testing.assert_allclose(out["triangles_areas"], ref["triangles_areas"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_graph_matches_reference_goldens(tag):
+    g = np.load(GOLD)
+    out = _run(g["in_valid"], g["in_index_map"], g["in_points"], g["in_norms"], int(g["in_H"]), int(g["in_W"]), VARIANTS[tag])
+    _check(out, {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + "_")})
+
+
+def test_graph_full_size_with_isolated_anchors_matches_oracle():
+    """480x640 with 35 % holes (some anchors have no edge: their radius is the mean of the others) and
+    the reference's default step-size range."""
+    from super_amd import synth
+    sc = synth.make_scene(N=1000, J=12, H=480, W=640, seed=3, tgt_holes=0.35)
+    for step in (30, 13):
+        out = _run(sc.valid, sc.index_map, sc.f64("tgt_points"), sc.f64("tgt_norms"), sc.H, sc.W, step)
+        ref = gro.direct_deform_graph(sc.valid, sc.index_map, sc.f64("tgt_points"), sc.f64("tgt_norms"), step)
+        _check(out, ref)
+        assert out["num"] > 100
