@@ -1,0 +1,102 @@
+"""The reference's per-frame driver with every stage on the device: mirrors of ``SuPer``
+(``super/super.py:11-77``) and of the parts of ``Surfels`` (``super/nodes.py:96-149``) it needs.
+
+    model = SuPer(opt)                 # opt as parsed by the reference's options.py
+    for inputs in dataloader:          # inputs[("depth",0)], inputs["K"], inputs["inv_K"], ...
+        model(models, inputs)          # model.sf is the surfel model, model.deform_param the last warp
+
+``forward`` runs ``depth_preprocessing`` -> (first frame: ``models.mesh_encoder`` or the grid-mesh
+``DirectDeformGraph``, ``Surfels``) -> ``LM_Solver.LM`` or ``GraphFit`` -> ``Surfels.update`` ->
+``fuseInputData`` -> ``prepareStableIndexNSwapAllModel``, each through libsuper_lm.so.  Depth /
+segmentation networks (``pred_depth`` / ``pred_seg``), tracked evaluation points, TensorBoard output and
+rendering are outside this mirror: depth must be loaded (``opt.load_depth``).
+"""
+from __future__ import annotations
+
+import logging
+from types import SimpleNamespace
+
+import torch
+
+from . import fusion, nodes
+from .LM import LM_Solver
+from .data_loader import depth_preprocessing
+from .deform_mesh import GraphFit
+from .graph_encoder import DirectDeformGraph
+
+
+class Surfels:
+    """Surfel model (``super/nodes.py:96-149``): the fields of the first frame's ``sfdata`` plus the
+    ED graph, stability flags, time stamps and skinning tables."""
+
+    def __init__(self, opt, models, inputs, data):
+        self.opt, self.models = opt, models
+        self.evaluate_tracking = False
+        self.hard_seg = False
+        self.logger = logging.getLogger("super_amd.Surfels")
+        for key, v in vars(data).items():
+            if key != "valid":
+                setattr(self, key, v)
+        self.sf_num = int(self.points.shape[0])
+        dev = self.points.device
+        self.isStable = torch.ones(self.sf_num, dtype=torch.bool, device=dev)
+        if opt.phase == "test":
+            self.time_stamp = float(self.time) * torch.ones(self.sf_num, device=dev)
+        self.projdata = torch.flip(data.valid.view(opt.height, opt.width).nonzero(), dims=[-1]).to(torch.float32)
+        self.update_ed()
+        self.update_sfed_knn()
+
+    update_ed = nodes.update_ed
+    update_sfed_knn = nodes.update_sfed_knn
+    update = nodes.update
+    fuseInputData = fusion.fuseInputData
+    prepareStableIndexNSwapAllModel = fusion.prepareStableIndexNSwapAllModel
+
+
+class SuPer:
+    def __init__(self, opt):
+        self.opt = opt
+        self.sf = None
+        self.deform_param = None
+        if opt.use_derived_gradient:
+            self.lm = LM_Solver(opt)
+        else:
+            self.graph_fit = GraphFit(opt)
+
+    def forward(self, models, inputs):
+        if not getattr(self.opt, "load_depth", True):
+            raise NotImplementedError("super_amd.SuPer: depth must be loaded (no depth network here)")
+        for key, v in list(inputs.items()):
+            if torch.is_tensor(v):
+                if key == "divterm":
+                    inputs[key] = v.item()
+                elif key != "filename":
+                    inputs[key] = v.cuda()
+        sfdata, inputs = depth_preprocessing(self.opt, models, inputs)
+        if self.sf is None:
+            if getattr(self.opt, "deform_udpate_method", "super_edg") == "super_edg":
+                encoder = getattr(models, "mesh_encoder", None) or DirectDeformGraph(self.opt)
+                sfdata.ED_nodes = encoder(inputs, sfdata)
+            self.init_surfels(models, inputs, sfdata)
+            self.deform_param = None
+        else:
+            self.deform_param = self.fusion(models, inputs, sfdata)
+        return self.deform_param
+
+    __call__ = forward
+
+    def init_surfels(self, models, inputs, sfdata):
+        self.sf = Surfels(self.opt, models, inputs, sfdata)
+        if self.opt.phase == "test":
+            self.sf.prepareStableIndexNSwapAllModel(inputs, sfdata)
+
+    def fusion(self, models, inputs, sfdata):
+        if self.opt.use_derived_gradient:
+            deform_param = self.lm.LM(self.sf, inputs, sfdata)
+        else:
+            deform_param = self.graph_fit(inputs, self.sf, sfdata, models)
+        self.sf.update(deform_param)
+        if self.opt.phase == "test":
+            self.sf.fuseInputData(inputs, sfdata)
+            self.sf.prepareStableIndexNSwapAllModel(inputs, sfdata)
+        return deform_param
