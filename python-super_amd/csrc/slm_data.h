@@ -17,16 +17,14 @@ struct SurfelEval {
 
 // npk: packed node table (fd.node_pk at beta, fd.node_pk_try at the trial point beta + delta).
 // sf_pts / sf_idx / sf_w: the surfel streams to read (caller order or tuple-sorted copies).
+// The evaluation is a chain of dependent gathers (surfel -> its 4 nodes -> projected pixel ->
+// 4 target rows); the loads of each stage are issued together, and callers that can fetch the
+// surfel stream entries early pass them in (eval_surfel_core).
 template <bool GRAD>
-__device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* __restrict__ sf_pts,
-                                               const int* __restrict__ sf_idx,
-                                               const float* __restrict__ sf_w, double lam,
-                                               const double* __restrict__ npk, int i,
-                                               SurfelEval& out) {
+__device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, float px, float py, float pz, int4 ids, float4 wf,
+                                                 double lam, const double* __restrict__ npk, SurfelEval& out) {
   const slm_frame& f = fd.f;
-  const d3 p = {(double)sf_pts[3 * i], (double)sf_pts[3 * i + 1], (double)sf_pts[3 * i + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(sf_idx + 4 * i);
-  const float4 wf = *reinterpret_cast<const float4*>(sf_w + 4 * i);
+  const d3 p = {(double)px, (double)py, (double)pz};
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
   const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
 
@@ -61,24 +59,26 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* 
   const double ur = rint(u_), vr = rint(v_);   // torch.round: half to even
   const int H = f.H, W = f.W;
   // proj_valid (false for NaN): 0 <= v < H-1, 0 <= u < W-1
-  if (!(vr >= 0.0 && vr < (double)(H - 1) && ur >= 0.0 && ur < (double)(W - 1))) return;
-  const int coords = (int)vr * W + (int)ur;
-  if (!f.tgt_valid[coords]) return;   // valid_pair (loss.py:229-234)
-
-  // ---- bilinear taps (loss.py:107-129) ----
+  const bool pv = vr >= 0.0 && vr < (double)(H - 1) && ur >= 0.0 && ur < (double)(W - 1);
+  // valid_pair (loss.py:229-234) and the four bilinear taps (loss.py:107-129): one round trip
+  const int coords = pv ? (int)vr * W + (int)ur : 0;
   const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
   const double nn[4] = {fv, fv, cv, cv};
   const double mm[4] = {fu, cu, fu, cu};
+  const uint8_t tv = pv ? f.tgt_valid[coords] : (uint8_t)0;
   int rows[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ni = (int)nn[t], mi = (int)mm[t];
+    const bool inside = pv && (ni >= 0) && (ni < H) && (mi >= 0) && (mi < W);
+    rows[t] = inside ? f.index_map[ni * W + mi] : -1;
+  }
+  if (!tv) return;
   bool all_ok = true;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    int ni = (int)nn[t], mi = (int)mm[t];
-    bool inside = (ni >= 0) && (ni < H) && (mi >= 0) && (mi < W);
-    int row = inside ? f.index_map[ni * W + mi] : -1;
-    rows[t] = row;
-    out.taps[t] = row;
-    all_ok = all_ok && (row >= 0);
+    out.taps[t] = rows[t];
+    all_ok = all_ok && (rows[t] >= 0);
   }
   if (!all_ok) return;   // NaN fill -> surfel dropped (loss.py:241)
 
@@ -132,6 +132,17 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* 
     out.row[7 * k + 5] = lw * c.y;
     out.row[7 * k + 6] = lw * c.z;
   }
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* __restrict__ sf_pts,
+                                               const int* __restrict__ sf_idx,
+                                               const float* __restrict__ sf_w, double lam,
+                                               const double* __restrict__ npk, int i,
+                                               SurfelEval& out) {
+  eval_surfel_core<GRAD>(fd, sf_pts[3 * i], sf_pts[3 * i + 1], sf_pts[3 * i + 2],
+                         *reinterpret_cast<const int4*>(sf_idx + 4 * i), *reinterpret_cast<const float4*>(sf_w + 4 * i),
+                         lam, npk, out);
 }
 
 template <bool GRAD>

@@ -37,34 +37,71 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
                                                        int dbg) {
   __shared__ double rows[4][64 * ROW_STRIDE];
   __shared__ double recs[MERGE ? SLM_LB_MAX * SLM_WREC : 1];
+  __shared__ uint8_t lidx[4][MERGE ? 160 : 4];   // per wave: record of each of the 10 node pairs of its 16 groups
   const FrameDev& fd = frames[blockIdx.y];
-  if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
+  // (no test of st->stopped here: a stopped slot only wastes this pass, and the test would put one more
+  //  dependent load in front of everything)
+  if (!fd.bound || !fd.v1_ready) return;
   if (MERGE != (fd.v2_ready != 0)) return;   // the host launches both variants when slots differ
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int base = (blockIdx.x * 4 + w) * 64;
   if (blockIdx.x * 256 >= fd.n_pos) return;
   if ((int)blockIdx.x < fd.wg_lo || (int)blockIdx.x >= fd.wg_hi) return;   // another rank's share
+  const bool wact = base < fd.n_pos;
+  const int pos = base + l;
+  const int lc = l & 15, lq = l >> 4;
+  // ---- stage 0: everything that only depends on the position is requested at once ----
   int rec0 = 0, nrec = 0;
   if (MERGE) {
     rec0 = fd.wg_first[blockIdx.x];
     nrec = fd.wg_last[blockIdx.x] - rec0 + 1;
-    for (int i = threadIdx.x; i < nrec * SLM_WREC; i += 256) recs[i] = 0.0;
-    __syncthreads();
   }
-  if (base < fd.n_pos) {
-  const int pos = base + l;
+  int my_run = -1;
+  int4 ids = {-1, -1, -1, -1};
+  float4 wf = {0, 0, 0, 0};
+  float px = 0, py = 0, pz = 0;
+  if (wact) {
+    my_run = fd.grp_run[(base >> 2) + lc];   // lane (l & 15) holds the run of group (l & 15)
+    ids = *reinterpret_cast<const int4*>(fd.s_idx + 4 * (size_t)pos);
+    wf = *reinterpret_cast<const float4*>(fd.s_w + 4 * (size_t)pos);
+    px = fd.s_pts[3 * (size_t)pos];
+    py = fd.s_pts[3 * (size_t)pos + 1];
+    pz = fd.s_pts[3 * (size_t)pos + 2];
+  }
+  // ---- stage 1: record numbers of the wave's runs (needs my_run), in flight with the node gathers ----
+  uint8_t lv0 = 0, lv1 = 0, lv2 = 0;
+  if (MERGE && wact) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = l + 64 * k;                      // entry idx = group * 10 + pair slot, 160 per wave
+      const int g = idx / 10, e = idx - 10 * g;
+      const int run = __shfl(my_run, g < 16 ? g : 0, 64);
+      const uint8_t v = (idx < 160 && run >= 0) ? fd.run_lidx[10 * (size_t)run + e] : (uint8_t)0;
+      if (k == 0) lv0 = v; else if (k == 1) lv1 = v; else lv2 = v;
+    }
+  }
+  if (MERGE)
+    for (int i = threadIdx.x; i < nrec * SLM_WREC; i += 256) recs[i] = 0.0;
   double* myrow = &rows[w][l * ROW_STRIDE];
 
   // ---- per-surfel evaluation -----------------------------------------------------
   SurfelEval ev;
   ev.match = false;
-  const bool live = fd.s_idx[4 * pos] >= 0;
+  ev.id[0] = ev.id[1] = ev.id[2] = ev.id[3] = -1;
+  const bool live = wact && ids.x >= 0;
 #ifdef SLM_STAMPS
   if (live && !(dbg & 4))
 #else
   if (live)
 #endif
-    eval_surfel_at<true>(fd, fd.s_pts, fd.s_idx, fd.s_w, lam, fd.node_pk, pos, ev);
+    eval_surfel_core<true>(fd, px, py, pz, ids, wf, lam, fd.node_pk, ev);
+  if (MERGE && wact) {
+    lidx[w][l] = lv0;
+    lidx[w][l + 64] = lv1;
+    if (l + 128 < 160) lidx[w][l + 128] = lv2;
+  }
+  if (MERGE) __syncthreads();   // accumulators zeroed, record numbers in place
+  if (wact) {
   const unsigned long long mm = __ballot(ev.match);
   if (l == 0 && mm) atomicAdd(&fd.st->m_grad, __popcll(mm));
 
@@ -76,7 +113,6 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) slot[k] += (ev.id[k2] < ev.id[k]) ? 1 : 0;
   }
-  const int lc = l & 15, lq = l >> 4;
   double a0[16];   // first-half operands of the 16 groups: rows[4g + lq][lc]
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -106,17 +142,16 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   }
 
   // ---- Gram accumulation per run ---------------------------------------------------
-  const int my_run = fd.grp_run[(base >> 2) + lc];   // lane (l & 15) holds the run of group (l & 15)
   double4_t g00 = {0, 0, 0, 0}, g10 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
   int cur = -1;
 
-  auto flush = [&](int run) {
+  auto flush = [&](int run, int grp) {
 #ifdef SLM_STAMPS
     if (dbg & 1) return;
 #endif
     if (MERGE) {
       // accumulator element (tile, r) of lane l is G[i][j], i = 4r + lq (+16), j = lc (+16)
-      const int lv = fd.run_lidx[10 * run + (l < 10 ? l : 0)];   // record of each of the 10 node pairs
+      const uint8_t* lvp = &lidx[w][10 * grp];   // record of each of the 10 node pairs of this run
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -130,7 +165,7 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
           // row 28 (J^T r) goes to the diagonal record of node slot pb, entries 49..55
           int ps = jrow ? (pb * (pb + 1) / 2 + pb) : (pa * (pa + 1) / 2 + pb);
           ps = act ? ps : 0;
-          const int rec = __shfl(lv, ps);
+          const int rec = lvp[ps];
           if (act) unsafeAtomicAdd(&recs[rec * SLM_WREC + (jrow ? 49 + cb : 7 * ca + cb)], v);
         }
     } else {
@@ -149,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   for (int g = 0; g < 16; ++g) {
     const int run = __builtin_amdgcn_readlane(my_run, g);
     if (run != cur) {
-      if (cur >= 0) flush(cur);
+      if (cur >= 0) flush(cur, g - 1);
       g00 = double4_t{0, 0, 0, 0};
       g10 = double4_t{0, 0, 0, 0};
       g11 = double4_t{0, 0, 0, 0};
@@ -164,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
     g10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a0[g], g10, 0, 0, 0);
     g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
   }
-  if (cur >= 0) flush(cur);
+  if (cur >= 0) flush(cur, 15);
   }   // wave has positions
   if (MERGE) {
     __syncthreads();
