@@ -96,8 +96,19 @@ __global__ void __launch_bounds__(256) k_front_assemble(const FrameDev* __restri
   if (fd.v2_ready) {
     // one 56-double record per (workgroup, pair): 49 block entries + 7 entries of J^T r
     const int s0 = fd.blk2_start[bi], s1 = fd.blk2_start[bi + 1];
-    if (l < SLM_WREC)
-      for (int s = s0; s < s1; ++s) acc += fd.wgslab[(size_t)fd.blk2_entry[s] * SLM_WREC + l];
+    // record numbers in chunks of 8, then the 8 record reads together (two round trips per chunk
+    // instead of two per record); the sum keeps the record order
+    for (int sb = s0; sb < s1; sb += 8) {
+      int ent[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ent[k] = sb + k < s1 ? fd.blk2_entry[sb + k] : -1;
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (ent[k] >= 0 && l < SLM_WREC) ? fd.wgslab[(size_t)ent[k] * SLM_WREC + l] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (ent[k] >= 0) acc += v[k];
+    }
   } else {
     const int s0 = fd.blk_start[bi], s1 = fd.blk_start[bi + 1];
     for (int s = s0; s < s1; ++s) {
