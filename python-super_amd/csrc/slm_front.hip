@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
   double* vec = wt + 4 * 256;
   int* s_ok = reinterpret_cast<int*>(vec + NB);
   const FrameDev& fd = frames[blockIdx.z];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + blockIdx.y;
   if (fi >= fd.level_start[level + 1]) return;
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
   double* part = vec + NB;         // NB scratch
   int* s_ok = reinterpret_cast<int*>(part + NB);
   const FrameDev& fd = frames[blockIdx.z];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + blockIdx.y;
   if (fi >= fd.level_start[level + 1]) return;
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frame
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
@@ -749,7 +749,7 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   if (!wg_decode(map, wg)) return;
   const int t = wg.unit;
   const FrameDev& fd = frames[wg.frame];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + wg.front;
   if (fi >= fd.level_start[level + 1]) return;
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
 __global__ void __launch_bounds__(256) k_fback_prep(const FrameDev* __restrict__ frames, int level) {
   extern __shared__ double xb[];   // n2p doubles
   const FrameDev& fd = frames[blockIdx.z];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + blockIdx.y;
   if (fi >= fd.level_start[level + 1]) return;
@@ -884,7 +884,7 @@ __global__ void __launch_bounds__(256) k_fback_prep(const FrameDev* __restrict__
 __global__ void __launch_bounds__(256) k_fbacksub(const FrameDev* __restrict__ frames, int level,
                                                    int step) {
   const FrameDev& fd = frames[blockIdx.z];
-  if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   if (level >= fd.n_levels) return;
   const int fi = fd.level_start[level] + blockIdx.y;
   if (fi >= fd.level_start[level + 1]) return;
