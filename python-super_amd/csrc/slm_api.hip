@@ -407,9 +407,12 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
   if (d.nd) {
     for (int i = first; i < first + n; ++i) {
       const auto& sc = s->slots[i].nd.sched;
-      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0});
+      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2});
       for (size_t l = 0; l < sc.size(); ++l) {
         NDLevelSched& m = d.sched[l];
+        // same first front and front count in every slot -> passed to the kernels by value
+        if (m.first == -2) m.first = sc[l].first;
+        else if (m.first != sc[l].first || m.n_fronts != sc[l].n_fronts) m.first = -1;
         m.n_fronts = std::max(m.n_fronts, sc[l].n_fronts);
         m.max_npt = std::max(m.max_npt, sc[l].max_npt);
         m.max_nt = std::max(m.max_nt, sc[l].max_nt);
@@ -418,6 +421,13 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
       }
     }
   }
+  if (d.nd && n > 1) {
+    // slots with fewer levels than the batch maximum: their level tables must be read on the device
+    for (int i = first; i < first + n; ++i)
+      for (size_t l = s->slots[i].nd.sched.size(); l < d.sched.size(); ++l) d.sched[l].first = -1;
+  }
+  for (auto& m : d.sched)
+    if (m.first == -2) m.first = -1;
   if (s->cfg.use_arap || s->cfg.use_rot)
     d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);
   return d;

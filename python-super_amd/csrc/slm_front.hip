@@ -45,6 +45,21 @@ __device__ __forceinline__ double* dest_entry(const FrameDev& fd, const NDDest& 
 struct WgMap {
   int n_units, n_fronts, n_frames, xcd;
 };
+// Level of the separator tree a launch works on.  When every slot of the batch has the same plan
+// the host passes the level's first front and front count by value (first >= 0), which takes a
+// dependent load (the slot's level table) out of every kernel prologue.
+struct LevelRef {
+  int level, first, count;
+};
+__device__ __forceinline__ bool level_front(const FrameDev& fd, const LevelRef& lr, int idx, int& fi) {
+  if (lr.first >= 0) {
+    fi = lr.first + idx;
+    return idx < lr.count;
+  }
+  if (lr.level >= fd.n_levels) return false;
+  fi = fd.level_start[lr.level] + idx;
+  return fi < fd.level_start[lr.level + 1];
+}
 struct WgId {
   int unit, front, frame;
 };
@@ -320,7 +335,7 @@ __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restric
 // ---------------------------------------------------------------------------------
 // Dense partial Cholesky of the fronts of one level, tile column c.
 // grid = (max tiles below + 1, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ frames, int level,
+__global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                  int c, double u_override, WgMap map) {
   extern __shared__ double lds[];
   double* S = lds;
@@ -333,9 +348,8 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + wg.front;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, wg.front, fi)) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
   const int d = wg.unit;
@@ -343,7 +357,7 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   const double u = (u_override >= 0.0) ? u_override : fd.st->u;
 
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
-  const bool stamp = (c == 1 && wg.frame == 0 && wg.front == 0 && d == 1 && level == fd.n_levels - 1);
+  const bool stamp = (c == 1 && wg.frame == 0 && wg.front == 0 && d == 1 && lvl.level == fd.n_levels - 1);
   SLM_STAMP(fd, stamp, 0);
   double* At = ftile(fd, f, c + d, c);
   double* yv = fd.fvec + f.vec_off + (size_t)c * NB;
@@ -403,7 +417,7 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
 //   k_fpotrf  one block per front: factor, full inverse -> flinv, forward substitution
 //   k_ftrsm   block d >= 1: L(c+d,c) = A(c+d,c) L_cc^-T as one tile product with L_cc^-1
 // grid = (1, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ frames, int level, int c,
+__global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ frames, LevelRef lvl, int c,
                                                  double u_override) {
   extern __shared__ double lds[];
   double* S = lds;
@@ -414,9 +428,8 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
   int* s_ok = reinterpret_cast<int*>(vec + NB);
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, blockIdx.y, fi)) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
   const double u = (u_override >= 0.0) ? u_override : fd.st->u;
@@ -451,15 +464,14 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
 }
 
 // grid = (max tiles below, fronts in level, n_frames): block d-1 -> tile (c+d, c)
-__global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ frames, int level, int c, WgMap map) {
+__global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ frames, LevelRef lvl, int c, WgMap map) {
   __shared__ double Bl[TILE];
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + wg.front;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, wg.front, fi)) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
   const int d = wg.unit + 1;
@@ -494,7 +506,7 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
 // grid k_fL11 = (1, fronts in level, n_frames); k_fL21 = (max boundary tiles, fronts, frames)
 #define L11_LDS_DOUBLES (3 * TILE + 8 * 256 + 2 * NB + 8)
 
-__global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frames, int level,
+__global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                double u_override) {
   extern __shared__ double lds[];
   double* S = lds;
@@ -507,9 +519,8 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
   int* s_ok = reinterpret_cast<int*>(part + NB);
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, blockIdx.y, fi)) return;
   const NDFront& f = fd.fronts[fi];
   if (f.npt == 0) return;
   const double u = (u_override >= 0.0) ? u_override : fd.st->u;
@@ -598,16 +609,15 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
   }
 }
 
-__global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frames, int level, WgMap map) {
+__global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frames, LevelRef lvl, WgMap map) {
   __shared__ double Bl[TILE];
   __shared__ double yv[NB];
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + wg.front;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, wg.front, fi)) return;
   const NDFront& f = fd.fronts[fi];
   const int r = f.npt + wg.unit;
   if (f.npt == 0 || r >= f.nt) return;
@@ -678,16 +688,15 @@ __global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frame
 // front by k_fschur with the whole pivot block as the inner dimension.
 // Block index t: columns b = s-c = 1..bcap, rows a = r-c = b..mcap, then mcap rhs blocks.
 // grid = (ntile_cap + mcap, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ frames, int level,
+__global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                  int c, int mcap, int bcap, int ntile_cap, WgMap map) {
   __shared__ double Bl[TILE];
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + wg.front;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, wg.front, fi)) return;
   const NDFront& f = fd.fronts[fi];
   if (c >= f.npt) return;
   const int m = f.nt - 1 - c;
@@ -741,7 +750,7 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 // row / column index maps.  The next pivot column's operands are fetched while the current one
 // is on the MFMA.  `which` selects the children with that index (see launch_front_solve).
 // grid = (max boundary tile pairs, fronts in level, n_frames)
-__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, int level, int which,
+__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, LevelRef lvl, int which,
                                                  WgMap map) {
   __shared__ double Bl[TILE];
   __shared__ int rmap[NB], cmap[NB];
@@ -750,9 +759,8 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   const int t = wg.unit;
   const FrameDev& fd = frames[wg.frame];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + wg.front;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, wg.front, fi)) return;
   const NDFront& f = fd.fronts[fi];
   if (f.parent < 0 || f.which_child != which) return;   // the root has no boundary
   const int nbt = f.nt - f.npt;
@@ -851,13 +859,12 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
 // Back substitution, part 1: y_c -= sum over boundary tiles r of L(r,c)^T x_r, where x of
 // the boundary nodes is read from the global solution (their fronts are done already).
 // grid = (max npt, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fback_prep(const FrameDev* __restrict__ frames, int level) {
+__global__ void __launch_bounds__(256) k_fback_prep(const FrameDev* __restrict__ frames, LevelRef lvl) {
   extern __shared__ double xb[];   // n2p doubles
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, blockIdx.y, fi)) return;
   const NDFront& f = fd.fronts[fi];
   const int c = blockIdx.x;
   if (c >= f.npt || f.nb == 0) return;
@@ -881,13 +888,12 @@ __global__ void __launch_bounds__(256) k_fback_prep(const FrameDev* __restrict__
 // Back substitution, part 2, pivot tile column c = npt-1-step of every front of the level:
 // x_c = L_cc^-T y_c, y_(c-d) -= L(c,c-d)^T x_c; block 0 scatters x_c to the global solution.
 // grid = (max npt, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fbacksub(const FrameDev* __restrict__ frames, int level,
+__global__ void __launch_bounds__(256) k_fbacksub(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                    int step) {
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  if (level >= fd.n_levels) return;
-  const int fi = fd.level_start[level] + blockIdx.y;
-  if (fi >= fd.level_start[level + 1]) return;
+  int fi;
+  if (!level_front(fd, lvl, blockIdx.y, fi)) return;
   const NDFront& f = fd.fronts[fi];
   const int c = f.npt - 1 - step;
   if (c < 0) return;
@@ -977,12 +983,13 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
   for (int l = 0; l < n_levels; ++l) {
     const NDLevelSched& s = lv[l];
     if (s.n_fronts <= 0) continue;
+    const LevelRef lr{l, s.first, s.n_fronts};
     const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= 16;
     if (compact) {
-      hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, l, u_override);
+      hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, lr, u_override);
       if (s.max_n2p > 0) {
         const WgMap m = make_map(s.max_n2p / 64, s.n_fronts, n_frames);
-        hipLaunchKernelGGL(k_fL21, map_grid(m), dim3(256), 0, st, fr, l, m);
+        hipLaunchKernelGGL(k_fL21, map_grid(m), dim3(256), 0, st, fr, lr, m);
       }
     }
     for (int c = 0; !compact && c < s.max_npt; ++c) {
@@ -991,13 +998,13 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
       // factorisations would take more than ~2 blocks per CU
       if ((long)(mcap + 1) * s.n_fronts * n_frames <= 512) {
         const WgMap m = make_map(mcap + 1, s.n_fronts, n_frames);
-        hipLaunchKernelGGL(k_fpanel, map_grid(m), dim3(256), lds, st, fr, l, c, u_override, m);
+        hipLaunchKernelGGL(k_fpanel, map_grid(m), dim3(256), lds, st, fr, lr, c, u_override, m);
       } else {
-        hipLaunchKernelGGL(k_fpotrf, dim3(1, s.n_fronts, n_frames), dim3(256), lds, st, fr, l, c,
+        hipLaunchKernelGGL(k_fpotrf, dim3(1, s.n_fronts, n_frames), dim3(256), lds, st, fr, lr, c,
                            u_override);
         if (mcap > 0) {
           const WgMap m = make_map(mcap, s.n_fronts, n_frames);
-          hipLaunchKernelGGL(k_ftrsm, map_grid(m), dim3(256), 0, st, fr, l, c, m);
+          hipLaunchKernelGGL(k_ftrsm, map_grid(m), dim3(256), 0, st, fr, lr, c, m);
         }
       }
       const int bcap = std::min(mcap, s.max_npt - 1 - c);
@@ -1005,7 +1012,7 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
       for (int b = 1; b <= bcap; ++b) ntile += mcap - b + 1;
       if (ntile + mcap > 0) {
         const WgMap m = make_map(ntile + mcap, s.n_fronts, n_frames);
-        hipLaunchKernelGGL(k_ftrail, map_grid(m), dim3(256), 0, st, fr, l, c, mcap, bcap, ntile, m);
+        hipLaunchKernelGGL(k_ftrail, map_grid(m), dim3(256), 0, st, fr, lr, c, mcap, bcap, ntile, m);
       }
     }
     // Schur complements of this level, added straight into the parents (next level): one pass
@@ -1014,18 +1021,19 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     if (s.max_n2p > 0 && l + 1 < n_levels) {
       const int nbt = s.max_n2p / 64;
       const WgMap m = make_map(nbt * (nbt + 1) / 2, s.n_fronts, n_frames);
-      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, l, 0, m);
-      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, l, 1, m);
+      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, lr, 0, m);
+      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, lr, 1, m);
     }
   }
   for (int l = n_levels - 1; l >= 0; --l) {
     const NDLevelSched& s = lv[l];
     if (s.n_fronts <= 0 || s.max_npt <= 0) continue;
+    const LevelRef lr{l, s.first, s.n_fronts};
     if (s.max_n2p > 0)
       hipLaunchKernelGGL(k_fback_prep, dim3(s.max_npt, s.n_fronts, n_frames), dim3(256),
-                         (size_t)s.max_n2p * sizeof(double), st, fr, l);
+                         (size_t)s.max_n2p * sizeof(double), st, fr, lr);
     for (int e = 0; e < s.max_npt; ++e)
       hipLaunchKernelGGL(k_fbacksub, dim3(s.max_npt, s.n_fronts, n_frames), dim3(256), 0, st, fr,
-                         l, e);
+                         lr, e);
   }
 }

@@ -50,6 +50,7 @@ struct NDLevelSched {
   int32_t max_nt;      // tiles per side
   int32_t max_pairs;   // boundary node pairs nb*(nb+1)/2 (extend-add)
   int32_t max_n2p;     // padded boundary scalars
+  int32_t first;       // first front of the level when all slots of the batch agree, else -1
 };
 
 struct NDPlanHost {

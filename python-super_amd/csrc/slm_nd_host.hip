@@ -231,7 +231,8 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   }
   out.sched.clear();
   for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
-    NDLevelSched sc{0, 0, 0, 0, 0};
+    NDLevelSched sc{0, 0, 0, 0, 0, 0};
+    sc.first = out.level_start[l];
     sc.n_fronts = out.level_start[l + 1] - out.level_start[l];
     for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
       const NDFront& f = out.fronts[i];
