@@ -80,6 +80,8 @@ struct Slot {
   NDDest* d_dests = nullptr;    // block_dest | pair_dest
   double *ftiles = nullptr, *fvec = nullptr, *flinv = nullptr;
   double* pairbuf = nullptr;   // sharded frames: per-pair sums to exchange
+  double *band = nullptr, *linv = nullptr;   // block-banded path (allocated on demand)
+  bool band_ready = false;
   size_t cap_pairbuf = 0;
   size_t cap_fronts = 0, cap_ints = 0, cap_dests = 0, cap_ftiles = 0, cap_fvec = 0, cap_flinv = 0;
 };
@@ -154,8 +156,8 @@ int slm_destroy(slm_solver* s) {
     if (h.beta) (void)hipFree(h.beta);
     if (h.delta) (void)hipFree(h.delta);
     if (h.rhs) (void)hipFree(h.rhs);
-    if (h.band) (void)hipFree(h.band);
-    if (h.linv) (void)hipFree(h.linv);
+    if (sl.band) (void)hipFree(sl.band);
+    if (sl.linv) (void)hipFree(sl.linv);
     if (h.loss_part) (void)hipFree(h.loss_part);
     if (h.st) (void)hipFree(h.st);
     if (h.rec) (void)hipFree(h.rec);
@@ -182,6 +184,28 @@ int slm_destroy(slm_solver* s) {
   return SLM_OK;
 }
 
+// Block-banded path on demand: tile half-bandwidth of the normal matrix from the KNN tables (one
+// 4-byte read-back), band + diagonal-inverse storage, refreshed device copy of the slot.
+static int ensure_band(slm_solver* s, int slot, hipStream_t st) {
+  Slot& sl = s->slots[slot];
+  if (sl.band_ready) return SLM_OK;
+  FrameDev& h = sl.h;
+  launch_bandwidth(h.f, s->bw_dev, st);
+  HIPCHK(hipMemcpyAsync(s->bw_host, s->bw_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  int wb = *s->bw_host;
+  if (wb > h.nt - 1) wb = h.nt - 1;
+  h.wb = wb;
+  HIPCHK(grow(sl.band, sl.cap_band, (size_t)h.nt * (wb + 1) * SLM_NB * SLM_NB));
+  HIPCHK(grow(sl.linv, sl.cap_linv, (size_t)h.nt * SLM_NB * SLM_NB));
+  h.band = sl.band;
+  h.linv = sl.linv;
+  HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  sl.band_ready = true;
+  return SLM_OK;
+}
+
 int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream) {
   if (!s || !f) return fail(SLM_ERR_INVALID, "slm_bind_frame: null argument");
   if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad slot");
@@ -197,15 +221,12 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   Slot& sl = s->slots[slot];
   FrameDev& h = sl.h;
 
-  // tile half-bandwidth of the normal matrix (one 4-byte read-back)
-  launch_bandwidth(*f, s->bw_dev, st);
-  HIPCHK(hipMemcpyAsync(s->bw_host, s->bw_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
   const int P = 7 * f->J;
   const int nt = (P + SLM_NB - 1) / SLM_NB;
-  int wb = *s->bw_host;
-  if (wb > nt - 1) wb = nt - 1;
-
+  // the tile half-bandwidth and the band storage are only needed by the block-banded path
+  // (solver_path 1, a frame without an ND plan, slm_assemble): ensure_band() fills them in on demand
+  int wb = 0;
+  sl.band_ready = false;
   h.f = *f;
   h.P = P;
   h.nt = nt;
@@ -227,8 +248,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     HIPCHK(grow(h.rhs, c2, need));
     sl.cap_vec = c1 < c2 ? c1 : c2;
   }
-  HIPCHK(grow(h.band, sl.cap_band, (size_t)nt * (wb + 1) * SLM_NB * SLM_NB));
-  HIPCHK(grow(h.linv, sl.cap_linv, (size_t)nt * SLM_NB * SLM_NB));
+  h.band = sl.band;   // may be null until ensure_band()
+  h.linv = sl.linv;
   if (!h.loss_part) {
     cap_dummy = 0;
     HIPCHK(grow(h.loss_part, cap_dummy, (size_t)2 * (kLossBlocks + kRegBlocksMax)));
@@ -364,6 +385,10 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   h.bound = 1;
   HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // h is reused by later binds
+  if (!h.nd_ready) {
+    int rc = ensure_band(s, slot, st);
+    if (rc) return rc;
+  }
   launch_init_slot(s->frames_dev, slot, f->J, s->cfg, st);
   HIPCHK(hipGetLastError());
   return SLM_OK;
@@ -796,6 +821,8 @@ int slm_assemble(slm_solver* s, int32_t slot, double* jtj_dense, double* jtl, vo
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   rc = clear_flags(s, slot, st);
+  if (rc) return rc;
+  rc = ensure_band(s, slot, st);
   if (rc) return rc;
   const BatchDims d = dims_of(s, slot, 1);
   const FrameDev& h = s->slots[slot].h;
