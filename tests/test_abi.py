@@ -59,3 +59,25 @@ def test_argument_validation(lib):
     assert lib.slm_destroy(None) == 0
     assert lib.slm_knn(10, 0, 4, 0, None, None, None, None, None) != 0
     assert b"slm_knn" in lib.slm_last_error()
+
+
+def test_every_struct_matches_the_header_as_compiled_by_gcc(tmp_path):
+    """sizeof() of every struct of include/super_lm.h, compiled as plain C, equals the ctypes mirror
+    (a maintainer's cgo / ctypes binding sees exactly these layouts)."""
+    import subprocess
+    from super_amd import _lib
+    pairs = {"slm_config": _lib.SlmConfig, "slm_frame": _lib.SlmFrame, "slm_iter_record": _lib.SlmIterRecord,
+             "slm_gf_config": _lib.SlmGfConfig, "slm_gf_frame": _lib.SlmGfFrame, "slm_gf_semantic": _lib.SlmGfSemantic,
+             "slm_depth_config": _lib.SlmDepthConfig, "slm_depth_inputs": _lib.SlmDepthInputs,
+             "slm_depth_outputs": _lib.SlmDepthOutputs, "slm_fuse_config": _lib.SlmFuseConfig,
+             "slm_surfel_model": _lib.SlmSurfelModel, "slm_new_frame": _lib.SlmNewFrame,
+             "slm_graph_outputs": _lib.SlmGraphOutputs}
+    src = tmp_path / "sizes.c"
+    body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in pairs)
+    src.write_text('#include <stdio.h>\n#include "super_lm.h"\nint main(void) {\n' + body + "\n  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, ct in pairs.items():
+        assert int(out[name]) == C.sizeof(ct), (name, out[name], C.sizeof(ct))
