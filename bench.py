@@ -216,7 +216,7 @@ def fusion_timing(device):
         _lib.check(lib.slm_fuse_input_data(h, C.byref(cfg), C.byref(model.c), C.byref(fr), st), "fuse")
         e[1].record()
         n_fused = int(model.c.n)
-        _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), 41, st), "swap")
+        _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), 41, None, 0, None, st), "swap")
         e[2].record()
         torch.cuda.synchronize()
         if i >= 2:

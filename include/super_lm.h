@@ -429,6 +429,9 @@ typedef struct slm_surfel_model {  /* device pointers with room for `cap` rows; 
   int32_t J, pad;
   const double* ed_points;        /* (J,3) sf.ED_nodes.points */
   const double* ed_radii;         /* (J)   sf.ED_nodes.radii */
+  int32_t* merged_into;           /* (cap) or NULL.  slm_fuse_input_data: the surfel that absorbed row i
+                                     (-1: none) -- what the reference uses to re-point its tracked
+                                     evaluation ids, super/nodes.py:440-445 */
 } slm_surfel_model;
 
 typedef struct slm_new_frame {     /* sfdata from depth_preprocessing, device pointers */
@@ -448,9 +451,12 @@ int slm_fuse_destroy(slm_fuse* f);
  * Synchronises `stream` (three count read-backs). */
 int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model,
                         const slm_new_frame* frame, void* stream);
-/* Drops unstable / stale surfels (time = inputs["time"]); model->n becomes the new row count. */
+/* Drops unstable / stale surfels (time = inputs["time"]); model->n becomes the new row count.
+ * keep_ids (device, n_keep entries, may be NULL): rows kept regardless (the tracked evaluation
+ * points, super/nodes.py:559-560); new_index (device, old row count entries, may be NULL): new row
+ * of every old row or -1 (the reference's id_map, super/nodes.py:578-581). */
 int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, int32_t time,
-                         void* stream);
+                         const int32_t* keep_ids, int32_t n_keep, int32_t* new_index, void* stream);
 
 /* ===================================================================================
  * "Next" row f3: ED-graph construction at frame 0

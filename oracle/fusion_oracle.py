@@ -101,8 +101,10 @@ def _merge(m, opt, d1, idx1, d2, idx2, time, add_new):
     return valid
 
 
-def fuse_input_data(m: Model, opt, K, new, time):
-    """``fuseInputData``.  ``new`` has points, norms, colors, radii, confs (T rows), valid (H*W)."""
+def fuse_input_data(m: Model, opt, K, new, time, track_id=None):
+    """``fuseInputData``.  ``new`` has points, norms, colors, radii, confs (T rows), valid (H*W).
+    ``track_id`` (tracked evaluation points, modified in place): ids follow the surfel that absorbs
+    theirs and become -2 when their surfel is deleted (nodes.py:440-456)."""
     H, W = opt.height, opt.width
     HW = H * W
     valid = np.array(new.valid, bool).copy()
@@ -173,8 +175,19 @@ def fuse_input_data(m: Model, opt, K, new, time):
                 upd[vm] = ~mv
                 val_maps[j] &= upd
                 del_indices.append(idx2[mv])
+                if track_id is not None:
+                    a, b = idx1[mv], idx2[mv]
+                    for k in range(len(track_id)):
+                        hit = np.nonzero(b == track_id[k])[0]
+                        if len(hit):
+                            track_id[k] = a[hit[0]]
         if del_indices:
-            m.isStable[np.unique(np.concatenate(del_indices))] = False
+            dels = np.unique(np.concatenate(del_indices))
+            if track_id is not None:
+                for k in range(len(track_id)):
+                    if track_id[k] in dels:
+                        track_id[k] = -2
+            m.isStable[dels] = False
 
     # skinning weights of every surfel at its (possibly fused) position
     d = np.sqrt(((m.points[:, None, :] - m.ed_points[m.knn_indices]) ** 2).sum(-1))
@@ -203,11 +216,22 @@ def fuse_input_data(m: Model, opt, K, new, time):
     return m
 
 
-def swap_stable(m: Model, opt, time):
-    """``prepareStableIndexNSwapAllModel`` (nodes.py:543-585) without tracked points."""
+def swap_stable(m: Model, opt, time, track_id=None):
+    """``prepareStableIndexNSwapAllModel`` (nodes.py:543-590); tracked surfels are kept and renumbered."""
     if not opt.disable_removing_unstable_surfels:
         keep = m.isStable & ((f32(time) - m.time_stamp).astype(f32) < opt.th_time_steps)
+        if track_id is not None:
+            keep[track_id[track_id >= 0]] = True
         for k in ("points", "norms", "colors", "confs", "radii", "time_stamp", "knn_indices", "knn_w", "projdata"):
             setattr(m, k, getattr(m, k)[keep])
+        if track_id is not None:
+            id_map = -np.ones(len(keep), np.int64)
+            id_map[keep] = np.arange(int(keep.sum()))
+            live = track_id >= 0
+            track_id[live] = id_map[track_id[live]]
         m.isStable = keep[keep]
+    if track_id is not None:
+        for k in range(len(track_id)):
+            if track_id[k] >= 0 and not m.isStable[track_id[k]]:
+                track_id[k] = -2
     return m

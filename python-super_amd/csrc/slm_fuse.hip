@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(256) k_fu_merge_exist(slm_fuse_config c, slm_s
       if (fu_merge(c, m, id[i], a, b, false, time)) {
         present &= ~(1u << j);                  // val_maps[j] loses the pixel for the later i loops
         dead[id[j]] = 1;
+        if (m.merged_into) m.merged_into[id[j]] = id[i];
       }
     }
   }
@@ -365,6 +366,17 @@ __global__ void __launch_bounds__(256) k_fu_keep(slm_fuse_config c, slm_surfel_m
   flag[i] = (m.is_stable[i] && age < (float)c.th_time_steps) ? 1 : 0;
 }
 
+__global__ void __launch_bounds__(64) k_fu_force_keep(int n, int n_keep, const int32_t* __restrict__ keep_ids, int32_t* __restrict__ flag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_keep && keep_ids[k] >= 0 && keep_ids[k] < n) flag[keep_ids[k]] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_fu_new_index(int n, const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
+                                                       int32_t* __restrict__ new_index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) new_index[i] = flag[i] ? pos[i] : -1;
+}
+
 __global__ void __launch_bounds__(256) k_fu_compact(slm_surfel_model m, slm_fuse s, const int32_t* __restrict__ flag,
                                                      const int32_t* __restrict__ pos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,6 +503,7 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
   const int HW = c.H * c.W, n = m.n;
   const dim3 blk(256), gp((HW + 255) / 256), gs((n + 255) / 256);
   // 1. per-pixel confidence-ordered layers
+  if (m.merged_into && n > 0) FCHK(hipMemsetAsync(m.merged_into, 0xFF, sizeof(int32_t) * (size_t)n, st));
   FCHK(hipMemsetAsync(f->layers, 0xFF, sizeof(int32_t) * FU_LAYERS * (size_t)HW, st));
   FCHK(hipMemsetAsync(f->dead, 0, (size_t)f->cap, st));
   FCHK(hipMemsetAsync(f->counters, 0, sizeof(int32_t) * 4, st));
@@ -537,16 +550,21 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
   return SLM_OK;
 }
 
-int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, int32_t time, void* stream) {
+int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_model* model, int32_t time,
+                         const int32_t* keep_ids, int32_t n_keep, int32_t* new_index, void* stream) {
   int rc = fuse_check(f, cfg, model);
   if (rc) return rc;
+  if (n_keep < 0 || (n_keep > 0 && !keep_ids)) return ffail(SLM_ERR_INVALID, "slm_fuse_swap_stable: bad keep_ids");
   if (!cfg->remove_unstable || model->n == 0) return SLM_OK;
   hipStream_t st = (hipStream_t)stream;
   slm_surfel_model m = *model;
   const int n = m.n;
   const dim3 blk(256), gs((n + 255) / 256);
   hipLaunchKernelGGL(k_fu_keep, gs, blk, 0, st, *cfg, m, time, f->flag);
+  if (n_keep > 0)
+    hipLaunchKernelGGL(k_fu_force_keep, dim3((n_keep + 63) / 64), dim3(64), 0, st, n, n_keep, keep_ids, f->flag);
   FCHK(scan_flags(f, n, st));
+  if (new_index) hipLaunchKernelGGL(k_fu_new_index, gs, blk, 0, st, n, f->flag, f->pos, new_index);
   int kept = 0;
   FCHK(count_flags(f, n, st, &kept));
   slm_fuse scratch = *f;

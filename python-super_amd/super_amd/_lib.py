@@ -103,7 +103,7 @@ class SlmSurfelModel(C.Structure):
                 ("colors", C.c_void_p), ("radii", C.c_void_p), ("confs", C.c_void_p),
                 ("time_stamp", C.c_void_p), ("is_stable", C.c_void_p), ("knn_idx", C.c_void_p),
                 ("knn_w", C.c_void_p), ("projdata", C.c_void_p), ("J", C.c_int32), ("pad", C.c_int32),
-                ("ed_points", C.c_void_p), ("ed_radii", C.c_void_p)]
+                ("ed_points", C.c_void_p), ("ed_radii", C.c_void_p), ("merged_into", C.c_void_p)]
 
 
 class SlmNewFrame(C.Structure):
@@ -191,7 +191,7 @@ def load():
         "slm_fuse_create": [i32, i32, i32, C.POINTER(vp)],
         "slm_fuse_destroy": [vp],
         "slm_fuse_input_data": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), C.POINTER(SlmNewFrame), vp],
-        "slm_fuse_swap_stable": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), i32, vp],
+        "slm_fuse_swap_stable": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), i32, vp, i32, vp, vp],
         "slm_depth_create": [i32, i32, C.POINTER(vp)],
         "slm_depth_destroy": [vp],
         "slm_depth_preprocess": [vp, C.POINTER(SlmDepthConfig), C.POINTER(SlmDepthInputs),

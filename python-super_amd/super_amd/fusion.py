@@ -6,9 +6,10 @@ libsuper_lm.so:
 
 Both take the reference's ``sf`` object (anything with the same attributes) and can be bound onto the
 reference class: ``Surfels.fuseInputData = super_amd.fusion.fuseInputData``.  Supported:
-``opt.method == "super"`` without tracked evaluation points (``opt.tracking_gt_file is None``), no
-segmentation fields; the logging / rendering calls at the end of the reference's swap are not
-part of the mirror.
+``opt.method == "super"`` without segmentation fields, with or without tracked evaluation points
+(``sf.track_id``: re-pointed when their surfel is absorbed, dropped (-2) when it is deleted, kept
+alive and renumbered by the swap, ``super/nodes.py:440-456,559-590``); the logging / rendering calls
+at the end of the reference's swap are not part of the mirror.
 """
 from __future__ import annotations
 
@@ -40,8 +41,6 @@ def _config(sf, inputs):
     o = sf.opt
     if getattr(o, "method", "super") != "super" or getattr(sf, "hard_seg", False) or hasattr(sf, "seg"):
         raise NotImplementedError("super_amd.fusion: only opt.method == 'super' without segmentation fields")
-    if getattr(sf, "evaluate_tracking", False):
-        raise NotImplementedError("super_amd.fusion: tracked evaluation points are not supported")
     K = inputs["K"][0].detach().cpu().float()
     c = SlmFuseConfig()
     c.H, c.W = int(o.height), int(o.width)
@@ -86,6 +85,10 @@ class _Model:
             setattr(m, cname, _dev_ptr(self.buf[name]))
         m.J = int(self.ed_points.shape[0])
         m.ed_points, m.ed_radii = _dev_ptr(self.ed_points), _dev_ptr(self.ed_radii)
+        self.merged_into = None
+        if hasattr(sf, "track_pts") or getattr(sf, "evaluate_tracking", False):
+            self.merged_into = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+            m.merged_into = _dev_ptr(self.merged_into)
         self.c = m
 
     def write_back(self, sf):
@@ -114,9 +117,22 @@ def fuseInputData(sf, inputs, sfdata):
     for k, v in keep.items():
         setattr(fr, k, _dev_ptr(v))
     sf.time = sfdata.time
+    stable_before = model.buf["isStable"][:n].clone()
     _lib.check(lib.slm_fuse_input_data(h, C.byref(cfg), C.byref(model.c), C.byref(fr), _stream_ptr(dev)),
                "slm_fuse_input_data")
     model.write_back(sf)
+    if model.merged_into is not None and hasattr(sf, "track_id") and cfg.merge_exist:
+        # tracked ids follow the surfel that absorbed theirs; ids of deleted surfels become -2
+        tid = sf.track_id.clone()
+        live = tid >= 0
+        if bool(live.any()):
+            t = tid[live].to(torch.long)
+            into = model.merged_into[:n].to(torch.long)[t]
+            t = torch.where(into >= 0, into, t)
+            gone = stable_before.to(torch.bool)[t] & ~sf.isStable[t]
+            t = torch.where(gone, torch.full_like(t, -2), t)
+            tid[live] = t.to(tid.dtype)
+        sf.track_id = tid
 
 
 def prepareStableIndexNSwapAllModel(sf, inputs, sfdata):
@@ -126,7 +142,34 @@ def prepareStableIndexNSwapAllModel(sf, inputs, sfdata):
     n = int(sf.points.shape[0])
     h, _ = _context(lib, cfg.H, cfg.W, n, dev)
     model = _Model(sf, n, dev)
-    _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), int(inputs["time"]), _stream_ptr(dev)),
+    tracking = bool(getattr(sf, "evaluate_tracking", False)) and hasattr(sf, "track_id")
+    keep, new_index, n_keep = None, None, 0
+    if tracking and cfg.remove_unstable:
+        keep = sf.track_id[sf.track_id >= 0].to(device=dev, dtype=torch.int32).contiguous()
+        n_keep = int(keep.numel())
+        new_index = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), int(inputs["time"]),
+                                        _dev_ptr(keep) if n_keep else None, n_keep,
+                                        _dev_ptr(new_index) if new_index is not None else None, _stream_ptr(dev)),
                "slm_fuse_swap_stable")
     model.write_back(sf)
+    if tracking:
+        tid = sf.track_id.clone()
+        live = tid >= 0
+        if cfg.remove_unstable and bool(live.any()):
+            tid[live] = new_index.to(torch.long)[tid[live].to(torch.long)].to(tid.dtype)
+        # ids whose surfel is unstable are given up (nodes.py:585-590)
+        live = tid >= 0
+        if bool(live.any()):
+            bad = ~sf.isStable[tid[live].to(torch.long)]
+            t = tid[live]
+            t[bad] = -2
+            tid[live] = t
+        sf.track_id = tid
     sf.surfel_num = int(sf.isStable.count_nonzero())
+    if tracking and hasattr(sf, "update_track_pts"):
+        name = inputs["filename"][0]
+        if int((sf.track_id >= 0).count_nonzero()) > 0:
+            sf.update_track_pts(sfdata, name)
+        if int((sf.track_id == -1).count_nonzero()) > 0:
+            sf.init_track_pts(sfdata, name)

@@ -32,6 +32,8 @@ VARIANTS = {
     "nomerge_exist": dict(disable_merging_exist_surfels=True, th_dist=0.008, _store_swap=False),
     "noadd": dict(disable_adding_new_surfels=True, th_dist=0.008, _store_swap=False),
     "keepall": dict(disable_removing_unstable_surfels=True, th_dist=0.02),
+    # tracked evaluation points: some ids sit on surfels that get absorbed / deleted / go stale
+    "track": dict(th_dist=0.02, _track=True),
 }
 
 STATE = ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable", "knn_indices", "knn_w", "projdata")
@@ -67,6 +69,10 @@ def make_inputs(seed=11):
                 new_radii=rng.uniform(0.002, 0.004, T),
                 new_confs=rng.uniform(0.05, 1.0, T).astype(np.float32),
                 new_valid=sc.valid, new_index_map=sc.index_map, time=41)
+    # 20 tracked ids: duplicated surfels (likely absorbed), their originals, stale ones, unassigned (-1)
+    n0 = sc.N
+    stale = np.nonzero(base["sf_time_stamp"] < 11)[0]
+    base["track_id"] = np.concatenate([np.arange(n0, n0 + 8), dup[:4], stale[:4], rng.choice(n0, 2), [-1, -1]]).astype(np.int64)
     return base
 
 
@@ -93,10 +99,21 @@ def run_reference(ref, b, okw):
                            radii=t(b["new_radii"]), confs=t(b["new_confs"]), valid=t(b["new_valid"]),
                            index_map=t(b["new_index_map"]), time=int(b["time"]))
     out = {}
+    if okw.get("_track"):
+        me.track_pts = {}
+        me.track_id = t(b["track_id"])
+        me.gt, me.gt_strkeys, me.track_rsts = {}, [], {}
+        me.update_track_pts = lambda *a, **k: ref.nodes.Surfels.update_track_pts(me, *a, **k)
+        me.init_track_pts = lambda *a, **k: ref.nodes.Surfels.init_track_pts(me, *a, **k)
     ref.nodes.Surfels.fuseInputData(me, inputs, sfdata)
+    if okw.get("_track"):
+        out["fuse_track_id"] = me.track_id.cpu().numpy().copy()
+        me.evaluate_tracking = True
     for k in STATE:
         out["fuse_" + k] = getattr(me, k).detach().cpu().numpy().copy()
     ref.nodes.Surfels.prepareStableIndexNSwapAllModel(me, inputs, sfdata)
+    if okw.get("_track"):
+        out["swap_track_id"] = me.track_id.cpu().numpy().copy()
     if okw.get("_store_swap", True):
         for k in STATE:
             out["swap_" + k] = getattr(me, k).detach().cpu().numpy().copy()

@@ -18,6 +18,7 @@ VARIANTS = {
     "nomerge_exist": dict(disable_merging_exist_surfels=True, th_dist=0.008),
     "noadd": dict(disable_adding_new_surfels=True, th_dist=0.008),
     "keepall": dict(disable_removing_unstable_surfels=True, th_dist=0.02),
+    "track": dict(th_dist=0.02),
 }
 STATE = ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable", "knn_indices", "knn_w", "projdata")
 
@@ -50,9 +51,15 @@ def test_fusion_matches_reference(tag):
     g = np.load(GOLD)
     b, m, new = load(g)
     opt = fuo.default_opt(height=int(b["H"]), width=int(b["W"]), **VARIANTS[tag])
-    fuo.fuse_input_data(m, opt, b["K"], new, int(b["time"]))
+    tid = b["track_id"].copy() if tag == "track" else None
+    fuo.fuse_input_data(m, opt, b["K"], new, int(b["time"]), track_id=tid)
     check(m, g, f"{tag}_fuse_")
-    fuo.swap_stable(m, opt, int(b["time"]))
+    if tid is not None:
+        np.testing.assert_array_equal(tid, g["track_fuse_track_id"])
+        assert (tid != b["track_id"]).sum() >= 4          # some tracked surfels were absorbed by others
+    fuo.swap_stable(m, opt, int(b["time"]), track_id=tid)
+    if tid is not None:
+        np.testing.assert_array_equal(tid, g["track_swap_track_id"])
     if f"{tag}_swap_points" in g.files:
         check(m, g, f"{tag}_swap_")
     else:
@@ -68,3 +75,30 @@ def test_fixture_exercises_layers_merges_and_additions():
     assert (b["sf_isStable"] & ~fused[:n0]).sum() > 50       # surfels merged into others and deleted
     assert (g["default_fuse_confs"][:n0] != b["sf_confs"]).sum() > 500     # new points merged into surfels
     assert len(g["tight_fuse_points"]) > len(g["default_fuse_points"])     # a tighter test adds more surfels
+
+
+def test_tracking_ground_truth_format_and_error(tmp_path):
+    """Row f4: the pickled-dict .npy wire format of opt.tracking_gt_file and the reprojection error."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "python-super_amd"))
+    from super_amd import evaluation as ev
+    rng = np.random.default_rng(0)
+    gt = {f"{10 * k:06d}": np.concatenate([rng.uniform(0, 480, (20, 2)), rng.integers(0, 2, (20, 1))], 1) for k in range(1, 6)}
+    blob = {"gt": gt, "super_cpp": {k: v + 1.0 for k, v in gt.items()}, "SURF": {}}
+    np.save(tmp_path / "pts.npy", blob, allow_pickle=True)
+    args = SimpleNamespace(data_dir=str(tmp_path), tracking_gt_file="pts.npy")
+    every, g, ik, sk, arr = ev.get_gt(args)
+    assert ik == [10, 20, 30, 40, 50] and sk == ["000010", "000020", "000030", "000040", "000050"]
+    assert arr.shape == (5, 20, 3) and set(every) == {"gt", "super_cpp", "SURF"}
+    np.testing.assert_array_equal(arr[2], gt["000030"])
+    est = gt["000020"].copy()
+    est[:, 0] += 3.0
+    est[:, 1] -= 4.0
+    d = ev.evaluate(gt["000020"], est)
+    seen = gt["000020"][:, 2] == 1
+    np.testing.assert_allclose(d[seen], 5.0)
+    assert (d[~seen] == -1).all()
+    d2 = ev.evaluate(gt["000020"], est, igonored_ids=[1, 2], normalize=True)
+    assert d2[0] == -1 / 480 and d2[1] == -1 / 480
+    with pytest.raises(ValueError):
+        ev.get_gt(SimpleNamespace(data_dir=str(tmp_path), tracking_gt_file="missing.npy"))

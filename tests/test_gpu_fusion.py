@@ -54,14 +54,77 @@ def test_fusion_matches_reference_goldens(tag):
     g = np.load(GOLD)
     b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
     sf, inputs, sfdata = _objects(b, VARIANTS[tag])
+    if tag == "track":
+        import torch
+        sf.track_pts, sf.evaluate_tracking = {}, False
+        sf.track_id = torch.from_numpy(b["track_id"].copy()).cuda()
+        inputs["filename"] = ["000041"]
     fusion.fuseInputData(sf, inputs, sfdata)
     _check(sf, g, f"{tag}_fuse_")
+    if tag == "track":
+        np.testing.assert_array_equal(sf.track_id.cpu().numpy(), g["track_fuse_track_id"])
+        sf.evaluate_tracking = True
     fusion.prepareStableIndexNSwapAllModel(sf, inputs, sfdata)
+    if tag == "track":
+        np.testing.assert_array_equal(sf.track_id.cpu().numpy(), g["track_swap_track_id"])
     if f"{tag}_swap_points" in g.files:
         _check(sf, g, f"{tag}_swap_")
     else:
         assert len(sf.points) == int(g[f"{tag}_swap_count"])
     assert bool(sf.isStable.all()) or VARIANTS[tag].get("disable_removing_unstable_surfels", False)
+
+
+def test_tracked_points_follow_the_surface_through_the_driver():
+    """Labelled points (row f4) attached by init_track_pts stay on their surfels through LM, update,
+    fusion and swap for several frames: the ids stay assigned and point at live surfels, the recorded
+    positions are those surfels' projections, and they drift by no more than a few pixels (the
+    synthetic surface deforms in depth; there is no material ground truth to compare with)."""
+    import torch
+    from super_amd import evaluation as ev, synth
+    from super_amd.super import SuPer
+    H, W = 96, 128
+    K = synth._scaled_intrinsics(H, W)
+    inv_K = np.linalg.pinv(K)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    color = np.random.default_rng(2).uniform(0, 255, (3, H, W)).astype(np.float32)
+    opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, depth_model="monodepth2",
+                          dilate_invalid_kernel=0, normal_model="naive", phase="test", method="super", load_depth=True,
+                          deform_udpate_method="super_edg", mesh_step_size=8, use_derived_gradient=True,
+                          sf_point_plane=True, mesh_arap=True, mesh_rot=True, sf_point_plane_weight=1.0,
+                          mesh_arap_weight=10.0, mesh_rot_weight=1.0, num_optimize_iterations=10, num_neighbors=4,
+                          num_ED_neighbors=4, th_dist=0.02, th_cosine_ang=0.4, th_time_steps=30,
+                          disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
+                          disable_adding_new_surfels=False, disable_removing_unstable_surfels=False)
+    rng = np.random.default_rng(4)
+    labels = np.stack([rng.integers(20, W - 20, 20), rng.integers(20, H - 20, 20), np.ones(20)], 1).astype(np.int64)
+    gt = {"%06d" % k: torch.from_numpy(labels.copy()) for k in range(5)}      # a camera-fixed pattern: the surface only moves in depth
+    model = SuPer(opt)
+    for k in range(5):
+        depth = synth._surface(uu, vv, H, W, 0.3 + 0.03 * k).astype(np.float32)
+        depth[:4] = 0.0
+        depth[:, :4] = 0.0
+        inputs = {("depth", 0): torch.from_numpy(depth.copy())[None, None], ("disp", 0): torch.zeros(1, 1, H, W),
+                  "inv_K": torch.from_numpy(inv_K)[None], "K": torch.from_numpy(K)[None],
+                  ("color", 0): torch.from_numpy(color)[None], "divterm": torch.tensor(1.0 / (2 * 0.6 * 0.6)),
+                  "filename": ["%06d" % k], "time": k, "ID": torch.tensor([k])}
+        if k == 1:       # tracking is switched on once the model exists
+            sf = model.sf
+            sf.evaluate_tracking, sf.track_pts = True, {}
+            sf.gt, sf.gt_strkeys = gt, sorted(gt)
+            sf.track_num, sf.track_rsts = 20, {}
+            sf.track_id = -torch.ones(20, dtype=torch.long, device="cuda")
+            sf.init_track_pts = lambda d, n: ev.init_track_pts(sf, d, n)
+            sf.update_track_pts = lambda d, n: ev.update_track_pts(sf, d, n)
+        model(SimpleNamespace(), inputs)
+    sf = model.sf
+    assert int((sf.track_id >= 0).sum()) >= 18            # nearly every label found its surfel and kept it
+    live = sf.track_id >= 0
+    assert bool(sf.isStable[sf.track_id[live]].all())
+    np.testing.assert_array_equal(sf.track_rsts["000004"][live.cpu()][:, :2].cpu().numpy(),
+                                  sf.projdata[sf.track_id[live]].cpu().numpy())
+    for name in ("000002", "000004"):
+        err = ev.evaluate(gt[name].numpy(), sf.track_rsts[name].cpu().numpy())
+        assert 0 <= err[live.cpu().numpy()].max() < 4.0, (name, err)
 
 
 def test_fusion_full_size_matches_oracle():
