@@ -344,7 +344,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     } else if (nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), sl.h_pairs.data(), h.n_blocks, sl.nd)) {
       sl.nd_valid = false;
       NDPlanHost& nd = sl.nd;
-      const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J;
+      const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
+                            nd.in_start.size() + nd.in_edge.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
       HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
       HIPCHK(grow(sl.d_ints, sl.cap_ints, n_ints));
@@ -364,6 +365,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.nd_eamap = p;    HIPCHK(up(nd.eamap));
       h.node_front = p;  HIPCHK(up(nd.node_front));
       h.node_pos = p;    HIPCHK(up(nd.node_pos));
+      h.in_start = p;    HIPCHK(up(nd.in_start));
+      h.in_edge = p;     HIPCHK(up(nd.in_edge));
       if (!nd.block_dest.empty())
         HIPCHK(hipMemcpyAsync(sl.d_dests, nd.block_dest.data(), sizeof(NDDest) * nd.block_dest.size(), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(sl.d_dests + nd.block_dest.size(), nd.pair_dest.data(), sizeof(NDDest) * nd.pair_dest.size(), hipMemcpyHostToDevice, st));

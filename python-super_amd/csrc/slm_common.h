@@ -92,6 +92,8 @@ struct FrameDev {
   const int32_t* node_pos;     // (J) local pivot position
   const NDDest* block_dest;    // (n_blocks) destination of every data-term block
   const NDDest* pair_dest;     // (J*K_ED) destination of every ARAP pair block
+  const int32_t* in_start;     // (J+1) ARAP edges grouped by target node (reverse KNN graph)
+  const int32_t* in_edge;
   double* ftiles;              // front tile storage
   double* fvec;                // front vectors (rhs -> y -> x)
   double* flinv;               // inverses of the diagonal Cholesky blocks of the fronts

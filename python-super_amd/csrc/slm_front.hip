@@ -223,74 +223,116 @@ __device__ __forceinline__ void nd_rot_products32(const float q[4], float lam32,
   }
 }
 
+// ARAP residual of edge (j -> k) and the quaternion Jacobian of node k's part (reference
+// super/loss.py:408-455): r = lam [R(q_k) d + b_k - d - b_j], d = g_j - g_k
+__device__ __forceinline__ void nd_arap_edge(const FrameDev& fd, int j, int k, double lam_a, double r[3], double Jq[3][4]) {
+  const float* g = fd.f.ed_points;
+  const d3 d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
+                (double)g[3 * j + 2] - (double)g[3 * k + 2]};
+  double bk[7], bj[7];
+  nd_load_beta(fd.beta, k, bk);
+  nd_load_beta(fd.beta, j, bj);
+  const d3 tt = quat_apply(bk[0], {bk[1], bk[2], bk[3]}, d);
+  r[0] = lam_a * (tt.x + bk[4] - d.x - bj[4]);
+  r[1] = lam_a * (tt.y + bk[5] - d.y - bj[5]);
+  r[2] = lam_a * (tt.z + bk[6] - d.z - bj[6]);
+  quat_jac(bk[0], {bk[1], bk[2], bk[3]}, d, Jq);
+}
+
+// No atomics and a fixed summation order: thread (j, slot) owns the cross block of edge j -> k; the
+// thread with slot 0 also owns node j's diagonal block and right-hand side, which it GATHERS from the
+// edges that end in j (reverse KNN graph, ascending edge number), then its own out-edges, then Rot.
+// Entries are read-modify-written by exactly one thread (k_front_assemble stored the data term first).
 __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict__ frames, int use_arap,
                                                       double lam_a, int use_rot, double lam_r) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
-  const int Ke = fd.f.K_ED;
+  const int Ke = fd.f.K_ED, J = fd.f.J;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = t / Ke, slot = t % Ke;
-  if (j >= fd.f.J) return;
-  // front / base of node j's diagonal block, resolved once
-  const NDFront fj = fd.fronts[fd.node_front[j]];
-  const int bj0 = nd_base(fj, fd.node_pos[j]);
+  if (j >= J) return;
+  const double l2 = lam_a * lam_a;
   if (use_arap) {
+    // ---- cross block between the nodes of edge j -> k ----
     const int k = fd.f.ed_knn_idx[j * Ke + slot];
-    const NDFront fk = fd.fronts[fd.node_front[k]];
-    const int bk0 = nd_base(fk, fd.node_pos[k]);
-    const NDDest pd = fd.pair_dest[j * Ke + slot];   // block (max(j,k), min(j,k))
-    const NDFront fp = fd.fronts[pd.front];
-    const int prb = nd_base(fp, pd.prow), pcb = nd_base(fp, pd.pcol);
-    // is node k the ROW node of the stored (lower) cross block?
-    const bool k_is_row = ((k > j) != (pd.transpose != 0));
-    const float* g = fd.f.ed_points;
-    const d3 d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
-                  (double)g[3 * j + 2] - (double)g[3 * k + 2]};
-    double bk[7], bj[7];
-    nd_load_beta(fd.beta, k, bk);
-    nd_load_beta(fd.beta, j, bj);
-    const d3 tt = quat_apply(bk[0], {bk[1], bk[2], bk[3]}, d);
-    const double r[3] = {lam_a * (tt.x + bk[4] - d.x - bj[4]), lam_a * (tt.y + bk[5] - d.y - bj[5]),
-                         lam_a * (tt.z + bk[6] - d.z - bj[6])};
-    double Jq[3][4];
-    quat_jac(bk[0], {bk[1], bk[2], bk[3]}, d, Jq);
-    const double l2 = lam_a * lam_a;
-    // The three residual rows c share their node-k quaternion columns: sum over c first.
-    //   K block (7x7 lower):  qq[a][b] = l2 sum_c Jq[c][a]Jq[c][b];  (4+c, a) = l2 Jq[c][a];  (4+c,4+c) = l2
-    //   cross block k-j:      (k a, j 4+c) = -l2 Jq[c][a];  (k 4+c, j 4+c) = -l2
-    //   J block:              (4+c, 4+c) = l2
+    if (k >= 0 && k < J && k != j) {
+      const NDDest pd = fd.pair_dest[j * Ke + slot];   // block (max(j,k), min(j,k))
+      const NDFront fp = fd.fronts[pd.front];
+      const int prb = nd_base(fp, pd.prow), pcb = nd_base(fp, pd.pcol);
+      const bool k_is_row = ((k > j) != (pd.transpose != 0));   // is node k the ROW node of the stored block?
+      double r[3], Jq[3][4];
+      nd_arap_edge(fd, j, k, lam_a, r, Jq);
+      // the reverse edge k -> j (if it exists) shares the three (translation, translation) entries:
+      // the edge with the smaller source node writes them for both
+      bool reverse = false;
+      for (int s2 = 0; s2 < Ke; ++s2) reverse = reverse || fd.f.ed_knn_idx[k * Ke + s2] == j;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      double gr = 0.0;
+      for (int c = 0; c < 3; ++c) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gr += Jq[c][a] * r[c];
-      atomic_add_f64(fd.rhs + 7 * k + a, -lam_a * gr);
-#pragma unroll
-      for (int b = 0; b <= a; ++b) {
-        double q = 0.0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) q += Jq[c][a] * Jq[c][b];
-        atomic_add_f64(front_entry(fd, fk, bk0 + a, bk0 + b), l2 * q);
+        for (int a = 0; a < 4; ++a) {
+          const double cv = -l2 * Jq[c][a];                       // between (k, a) and (j, 4+c)
+          if (k_is_row) *front_entry(fd, fp, prb + a, pcb + 4 + c) += cv;
+          else *front_entry(fd, fp, prb + 4 + c, pcb + a) += cv;
+        }
+        if (!reverse || j < k) {
+          double* e = front_entry(fd, fp, prb + 4 + c, pcb + 4 + c);   // between (k, 4+c) and (j, 4+c)
+          double v = *e - l2;
+          if (reverse) v -= l2;
+          *e = v;
+        }
       }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      atomic_add_f64(fd.rhs + 7 * k + 4 + c, -lam_a * r[c]);
-      atomic_add_f64(fd.rhs + 7 * j + 4 + c, lam_a * r[c]);
-      atomic_add_f64(front_entry(fd, fk, bk0 + 4 + c, bk0 + 4 + c), l2);
-      atomic_add_f64(front_entry(fd, fj, bj0 + 4 + c, bj0 + 4 + c), l2);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        atomic_add_f64(front_entry(fd, fk, bk0 + 4 + c, bk0 + a), l2 * Jq[c][a]);
-        const double cv = -l2 * Jq[c][a];                       // between (k, a) and (j, 4+c)
-        if (k_is_row) atomic_add_f64(front_entry(fd, fp, prb + a, pcb + 4 + c), cv);
-        else atomic_add_f64(front_entry(fd, fp, prb + 4 + c, pcb + a), cv);
-      }
-      // between (k, 4+c) and (j, 4+c): same component on both sides
-      atomic_add_f64(front_entry(fd, fp, prb + 4 + c, pcb + 4 + c), -l2);
     }
   }
-  if (use_rot && slot == 0) {
+  if (slot != 0) return;
+  // ---- node j: diagonal block (lower 7x7) and right-hand side ----
+  double acc[7][7], rh[7];
+#pragma unroll
+  for (int a = 0; a < 7; ++a) {
+    rh[a] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) acc[a][b] = 0.0;
+  }
+  if (use_arap) {
+    for (int ie = fd.in_start[j]; ie < fd.in_start[j + 1]; ++ie) {   // edges src -> j: j plays node k
+      const int src = fd.in_edge[ie] / Ke;
+      if (src == j) continue;
+      double r[3], Jq[3][4];
+      nd_arap_edge(fd, src, j, lam_a, r, Jq);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        double gr = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gr += Jq[c][a] * r[c];
+        rh[a] += -lam_a * gr;
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double q = 0.0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) q += Jq[c][a] * Jq[c][b];
+          acc[a][b] += l2 * q;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rh[4 + c] += -lam_a * r[c];
+        acc[4 + c][4 + c] += l2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[4 + c][a] += l2 * Jq[c][a];
+      }
+    }
+    for (int s2 = 0; s2 < Ke; ++s2) {                                  // edges j -> k: j plays node j
+      const int k = fd.f.ed_knn_idx[j * Ke + s2];
+      if (k < 0 || k >= J || k == j) continue;
+      double r[3], Jq[3][4];
+      nd_arap_edge(fd, j, k, lam_a, r, Jq);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rh[4 + c] += lam_a * r[c];
+        acc[4 + c][4 + c] += l2;
+      }
+    }
+  }
+  if (use_rot) {
     double bb[7];
     nd_load_beta(fd.beta, j, bb);
     float q[4];
@@ -300,10 +342,19 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
     nd_rot_products32(q, lam32, r, jtj, jtr);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      atomic_add_f64(fd.rhs + 7 * j + a, (double)jtr[a]);
+      rh[a] += (double)jtr[a];
 #pragma unroll
-      for (int b = 0; b <= a; ++b) atomic_add_f64(front_entry(fd, fj, bj0 + a, bj0 + b), (double)jtj[a][b]);
+      for (int b = 0; b <= a; ++b) acc[a][b] += (double)jtj[a][b];
     }
+  }
+  const NDFront fj = fd.fronts[fd.node_front[j]];
+  const int bj0 = nd_base(fj, fd.node_pos[j]);
+#pragma unroll
+  for (int a = 0; a < 7; ++a) {
+    fd.rhs[7 * j + a] += rh[a];
+#pragma unroll
+    for (int b = 0; b <= a; ++b)
+      if (acc[a][b] != 0.0) *front_entry(fd, fj, bj0 + a, bj0 + b) += acc[a][b];
   }
 }
 

@@ -60,6 +60,8 @@ struct NDPlanHost {
   std::vector<int32_t> eamap;
   std::vector<int32_t> node_front;    // (J) front that eliminates the node
   std::vector<int32_t> node_pos;      // (J) its local pivot position
+  std::vector<int32_t> in_start;      // (J+1) CSR over in_edge
+  std::vector<int32_t> in_edge;       // ARAP edges e = j*K_ED + slot grouped by their TARGET node k, ascending e
   std::vector<NDDest> block_dest;     // per data-term block (order of blk_key)
   std::vector<NDDest> pair_dest;      // per (j, slot) ARAP pair, J*K_ED
   int64_t tile_doubles = 0, vec_doubles = 0, linv_doubles = 0;

@@ -280,6 +280,22 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     const int a = (int)(pairs[i] / (uint32_t)J), bb = (int)(pairs[i] % (uint32_t)J);
     if (!dest_of(a, bb, out.block_dest[i])) return false;
   }
+  // reverse adjacency of the node KNN graph: which ARAP edges end in node k (k_reg_grad_nd gathers
+  // a node's diagonal block from them instead of scattering with atomics)
+  out.in_start.assign(J + 1, 0);
+  for (int e = 0; e < J * K_ED; ++e) {
+    const int k = ed_knn[e];
+    if (k >= 0 && k < J) out.in_start[k + 1]++;
+  }
+  for (int k = 0; k < J; ++k) out.in_start[k + 1] += out.in_start[k];
+  out.in_edge.assign(out.in_start[J], 0);
+  {
+    std::vector<int32_t> fill(out.in_start.begin(), out.in_start.end() - 1);
+    for (int e = 0; e < J * K_ED; ++e) {
+      const int k = ed_knn[e];
+      if (k >= 0 && k < J) out.in_edge[fill[k]++] = e;
+    }
+  }
   out.pair_dest.resize((size_t)J * K_ED);
   for (int j = 0; j < J; ++j)
     for (int s = 0; s < K_ED; ++s) {

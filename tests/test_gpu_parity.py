@@ -271,3 +271,22 @@ def test_surfel_sharded_lm_reproduces_the_single_gpu_solve(name, world):
     np.testing.assert_allclose([x["loss"] for x in recs[0]], g["lm_loss"], rtol=1e-6)
     assert [x["accepted"] for x in recs[0]] == [bool(a) for a in g["lm_accepted"]]
     assert recs[0][0]["M_grad"] == len(g["b0_match"])
+
+
+def test_lm_is_bitwise_reproducible_with_the_per_run_slab():
+    """No kernel of the LM path uses atomics on floating-point data any more except the LDS merge of
+    the data-term records; with data_path=2 (one Gram per run) two runs give bit-identical results."""
+    from super_amd.LM import LM_Solver
+    g, sc, opt = load_golden("s120x160_j108")
+    sf, inputs, new_data = torch_frame(sc)
+    o = ref_opt(opt)
+    o.slm_data_path = 2
+    runs = []
+    for _ in range(3):
+        lm = LM_Solver(o)
+        beta = lm.LM(sf, inputs, new_data).cpu().numpy()
+        runs.append((beta, [r["loss"] for r in lm.last_records[0]]))
+    for beta, losses in runs[1:]:
+        np.testing.assert_array_equal(beta, runs[0][0])
+        assert losses == runs[0][1]
+    np.testing.assert_allclose(runs[0][0], g["lm_beta"], rtol=0, atol=TOL_BETA)
