@@ -555,17 +555,19 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
 //           X_c = (A(r,c) - sum_{c'<c} X_c' L(c,c')^T) L_cc^-T, results chained in registers
 //           (accumulator layout == next A-fragment layout), rhs row updated at the end.
 // grid k_fL11 = (1, fronts in level, n_frames); k_fL21 = (max boundary tiles, fronts, frames)
-#define L11_LDS_DOUBLES (3 * TILE + 8 * 256 + 2 * NB + 8)
+// S (tile being factored; later the B operand of the trailing update), M (its inverse), the four
+// diagonal-block inverses, three 16x16 scratch blocks, two vectors: 80 960 B, two workgroups per CU
+#define L11_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 8)
 
 __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                double u_override) {
   extern __shared__ double lds[];
   double* S = lds;
   double* M = lds + TILE;
-  double* Bl = lds + 2 * TILE;
-  double* dinv = lds + 3 * TILE;
-  double* wt = dinv + 4 * 256;
-  double* vec = wt + 4 * 256;      // NB: rhs tile in / y tile out
+  double* Bl = S;                  // S is dead once its inverse M exists
+  double* dinv = lds + 2 * TILE;
+  double* wt = dinv + 4 * 256;     // 3 blocks: inverse_assemble64 runs on at most 3 waves; diag16 uses 128 doubles
+  double* vec = wt + 3 * 256;      // NB: rhs tile in / y tile out
   double* part = vec + NB;         // NB scratch
   int* s_ok = reinterpret_cast<int*>(part + NB);
   const FrameDev& fd = frames[blockIdx.z];
