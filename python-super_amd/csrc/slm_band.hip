@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(256) k_panel(const FrameDev* __restrict__ fram
   double* S = lds;
   double* M = lds + TILE;
   double* dinv = lds + 2 * TILE;
-  double* wt = dinv + 4 * 256;
-  double* vec = wt + 4 * 256;
+  double* wt = dinv + 4 * 256;   // 3 scratch blocks (inverse_assemble64 runs on at most 3 waves)
+  double* vec = wt + 3 * 256;
   int* s_ok = reinterpret_cast<int*>(vec + NB);
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || fd.st->stopped || c >= fd.nt) return;

@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   double* S = lds;
   double* M = lds + TILE;
   double* dinv = lds + 2 * TILE;
-  double* wt = dinv + 4 * 256;
-  double* vec = wt + 4 * 256;
+  double* wt = dinv + 4 * 256;   // 3 scratch blocks (inverse_assemble64 runs on at most 3 waves)
+  double* vec = wt + 3 * 256;
   int* s_ok = reinterpret_cast<int*>(vec + NB);
   WgId wg;
   if (!wg_decode(map, wg)) return;
@@ -474,8 +474,8 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
   double* S = lds;
   double* M = lds + TILE;
   double* dinv = lds + 2 * TILE;
-  double* wt = dinv + 4 * 256;
-  double* vec = wt + 4 * 256;
+  double* wt = dinv + 4 * 256;   // 3 scratch blocks (inverse_assemble64 runs on at most 3 waves)
+  double* vec = wt + 3 * 256;
   int* s_ok = reinterpret_cast<int*>(vec + NB);
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)

@@ -269,7 +269,8 @@ __device__ __forceinline__ void store_c_frags(double* __restrict__ Cg, const dou
     for (int r = 0; r < 4; ++r) Cg[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * r) * NB] = acc[ni][r];
 }
 
-#define PANEL_LDS_DOUBLES (2 * TILE + 8 * 256 + NB + 8)
+// S, M, 4 diagonal-block inverses, 3 scratch blocks, one vector: 80 448 B -> two workgroups per CU
+#define PANEL_LDS_DOUBLES (2 * TILE + 7 * 256 + NB + 8)
 
 // Rows [16w,16w+16) of X = A L^-T for one 64x64 tile, blockwise forward substitution on
 // the MFMA with everything in registers: x[kb] / a[kb] are 16x16 blocks in accumulator
