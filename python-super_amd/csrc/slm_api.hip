@@ -345,7 +345,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       sl.nd_valid = false;
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
-                            nd.in_start.size() + nd.in_edge.size();
+                            nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
       HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
       HIPCHK(grow(sl.d_ints, sl.cap_ints, n_ints));
@@ -367,6 +367,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.node_pos = p;    HIPCHK(up(nd.node_pos));
       h.in_start = p;    HIPCHK(up(nd.in_start));
       h.in_edge = p;     HIPCHK(up(nd.in_edge));
+      h.schur_items = p; HIPCHK(up(nd.schur_items));
+      h.schur_off = p;   HIPCHK(up(nd.schur_off));
       if (!nd.block_dest.empty())
         HIPCHK(hipMemcpyAsync(sl.d_dests, nd.block_dest.data(), sizeof(NDDest) * nd.block_dest.size(), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(sl.d_dests + nd.block_dest.size(), nd.pair_dest.data(), sizeof(NDDest) * nd.pair_dest.size(), hipMemcpyHostToDevice, st));
@@ -435,7 +437,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
   if (d.nd) {
     for (int i = first; i < first + n; ++i) {
       const auto& sc = s->slots[i].nd.sched;
-      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2});
+      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2, {0, 0}, {-2, -2}});
       for (size_t l = 0; l < sc.size(); ++l) {
         NDLevelSched& m = d.sched[l];
         // same first front and front count in every slot -> passed to the kernels by value
@@ -446,16 +448,24 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
         m.max_nt = std::max(m.max_nt, sc[l].max_nt);
         m.max_pairs = std::max(m.max_pairs, sc[l].max_pairs);
         m.max_n2p = std::max(m.max_n2p, sc[l].max_n2p);
+        for (int w = 0; w < 2; ++w) {
+          if (m.schur_at[w] == -2) m.schur_at[w] = sc[l].schur_at[w];
+          else if (m.schur_at[w] != sc[l].schur_at[w] || m.n_schur[w] != sc[l].n_schur[w]) m.schur_at[w] = -1;
+          m.n_schur[w] = std::max(m.n_schur[w], sc[l].n_schur[w]);
+        }
       }
     }
   }
   if (d.nd && n > 1) {
     // slots with fewer levels than the batch maximum: their level tables must be read on the device
     for (int i = first; i < first + n; ++i)
-      for (size_t l = s->slots[i].nd.sched.size(); l < d.sched.size(); ++l) d.sched[l].first = -1;
+      for (size_t l = s->slots[i].nd.sched.size(); l < d.sched.size(); ++l)
+        d.sched[l].first = d.sched[l].schur_at[0] = d.sched[l].schur_at[1] = -1;
   }
-  for (auto& m : d.sched)
+  for (auto& m : d.sched) {
     if (m.first == -2) m.first = -1;
+    if (m.first < 0) m.schur_at[0] = m.schur_at[1] = -1;
+  }
   if (s->cfg.use_arap || s->cfg.use_rot)
     d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);
   return d;

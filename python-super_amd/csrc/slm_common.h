@@ -92,6 +92,8 @@ struct FrameDev {
   const int32_t* node_pos;     // (J) local pivot position
   const NDDest* block_dest;    // (n_blocks) destination of every data-term block
   const NDDest* pair_dest;     // (J*K_ED) destination of every ARAP pair block
+  const int32_t* schur_items;  // Schur work lists (slm_nd.h)
+  const int32_t* schur_off;    // (2*n_levels + 1)
   const int32_t* in_start;     // (J+1) ARAP edges grouped by target node (reverse KNN graph)
   const int32_t* in_edge;
   double* ftiles;              // front tile storage

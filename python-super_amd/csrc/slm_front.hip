@@ -804,24 +804,32 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 // is on the MFMA.  `which` selects the children with that index (see launch_front_solve).
 // grid = (max boundary tile pairs, fronts in level, n_frames)
 __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, LevelRef lvl, int which,
-                                                 WgMap map) {
+                                                 int n_items, int items_at, int n_frames) {
   __shared__ double Bl[TILE];
   __shared__ int rmap[NB], cmap[NB];
-  WgId wg;
-  if (!wg_decode(map, wg)) return;
-  const int t = wg.unit;
-  const FrameDev& fd = frames[wg.frame];
+  // Work items come from the plan's exact list for (level, child index): no empty workgroups, no
+  // index arithmetic.  XCD-aware order: blocks b and b+8 share an XCD, so XCD x takes the contiguous
+  // range [x*chunk, (x+1)*chunk) of the (frame, item) space -- the tiles of a front (adjacent items)
+  // run on one XCD, back to back, and its L21 operands are fetched from HBM once.
+  const int total = n_items * n_frames;
+  const int chunk = (total + 7) >> 3;
+  const int q = blockIdx.x >> 3;
+  const int w_id = (blockIdx.x & 7) * chunk + q;
+  if (q >= chunk || w_id >= total) return;
+  const int frame = w_id / n_items, item_idx = w_id - frame * n_items;
+  const FrameDev& fd = frames[frame];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  int fi;
-  if (!level_front(fd, lvl, wg.front, fi)) return;
+  int i0 = items_at, first = lvl.first;
+  if (items_at < 0) {   // slots with different plans: read this slot's tables
+    if (lvl.level >= fd.n_levels) return;
+    i0 = fd.schur_off[2 * lvl.level + which];
+    if (item_idx >= fd.schur_off[2 * lvl.level + which + 1] - i0) return;
+    first = fd.level_start[lvl.level];
+  }
+  const int item = fd.schur_items[i0 + item_idx];
+  const int tr = (item >> 8) & 255, tc = item & 255;
+  const int fi = first + (item >> 16);
   const NDFront& f = fd.fronts[fi];
-  if (f.parent < 0 || f.which_child != which) return;   // the root has no boundary
-  const int nbt = f.nt - f.npt;
-  if (t >= nbt * (nbt + 1) / 2) return;
-  int tr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-  while (tr * (tr + 1) / 2 > t) --tr;
-  const int tc = t - tr * (tr + 1) / 2;
   const int r = f.npt + tr, sc = f.npt + tc;
   // child boundary scalar -> scalar index in the parent front (extend-add maps)
   const NDFront& pf = fd.fronts[f.parent];
@@ -1072,10 +1080,12 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     // per child index so that the two children of a parent never update the same entry
     // concurrently (plain read-modify-write, fixed order: bitwise reproducible)
     if (s.max_n2p > 0 && l + 1 < n_levels) {
-      const int nbt = s.max_n2p / 64;
-      const WgMap m = make_map(nbt * (nbt + 1) / 2, s.n_fronts, n_frames);
-      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, lr, 0, m);
-      hipLaunchKernelGGL(k_fschur, map_grid(m), dim3(256), 0, st, fr, lr, 1, m);
+      for (int w = 0; w < 2; ++w) {
+        const int total = s.n_schur[w] * n_frames;
+        if (total > 0)
+          hipLaunchKernelGGL(k_fschur, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, fr, lr, w,
+                             s.n_schur[w], s.schur_at[w], n_frames);
+      }
     }
   }
   for (int l = n_levels - 1; l >= 0; --l) {

@@ -51,6 +51,8 @@ struct NDLevelSched {
   int32_t max_pairs;   // boundary node pairs nb*(nb+1)/2 (extend-add)
   int32_t max_n2p;     // padded boundary scalars
   int32_t first;       // first front of the level when all slots of the batch agree, else -1
+  int32_t n_schur[2];  // Schur work items (front, boundary tile pair) of the level per child index
+  int32_t schur_at[2]; // their offset in schur_items when all slots of the batch agree, else -1
 };
 
 struct NDPlanHost {
@@ -60,6 +62,10 @@ struct NDPlanHost {
   std::vector<int32_t> eamap;
   std::vector<int32_t> node_front;    // (J) front that eliminates the node
   std::vector<int32_t> node_pos;      // (J) its local pivot position
+  // Schur-complement work lists: per (level, child index) the (front, tile row, tile column) triples,
+  // packed front << 16 | tr << 8 | tc, front-major; schur_off[2*level + which] .. [+1] delimits a list
+  std::vector<int32_t> schur_items;
+  std::vector<int32_t> schur_off;
   std::vector<int32_t> in_start;      // (J+1) CSR over in_edge
   std::vector<int32_t> in_edge;       // ARAP edges e = j*K_ED + slot grouped by their TARGET node k, ascending e
   std::vector<NDDest> block_dest;     // per data-term block (order of blk_key)

@@ -231,7 +231,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   }
   out.sched.clear();
   for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
-    NDLevelSched sc{0, 0, 0, 0, 0, 0};
+    NDLevelSched sc{0, 0, 0, 0, 0, 0, {0, 0}, {0, 0}};
     sc.first = out.level_start[l];
     sc.n_fronts = out.level_start[l + 1] - out.level_start[l];
     for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
@@ -244,6 +244,23 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     out.sched.push_back(sc);
     out.max_level_fronts = std::max(out.max_level_fronts, sc.n_fronts);
   }
+  // exact work lists of the fused Schur / extend-add kernel (no empty workgroups)
+  out.schur_items.clear();
+  out.schur_off.assign(1, 0);
+  for (size_t l = 0; l + 1 < out.level_start.size(); ++l)
+    for (int w = 0; w < 2; ++w) {
+      for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
+        const NDFront& f = out.fronts[i];
+        if (f.parent < 0 || f.which_child != w) continue;
+        const int nbt = f.nt - f.npt;
+        if (nbt > 255 || i - out.level_start[l] > 32767) return false;
+        for (int tr = 0; tr < nbt; ++tr)
+          for (int tc = 0; tc <= tr; ++tc) out.schur_items.push_back(((i - out.level_start[l]) << 16) | (tr << 8) | tc);
+      }
+      out.schur_off.push_back((int32_t)out.schur_items.size());
+      out.sched[l].schur_at[w] = out.schur_off[out.schur_off.size() - 2];
+      out.sched[l].n_schur[w] = out.schur_off.back() - out.sched[l].schur_at[w];
+    }
   // extend-add maps: boundary index of a child -> local node position in the parent
   for (int i = 0; i < T; ++i) {
     const int id = proc[i];
