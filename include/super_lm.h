@@ -394,7 +394,7 @@ int slm_depth_preprocess(slm_depth* d, const slm_depth_config* cfg, const slm_de
  * "Next" row f1: surfel fusion, the step right after the solve every frame
  *   slm_fuse_input_data   <- Surfels.fuseInputData                     super/nodes.py:268-541
  *   slm_fuse_swap_stable  <- Surfels.prepareStableIndexNSwapAllModel   super/nodes.py:543-585
- * for opt.method == "super" without tracked evaluation points.  Geometry is float64 like the
+ * for opt.method == "super" and "semantic-super" (slm_fuse_bind_semantic).  Geometry is float64 like the
  * reference's tensors, colours / confidences / time stamps float32.  Unpinned by the reference:
  * the order of surfels with EQUAL confidence on one pixel (torch.sort(descending=True) is not
  * stable); here the lower index comes first.
@@ -445,7 +445,32 @@ typedef struct slm_new_frame {     /* sfdata from depth_preprocessing, device po
   const int32_t* index_map;       /* (H,W), -1 invalid */
 } slm_new_frame;
 
+/* Segmentation fields of Semantic-SuPer (sf.seg / sf.seg_conf / sf.dist2edge exist iff the frames carry
+ * them, super/nodes.py:60-75): fused in merge_data (nodes.py:348-353), appended with the new surfels
+ * (nodes.py:524-525), compacted by the swap (nodes.py:572-575).  All device pointers. */
+typedef struct slm_fuse_semantic {
+  int32_t num_classes;            /* C, 1..SLM_MAX_CLASSES */
+  int32_t soft_weights;           /* opt.method == "semantic-super": skinning weights
+                                     softmax(exp(-JSD(node, surfel))^(1/2) * exp(-d/r)^(1/2)), nodes.py:467-477;
+                                     for the NEW surfels only without hard_seg (nodes.py:503-509) */
+  int32_t hard_seg;               /* sf.hard_seg: new surfels take their 4 nodes among the nodes of their own
+                                     class (find_knn with num_classes, utils/utils.py:223-242); a class with
+                                     fewer than 4 nodes is an error like the reference's assert */
+  int32_t merge_same_class;       /* hard_seg or opt.data == "superv1": only equal classes merge (nodes.py:314-316) */
+  int32_t* seg;                   /* (cap)   sf.seg */
+  double* seg_conf;               /* (cap,C) sf.seg_conf */
+  double* dist2edge;              /* (cap)   sf.dist2edge */
+  const int32_t* ed_seg;          /* (J)     sf.ED_nodes.seg      (hard_seg) */
+  const double* ed_seg_conf;      /* (J,C)   sf.ED_nodes.seg_conf (soft_weights) */
+  const int32_t* new_seg;         /* (T)     sfdata.seg */
+  const double* new_seg_conf;     /* (T,C)   sfdata.seg_conf */
+  const double* new_dist2edge;    /* (T)     sfdata.dist2edge */
+} slm_fuse_semantic;
+
 int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out);
+/* Binds (sem != NULL) or drops (NULL) the segmentation fields used by the next slm_fuse_input_data /
+ * slm_fuse_swap_stable calls on `f`; the struct is copied.  The swap only needs seg / seg_conf / dist2edge. */
+int slm_fuse_bind_semantic(slm_fuse* f, const slm_fuse_semantic* sem);
 int slm_fuse_destroy(slm_fuse* f);
 /* Fuses the frame into the model in place; model->n (host struct) becomes the new row count.
  * Synchronises `stream` (three count read-backs). */

@@ -3,7 +3,9 @@
 NumPy restatement of the reference's surfel fusion step, SURVEY.md 8(f) row f1:
 ``Surfels.fuseInputData`` (``super/nodes.py:268-541``) and
 ``Surfels.prepareStableIndexNSwapAllModel`` (``super/nodes.py:543-585``), for ``opt.method ==
-"super"`` without tracked evaluation points: project the surfels, build up to 16 confidence-ordered
+"super"`` and ``"semantic-super"`` (segmentation fields carried and fused, Jensen-Shannon skinning
+weights, ``hard_seg`` class-restricted neighbours), with or without tracked evaluation points:
+project the surfels, build up to 16 confidence-ordered
 surfel layers per pixel, merge the new frame's points into them, merge surfels that share a pixel,
 refresh the skinning weights, append unmatched points as new surfels, then drop unstable / stale
 surfels.  The float32 / float64 mix of the reference's tensors is kept operation by operation
@@ -29,7 +31,8 @@ def default_opt(**kw):
     o = SimpleNamespace(height=0, width=0, th_dist=0.1, th_cosine_ang=0.4, th_time_steps=30,
                         disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
                         disable_adding_new_surfels=False, disable_removing_unstable_surfels=False,
-                        phase="test", num_neighbors=4)
+                        phase="test", num_neighbors=4, method="super", data="superv2", num_classes=0,
+                        hard_seg=False)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -39,7 +42,7 @@ class Model:
     """The surfel arrays ``fuseInputData`` reads and writes (names as in the reference)."""
 
     def __init__(self, points, norms, colors, radii, confs, time_stamp, isStable, knn_indices, knn_w, ed_points,
-                 ed_radii):
+                 ed_radii, seg=None, seg_conf=None, dist2edge=None, ed_seg=None, ed_seg_conf=None):
         self.points = np.array(points, np.float64)
         self.norms = np.array(norms, np.float64)
         self.colors = np.array(colors, f32)
@@ -52,6 +55,12 @@ class Model:
         self.ed_points = np.asarray(ed_points, np.float64)
         self.ed_radii = np.asarray(ed_radii, np.float64)
         self.projdata = np.zeros((len(self.points), 2), f32)
+        # segmentation fields (Semantic-SuPer): present on the model iff the frames carry them
+        self.seg = None if seg is None else np.array(seg, np.int64)
+        self.seg_conf = None if seg_conf is None else np.array(seg_conf, np.float64)
+        self.dist2edge = None if dist2edge is None else np.array(dist2edge, np.float64)
+        self.ed_seg = None if ed_seg is None else np.asarray(ed_seg, np.int64)
+        self.ed_seg_conf = None if ed_seg_conf is None else np.asarray(ed_seg_conf, np.float64)
 
 
 def project(points, K, H, W):
@@ -79,6 +88,11 @@ def _merge(m, opt, d1, idx1, d2, idx2, time, add_new):
     if len(p) == 0:
         return np.zeros(0, bool)
     valid = (np.sqrt(((p - p2) ** 2).sum(-1)) < opt.th_dist) & ((n * n2).sum(-1) > opt.th_cosine_ang)
+    has_seg = m.seg is not None and getattr(d2, "seg", None) is not None
+    if (opt.hard_seg or opt.data == "superv1") and has_seg:
+        valid &= d1.seg[idx1] == d2.seg[idx2]                    # nodes.py:314-316
+    if has_seg:                                                   # read before the rows are overwritten
+        sc1, sc2 = d1.seg_conf[idx1][valid], d2.seg_conf[idx2][valid]
     ids = idx1[valid]
     w, w2 = w[valid], w2[valid]
     wu = (w + w2).astype(f32)
@@ -98,7 +112,47 @@ def _merge(m, opt, d1, idx1, d2, idx2, time, add_new):
         m.colors[ids] = (wc * c[valid]).astype(f32) + (wc2 * c2[valid]).astype(f32)
     if time is not None:
         m.time_stamp[ids] = f32(time)
+    if has_seg:                                                   # nodes.py:348-353
+        sc = wc.astype(np.float64) * sc1 + wc2.astype(np.float64) * sc2
+        sc = sc / sc.sum(1, keepdims=True)
+        m.seg_conf[ids] = sc
+        m.seg[ids] = np.argmax(sc, axis=1)
     return valid
+
+
+def kld(P, Q, eps=1e-13):
+    """``KLD`` (utils/utils.py:244-250)."""
+    return (P * np.log(P / (Q + eps) + eps)).sum(-1)
+
+
+def jsd(P, Q, eps=1e-13):
+    """``JSD`` (utils/utils.py:252-254)."""
+    M = 0.5 * (P + Q)
+    return 0.5 * (kld(P, M, eps) + kld(Q, M, eps))
+
+
+def semantic_weights(dist, rad, P, Q):
+    """softmax(exp(-JSD)^(1/2) * exp(-d/r)^(1/2)) (nodes.py:183-189,472-477,503-509)."""
+    e = np.power(np.exp(-jsd(P, Q)), 0.5) * np.power(np.exp(-dist / rad), 0.5)
+    e = np.exp(e - e.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def class_knn(points, seg, nodes, node_seg, k, num_classes):
+    """``find_knn`` with ``num_classes > 0`` (utils/utils.py:223-242): neighbours among the nodes of
+    the point's own class (lowest node index first on ties)."""
+    dist = np.full((len(points), k), 1e8)
+    idx = -np.ones((len(points), k), np.int64)
+    for c in range(num_classes):
+        v1 = seg == c
+        v2 = np.nonzero(node_seg == c)[0]
+        if not v1.any() and len(v2) == 0:
+            continue
+        assert v1.any() and len(v2) >= k
+        d, i = orc.knn(points[v1], nodes[v2], k)
+        dist[v1] = d
+        idx[v1] = v2[i]
+    return dist, idx
 
 
 def fuse_input_data(m: Model, opt, K, new, time, track_id=None):
@@ -191,16 +245,25 @@ def fuse_input_data(m: Model, opt, K, new, time, track_id=None):
 
     # skinning weights of every surfel at its (possibly fused) position
     d = np.sqrt(((m.points[:, None, :] - m.ed_points[m.knn_indices]) ** 2).sum(-1))
-    m.knn_w = orc.knn_weights(d, m.ed_radii[m.knn_indices])
+    if opt.method == "semantic-super":                            # nodes.py:467-477 (also with hard_seg)
+        m.knn_w = semantic_weights(d, m.ed_radii[m.knn_indices], m.ed_seg_conf[m.knn_indices], m.seg_conf[:, None, :])
+    else:
+        m.knn_w = orc.knn_weights(d, m.ed_radii[m.knn_indices])
 
     if not opt.disable_adding_new_surfels and add_valid is not None:
         add = add_valid[np.array(new.valid, bool)]
         if add.any():
             pts = new.points[add]
-            dist, idx = orc.knn(pts, m.ed_points, opt.num_neighbors)
+            if opt.hard_seg:                                      # nodes.py:494-497
+                dist, idx = class_knn(pts, new.seg[add], m.ed_points, m.ed_seg, opt.num_neighbors, opt.num_classes)
+            else:
+                dist, idx = orc.knn(pts, m.ed_points, opt.num_neighbors)
             rad = m.ed_radii[idx]
             st = (dist <= rad).any(1)
-            w = orc.knn_weights(dist, rad)
+            if opt.method == "semantic-super" and not opt.hard_seg:
+                w = semantic_weights(dist, rad, m.ed_seg_conf[idx], new.seg_conf[add][:, None, :])
+            else:
+                w = orc.knn_weights(dist, rad)
             k = int(st.sum())
             m.isStable = np.concatenate([m.isStable, np.ones(k, bool)])
             m.knn_w = np.concatenate([m.knn_w, w[st]])
@@ -211,6 +274,11 @@ def fuse_input_data(m: Model, opt, K, new, time, track_id=None):
             m.radii = np.concatenate([m.radii, new.radii[add][st]])
             m.confs = np.concatenate([m.confs, new.confs[add][st].astype(f32)])
             m.time_stamp = np.concatenate([m.time_stamp, np.full(k, time, f32)])
+            if m.seg is not None:                                 # nodes.py:524-525
+                m.seg = np.concatenate([m.seg, new.seg[add][st]])
+                m.seg_conf = np.concatenate([m.seg_conf, new.seg_conf[add][st]])
+                if m.dist2edge is not None:
+                    m.dist2edge = np.concatenate([m.dist2edge, new.dist2edge[add][st]])
     v_, u_, _, _ = project(m.points, K, H, W)
     m.projdata = np.stack([u_, v_], 1).astype(f32)
     return m
@@ -222,8 +290,10 @@ def swap_stable(m: Model, opt, time, track_id=None):
         keep = m.isStable & ((f32(time) - m.time_stamp).astype(f32) < opt.th_time_steps)
         if track_id is not None:
             keep[track_id[track_id >= 0]] = True
-        for k in ("points", "norms", "colors", "confs", "radii", "time_stamp", "knn_indices", "knn_w", "projdata"):
-            setattr(m, k, getattr(m, k)[keep])
+        for k in ("points", "norms", "colors", "confs", "radii", "time_stamp", "knn_indices", "knn_w", "projdata",
+                  "seg", "seg_conf", "dist2edge"):
+            if getattr(m, k) is not None:
+                setattr(m, k, getattr(m, k)[keep])
         if track_id is not None:
             id_map = -np.ones(len(keep), np.int64)
             id_map[keep] = np.arange(int(keep.sum()))

@@ -1,5 +1,5 @@
 // slm_fuse.hip -- "next" row f1: surfel fusion after the solve (reference Surfels.fuseInputData and
-// prepareStableIndexNSwapAllModel, super/nodes.py:268-585, opt.method == "super").
+// prepareStableIndexNSwapAllModel, super/nodes.py:268-585, opt.method == "super" / "semantic-super").
 //
 //   k_fu_keys        project every surfel (pcd2depth, rounded), key = (pixel << 32) | ~confidence
 //   rocPRIM sort     stable radix sort by key: per pixel the surfels in descending confidence
@@ -37,7 +37,10 @@ struct slm_fuse {
   int32_t* cand_idx = nullptr;  // (H*W,4) nearest nodes of the candidate pixels
   double* cand_w = nullptr;     // (H*W,4)
   uint8_t* dead = nullptr;      // (cap) surfels to drop after the pairwise merges
-  int32_t* counters = nullptr;  // [0] layers in use
+  int32_t* counters = nullptr;  // [0] layers in use, [1] candidates without 4 nodes of their class
+  slm_fuse_semantic sem{};      // segmentation fields (num_classes == 0: none)
+  int32_t* s_seg = nullptr;     // compaction scratch of the segmentation fields
+  double *s_sc = nullptr, *s_d2e = nullptr;
   void* tmp = nullptr;
   size_t cap_tmp = 0;
   // compaction scratch (swap)
@@ -110,10 +113,17 @@ __global__ void __launch_bounds__(256) k_fu_layers(int n, int HW, const unsigned
 struct FuRow {
   double p[3], n[3], r;
   float c[3], w;
+  int seg;
+  double sc[SLM_MAX_CLASSES];
 };
 
-__device__ __forceinline__ FuRow fu_load(const slm_surfel_model& m, int i) {
+__device__ __forceinline__ FuRow fu_load(const slm_surfel_model& m, const slm_fuse_semantic& sm, int i) {
   FuRow x;
+  x.seg = 0;
+  if (sm.num_classes > 0) {
+    x.seg = sm.seg[i];
+    for (int k = 0; k < sm.num_classes; ++k) x.sc[k] = sm.seg_conf[(size_t)sm.num_classes * i + k];
+  }
   for (int k = 0; k < 3; ++k) {
     x.p[k] = m.points[3 * (size_t)i + k];
     x.n[k] = m.norms[3 * (size_t)i + k];
@@ -125,13 +135,15 @@ __device__ __forceinline__ FuRow fu_load(const slm_surfel_model& m, int i) {
 }
 
 // merge_data (nodes.py:296-357) for one pair: `a` is the surfel that stays (row ia of the model)
-__device__ __forceinline__ bool fu_merge(const slm_fuse_config& c, const slm_surfel_model& m, int ia, const FuRow& a,
-                                         const FuRow& b, bool add_new, int time) {
+__device__ __forceinline__ bool fu_merge(const slm_fuse_config& c, const slm_surfel_model& m,
+                                         const slm_fuse_semantic& sm, int ia, const FuRow& a, const FuRow& b,
+                                         bool add_new, int time) {
 #pragma clang fp contract(off)
   const double dx = a.p[0] - b.p[0], dy = a.p[1] - b.p[1], dz = a.p[2] - b.p[2];
   const double dist = sqrt(dx * dx + dy * dy + dz * dz);
   const double cosang = a.n[0] * b.n[0] + a.n[1] * b.n[1] + a.n[2] * b.n[2];
   if (!(dist < c.th_dist && cosang > c.th_cosine_ang)) return false;
+  if (sm.num_classes > 0 && sm.merge_same_class && a.seg != b.seg) return false;
   const float wu = a.w + b.w;
   const float w = a.w / wu, w2 = b.w / wu;
   const double wd = (double)w, w2d = (double)w2;
@@ -153,13 +165,28 @@ __device__ __forceinline__ bool fu_merge(const slm_fuse_config& c, const slm_sur
     for (int k = 0; k < 3; ++k) m.colors[3 * (size_t)ia + k] = w * a.c[k] + w2 * b.c[k];
   }
   if (c.phase_test) m.time_stamp[ia] = (float)time;
+  if (sm.num_classes > 0) {
+    // fused class confidences, renormalised; class = first maximum (nodes.py:348-353)
+    double q[SLM_MAX_CLASSES], tot = 0.0;
+    for (int k = 0; k < sm.num_classes; ++k) {
+      q[k] = wd * a.sc[k] + w2d * b.sc[k];
+      tot += q[k];
+    }
+    int best = 0;
+    for (int k = 0; k < sm.num_classes; ++k) {
+      q[k] /= tot;
+      sm.seg_conf[(size_t)sm.num_classes * ia + k] = q[k];
+      if (q[k] > q[best]) best = k;
+    }
+    sm.seg[ia] = best;
+  }
   return true;
 }
 
 // one thread per pixel: new point -> first matching layer, else candidate (flag = 1)
-__global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_surfel_model m, slm_new_frame fr,
-                                                       const int32_t* __restrict__ layers, int n_layers,
-                                                       int32_t* __restrict__ flag) {
+__global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm,
+                                                       slm_new_frame fr, const int32_t* __restrict__ layers,
+                                                       int n_layers, int32_t* __restrict__ flag) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   const int HW = c.H * c.W;
   if (pix >= HW) return;
@@ -176,11 +203,16 @@ __global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_sur
       }
       b.r = fr.radii[t];
       b.w = fr.confs[t];
+      b.seg = 0;
+      if (sm.num_classes > 0) {
+        b.seg = sm.new_seg[t];
+        for (int k = 0; k < sm.num_classes; ++k) b.sc[k] = sm.new_seg_conf[(size_t)sm.num_classes * t + k];
+      }
       for (int l = 0; l < n_layers; ++l) {
         const int s = layers[(size_t)l * HW + pix];
         if (s < 0) break;
-        const FuRow a = fu_load(m, s);
-        if (fu_merge(c, m, s, a, b, true, fr.time)) {
+        const FuRow a = fu_load(m, sm, s);
+        if (fu_merge(c, m, sm, s, a, b, true, fr.time)) {
           out = 0;
           break;
         }
@@ -193,7 +225,7 @@ __global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_sur
 }
 
 // one thread per pixel: pairwise fusion of the surfels that share the pixel (nodes.py:424-447)
-__global__ void __launch_bounds__(256) k_fu_merge_exist(slm_fuse_config c, slm_surfel_model m, int time,
+__global__ void __launch_bounds__(256) k_fu_merge_exist(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm, int time,
                                                          const int32_t* __restrict__ layers, int n_layers,
                                                          uint8_t* __restrict__ dead) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,8 +243,8 @@ __global__ void __launch_bounds__(256) k_fu_merge_exist(slm_fuse_config c, slm_s
     for (int j = i + 1; j < n_layers && alive; ++j) {
       alive = alive && ((present >> j) & 1u);
       if (!alive) break;
-      const FuRow a = fu_load(m, id[i]), b = fu_load(m, id[j]);
-      if (fu_merge(c, m, id[i], a, b, false, time)) {
+      const FuRow a = fu_load(m, sm, id[i]), b = fu_load(m, sm, id[j]);
+      if (fu_merge(c, m, sm, id[i], a, b, false, time)) {
         present &= ~(1u << j);                  // val_maps[j] loses the pixel for the later i loops
         dead[id[j]] = 1;
         if (m.merged_into) m.merged_into[id[j]] = id[i];
@@ -239,8 +271,33 @@ __device__ __forceinline__ void fu_softmax4(const double d[4], const double r[4]
   for (int k = 0; k < 4; ++k) w[k] /= s;
 }
 
-// knn_w = softmax(exp(-dist / radius)) at the current positions (nodes.py:466-469)
-__global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m) {
+// Jensen-Shannon divergence of two class distributions (utils/utils.py:244-254)
+__device__ __forceinline__ double fu_jsd(const double* P, const double* Q, int C) {
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < C; ++k) {
+    const double M = 0.5 * (P[k] + Q[k]);
+    a += P[k] * log(P[k] / (M + 1e-13) + 1e-13);
+    b += Q[k] * log(Q[k] / (M + 1e-13) + 1e-13);
+  }
+  return 0.5 * (a + b);
+}
+
+// softmax(exp(-JSD)^(1/2) * exp(-d/r)^(1/2)) (nodes.py:472-477, power_arg = (1/2, 1/2))
+__device__ __forceinline__ void fu_softmax4_sem(const double d[4], const double r[4], const double js[4], double w[4]) {
+  double e[4], mx = -1e300, s = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    e[k] = sqrt(exp(-js[k])) * sqrt(exp(-d[k] / r[k]));
+    mx = fmax(mx, e[k]);
+  }
+  for (int k = 0; k < 4; ++k) {
+    w[k] = exp(e[k] - mx);
+    s += w[k];
+  }
+  for (int k = 0; k < 4; ++k) w[k] /= s;
+}
+
+// knn_w = softmax(exp(-dist / radius)) at the current positions (nodes.py:466-481)
+__global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m, slm_fuse_semantic sm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
   double d[4], r[4], w[4];
@@ -254,7 +311,15 @@ __global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m) {
     d[k] = sqrt(s);
     r[k] = m.ed_radii[j];
   }
-  fu_softmax4(d, r, w);
+  if (sm.num_classes > 0 && sm.soft_weights) {
+    const int C = sm.num_classes;
+    double js[4];
+    for (int k = 0; k < 4; ++k)
+      js[k] = fu_jsd(sm.ed_seg_conf + (size_t)C * m.knn_idx[4 * (size_t)i + k], sm.seg_conf + (size_t)C * i, C);
+    fu_softmax4_sem(d, r, js, w);
+  } else {
+    fu_softmax4(d, r, w);
+  }
   for (int k = 0; k < 4; ++k) m.knn_w[4 * (size_t)i + k] = w[k];
 }
 
@@ -262,18 +327,23 @@ __global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m) {
 // Node positions are staged through LDS in tiles of FU_TILE (broadcast reads), four distances per
 // step, and the sorted insertion only runs when one of them beats the current 4th best.
 #define FU_TILE 1024
-__global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_surfel_model m, slm_new_frame fr,
-                                                        int32_t* __restrict__ flag, int32_t* __restrict__ cand_idx,
-                                                        double* __restrict__ cand_w) {
+__global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm,
+                                                        slm_new_frame fr, int32_t* __restrict__ flag,
+                                                        int32_t* __restrict__ cand_idx, double* __restrict__ cand_w,
+                                                        int32_t* __restrict__ counters) {
   __shared__ double nodes[3 * FU_TILE];
+  __shared__ int ncls[FU_TILE];
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = pix < c.H * c.W && flag[pix] != 0;
+  const bool by_class = sm.num_classes > 0 && sm.hard_seg;   // neighbours among the nodes of the point's class
   double px = 0.0, py = 0.0, pz = 0.0;
+  int t = 0, cls = 0;
   if (act) {
-    const int t = fr.index_map[pix];
+    t = fr.index_map[pix];
     px = fr.points[3 * (size_t)t];
     py = fr.points[3 * (size_t)t + 1];
     pz = fr.points[3 * (size_t)t + 2];
+    if (by_class) cls = sm.new_seg[t];
   }
   double bd[4] = {1e300, 1e300, 1e300, 1e300};
   int bi[4] = {-1, -1, -1, -1};
@@ -281,6 +351,8 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
     const int cnt = min(FU_TILE, m.J - j0);
     __syncthreads();
     for (int e = threadIdx.x; e < 3 * cnt; e += blockDim.x) nodes[e] = m.ed_points[3 * (size_t)j0 + e];
+    if (by_class)
+      for (int e = threadIdx.x; e < cnt; e += blockDim.x) ncls[e] = sm.ed_seg[j0 + e];
     __syncthreads();
     if (!act) continue;
     for (int jj = 0; jj < cnt; jj += 4) {
@@ -290,6 +362,7 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
         const int k = jj + q < cnt ? jj + q : cnt - 1;     // tail: repeats the last node, rejected below
         const double dx = px - nodes[3 * k], dy = py - nodes[3 * k + 1], dz = pz - nodes[3 * k + 2];
         d2[q] = dx * dx + dy * dy + dz * dz;
+        if (by_class && ncls[k] != cls) d2[q] = 1e300;       // other class: never a neighbour
       }
       if (fmin(fmin(d2[0], d2[1]), fmin(d2[2], d2[3])) < bd[3]) {
 #pragma unroll
@@ -309,6 +382,11 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
     }
   }
   if (!act) return;
+  if (bi[3] < 0) {       // fewer than 4 nodes of this class: the reference asserts (utils/utils.py:237)
+    atomicAdd(&counters[1], 1);
+    flag[pix] = 0;
+    return;
+  }
   double d[4], r[4], w[4];
   bool stable = false;
   for (int k = 0; k < 4; ++k) {
@@ -320,14 +398,21 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
     flag[pix] = 0;       // too far from its nodes: not added (nodes.py:500)
     return;
   }
-  fu_softmax4(d, r, w);
+  if (sm.num_classes > 0 && sm.soft_weights && !sm.hard_seg) {
+    const int C = sm.num_classes;
+    double js[4];
+    for (int k = 0; k < 4; ++k) js[k] = fu_jsd(sm.ed_seg_conf + (size_t)C * bi[k], sm.new_seg_conf + (size_t)C * t, C);
+    fu_softmax4_sem(d, r, js, w);
+  } else {
+    fu_softmax4(d, r, w);
+  }
   for (int k = 0; k < 4; ++k) {
     cand_idx[4 * (size_t)pix + k] = bi[k];
     cand_w[4 * (size_t)pix + k] = w[k];
   }
 }
 
-__global__ void __launch_bounds__(256) k_fu_append(slm_fuse_config c, slm_surfel_model m, slm_new_frame fr,
+__global__ void __launch_bounds__(256) k_fu_append(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm, slm_new_frame fr,
                                                     const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
                                                     const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_w) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,6 +432,12 @@ __global__ void __launch_bounds__(256) k_fu_append(slm_fuse_config c, slm_surfel
   for (int k = 0; k < 4; ++k) {
     m.knn_idx[4 * o + k] = cand_idx[4 * (size_t)pix + k];
     m.knn_w[4 * o + k] = cand_w[4 * (size_t)pix + k];
+  }
+  if (sm.num_classes > 0) {
+    sm.seg[o] = sm.new_seg[t];
+    for (int k = 0; k < sm.num_classes; ++k)
+      sm.seg_conf[(size_t)sm.num_classes * o + k] = sm.new_seg_conf[(size_t)sm.num_classes * t + k];
+    sm.dist2edge[o] = sm.new_dist2edge[t];
   }
 }
 
@@ -396,6 +487,12 @@ __global__ void __launch_bounds__(256) k_fu_compact(slm_surfel_model m, slm_fuse
   }
   s.s_f2[2 * o] = m.projdata[2 * (size_t)i];
   s.s_f2[2 * o + 1] = m.projdata[2 * (size_t)i + 1];
+  if (s.sem.num_classes > 0) {
+    const int C = s.sem.num_classes;
+    s.s_seg[o] = s.sem.seg[i];
+    for (int k = 0; k < C; ++k) s.s_sc[(size_t)C * o + k] = s.sem.seg_conf[(size_t)C * i + k];
+    s.s_d2e[o] = s.sem.dist2edge[i];
+  }
 }
 
 template <typename T>
@@ -461,6 +558,9 @@ int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out) {
   if (e == hipSuccess) e = falloc(f->s_f1, 2 * cap);
   if (e == hipSuccess) e = falloc(f->s_f2, 2 * cap);
   if (e == hipSuccess) e = falloc(f->s_i4, 4 * cap);
+  if (e == hipSuccess) e = falloc(f->s_seg, cap);
+  if (e == hipSuccess) e = falloc(f->s_sc, SLM_MAX_CLASSES * cap);
+  if (e == hipSuccess) e = falloc(f->s_d2e, cap);
   if (e != hipSuccess) {
     slm_set_error_text((std::string("slm_fuse_create: ") + hipGetErrorString(e)).c_str());
     slm_fuse_destroy(f);
@@ -473,10 +573,27 @@ int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out) {
 int slm_fuse_destroy(slm_fuse* f) {
   if (!f) return SLM_OK;
   void* ptrs[] = {f->keys, f->skeys, f->ids, f->sids, f->layers, f->flag, f->pos, f->cand_idx, f->cand_w, f->dead,
-                  f->counters, f->tmp, f->s_d3, f->s_d1, f->s_d4, f->s_f3, f->s_f1, f->s_f2, f->s_i4};
+                  f->counters, f->tmp, f->s_d3, f->s_d1, f->s_d4, f->s_f3, f->s_f1, f->s_f2, f->s_i4, f->s_seg, f->s_sc,
+                  f->s_d2e};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete f;
+  return SLM_OK;
+}
+
+int slm_fuse_bind_semantic(slm_fuse* f, const slm_fuse_semantic* sem) {
+  if (!f) return ffail(SLM_ERR_INVALID, "slm_fuse_bind_semantic: null handle");
+  if (!sem) {
+    f->sem = slm_fuse_semantic{};
+    return SLM_OK;
+  }
+  if (sem->num_classes < 1 || sem->num_classes > SLM_MAX_CLASSES)
+    return ffail(SLM_ERR_UNSUPPORTED, "slm_fuse_bind_semantic: num_classes must be in 1..4");
+  if (!sem->seg || !sem->seg_conf || !sem->dist2edge)
+    return ffail(SLM_ERR_INVALID, "slm_fuse_bind_semantic: seg / seg_conf / dist2edge must be given");
+  if ((sem->soft_weights && !sem->ed_seg_conf) || (sem->hard_seg && !sem->ed_seg))
+    return ffail(SLM_ERR_INVALID, "slm_fuse_bind_semantic: the ED nodes' seg_conf (soft weights) / seg (hard_seg) is missing");
+  f->sem = *sem;
   return SLM_OK;
 }
 
@@ -497,6 +614,9 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
   if (!frame || !frame->valid || !frame->index_map ||
       (frame->T > 0 && (!frame->points || !frame->norms || !frame->colors || !frame->radii || !frame->confs)))
     return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: null frame pointer");
+  const slm_fuse_semantic sm = f->sem;
+  if (sm.num_classes > 0 && frame->T > 0 && (!sm.new_seg || !sm.new_seg_conf || !sm.new_dist2edge))
+    return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: the frame's seg / seg_conf / dist2edge are not bound");
   hipStream_t st = (hipStream_t)stream;
   const slm_fuse_config c = *cfg;
   slm_surfel_model m = *model;
@@ -525,23 +645,30 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
     FCHK(hipStreamSynchronize(st));
   }
   // 2. the frame's points into the layers; flag = candidate new surfel
-  hipLaunchKernelGGL(k_fu_merge_new, gp, blk, 0, st, c, m, *frame, f->layers, n_layers, f->flag);
+  hipLaunchKernelGGL(k_fu_merge_new, gp, blk, 0, st, c, m, sm, *frame, f->layers, n_layers, f->flag);
   // 3. surfels that share a pixel; drop the absorbed ones and those beyond the 16 maps
   if (c.merge_exist && n_layers > 0) {
     if (n_layers > 1)
-      hipLaunchKernelGGL(k_fu_merge_exist, gp, blk, 0, st, c, m, frame->time, f->layers, n_layers, f->dead);
+      hipLaunchKernelGGL(k_fu_merge_exist, gp, blk, 0, st, c, m, sm, frame->time, f->layers, n_layers, f->dead);
     hipLaunchKernelGGL(k_fu_apply_dead, gs, blk, 0, st, n, f->dead, m.is_stable);
   }
   // 4. skinning weights at the fused positions
-  if (n > 0) hipLaunchKernelGGL(k_fu_weights, gs, blk, 0, st, m);
+  if (n > 0) hipLaunchKernelGGL(k_fu_weights, gs, blk, 0, st, m, sm);
   // 5. unmatched points with a nearby node become new surfels, in row-major pixel (= sfdata) order
   int n_new = 0;
   if (c.add_new && c.merge_new && n_layers > 0) {
-    hipLaunchKernelGGL(k_fu_candidates, gp, blk, 0, st, c, m, *frame, f->flag, f->cand_idx, f->cand_w);
+    hipLaunchKernelGGL(k_fu_candidates, gp, blk, 0, st, c, m, sm, *frame, f->flag, f->cand_idx, f->cand_w,
+                       f->counters);
     FCHK(scan_flags(f, HW, st));
+    int n_short = 0;
+    if (sm.num_classes > 0 && sm.hard_seg)
+      FCHK(hipMemcpyAsync(&n_short, f->counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     FCHK(count_flags(f, HW, st, &n_new));
+    if (n_short > 0)
+      return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: hard_seg needs at least 4 ED nodes of every class that has new points");
     if (n + n_new > m.cap) return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: model capacity too small for the new surfels");
-    if (n_new > 0) hipLaunchKernelGGL(k_fu_append, gp, blk, 0, st, c, m, *frame, f->flag, f->pos, f->cand_idx, f->cand_w);
+    if (n_new > 0)
+      hipLaunchKernelGGL(k_fu_append, gp, blk, 0, st, c, m, sm, *frame, f->flag, f->pos, f->cand_idx, f->cand_w);
   }
   m.n = n + n_new;
   if (m.n > 0) hipLaunchKernelGGL(k_fu_proj, dim3((m.n + 255) / 256), blk, 0, st, c, m, m.n);
@@ -581,6 +708,11 @@ int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mod
     FCHK(hipMemcpyAsync(m.knn_w, f->s_d4, sizeof(double) * 4 * k, hipMemcpyDeviceToDevice, st));
     FCHK(hipMemcpyAsync(m.projdata, f->s_f2, sizeof(float) * 2 * k, hipMemcpyDeviceToDevice, st));
     FCHK(hipMemsetAsync(m.is_stable, 1, k, st));
+    if (f->sem.num_classes > 0) {
+      FCHK(hipMemcpyAsync(f->sem.seg, f->s_seg, sizeof(int32_t) * k, hipMemcpyDeviceToDevice, st));
+      FCHK(hipMemcpyAsync(f->sem.seg_conf, f->s_sc, sizeof(double) * f->sem.num_classes * k, hipMemcpyDeviceToDevice, st));
+      FCHK(hipMemcpyAsync(f->sem.dist2edge, f->s_d2e, sizeof(double) * k, hipMemcpyDeviceToDevice, st));
+    }
   }
   FCHK(hipGetLastError());
   model->n = kept;

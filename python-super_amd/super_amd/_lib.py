@@ -25,6 +25,7 @@ EXPORTS = [
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
+    "slm_fuse_bind_semantic",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -112,6 +113,16 @@ class SlmNewFrame(C.Structure):
                 ("index_map", C.c_void_p)]
 
 
+SLM_MAX_CLASSES = 4   # include/super_lm.h
+
+
+class SlmFuseSemantic(C.Structure):
+    _fields_ = [("num_classes", C.c_int32), ("soft_weights", C.c_int32), ("hard_seg", C.c_int32),
+                ("merge_same_class", C.c_int32), ("seg", C.c_void_p), ("seg_conf", C.c_void_p),
+                ("dist2edge", C.c_void_p), ("ed_seg", C.c_void_p), ("ed_seg_conf", C.c_void_p),
+                ("new_seg", C.c_void_p), ("new_seg_conf", C.c_void_p), ("new_dist2edge", C.c_void_p)]
+
+
 class SlmGraphOutputs(C.Structure):
     _fields_ = [("cap_nodes", C.c_int32), ("pad", C.c_int32), ("points", C.c_void_p), ("norms", C.c_void_p),
                 ("radii", C.c_void_p), ("edge_index", C.c_void_p), ("edges_lens", C.c_void_p),
@@ -190,6 +201,7 @@ def load():
         "slm_graph_init": [i32, i32, i32, vp, vp, vp, vp, C.POINTER(SlmGraphOutputs), C.POINTER(C.c_int32), vp],
         "slm_fuse_create": [i32, i32, i32, C.POINTER(vp)],
         "slm_fuse_destroy": [vp],
+        "slm_fuse_bind_semantic": [vp, C.POINTER(SlmFuseSemantic)],
         "slm_fuse_input_data": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), C.POINTER(SlmNewFrame), vp],
         "slm_fuse_swap_stable": [vp, C.POINTER(SlmFuseConfig), C.POINTER(SlmSurfelModel), i32, vp, i32, vp, vp],
         "slm_depth_create": [i32, i32, C.POINTER(vp)],

@@ -6,7 +6,9 @@ libsuper_lm.so:
 
 Both take the reference's ``sf`` object (anything with the same attributes) and can be bound onto the
 reference class: ``Surfels.fuseInputData = super_amd.fusion.fuseInputData``.  Supported:
-``opt.method == "super"`` without segmentation fields, with or without tracked evaluation points
+``opt.method == "super"`` and ``"semantic-super"`` (segmentation fields ``seg`` / ``seg_conf`` /
+``dist2edge`` fused, appended and compacted; Jensen-Shannon skinning weights; ``hard_seg``
+class-restricted neighbours, ``super/nodes.py:314-316,348-353,467-509``), with or without tracked evaluation points
 (``sf.track_id``: re-pointed when their surfel is absorbed, dropped (-2) when it is deleted, kept
 alive and renumbered by the swap, ``super/nodes.py:440-456,559-590``); the logging / rendering calls
 at the end of the reference's swap are not part of the mirror.
@@ -18,7 +20,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import SlmFuseConfig, SlmNewFrame, SlmSurfelModel
+from ._lib import SlmFuseConfig, SlmFuseSemantic, SlmNewFrame, SlmSurfelModel
 from .LM import _as, _dev_ptr, _stream_ptr
 
 _ctx = {}
@@ -39,8 +41,8 @@ def _context(lib, H, W, cap, dev):
 
 def _config(sf, inputs):
     o = sf.opt
-    if getattr(o, "method", "super") != "super" or getattr(sf, "hard_seg", False) or hasattr(sf, "seg"):
-        raise NotImplementedError("super_amd.fusion: only opt.method == 'super' without segmentation fields")
+    if getattr(o, "method", "super") not in ("super", "semantic-super"):
+        raise NotImplementedError("super_amd.fusion: opt.method must be 'super' or 'semantic-super'")
     K = inputs["K"][0].detach().cpu().float()
     c = SlmFuseConfig()
     c.H, c.W = int(o.height), int(o.width)
@@ -62,6 +64,7 @@ class _Model:
               ("radii", torch.float64, 0), ("confs", torch.float32, 0), ("time_stamp", torch.float32, 0),
               ("isStable", torch.uint8, 0), ("knn_indices", torch.int32, 4), ("knn_w", torch.float64, 4),
               ("projdata", torch.float32, 2))
+    SEG_DTYPES = {"seg": torch.long, "seg_conf": torch.float64, "dist2edge": torch.float64}
 
     def __init__(self, sf, cap, dev):
         n = int(sf.points.shape[0])
@@ -90,6 +93,46 @@ class _Model:
             self.merged_into = torch.full((cap,), -1, dtype=torch.int32, device=dev)
             m.merged_into = _dev_ptr(self.merged_into)
         self.c = m
+        self.sem = None
+        if hasattr(sf, "seg"):
+            self._bind_segmentation(sf, n, cap, dev)
+
+    def _bind_segmentation(self, sf, n, cap, dev):
+        """sf.seg / seg_conf / dist2edge with spare rows + the ED nodes' class fields."""
+        o = sf.opt
+        C_ = int(sf.seg_conf.shape[1])
+        if C_ > _lib.SLM_MAX_CLASSES:
+            raise NotImplementedError(f"super_amd.fusion: at most {_lib.SLM_MAX_CLASSES} classes")
+        if not hasattr(sf, "dist2edge"):
+            raise ValueError("super_amd.fusion: sf.seg without sf.dist2edge (the reference keeps both, nodes.py:575)")
+        self.buf["seg"] = torch.zeros(cap, dtype=torch.int32, device=dev)
+        self.buf["seg_conf"] = torch.zeros((cap, C_), dtype=torch.float64, device=dev)
+        self.buf["dist2edge"] = torch.zeros(cap, dtype=torch.float64, device=dev)
+        self.buf["seg"][:n] = _as(sf.seg, torch.int32, dev)
+        self.buf["seg_conf"][:n] = _as(sf.seg_conf, torch.float64, dev)
+        self.buf["dist2edge"][:n] = _as(sf.dist2edge, torch.float64, dev)
+        s = SlmFuseSemantic()
+        s.num_classes = C_
+        hard = bool(getattr(sf, "hard_seg", False))
+        s.soft_weights = int(getattr(o, "method", "super") == "semantic-super")
+        s.hard_seg = int(hard)
+        s.merge_same_class = int(hard or getattr(o, "data", "") == "superv1")
+        s.seg, s.seg_conf, s.dist2edge = (_dev_ptr(self.buf[k]) for k in ("seg", "seg_conf", "dist2edge"))
+        ed = sf.ED_nodes
+        if s.soft_weights:
+            self.ed_seg_conf = _as(ed.seg_conf, torch.float64, dev)
+            s.ed_seg_conf = _dev_ptr(self.ed_seg_conf)
+        if hard:
+            self.ed_seg = _as(ed.seg, torch.int32, dev)
+            s.ed_seg = _dev_ptr(self.ed_seg)
+        self.sem = s
+
+    def bind_frame_segmentation(self, sfdata, dev):
+        self.new_seg = _as(sfdata.seg, torch.int32, dev)
+        self.new_seg_conf = _as(sfdata.seg_conf, torch.float64, dev)
+        self.new_dist2edge = _as(sfdata.dist2edge, torch.float64, dev)
+        self.sem.new_seg, self.sem.new_seg_conf = _dev_ptr(self.new_seg), _dev_ptr(self.new_seg_conf)
+        self.sem.new_dist2edge = _dev_ptr(self.new_dist2edge)
 
     def write_back(self, sf):
         n = int(self.c.n)
@@ -98,6 +141,9 @@ class _Model:
                "knn_indices": torch.long, "knn_w": torch.float64, "projdata": torch.float32}
         for name, dt in ref.items():
             setattr(sf, name, self.buf[name][:n].to(dt))
+        if self.sem is not None:
+            for name, dt in self.SEG_DTYPES.items():
+                setattr(sf, name, self.buf[name][:n].to(dt))
 
 
 def fuseInputData(sf, inputs, sfdata):
@@ -118,6 +164,10 @@ def fuseInputData(sf, inputs, sfdata):
         setattr(fr, k, _dev_ptr(v))
     sf.time = sfdata.time
     stable_before = model.buf["isStable"][:n].clone()
+    if model.sem is not None:
+        model.bind_frame_segmentation(sfdata, dev)
+    _lib.check(lib.slm_fuse_bind_semantic(h, C.byref(model.sem) if model.sem is not None else None),
+               "slm_fuse_bind_semantic")
     _lib.check(lib.slm_fuse_input_data(h, C.byref(cfg), C.byref(model.c), C.byref(fr), _stream_ptr(dev)),
                "slm_fuse_input_data")
     model.write_back(sf)
@@ -148,6 +198,8 @@ def prepareStableIndexNSwapAllModel(sf, inputs, sfdata):
         keep = sf.track_id[sf.track_id >= 0].to(device=dev, dtype=torch.int32).contiguous()
         n_keep = int(keep.numel())
         new_index = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.slm_fuse_bind_semantic(h, C.byref(model.sem) if model.sem is not None else None),
+               "slm_fuse_bind_semantic")
     _lib.check(lib.slm_fuse_swap_stable(h, C.byref(cfg), C.byref(model.c), int(inputs["time"]),
                                         _dev_ptr(keep) if n_keep else None, n_keep,
                                         _dev_ptr(new_index) if new_index is not None else None, _stream_ptr(dev)),

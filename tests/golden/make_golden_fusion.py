@@ -34,15 +34,22 @@ VARIANTS = {
     "keepall": dict(disable_removing_unstable_surfels=True, th_dist=0.02),
     # tracked evaluation points: some ids sit on surfels that get absorbed / deleted / go stale
     "track": dict(th_dist=0.02, _track=True),
+    # Semantic-SuPer: segmentation fields fused and carried, Jensen-Shannon skinning weights
+    "sem": dict(method="semantic-super", num_classes=3, th_dist=0.02, _seg=True),
+    # hard_seg: only equal classes merge, new surfels take neighbours of their own class
+    "hard": dict(method="semantic-super", num_classes=3, th_dist=0.02, _seg=True, _hard=True),
+    # opt.data == "superv1" with segmentation fields: class test in the merge, plain weights
+    "v1seg": dict(data="superv1", num_classes=3, th_dist=0.02, _seg=True),
 }
 
 STATE = ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable", "knn_indices", "knn_w", "projdata")
+SEG_STATE = ("seg", "seg_conf", "dist2edge")
 
 
 def make_inputs(seed=11):
     """Surfel model (with several surfels on many pixels and a few unstable / stale ones) + new frame."""
     sc = synth.make_scene(N=1500, J=30, H=48, W=64, seed=seed, src_border=4, tgt_border=5, tgt_holes=0.02,
-                          jitter=0.49)
+                          jitter=0.49, semantic=True, num_classes=3)
     rng = np.random.default_rng(seed)
     # surfels are sampled one per pixel: add perturbed copies so that many pixels carry 2-4 layers
     P0, N0, I0, W0 = sc.f64("sf_points"), sc.f64("sf_norms"), sc.sf_knn_idx, sc.f64("sf_knn_w")
@@ -73,6 +80,22 @@ def make_inputs(seed=11):
     n0 = sc.N
     stale = np.nonzero(base["sf_time_stamp"] < 11)[0]
     base["track_id"] = np.concatenate([np.arange(n0, n0 + 8), dup[:4], stale[:4], rng.choice(n0, 2), [-1, -1]]).astype(np.int64)
+    # segmentation fields (own generator: drawn after everything above so the other inputs keep their values)
+    rs = np.random.default_rng(seed + 1000)
+    C = sc.num_classes
+
+    def smooth_conf(conf, noise):
+        c = np.asarray(conf, np.float64) + rs.uniform(0, noise, conf.shape)
+        return c / c.sum(1, keepdims=True)
+
+    sf_conf = smooth_conf(np.concatenate([sc.sf_seg_conf, sc.sf_seg_conf[dup]]), 0.3)
+    new_conf = smooth_conf(sc.tgt_seg_conf, 0.3)
+    near = np.argmin(((sc.f64("ed_points")[:, None, :] - P0[None, :, :]) ** 2).sum(-1), axis=1)
+    ed_conf = smooth_conf(sc.sf_seg_conf[near], 0.1)
+    base.update(num_classes=C, sf_seg=np.argmax(sf_conf, 1).astype(np.int64), sf_seg_conf=sf_conf,
+                sf_dist2edge=rs.uniform(0, 20, N), new_seg=np.argmax(new_conf, 1).astype(np.int64),
+                new_seg_conf=new_conf, new_dist2edge=rs.uniform(0, 20, T),
+                ed_seg=np.argmax(ed_conf, 1).astype(np.int64), ed_seg_conf=ed_conf)
     return base
 
 
@@ -98,6 +121,14 @@ def run_reference(ref, b, okw):
     sfdata = ref_shim.Data(points=t(b["new_points"]), norms=t(b["new_norms"]), colors=t(b["new_colors"]),
                            radii=t(b["new_radii"]), confs=t(b["new_confs"]), valid=t(b["new_valid"]),
                            index_map=t(b["new_index_map"]), time=int(b["time"]))
+    state = STATE
+    if okw.get("_seg"):
+        state = STATE + SEG_STATE
+        me.hard_seg = bool(okw.get("_hard", False))
+        me.power_arg = (1 / 2, 1 / 2)                              # nodes.py:99
+        me.seg, me.seg_conf, me.dist2edge = t(b["sf_seg"]), t(b["sf_seg_conf"]), t(b["sf_dist2edge"])
+        ed.seg, ed.seg_conf = t(b["ed_seg"]), t(b["ed_seg_conf"])
+        sfdata.seg, sfdata.seg_conf, sfdata.dist2edge = t(b["new_seg"]), t(b["new_seg_conf"]), t(b["new_dist2edge"])
     out = {}
     if okw.get("_track"):
         me.track_pts = {}
@@ -109,13 +140,13 @@ def run_reference(ref, b, okw):
     if okw.get("_track"):
         out["fuse_track_id"] = me.track_id.cpu().numpy().copy()
         me.evaluate_tracking = True
-    for k in STATE:
+    for k in state:
         out["fuse_" + k] = getattr(me, k).detach().cpu().numpy().copy()
     ref.nodes.Surfels.prepareStableIndexNSwapAllModel(me, inputs, sfdata)
     if okw.get("_track"):
         out["swap_track_id"] = me.track_id.cpu().numpy().copy()
     if okw.get("_store_swap", True):
-        for k in STATE:
+        for k in state:
             out["swap_" + k] = getattr(me, k).detach().cpu().numpy().copy()
     else:
         out["swap_count"] = np.array(len(me.points))

@@ -71,6 +71,7 @@ def test_every_struct_matches_the_header_as_compiled_by_gcc(tmp_path):
              "slm_depth_config": _lib.SlmDepthConfig, "slm_depth_inputs": _lib.SlmDepthInputs,
              "slm_depth_outputs": _lib.SlmDepthOutputs, "slm_fuse_config": _lib.SlmFuseConfig,
              "slm_surfel_model": _lib.SlmSurfelModel, "slm_new_frame": _lib.SlmNewFrame,
+             "slm_fuse_semantic": _lib.SlmFuseSemantic,
              "slm_graph_outputs": _lib.SlmGraphOutputs}
     src = tmp_path / "sizes.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in pairs)

@@ -19,16 +19,24 @@ VARIANTS = {
     "noadd": dict(disable_adding_new_surfels=True, th_dist=0.008),
     "keepall": dict(disable_removing_unstable_surfels=True, th_dist=0.02),
     "track": dict(th_dist=0.02),
+    "sem": dict(method="semantic-super", num_classes=3, th_dist=0.02),
+    "hard": dict(method="semantic-super", num_classes=3, th_dist=0.02, hard_seg=True),
+    "v1seg": dict(data="superv1", num_classes=3, th_dist=0.02),
 }
+SEG = ("sem", "hard", "v1seg")
 STATE = ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable", "knn_indices", "knn_w", "projdata")
 
 
-def load(g):
+def load(g, seg=False):
     b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    kw = dict(seg=b["sf_seg"], seg_conf=b["sf_seg_conf"], dist2edge=b["sf_dist2edge"], ed_seg=b["ed_seg"],
+              ed_seg_conf=b["ed_seg_conf"]) if seg else {}
     m = fuo.Model(b["sf_points"], b["sf_norms"], b["sf_colors"], b["sf_radii"], b["sf_confs"], b["sf_time_stamp"],
-                  b["sf_isStable"], b["sf_knn_idx"], b["sf_knn_w"], b["ed_points"], b["ed_radii"])
+                  b["sf_isStable"], b["sf_knn_idx"], b["sf_knn_w"], b["ed_points"], b["ed_radii"], **kw)
     new = SimpleNamespace(points=b["new_points"], norms=b["new_norms"], colors=b["new_colors"], radii=b["new_radii"],
                           confs=b["new_confs"], valid=b["new_valid"])
+    if seg:
+        new.seg, new.seg_conf, new.dist2edge = b["new_seg"], b["new_seg_conf"], b["new_dist2edge"]
     return b, m, new
 
 
@@ -44,12 +52,16 @@ def check(m, g, prefix):
     np.testing.assert_allclose(m.colors, g[prefix + "colors"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(m.knn_w, g[prefix + "knn_w"], rtol=0, atol=1e-13)
     np.testing.assert_allclose(m.projdata, g[prefix + "projdata"], rtol=0, atol=1e-4)
+    if prefix + "seg" in g.files:
+        np.testing.assert_array_equal(m.seg, g[prefix + "seg"])
+        np.testing.assert_allclose(m.seg_conf, g[prefix + "seg_conf"], rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(m.dist2edge, g[prefix + "dist2edge"])
 
 
 @pytest.mark.parametrize("tag", list(VARIANTS))
 def test_fusion_matches_reference(tag):
     g = np.load(GOLD)
-    b, m, new = load(g)
+    b, m, new = load(g, seg=tag in SEG)
     opt = fuo.default_opt(height=int(b["H"]), width=int(b["W"]), **VARIANTS[tag])
     tid = b["track_id"].copy() if tag == "track" else None
     fuo.fuse_input_data(m, opt, b["K"], new, int(b["time"]), track_id=tid)
@@ -75,6 +87,23 @@ def test_fixture_exercises_layers_merges_and_additions():
     assert (b["sf_isStable"] & ~fused[:n0]).sum() > 50       # surfels merged into others and deleted
     assert (g["default_fuse_confs"][:n0] != b["sf_confs"]).sum() > 500     # new points merged into surfels
     assert len(g["tight_fuse_points"]) > len(g["default_fuse_points"])     # a tighter test adds more surfels
+
+
+def test_semantic_fixture_exercises_class_test_and_weights():
+    g = np.load(GOLD)
+    b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    n0 = len(b["sf_points"])
+    # fused segmentation confidences differ from the inputs and flip some classes
+    assert (np.abs(g["sem_fuse_seg_conf"][:n0] - b["sf_seg_conf"]).max(1) > 1e-3).sum() > 300
+    assert (g["sem_fuse_seg"][:n0] != b["sf_seg"]).sum() > 0
+    # Jensen-Shannon weights differ from the plain ones; the class test rejects merges (more new surfels)
+    assert np.abs(g["sem_fuse_knn_w"][:n0] - g["track_fuse_knn_w"][:n0]).max() > 1e-3
+    assert len(g["hard_fuse_points"]) > len(g["sem_fuse_points"])
+    assert len(g["v1seg_fuse_points"]) > len(g["sem_fuse_points"])
+    # hard_seg: every new surfel's nodes have its class
+    new_rows = slice(n0, None)
+    cls = b["ed_seg"][g["hard_fuse_knn_indices"][new_rows]]
+    assert (cls == g["hard_fuse_seg"][new_rows][:, None]).all()
 
 
 def test_tracking_ground_truth_format_and_error(tmp_path):

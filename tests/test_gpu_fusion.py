@@ -6,12 +6,12 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
-from test_fusion_oracle import GOLD, VARIANTS
+from test_fusion_oracle import GOLD, SEG, VARIANTS
 
 pytestmark = pytest.mark.gpu
 
 
-def _objects(b, okw):
+def _objects(b, okw, seg=False):
     import torch
     t = lambda a: torch.from_numpy(np.array(a, copy=True)).cuda()
     opt = SimpleNamespace(height=int(b["H"]), width=int(b["W"]), th_dist=0.1, th_cosine_ang=0.4, th_time_steps=30,
@@ -30,6 +30,11 @@ def _objects(b, okw):
     sfdata = SimpleNamespace(points=t(b["new_points"]), norms=t(b["new_norms"]), colors=t(b["new_colors"]),
                              radii=t(b["new_radii"]), confs=t(b["new_confs"]), valid=t(b["new_valid"]),
                              index_map=t(b["new_index_map"]), time=int(b["time"]))
+    if seg:
+        sf.hard_seg = bool(okw.get("hard_seg", False))
+        sf.seg, sf.seg_conf, sf.dist2edge = t(b["sf_seg"]), t(b["sf_seg_conf"]), t(b["sf_dist2edge"])
+        sf.ED_nodes.seg, sf.ED_nodes.seg_conf = t(b["ed_seg"]), t(b["ed_seg_conf"])
+        sfdata.seg, sfdata.seg_conf, sfdata.dist2edge = t(b["new_seg"]), t(b["new_seg_conf"]), t(b["new_dist2edge"])
     return sf, inputs, sfdata
 
 
@@ -46,6 +51,12 @@ def _check(sf, g, prefix):
     np.testing.assert_allclose(get("colors"), g[prefix + "colors"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(get("knn_w"), g[prefix + "knn_w"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(get("projdata"), g[prefix + "projdata"], rtol=0, atol=1e-4)
+    if prefix + "seg" in (g.files if hasattr(g, "files") else g):
+        import torch
+        assert sf.seg.dtype == torch.long and sf.seg_conf.dtype == torch.float64
+        np.testing.assert_array_equal(get("seg"), g[prefix + "seg"])
+        np.testing.assert_allclose(get("seg_conf"), g[prefix + "seg_conf"], rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(get("dist2edge"), g[prefix + "dist2edge"])
 
 
 @pytest.mark.parametrize("tag", list(VARIANTS))
@@ -53,7 +64,7 @@ def test_fusion_matches_reference_goldens(tag):
     from super_amd import fusion
     g = np.load(GOLD)
     b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
-    sf, inputs, sfdata = _objects(b, VARIANTS[tag])
+    sf, inputs, sfdata = _objects(b, VARIANTS[tag], seg=tag in SEG)
     if tag == "track":
         import torch
         sf.track_pts, sf.evaluate_tracking = {}, False
@@ -127,13 +138,16 @@ def test_tracked_points_follow_the_surface_through_the_driver():
         assert 0 <= err[live.cpu().numpy()].max() < 4.0, (name, err)
 
 
-def test_fusion_full_size_matches_oracle():
+@pytest.mark.parametrize("mode", ["plain", "sem", "hard"])
+def test_fusion_full_size_matches_oracle(mode):
     """480x640 frame, 120k surfels (with duplicated surfels so that pixels carry several layers),
-    2k nodes: fuse + swap on the device == the NumPy oracle; the fused model is a valid LM input."""
+    2k nodes: fuse + swap on the device == the NumPy oracle; the fused model is a valid LM input.
+    `sem` / `hard`: Semantic-SuPer segmentation fields, Jensen-Shannon weights, class-restricted neighbours."""
     import torch
     from oracle import fusion_oracle as fuo
     from super_amd import fusion, synth
-    sc = synth.make_scene(N=100_000, J=2000, H=480, W=640, seed=5, tgt_holes=0.01)
+    seg = mode != "plain"
+    sc = synth.make_scene(N=100_000, J=2000, H=480, W=640, seed=5, tgt_holes=0.01, semantic=seg, num_classes=3)
     rng = np.random.default_rng(5)
     P0, N0 = sc.f64("sf_points"), sc.f64("sf_norms")
     dup = rng.choice(sc.N, 20_000, replace=False)
@@ -152,24 +166,64 @@ def test_fusion_full_size_matches_oracle():
              new_radii=rng.uniform(0.002, 0.004, sc.T), new_confs=rng.uniform(0.05, 1.0, sc.T).astype(np.float32),
              new_valid=sc.valid, new_index_map=sc.index_map, time=41)
     okw = dict(th_dist=0.006, th_cosine_ang=0.8)
-    sf, inputs, sfdata = _objects(b, okw)
+    kw = {}
+    if seg:
+        okw.update(method="semantic-super", num_classes=3, hard_seg=mode == "hard")
+
+        def noisy(c):
+            c = np.asarray(c, np.float64) + rng.uniform(0, 0.3, np.shape(c))
+            return c / c.sum(1, keepdims=True)
+
+        sf_conf = noisy(np.concatenate([sc.sf_seg_conf, sc.sf_seg_conf[dup]]))
+        new_conf = noisy(sc.tgt_seg_conf)
+        # ED nodes: class distribution of the pixel they project to
+        e = np.exp(sc.img_seg_conf.astype(np.float64))
+        img = e / e.sum(0, keepdims=True)
+        g_ = sc.f64("ed_points")
+        u = np.clip(np.rint(g_[:, 0] * sc.K[0, 0] / g_[:, 2] + sc.K[0, 2]).astype(int), 0, sc.W - 1)
+        v = np.clip(np.rint(g_[:, 1] * sc.K[1, 1] / g_[:, 2] + sc.K[1, 2]).astype(int), 0, sc.H - 1)
+        ed_conf = noisy(img[:, v, u].T)
+        b.update(sf_seg=np.argmax(sf_conf, 1), sf_seg_conf=sf_conf, sf_dist2edge=rng.uniform(0, 20, n),
+                 new_seg=np.argmax(new_conf, 1), new_seg_conf=new_conf, new_dist2edge=rng.uniform(0, 20, sc.T),
+                 ed_seg=np.argmax(ed_conf, 1), ed_seg_conf=ed_conf)
+        assert np.bincount(b["ed_seg"], minlength=3).min() >= 4
+        kw = dict(seg=b["sf_seg"], seg_conf=b["sf_seg_conf"], dist2edge=b["sf_dist2edge"], ed_seg=b["ed_seg"],
+                  ed_seg_conf=b["ed_seg_conf"])
+    sf, inputs, sfdata = _objects(b, okw, seg=seg)
     fusion.fuseInputData(sf, inputs, sfdata)
     m = fuo.Model(b["sf_points"], b["sf_norms"], b["sf_colors"], b["sf_radii"], b["sf_confs"], b["sf_time_stamp"],
-                  b["sf_isStable"], b["sf_knn_idx"], b["sf_knn_w"], b["ed_points"], b["ed_radii"])
+                  b["sf_isStable"], b["sf_knn_idx"], b["sf_knn_w"], b["ed_points"], b["ed_radii"], **kw)
     new = SimpleNamespace(points=b["new_points"], norms=b["new_norms"], colors=b["new_colors"], radii=b["new_radii"],
                           confs=b["new_confs"], valid=b["new_valid"])
+    if seg:
+        new.seg, new.seg_conf, new.dist2edge = b["new_seg"], b["new_seg_conf"], b["new_dist2edge"]
     opt = fuo.default_opt(height=sc.H, width=sc.W, **okw)
     fuo.fuse_input_data(m, opt, b["K"], new, 41)
-    ref = {"x_" + k: getattr(m, k) for k in ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable",
-                                              "knn_indices", "knn_w", "projdata")}
+    names = ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable", "knn_indices", "knn_w",
+             "projdata") + (("seg", "seg_conf", "dist2edge") if seg else ())
+    ref = {"x_" + k: getattr(m, k) for k in names}
     _check(sf, ref, "x_")
     assert len(sf.points) > n and (~sf.isStable[:n].cpu().numpy() & b["sf_isStable"]).sum() > 1000
     fusion.prepareStableIndexNSwapAllModel(sf, inputs, sfdata)
     fuo.swap_stable(m, opt, 41)
-    _check(sf, {"y_" + k: getattr(m, k) for k in ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable",
-                                                    "knn_indices", "knn_w", "projdata")}, "y_")
+    _check(sf, {"y_" + k: getattr(m, k) for k in names}, "y_")
     w = sf.knn_w.cpu().numpy()
     np.testing.assert_allclose(w.sum(1), 1.0, rtol=0, atol=1e-12)
+
+
+def test_hard_seg_with_too_few_nodes_of_a_class_fails_loudly():
+    """The reference asserts len(p2) >= k per class (utils/utils.py:237); the device path reports it."""
+    from super_amd import fusion
+    from super_amd._lib import SuperLMError
+    g = np.load(GOLD)
+    b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    b["ed_seg"] = b["ed_seg"].copy()
+    keep = np.nonzero(b["ed_seg"] == 2)[0][:3]
+    b["ed_seg"][b["ed_seg"] == 2] = 0
+    b["ed_seg"][keep] = 2                      # class 2 keeps 3 nodes only
+    sf, inputs, sfdata = _objects(b, VARIANTS["hard"], seg=True)
+    with pytest.raises(SuperLMError, match="at least 4 ED nodes"):
+        fusion.fuseInputData(sf, inputs, sfdata)
 
 
 def test_whole_frame_pipeline_depth_lm_update_fusion():
