@@ -228,6 +228,20 @@ int slm_knn_weights(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* i
                     const float* dist, const float* node_radii, float* w_out,
                     uint8_t* stable_io, void* stream);
 
+/* float64 feeder with the Semantic-SuPer branches (the reference's tensors are float64):
+ * q_seg / node_seg (both or neither): a query only sees the nodes of its own class -- find_knn with
+ * num_classes, utils/utils.py:223-242, used by update_ed / update_sfed_knn under hard_seg
+ * (super/nodes.py:157-160,172-175); a class with fewer nodes than asked for is an error like the
+ * reference's assert (the call synchronises `stream` in that mode).  dist (Nq,K) float64. */
+int slm_knn_f64(int32_t Nq, int32_t Nn, int32_t K, int32_t skip_self, const double* query_points,
+                const double* node_points, const int32_t* q_seg, const int32_t* node_seg, int32_t* idx_out,
+                double* dist_out, void* stream);
+/* As slm_knn_weights in float64; num_classes > 0 with q_seg_conf (Nq,C) and node_seg_conf (Nn,C):
+ * softmax(exp(-JSD(node, query))^(1/2) * exp(-dist/radius)^(1/2)), super/nodes.py:183-189. */
+int slm_knn_weights_f64(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* idx, const double* dist,
+                        const double* node_radii, int32_t num_classes, const double* q_seg_conf,
+                        const double* node_seg_conf, double* w_out, uint8_t* stable_io, void* stream);
+
 /* =====================================================================================
  * The reference's DEFAULT per-frame optimiser (no --use_derived_gradient): GraphFit,
  * autograd + SGD(momentum 0.9) / Adam over (J+1,7) rows, last row = global transform T_g.

@@ -155,6 +155,36 @@ def class_knn(points, seg, nodes, node_seg, k, num_classes):
     return dist, idx
 
 
+def update_ed(ed_points, ed_radii, opt, hard_seg=False, ed_seg=None):
+    """``Surfels.update_ed`` (nodes.py:154-168): K_ED nearest other nodes (of the node's own class with
+    ``hard_seg``), weights ``softmax(exp(-d / radius_self))``.  Returns (knn_indices, knn_w)."""
+    k = opt.num_ED_neighbors + 1
+    if hard_seg:
+        dist, idx = class_knn(ed_points, ed_seg, ed_points, ed_seg, k, opt.num_classes)
+    else:
+        dist, idx = orc.knn(ed_points, ed_points, k)
+    dist, idx = dist[:, 1:] / np.asarray(ed_radii, np.float64)[:, None], idx[:, 1:]
+    e = np.exp(-dist)
+    e = np.exp(e - e.max(-1, keepdims=True))
+    return idx, e / e.sum(-1, keepdims=True)
+
+
+def update_sfed_knn(points, is_stable, ed_points, ed_radii, opt, hard_seg=False, seg=None, seg_conf=None, ed_seg=None,
+                    ed_seg_conf=None):
+    """``Surfels.update_sfed_knn`` (nodes.py:170-191).  Returns (knn_indices, knn_w, isStable)."""
+    if hard_seg:
+        dist, idx = class_knn(points, seg, ed_points, ed_seg, opt.num_neighbors, opt.num_classes)
+    else:
+        dist, idx = orc.knn(points, ed_points, opt.num_neighbors)
+    rad = np.asarray(ed_radii, np.float64)[idx]
+    stable = np.array(is_stable, bool) & (dist <= rad).any(1)
+    if opt.method == "semantic-super" and not hard_seg:
+        w = semantic_weights(dist, rad, np.asarray(ed_seg_conf)[idx], np.asarray(seg_conf)[:, None, :])
+    else:
+        w = orc.knn_weights(dist, rad)
+    return idx, w, stable
+
+
 def fuse_input_data(m: Model, opt, K, new, time, track_id=None):
     """``fuseInputData``.  ``new`` has points, norms, colors, radii, confs (T rows), valid (H*W).
     ``track_id`` (tracked evaluation points, modified in place): ids follow the surfel that absorbs

@@ -38,6 +38,10 @@ void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
 void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
                    hipStream_t);
 void launch_knn(int, int, int, int, const float*, const float*, int*, float*, hipStream_t);
+void launch_knn64(int, int, int, int, const double*, const double*, const int*, const int*, int*, double*, int*,
+                  hipStream_t);
+void launch_knn_weights64(int, int, int, const int*, const double*, const double*, int, const double*, const double*,
+                          double*, uint8_t*, hipStream_t);
 void launch_knn_weights(int, int, int, const int*, const float*, const float*, float*, uint8_t*,
                         hipStream_t);
 
@@ -964,6 +968,42 @@ int slm_knn_weights(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* i
   if (Nq < 0 || K < 1 || K > 9 || !idx || !dist || !radii || !w)
     return fail(SLM_ERR_INVALID, "slm_knn_weights: bad argument");
   launch_knn_weights(Nq, K, radius_mode, idx, dist, radii, w, stable, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_knn_f64(int32_t Nq, int32_t Nn, int32_t K, int32_t skip_self, const double* q, const double* nodes,
+                const int32_t* q_seg, const int32_t* node_seg, int32_t* idx, double* dist, void* stream) {
+  if (Nq < 0 || Nn < 1 || K < 1 || K + (skip_self ? 1 : 0) > 9 || !nodes || !idx || !dist || (Nq > 0 && !q) ||
+      ((q_seg == nullptr) != (node_seg == nullptr)))
+    return fail(SLM_ERR_INVALID, "slm_knn_f64: bad argument (K + skip_self <= 9; both class arrays or none)");
+  hipStream_t st = (hipStream_t)stream;
+  int* counter = nullptr;
+  if (q_seg) {
+    HIPCHK(hipMalloc((void**)&counter, sizeof(int)));
+    HIPCHK(hipMemsetAsync(counter, 0, sizeof(int), st));
+  }
+  launch_knn64(Nq, Nn, K, skip_self, q, nodes, q_seg, node_seg, idx, dist, counter, st);
+  HIPCHK(hipGetLastError());
+  if (counter) {
+    int n_short = 0;
+    HIPCHK(hipMemcpyAsync(&n_short, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(counter));
+    if (n_short > 0)
+      return fail(SLM_ERR_INVALID, "slm_knn_f64: a class has fewer nodes than the neighbours asked for");
+  }
+  return SLM_OK;
+}
+
+int slm_knn_weights_f64(int32_t Nq, int32_t K, int32_t radius_mode, const int32_t* idx, const double* dist,
+                        const double* radii, int32_t num_classes, const double* q_seg_conf,
+                        const double* node_seg_conf, double* w, uint8_t* stable, void* stream) {
+  if (Nq < 0 || K < 1 || K > 9 || !idx || !dist || !radii || !w || num_classes < 0 || num_classes > SLM_MAX_CLASSES ||
+      (num_classes > 0 && (!q_seg_conf || !node_seg_conf)))
+    return fail(SLM_ERR_INVALID, "slm_knn_weights_f64: bad argument");
+  launch_knn_weights64(Nq, K, radius_mode, idx, dist, radii, num_classes, q_seg_conf, node_seg_conf, w, stable,
+                       (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }

@@ -348,6 +348,117 @@ __global__ void __launch_bounds__(256) k_knn_weights(int Nq, int K, int radius_m
   if (stable_io && !any_in) stable_io[i] = 0;
 }
 
+// float64 variant of the feeder with the Semantic-SuPer branches (find_knn with num_classes,
+// utils/utils.py:223-242: a query only sees the nodes of its own class; weights with the
+// Jensen-Shannon factor, super/nodes.py:183-189).  counter[0] counts queries that found fewer than
+// K (+ self) nodes of their class -- the reference asserts on those.
+__global__ void __launch_bounds__(256) k_knn64(int Nq, int Nn, int K, int skip_self, const double* __restrict__ q,
+                                                const double* __restrict__ nodes, const int* __restrict__ q_seg,
+                                                const int* __restrict__ node_seg, int* __restrict__ idx_out,
+                                                double* __restrict__ dist_out, int* __restrict__ counter) {
+  __shared__ double sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
+  __shared__ int sc[KNN_TILE];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool by_class = q_seg != nullptr && node_seg != nullptr;
+  double bd[KNN_MAXK];
+  int bi[KNN_MAXK];
+#pragma unroll
+  for (int k = 0; k < KNN_MAXK; ++k) {
+    bd[k] = 1e300;
+    bi[k] = -1;
+  }
+  double px = 0, py = 0, pz = 0;
+  int cls = 0;
+  if (i < Nq) {
+    px = q[3 * (size_t)i];
+    py = q[3 * (size_t)i + 1];
+    pz = q[3 * (size_t)i + 2];
+    if (by_class) cls = q_seg[i];
+  }
+  for (int base = 0; base < Nn; base += KNN_TILE) {
+    const int cnt = min(KNN_TILE, Nn - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+      sx[t] = nodes[3 * (size_t)(base + t)];
+      sy[t] = nodes[3 * (size_t)(base + t) + 1];
+      sz[t] = nodes[3 * (size_t)(base + t) + 2];
+      if (by_class) sc[t] = node_seg[base + t];
+    }
+    __syncthreads();
+    if (i < Nq) {
+      for (int t = 0; t < cnt; ++t) {
+        if (by_class && sc[t] != cls) continue;
+        const double dx = px - sx[t], dy = py - sy[t], dz = pz - sz[t];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < bd[KNN_MAXK - 1]) {
+          double cd = d2;
+          int ci = base + t;
+#pragma unroll
+          for (int k = 0; k < KNN_MAXK; ++k) {
+            if (cd < bd[k]) {
+              const double td = bd[k];
+              const int ti = bi[k];
+              bd[k] = cd;
+              bi[k] = ci;
+              cd = td;
+              ci = ti;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (i < Nq) {
+    const int off = skip_self ? 1 : 0;
+    bool short_of = false;
+    for (int k = 0; k < K; ++k) {
+      idx_out[(size_t)i * K + k] = bi[k + off];
+      dist_out[(size_t)i * K + k] = sqrt(bd[k + off]);
+      short_of = short_of || bi[k + off] < 0;
+    }
+    if (short_of && counter) atomicAdd(counter, 1);
+  }
+}
+
+// weights in float64; q_seg_conf / node_seg_conf (C columns) switch on the Jensen-Shannon factor
+__global__ void __launch_bounds__(256) k_knn_weights64(int Nq, int K, int radius_mode, const int* __restrict__ idx,
+                                                        const double* __restrict__ dist, const double* __restrict__ radii,
+                                                        int C, const double* __restrict__ q_seg_conf,
+                                                        const double* __restrict__ node_seg_conf,
+                                                        double* __restrict__ w_out, uint8_t* __restrict__ stable_io) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Nq) return;
+  double e[KNN_MAXK];
+  double emax = -1e300;
+  bool any_in = false;
+  for (int k = 0; k < K; ++k) {
+    const int j = idx[(size_t)i * K + k];
+    const double r = radii[radius_mode == 0 ? j : i];
+    const double d = dist[(size_t)i * K + k];
+    any_in = any_in || (d <= r);
+    e[k] = exp(-d / r);
+    if (C > 0) {
+      const double* P = node_seg_conf + (size_t)C * j;
+      const double* Q = q_seg_conf + (size_t)C * i;
+      double a = 0.0, b = 0.0;
+      for (int c = 0; c < C; ++c) {
+        const double M = 0.5 * (P[c] + Q[c]);
+        a += P[c] * log(P[c] / (M + 1e-13) + 1e-13);
+        b += Q[c] * log(Q[c] / (M + 1e-13) + 1e-13);
+      }
+      e[k] = sqrt(exp(-0.5 * (a + b))) * sqrt(e[k]);
+    }
+    emax = fmax(emax, e[k]);
+  }
+  double s = 0.0;
+  for (int k = 0; k < K; ++k) {
+    e[k] = exp(e[k] - emax);
+    s += e[k];
+  }
+  for (int k = 0; k < K; ++k) w_out[(size_t)i * K + k] = e[k] / s;
+  if (stable_io && !any_in) stable_io[i] = 0;
+}
+
 // ---- host launchers --------------------------------------------------------------
 void launch_init_slot(const FrameDev* frames_dev, int slot, int J, const slm_config& cfg,
                       hipStream_t st) {
@@ -403,6 +514,21 @@ void launch_knn(int Nq, int Nn, int K, int skip_self, const float* q, const floa
   if (Nq <= 0) return;
   hipLaunchKernelGGL(k_knn, dim3((Nq + 255) / 256), dim3(256), 0, st, Nq, Nn, K, skip_self, q, nodes,
                      idx, dist);
+}
+
+void launch_knn64(int Nq, int Nn, int K, int skip_self, const double* q, const double* nodes, const int* q_seg,
+                  const int* node_seg, int* idx, double* dist, int* counter, hipStream_t st) {
+  if (Nq <= 0) return;
+  hipLaunchKernelGGL(k_knn64, dim3((Nq + 255) / 256), dim3(256), 0, st, Nq, Nn, K, skip_self, q, nodes, q_seg,
+                     node_seg, idx, dist, counter);
+}
+
+void launch_knn_weights64(int Nq, int K, int radius_mode, const int* idx, const double* dist, const double* radii,
+                          int C, const double* q_conf, const double* node_conf, double* w, uint8_t* stable,
+                          hipStream_t st) {
+  if (Nq <= 0) return;
+  hipLaunchKernelGGL(k_knn_weights64, dim3((Nq + 255) / 256), dim3(256), 0, st, Nq, K, radius_mode, idx, dist,
+                     radii, C, q_conf, node_conf, w, stable);
 }
 
 void launch_knn_weights(int Nq, int K, int radius_mode, const int* idx, const float* dist,

@@ -25,7 +25,7 @@ EXPORTS = [
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
-    "slm_fuse_bind_semantic",
+    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -178,6 +178,8 @@ def load():
         "slm_apply_update": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
         "slm_knn": [i32, i32, i32, i32, vp, vp, vp, vp, vp],
         "slm_knn_weights": [i32, i32, i32, vp, vp, vp, vp, vp, vp],
+        "slm_knn_f64": [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+        "slm_knn_weights_f64": [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp],
         "slm_gf_create": [C.POINTER(SlmGfConfig), C.POINTER(vp)],
         "slm_gf_destroy": [vp],
         "slm_gf_bind_frame": [vp, i32, C.POINTER(SlmGfFrame), vp],

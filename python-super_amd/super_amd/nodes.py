@@ -3,7 +3,11 @@
 * :func:`update`          <- ``Surfels.update``            (``super/nodes.py:193-223``)
 * :func:`update_sfed_knn` <- ``Surfels.update_sfed_knn``   (``super/nodes.py:170-191``)
 * :func:`update_ed`       <- ``Surfels.update_ed``         (``super/nodes.py:154-168``)
-* :func:`find_knn`        <- ``utils.utils.find_knn``      (``utils/utils.py:212-221``)
+* :func:`find_knn`        <- ``utils.utils.find_knn``      (``utils/utils.py:212-242``)
+
+``update_ed`` / ``update_sfed_knn`` follow the Semantic-SuPer branches too: with ``sf.hard_seg`` the
+neighbours come from the nodes of the point's own class, with ``opt.method == "semantic-super"`` (and no
+``hard_seg``) the surfel weights carry the Jensen-Shannon factor (``super/nodes.py:157-160,172-189``).
 
 Each takes the reference's ``sf`` object (anything with the same attributes), runs the
 HIP kernels through the C ABI and writes the results back with the reference's
@@ -18,12 +22,23 @@ from . import _lib
 from .LM import _as, _dev_ptr, _stream_ptr
 
 
-def find_knn(points1, points2, k=20, skip_self=False):
+def find_knn(points1, points2, num_classes=-1, seg1=None, seg2=None, k=20, skip_self=False):
     """K nearest rows of ``points2`` for each row of ``points1``: returns
     ``(dists (N,k) float64 = sqrt(d2), idx (N,k) int64)``, squared-L2 ascending,
-    ties -> lowest index."""
+    ties -> lowest index.  ``num_classes > 0`` with ``seg1`` / ``seg2``: neighbours among the rows of
+    the query's own class (float64 kernel; a class with fewer than k rows raises like the reference's
+    assert)."""
     lib = _lib.load()
     dev = points1.device
+    if num_classes > 0:
+        q = _as(points1, torch.float64, dev)
+        n = _as(points2, torch.float64, dev)
+        s1, s2 = _as(seg1, torch.int32, dev), _as(seg2, torch.int32, dev)
+        idx = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
+        dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=dev)
+        _lib.check(lib.slm_knn_f64(q.shape[0], n.shape[0], k, int(skip_self), _dev_ptr(q), _dev_ptr(n), _dev_ptr(s1),
+                                   _dev_ptr(s2), _dev_ptr(idx), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn_f64")
+        return dist, idx.to(torch.int64)
     q = _as(points1, torch.float32, dev)
     n = _as(points2, torch.float32, dev)
     idx = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
@@ -50,11 +65,38 @@ def _weights(idx, dist, radii, radius_mode, stable=None):
     return w, st8
 
 
+def _weights64(idx, dist, radii, radius_mode, stable=None, q_conf=None, node_conf=None):
+    """float64 weights, optionally with the Jensen-Shannon factor of Semantic-SuPer."""
+    lib = _lib.load()
+    dev = idx.device
+    idx32 = _as(idx, torch.int32, dev)
+    d = _as(dist, torch.float64, dev)
+    r = _as(radii, torch.float64, dev)
+    w = torch.empty(idx.shape, dtype=torch.float64, device=dev)
+    st8 = _as(stable, torch.uint8, dev).clone() if stable is not None else None
+    C_ = 0
+    if q_conf is not None:
+        q_conf, node_conf = _as(q_conf, torch.float64, dev), _as(node_conf, torch.float64, dev)
+        C_ = int(q_conf.shape[1])
+    _lib.check(lib.slm_knn_weights_f64(idx.shape[0], idx.shape[1], radius_mode, _dev_ptr(idx32), _dev_ptr(d),
+                                       _dev_ptr(r), C_, _dev_ptr(q_conf) if C_ else None,
+                                       _dev_ptr(node_conf) if C_ else None, _dev_ptr(w),
+                                       _dev_ptr(st8) if st8 is not None else None, _stream_ptr(dev)),
+               "slm_knn_weights_f64")
+    return w, st8
+
+
 def update_ed(sf):
     """Node-node KNN + ``softmax(exp(-dist/radius_self))`` weights (K_ED+1 nearest, self
-    dropped)."""
+    dropped); with ``sf.hard_seg`` among the nodes of the node's own class."""
     ed = sf.ED_nodes
     k = int(sf.opt.num_ED_neighbors)
+    if getattr(sf, "hard_seg", False):
+        dist, idx = find_knn(ed.points, ed.points, num_classes=int(sf.opt.num_classes), seg1=ed.seg, seg2=ed.seg,
+                             k=k, skip_self=True)
+        w, _ = _weights64(idx, dist, ed.radii, 1)
+        ed.knn_w, ed.knn_indices = w, idx
+        return
     dist, idx = find_knn(ed.points, ed.points, k=k, skip_self=True)
     w, _ = _weights(idx, dist, ed.radii, 1)
     ed.knn_w = w.to(torch.float64)
@@ -63,9 +105,29 @@ def update_ed(sf):
 
 def update_sfed_knn(sf):
     """Surfel-node KNN, stability test ``any(dist <= radius)`` and
-    ``softmax(exp(-dist/radius))`` weights."""
+    ``softmax(exp(-dist/radius))`` weights (Semantic-SuPer: class-restricted neighbours under
+    ``hard_seg``, Jensen-Shannon weights otherwise)."""
     ed = sf.ED_nodes
     k = int(sf.opt.num_neighbors)
+    hard = bool(getattr(sf, "hard_seg", False))
+    soft = getattr(sf.opt, "method", "super") == "semantic-super" and not hard
+    if hard or soft:
+        if hard:
+            dist, idx = find_knn(sf.points, ed.points, num_classes=int(sf.opt.num_classes), seg1=sf.seg, seg2=ed.seg, k=k)
+        else:
+            # float64 distances for the float64 weights
+            lib = _lib.load()
+            dev = sf.points.device
+            q, n = _as(sf.points, torch.float64, dev), _as(ed.points, torch.float64, dev)
+            idx32 = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
+            dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=dev)
+            _lib.check(lib.slm_knn_f64(q.shape[0], n.shape[0], k, 0, _dev_ptr(q), _dev_ptr(n), None, None,
+                                       _dev_ptr(idx32), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn_f64")
+            idx = idx32.to(torch.int64)
+        w, st8 = _weights64(idx, dist, ed.radii, 0, stable=sf.isStable,
+                            q_conf=sf.seg_conf if soft else None, node_conf=ed.seg_conf if soft else None)
+        sf.knn_indices, sf.knn_w, sf.isStable = idx, w, st8.to(torch.bool)
+        return
     dist, idx = find_knn(sf.points, ed.points, k=k)
     w, st8 = _weights(idx, dist, ed.radii, 0, stable=sf.isStable)
     sf.knn_indices = idx

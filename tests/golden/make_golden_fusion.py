@@ -153,10 +153,34 @@ def run_reference(ref, b, okw):
     return out
 
 
+KNN_MODES = {"plain": dict(), "sem": dict(method="semantic-super"), "hard": dict(method="semantic-super", _hard=True)}
+
+
+def run_knn(ref, b, okw):
+    """``Surfels.update_ed`` + ``update_sfed_knn`` (super/nodes.py:154-191) as run once at frame 0, with the
+    Semantic-SuPer branches (class-restricted neighbours, Jensen-Shannon weights)."""
+    t = lambda a: torch.from_numpy(np.array(a, copy=True))
+    opt = SimpleNamespace(method=okw.get("method", "super"), num_neighbors=4, num_ED_neighbors=4,
+                          num_classes=int(b["num_classes"]))
+    ed = ref_shim.Data(points=t(b["ed_points"]), radii=t(b["ed_radii"]), seg=t(b["ed_seg"]), seg_conf=t(b["ed_seg_conf"]))
+    n = len(b["sf_points"])
+    me = SimpleNamespace(opt=opt, hard_seg=bool(okw.get("_hard", False)), power_arg=(1 / 2, 1 / 2), ED_nodes=ed,
+                         points=t(b["sf_points"]), seg=t(b["sf_seg"]), seg_conf=t(b["sf_seg_conf"]),
+                         isStable=torch.ones(n, dtype=torch.bool))
+    ref.nodes.Surfels.update_ed(me)
+    ref.nodes.Surfels.update_sfed_knn(me)
+    return dict(sf_idx=me.knn_indices.numpy(), sf_w=me.knn_w.numpy(), sf_stable=me.isStable.numpy(),
+                ed_idx=ed.knn_indices.numpy(), ed_w=ed.knn_w.numpy())
+
+
 def main():
     ref = ref_shim.install()
     base = make_inputs()
     g = {"in_" + k: v for k, v in base.items()}
+    for tag, okw in KNN_MODES.items():
+        for k, v in run_knn(ref, base, okw).items():
+            g[f"knn_{tag}_{k}"] = v
+        print("knn", tag, "unstable", int((~g[f"knn_{tag}_sf_stable"]).sum()))
     for tag, okw in VARIANTS.items():
         out = run_reference(ref, base, okw)
         for k, v in out.items():

@@ -106,6 +106,27 @@ def test_semantic_fixture_exercises_class_test_and_weights():
     assert (cls == g["hard_fuse_seg"][new_rows][:, None]).all()
 
 
+@pytest.mark.parametrize("mode", ["plain", "sem", "hard"])
+def test_knn_feeder_matches_reference(mode):
+    """update_ed / update_sfed_knn at frame 0 incl. the Semantic-SuPer branches (nodes.py:154-191)."""
+    g = np.load(GOLD)
+    b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    opt = SimpleNamespace(method="super" if mode == "plain" else "semantic-super", num_neighbors=4, num_ED_neighbors=4,
+                          num_classes=int(b["num_classes"]))
+    hard = mode == "hard"
+    idx, w = fuo.update_ed(b["ed_points"], b["ed_radii"], opt, hard, b["ed_seg"])
+    np.testing.assert_array_equal(idx, g[f"knn_{mode}_ed_idx"])
+    np.testing.assert_allclose(w, g[f"knn_{mode}_ed_w"], rtol=0, atol=1e-14)
+    n = len(b["sf_points"])
+    idx, w, st = fuo.update_sfed_knn(b["sf_points"], np.ones(n, bool), b["ed_points"], b["ed_radii"], opt, hard,
+                                     b["sf_seg"], b["sf_seg_conf"], b["ed_seg"], b["ed_seg_conf"])
+    np.testing.assert_array_equal(idx, g[f"knn_{mode}_sf_idx"])
+    np.testing.assert_allclose(w, g[f"knn_{mode}_sf_w"], rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(st, g[f"knn_{mode}_sf_stable"])
+    if hard:
+        assert (b["ed_seg"][idx] == b["sf_seg"][:, None]).all() and (~st).sum() > 0
+
+
 def test_tracking_ground_truth_format_and_error(tmp_path):
     """Row f4: the pickled-dict .npy wire format of opt.tracking_gt_file and the reprojection error."""
     import sys

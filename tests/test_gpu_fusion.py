@@ -211,6 +211,45 @@ def test_fusion_full_size_matches_oracle(mode):
     np.testing.assert_allclose(w.sum(1), 1.0, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("mode", ["plain", "sem", "hard"])
+def test_knn_feeder_semantic_branches_match_reference(mode):
+    """update_ed / update_sfed_knn (frame 0) with hard_seg class-restricted neighbours and the
+    Jensen-Shannon weights of Semantic-SuPer, against the reference's goldens."""
+    import torch
+    from super_amd import nodes
+    g = np.load(GOLD)
+    b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    t = lambda a: torch.from_numpy(np.array(a, copy=True)).cuda()
+    opt = SimpleNamespace(method="super" if mode == "plain" else "semantic-super", num_neighbors=4, num_ED_neighbors=4,
+                          num_classes=int(b["num_classes"]))
+    ed = SimpleNamespace(points=t(b["ed_points"]), radii=t(b["ed_radii"]), seg=t(b["ed_seg"]), seg_conf=t(b["ed_seg_conf"]))
+    sf = SimpleNamespace(opt=opt, hard_seg=mode == "hard", ED_nodes=ed, points=t(b["sf_points"]), seg=t(b["sf_seg"]),
+                         seg_conf=t(b["sf_seg_conf"]), isStable=torch.ones(len(b["sf_points"]), dtype=torch.bool).cuda())
+    nodes.update_ed(sf)
+    nodes.update_sfed_knn(sf)
+    tol = 1e-6 if mode == "plain" else 1e-13          # the plain path stores float32 weights (LM feeder)
+    np.testing.assert_array_equal(ed.knn_indices.cpu().numpy(), g[f"knn_{mode}_ed_idx"])
+    np.testing.assert_array_equal(sf.knn_indices.cpu().numpy(), g[f"knn_{mode}_sf_idx"])
+    np.testing.assert_allclose(ed.knn_w.cpu().numpy(), g[f"knn_{mode}_ed_w"], rtol=0, atol=1e-6 if mode != "hard" else 1e-13)
+    np.testing.assert_allclose(sf.knn_w.cpu().numpy(), g[f"knn_{mode}_sf_w"], rtol=0, atol=tol)
+    np.testing.assert_array_equal(sf.isStable.cpu().numpy(), g[f"knn_{mode}_sf_stable"])
+    assert sf.knn_indices.dtype == torch.long and sf.knn_w.dtype == torch.float64
+
+
+def test_class_restricted_knn_with_too_few_nodes_fails_loudly():
+    import torch
+    from super_amd import nodes
+    from super_amd._lib import SuperLMError
+    p = torch.rand(50, 3, dtype=torch.float64).cuda()
+    n = torch.rand(10, 3, dtype=torch.float64).cuda()
+    s1 = torch.zeros(50, dtype=torch.long).cuda()
+    s2 = torch.tensor([0, 0, 0, 1, 1, 1, 1, 1, 1, 1]).cuda()
+    with pytest.raises(SuperLMError, match="fewer nodes"):
+        nodes.find_knn(p, n, num_classes=2, seg1=s1, seg2=s2, k=4)
+    d, i = nodes.find_knn(p, n, num_classes=2, seg1=torch.ones(50, dtype=torch.long).cuda(), seg2=s2, k=4)
+    assert int(i.min()) >= 3 and bool((d[:, 1:] >= d[:, :-1]).all())
+
+
 def test_hard_seg_with_too_few_nodes_of_a_class_fails_loudly():
     """The reference asserts len(p2) >= k per class (utils/utils.py:237); the device path reports it."""
     from super_amd import fusion
