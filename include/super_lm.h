@@ -523,6 +523,15 @@ int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t* valid, con
                    const double* points, const double* norms, const slm_graph_outputs* out,
                    int32_t* counts_host, void* stream);
 
+/* Semantic-SuPer variant (super/graph_encoder.py:134-151,190-192): seg_conf (T,C) = data.seg_conf; every
+ * node also gets node_seg_conf (cap_nodes,C) = seg_conf of its row and node_seg (cap_nodes) = first maximum;
+ * prune_class_edges (opt.hard_seg and opt.mesh_face): edges / triangles whose vertices differ in class are
+ * dropped before lengths, radii and areas are computed. */
+int slm_graph_init_semantic(int32_t H, int32_t W, int32_t step, const uint8_t* valid, const int32_t* index_map,
+                            const double* points, const double* norms, int32_t num_classes, const double* seg_conf,
+                            int32_t prune_class_edges, const slm_graph_outputs* out, int32_t* node_seg,
+                            double* node_seg_conf, int32_t* counts_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

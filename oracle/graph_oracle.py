@@ -47,13 +47,23 @@ def init_graph(valid, step):
     return index_map >= 0, e.T.copy(), f.T.copy()
 
 
-def direct_deform_graph(valid, data_index_map, points, norms, step):
+def direct_deform_graph(valid, data_index_map, points, norms, step, seg_conf=None, prune_class_edges=False):
     """``DirectDeformGraph.forward`` (grid_mesh): dict with points, norms, radii, edge_index, edges_lens,
-    triangles, triangles_areas, num."""
+    triangles, triangles_areas, num.  ``seg_conf`` (T,C): the nodes' class fields ``seg`` / ``seg_conf``
+    (graph_encoder.py:134-139); ``prune_class_edges`` (``opt.hard_seg and opt.mesh_face``): edges and
+    triangles whose vertices differ in class are dropped before lengths, radii and areas (:141-151)."""
     H, W = data_index_map.shape
     mask, edge_index, triangles = init_graph(np.asarray(valid, bool).reshape(H, W), step)
     rows = data_index_map[mask]
     P, N = points[rows], norms[rows]
+    sem = {}
+    if seg_conf is not None:
+        sc = np.asarray(seg_conf, np.float64)[rows]
+        seg = np.argmax(sc, axis=1)
+        sem = dict(seg=seg, seg_conf=sc)
+        if prune_class_edges:
+            edge_index = edge_index[:, seg[edge_index[0]] == seg[edge_index[1]]]
+            triangles = triangles[:, (seg[triangles[0]] == seg[triangles[1]]) & (seg[triangles[0]] == seg[triangles[2]])]
     lens = np.sqrt(((P[edge_index[0]] - P[edge_index[1]]) ** 2).sum(1))
     J = len(P)
     radii = np.full(J, np.nan)
@@ -67,4 +77,4 @@ def direct_deform_graph(valid, data_index_map, points, norms, step):
     c = np.cross(P[triangles[1]] - P[triangles[0]], P[triangles[2]] - P[triangles[0]])
     areas = 0.5 * np.sqrt((c ** 2).sum(1) + 1e-13)
     return dict(points=P, norms=N, radii=radii, edge_index=edge_index, edges_lens=lens, triangles=triangles,
-                triangles_areas=areas, num=J)
+                triangles_areas=areas, num=J, **sem)

@@ -7,6 +7,9 @@
 //                    kept when every vertex is a valid anchor; lengths and rest areas
 //   k_gr_radii       radius = mean length of the incident edges, gathered in edge order (deterministic)
 //   k_gr_fix_nan     isolated nodes get the mean radius of the others
+// Semantic-SuPer (slm_graph_init_semantic): the nodes' class confidences are gathered with their rows
+// (class = first maximum); with hard_seg + mesh_face an edge / triangle is only kept when its vertices
+// share a class (graph_encoder.py:134-151).
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -33,6 +36,13 @@ struct Grid {
   int H, W, step, gw, gh;   // gw x gh grid points: u = 0, step, ... < W-1; v likewise < H-1
 };
 
+struct GrSem {               // segmentation fields (C == 0: none)
+  int C, prune;
+  const double* seg_conf;    // (T,C) data.seg_conf
+  int32_t* node_seg;         // (cap_nodes)
+  double* node_seg_conf;     // (cap_nodes,C)
+};
+
 // the anchor at grid cell (gx, gy), or -1: valid pixel and inside the grid
 __device__ __forceinline__ int anchor_id(const Grid& g, const int32_t* __restrict__ node_of, int gx, int gy) {
   if (gx < 0 || gy < 0 || gx >= g.gw || gy >= g.gh) return -1;
@@ -50,7 +60,7 @@ __global__ void __launch_bounds__(256) k_gr_anchor(Grid g, const uint8_t* __rest
 __global__ void __launch_bounds__(256) k_gr_nodes(Grid g, const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
                                                    const int32_t* __restrict__ index_map, const double* __restrict__ points,
                                                    const double* __restrict__ norms, int32_t* __restrict__ node_of,
-                                                   slm_graph_outputs o) {
+                                                   slm_graph_outputs o, GrSem sm) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= g.gw * g.gh) return;
   if (!flag[c]) {
@@ -64,6 +74,15 @@ __global__ void __launch_bounds__(256) k_gr_nodes(Grid g, const int32_t* __restr
   for (int a = 0; a < 3; ++a) {
     o.points[3 * (size_t)k + a] = points[3 * (size_t)row + a];
     o.norms[3 * (size_t)k + a] = norms[3 * (size_t)row + a];
+  }
+  if (sm.C > 0) {
+    int best = 0;
+    for (int a = 0; a < sm.C; ++a) {
+      const double v = sm.seg_conf[(size_t)sm.C * row + a];
+      sm.node_seg_conf[(size_t)sm.C * k + a] = v;
+      if (v > sm.seg_conf[(size_t)sm.C * row + best]) best = a;
+    }
+    sm.node_seg[k] = best;
   }
 }
 
@@ -82,16 +101,23 @@ __device__ __forceinline__ void cell_edges(const Grid& g, const int32_t* __restr
 // per anchor cell: flags of its 4 edges and 2 triangles (positions come from scans over these)
 __global__ void __launch_bounds__(256) k_gr_cell_flags(Grid g, const int32_t* __restrict__ node_of, int J,
                                                         const int32_t* __restrict__ cell_of_node, int32_t* __restrict__ eflag,
-                                                        int32_t* __restrict__ tflag) {
+                                                        int32_t* __restrict__ tflag, GrSem sm) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= J) return;
   const int c = cell_of_node[k], gx = c % g.gw, gy = c / g.gw;
+  const bool prune = sm.C > 0 && sm.prune;
+  const int32_t* seg = sm.node_seg;
   int ea[4], eb[4];
   cell_edges(g, node_of, gx, gy, ea, eb);
-  for (int q = 0; q < 4; ++q) eflag[4 * k + q] = ea[q] >= 0 ? 1 : 0;
+  for (int q = 0; q < 4; ++q) eflag[4 * k + q] = (ea[q] >= 0 && (!prune || seg[ea[q]] == seg[eb[q]])) ? 1 : 0;
   const int p1 = anchor_id(g, node_of, gx + 1, gy), p2 = anchor_id(g, node_of, gx + 1, gy + 1), p3 = anchor_id(g, node_of, gx, gy + 1);
-  tflag[2 * k] = (p1 >= 0 && p2 >= 0) ? 1 : 0;       // (s, pt1, pt2)
-  tflag[2 * k + 1] = (p2 >= 0 && p3 >= 0) ? 1 : 0;   // (s, pt2, pt3)
+  bool t0 = p1 >= 0 && p2 >= 0, t1 = p2 >= 0 && p3 >= 0;    // (s, pt1, pt2), (s, pt2, pt3)
+  if (prune) {
+    t0 = t0 && seg[k] == seg[p1] && seg[k] == seg[p2];
+    t1 = t1 && seg[k] == seg[p2] && seg[k] == seg[p3];
+  }
+  tflag[2 * k] = t0 ? 1 : 0;
+  tflag[2 * k + 1] = t1 ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256) k_gr_cell_of_node(Grid g, const int32_t* __restrict__ node_of, int32_t* __restrict__ cell_of_node) {
@@ -182,9 +208,9 @@ __global__ void __launch_bounds__(256) k_gr_fix_nan(int J, double* __restrict__ 
 
 }  // namespace
 
-extern "C" int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t* valid, const int32_t* index_map,
-                              const double* points, const double* norms, const slm_graph_outputs* out,
-                              int32_t* counts_host, void* stream) {
+static int graph_init_impl(int32_t H, int32_t W, int32_t step, const uint8_t* valid, const int32_t* index_map,
+                           const double* points, const double* norms, const slm_graph_outputs* out, GrSem sm,
+                           int32_t* counts_host, void* stream) {
   if (H < 2 || W < 2 || step < 1 || !valid || !index_map || !points || !norms || !out || !out->points || !out->norms ||
       !out->radii || !out->edge_index || !out->edges_lens || !out->triangles || !out->triangles_areas) {
     slm_set_error_text("slm_graph_init: bad argument");
@@ -217,7 +243,7 @@ extern "C" int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t*
   hipLaunchKernelGGL(k_gr_anchor, gc, blk, 0, st, g, valid, flag);
   size_t b1 = bytes;
   GCHK(rocprim::exclusive_scan(tmp, b1, flag, pos, 0, (size_t)cells, rocprim::plus<int32_t>(), st));
-  hipLaunchKernelGGL(k_gr_nodes, gc, blk, 0, st, g, flag, pos, index_map, points, norms, node_of, *out);
+  hipLaunchKernelGGL(k_gr_nodes, gc, blk, 0, st, g, flag, pos, index_map, points, norms, node_of, *out, sm);
   int32_t last[2];
   GCHK(hipMemcpyAsync(&last[0], pos + cells - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   GCHK(hipMemcpyAsync(&last[1], flag + cells - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -229,7 +255,7 @@ extern "C" int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t*
     hipLaunchKernelGGL(k_gr_cell_of_node, gc, blk, 0, st, g, node_of, cell_of);
     int32_t* tflag = eflag + 4 * (size_t)cells;
     int32_t* tpos = epos + 4 * (size_t)cells;
-    hipLaunchKernelGGL(k_gr_cell_flags, gj, blk, 0, st, g, node_of, J, cell_of, eflag, tflag);
+    hipLaunchKernelGGL(k_gr_cell_flags, gj, blk, 0, st, g, node_of, J, cell_of, eflag, tflag, sm);
     b1 = bytes;
     GCHK(rocprim::exclusive_scan(tmp, b1, eflag, epos, 0, 4 * (size_t)J, rocprim::plus<int32_t>(), st));
     b1 = bytes;
@@ -257,4 +283,24 @@ extern "C" int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t*
   for (void* p : owned)
     if (p) (void)hipFree(p);
   return SLM_OK;
+}
+
+extern "C" int slm_graph_init(int32_t H, int32_t W, int32_t step, const uint8_t* valid, const int32_t* index_map,
+                              const double* points, const double* norms, const slm_graph_outputs* out,
+                              int32_t* counts_host, void* stream) {
+  return graph_init_impl(H, W, step, valid, index_map, points, norms, out, GrSem{0, 0, nullptr, nullptr, nullptr},
+                         counts_host, stream);
+}
+
+extern "C" int slm_graph_init_semantic(int32_t H, int32_t W, int32_t step, const uint8_t* valid, const int32_t* index_map,
+                                       const double* points, const double* norms, int32_t num_classes,
+                                       const double* seg_conf, int32_t prune_class_edges, const slm_graph_outputs* out,
+                                       int32_t* node_seg, double* node_seg_conf, int32_t* counts_host, void* stream) {
+  if (num_classes < 1 || num_classes > SLM_MAX_CLASSES || !seg_conf || !node_seg || !node_seg_conf) {
+    slm_set_error_text("slm_graph_init_semantic: bad argument (1..4 classes, seg_conf and both node outputs)");
+    return SLM_ERR_INVALID;
+  }
+  return graph_init_impl(H, W, step, valid, index_map, points, norms, out,
+                         GrSem{num_classes, prune_class_edges ? 1 : 0, seg_conf, node_seg, node_seg_conf}, counts_host,
+                         stream);
 }

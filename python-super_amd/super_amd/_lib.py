@@ -25,7 +25,7 @@ EXPORTS = [
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
-    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64",
+    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64", "slm_graph_init_semantic",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -201,6 +201,8 @@ def load():
         "slm_lm_exchange_get": [vp, i32, i32, vp, vp],
         "slm_lm_exchange_set": [vp, i32, i32, vp, vp],
         "slm_graph_init": [i32, i32, i32, vp, vp, vp, vp, C.POINTER(SlmGraphOutputs), C.POINTER(C.c_int32), vp],
+        "slm_graph_init_semantic": [i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, C.POINTER(SlmGraphOutputs), vp, vp,
+                                    C.POINTER(C.c_int32), vp],
         "slm_fuse_create": [i32, i32, i32, C.POINTER(vp)],
         "slm_fuse_destroy": [vp],
         "slm_fuse_bind_semantic": [vp, C.POINTER(SlmFuseSemantic)],

@@ -6,9 +6,11 @@ mesh) over libsuper_lm.so: the ED graph built from the fi
 
 Returns an attribute bag with the reference's field names: ``points``, ``norms`` (J,3) float64,
 ``radii`` (J,), ``edge_index`` (2,E) int64, ``edges_lens`` (E,), ``triangles`` (3,F) int64,
-``triangles_areas`` (F,), ``num``, ``param_num``.  Supported: the default ``grid_mesh`` construction
-for ``opt.method == "super"`` (no segmentation fields, no ``hard_seg`` edge pruning); the
-``ball_pivoting`` (open3d) and ``knn`` variants are not reachable from ``forward`` in the reference either.
+``triangles_areas`` (F,), ``num``, ``param_num``.  Supported: the default ``grid_mesh`` construction for
+``opt.method == "super"`` and ``"semantic-super"`` (``seg`` / ``seg_conf`` of the nodes when the frame carries
+``data.seg``; ``opt.hard_seg`` with ``opt.mesh_face`` drops edges / triangles across a class boundary,
+``super/graph_encoder.py:134-151,190-192``); the ``ball_pivoting`` (open3d) and ``knn`` variants are not
+reachable from ``forward`` in the reference either.
 """
 from __future__ import annotations
 
@@ -28,8 +30,8 @@ class DirectDeformGraph:
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.SuperLMError("no HIP device visible: super_amd has no CPU fallback")
-        if getattr(opt, "method", "super") != "super" or getattr(opt, "hard_seg", False):
-            raise NotImplementedError("super_amd.DirectDeformGraph: only opt.method == 'super' without hard_seg")
+        if getattr(opt, "method", "super") not in ("super", "semantic-super"):
+            raise NotImplementedError("super_amd.DirectDeformGraph: opt.method must be 'super' or 'semantic-super'")
 
     def forward(self, inputs, data):
         o = self.opt
@@ -51,12 +53,29 @@ class DirectDeformGraph:
         for k, v in buf.items():
             setattr(out, k, _dev_ptr(v))
         counts = (C.c_int32 * 3)()
-        _lib.check(self.lib.slm_graph_init(H, W, step, _dev_ptr(valid), _dev_ptr(imap), _dev_ptr(pts), _dev_ptr(nrm),
-                                           C.byref(out), counts, _stream_ptr(dev)), "slm_graph_init")
+        seg = seg_conf = None
+        if hasattr(data, "seg"):
+            conf = _as(data.seg_conf, f64, dev)
+            C_ = int(conf.shape[1])
+            if C_ > _lib.SLM_MAX_CLASSES:
+                raise NotImplementedError(f"super_amd.DirectDeformGraph: at most {_lib.SLM_MAX_CLASSES} classes")
+            seg = torch.empty(cap, dtype=torch.int32, device=dev)
+            seg_conf = torch.empty((cap, C_), dtype=f64, device=dev)
+            prune = bool(getattr(o, "hard_seg", False)) and bool(getattr(o, "mesh_face", False))
+            _lib.check(self.lib.slm_graph_init_semantic(H, W, step, _dev_ptr(valid), _dev_ptr(imap), _dev_ptr(pts),
+                                                        _dev_ptr(nrm), C_, _dev_ptr(conf), int(prune), C.byref(out),
+                                                        _dev_ptr(seg), _dev_ptr(seg_conf), counts, _stream_ptr(dev)),
+                       "slm_graph_init_semantic")
+        else:
+            _lib.check(self.lib.slm_graph_init(H, W, step, _dev_ptr(valid), _dev_ptr(imap), _dev_ptr(pts), _dev_ptr(nrm),
+                                               C.byref(out), counts, _stream_ptr(dev)), "slm_graph_init")
         J, E, F = int(counts[0]), int(counts[1]), int(counts[2])
-        return SimpleNamespace(points=buf["points"][:J], norms=buf["norms"][:J], radii=buf["radii"][:J],
-                               edge_index=buf["edge_index"][:, :E].to(torch.long), edges_lens=buf["edges_lens"][:E],
-                               triangles=buf["triangles"][:, :F].to(torch.long),
-                               triangles_areas=buf["triangles_areas"][:F], num=J, param_num=7 * J)
+        graph = SimpleNamespace(points=buf["points"][:J], norms=buf["norms"][:J], radii=buf["radii"][:J],
+                                edge_index=buf["edge_index"][:, :E].to(torch.long), edges_lens=buf["edges_lens"][:E],
+                                triangles=buf["triangles"][:, :F].to(torch.long),
+                                triangles_areas=buf["triangles_areas"][:F], num=J, param_num=7 * J)
+        if getattr(o, "method", "super") == "semantic-super" and seg is not None:      # graph_encoder.py:190-192
+            graph.seg, graph.seg_conf = seg[:J].to(torch.long), seg_conf[:J]
+        return graph
 
     __call__ = forward
