@@ -32,7 +32,9 @@ class Surfels:
     def __init__(self, opt, models, inputs, data):
         self.opt, self.models = opt, models
         self.evaluate_tracking = False
-        self.hard_seg = False
+        if getattr(opt, "method", "super") == "semantic-super":
+            self.power_arg = (1 / 2, 1 / 2)                      # nodes.py:99
+        self.hard_seg = bool(getattr(opt, "hard_seg", False))    # nodes.py:100-103
         self.logger = logging.getLogger("super_amd.Surfels")
         for key, v in vars(data).items():
             if key != "valid":

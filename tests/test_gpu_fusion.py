@@ -405,3 +405,74 @@ def test_super_driver_tracks_a_deforming_surface(derived):
     print("tracking error per frame", errs, "inter-frame motion", motion)
     assert max(errs[1:]) < (0.7 if derived else 1.2) * motion, (errs, motion)
     assert counts[-1] < 1.3 * counts[0]
+
+
+@pytest.mark.parametrize("hard", [False, True])
+def test_semantic_super_driver_runs_end_to_end(hard):
+    """opt.method == "semantic-super" through the driver mirror: depth_preprocessing with segmentation inputs,
+    grid-mesh graph with node classes (class-boundary edges dropped under hard_seg), Surfels with
+    Jensen-Shannon / class-restricted skinning, GraphFit with the soft segmentation point-plane weight,
+    fusion carrying seg / seg_conf / dist2edge.  Properties: every field stays consistent in length, class
+    ids follow the fused confidences, hard_seg neighbours share the surfel's class at initialisation, the
+    model follows the surface."""
+    import torch
+    from super_amd import synth
+    from super_amd.super import SuPer
+    H, W, C = 96, 128, 3
+    K = synth._scaled_intrinsics(H, W)
+    inv_K = np.linalg.pinv(K)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    rng = np.random.default_rng(7)
+    color = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
+    opt = SimpleNamespace(height=H, width=W, data="superv2", load_valid_mask=False, depth_model="monodepth2",
+                          dilate_invalid_kernel=0, normal_model="naive", phase="test", method="semantic-super",
+                          load_depth=True, num_classes=C, del_seg_classes=[], hard_seg=hard,
+                          deform_udpate_method="super_edg", mesh_step_size=8, use_derived_gradient=False,
+                          sf_point_plane=False, sf_soft_seg_point_plane=not hard, sf_hard_seg_point_plane=hard,
+                          mesh_arap=True, mesh_rot=True, mesh_face=True, sf_point_plane_weight=1.0,
+                          mesh_arap_weight=10.0, mesh_rot_weight=1.0, mesh_face_weight=1.0, num_optimize_iterations=10,
+                          optimizer="Adam", learning_rate=2e-4, num_neighbors=4, num_ED_neighbors=4, th_dist=0.02,
+                          th_cosine_ang=0.4, th_time_steps=30, disable_merging_new_surfels=False,
+                          disable_merging_exist_surfels=False, disable_adding_new_surfels=False,
+                          disable_removing_unstable_surfels=False)
+    model = SuPer(opt)
+    models = SimpleNamespace()
+    depth_of = lambda k: (synth._surface(uu, vv, H, W, 0.3 + 0.03 * k)).astype(np.float32)
+    # three vertical class bands, smooth logits
+    logits = np.stack([-((uu - c) / 18.0) ** 2 for c in (20.0, 64.0, 108.0)], 0) * 3.0
+    errs = []
+    for k in range(4):
+        depth = depth_of(k)
+        depth[:4] = 0.0
+        depth[:, :4] = 0.0
+        lg = (logits + rng.normal(0, 0.05, logits.shape)).astype(np.float64)
+        inputs = {("depth", 0): torch.from_numpy(depth.copy())[None, None], ("disp", 0): torch.zeros(1, 1, H, W),
+                  "inv_K": torch.from_numpy(inv_K)[None], "K": torch.from_numpy(K)[None],
+                  ("color", 0): torch.from_numpy(color)[None], "divterm": torch.tensor(1.0 / (2 * 0.6 * 0.6)),
+                  ("seg_conf", 0): torch.from_numpy(lg)[None], ("seg", 0): torch.from_numpy(np.argmax(lg, 0))[None, None],
+                  "filename": ["%06d" % k], "time": k, "ID": torch.tensor([k])}
+        deform = model(models, inputs)
+        sf = model.sf
+        n = int(sf.points.shape[0])
+        assert sf.seg.shape == (n,) and sf.seg_conf.shape == (n, C) and sf.dist2edge.shape == (n,)
+        assert sf.knn_w.shape == (n, 4) and torch.isfinite(sf.knn_w).all() and torch.isfinite(sf.points).all()
+        np.testing.assert_allclose(sf.seg_conf.sum(1).cpu().numpy(), 1.0, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(sf.seg.cpu().numpy(), sf.seg_conf.argmax(1).cpu().numpy())
+        np.testing.assert_allclose(sf.knn_w.sum(1).cpu().numpy(), 1.0, rtol=0, atol=1e-12)
+        ed = sf.ED_nodes
+        if k == 0:
+            assert deform is None and ed.num > 50 and ed.seg.shape == (ed.num,) and len(torch.unique(ed.seg)) == C
+            if hard:
+                assert bool((ed.seg[ed.edge_index[0]] == ed.seg[ed.edge_index[1]]).all())
+                assert bool((ed.seg[sf.knn_indices] == sf.seg[:, None]).all())
+                assert bool((ed.seg[ed.knn_indices] == ed.seg[:, None]).all())
+        else:
+            assert deform.shape == (ed.num + 1, 7) and torch.isfinite(deform).all()
+        P = sf.points.cpu().numpy()
+        u = np.rint(P[:, 0] * K[0, 0] / P[:, 2] + K[0, 2]).astype(int)
+        v = np.rint(P[:, 1] * K[1, 1] / P[:, 2] + K[1, 2]).astype(int)
+        ok = (u >= 5) & (u < W - 1) & (v >= 5) & (v < H - 1)
+        errs.append(float(np.abs(P[ok, 2] - depth[v[ok], u[ok]]).mean()))
+    motion = float(np.abs(depth_of(3) - depth_of(2))[5:, 5:].mean())
+    print("semantic driver: tracking error per frame", errs, "inter-frame motion", motion)
+    assert max(errs[1:]) < 1.5 * motion, (errs, motion)
