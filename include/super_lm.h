@@ -374,6 +374,9 @@ typedef struct slm_depth_config {
   float inv_K[9];                /* inputs["inv_K"][0,:3,:3], row-major */
   float fx, fy, cx, cy;          /* inputs["K"][0] */
   double divterm;                /* inputs["divterm"] */
+  int32_t use_ssim_conf;         /* hasattr(opt, "disable_ssim_conf") and not opt.disable_ssim_conf (the CLI default):
+                                    confs = 0.5 * confs + 0.5 * sigmoid(stereo SSIM confidence), data_loader.py:359-373,477-479 */
+  float stereo_P[12];            /* torch.matmul(inputs["K"], inputs["stereo_T"])[0,:3,:] row-major (float32) */
 } slm_depth_config;
 
 typedef struct slm_depth_inputs {   /* device pointers */
@@ -396,6 +399,8 @@ typedef struct slm_depth_outputs {  /* device pointers; row capacity H*W; NULL =
   double* seg_conf;              /* (T,C) data.seg_conf (per-pixel softmax) */
   double* dist2edge;             /* (T)   data.dist2edge */
   uint8_t* inval;                /* (H*W) the invalid-pixel map of step 1 (the reference NaNs depth / disp / pcd there) */
+  float* disp_conf;              /* (H,W) inputs[("disp_conf",0)] with use_ssim_conf: SSIM between the image and its
+                                    warp through the stereo transform, mean over the channels */
 } slm_depth_outputs;
 
 int slm_depth_create(int32_t H, int32_t W, slm_depth** out);

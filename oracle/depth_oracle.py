@@ -162,11 +162,84 @@ def edge_points_norm(img_seg, num_classes, kernel=3):
     return out
 
 
-def depth_preprocessing(opt, depth, K, inv_K, color, divterm, seg=None, seg_conf=None, valid_mask=None):
+def skimage_ssim_full(im1, im2, win_size=7, data_range=2.0, K1=0.01, K2=0.03):
+    """Full SSIM image of ``skimage.metrics.structural_similarity(im1, im2, channel_axis=0, full=True)``
+    as the reference calls it (utils/data_loader.py:368-371).  scikit-image is a dependency that is
+    absent from /root/reference and from this image and is NOT version-pinned by the reference
+    (``resources/environment.yaml:28``); this restates the published algorithm of the 0.19 line
+    (Wang et al. 2004 with a 7x7 uniform window, sample covariance, ``scipy.ndimage.uniform_filter``
+    with reflecting borders, float32 images, and -- no ``data_range`` given -- the float dtype range
+    -1..1, i.e. ``data_range = 2``).  PARITY UNPINNED for this function: no skimage output is available
+    to check it against.  im1, im2: (C,H,W) float32."""
+    from scipy.ndimage import uniform_filter
+    C1, C2 = f32((K1 * data_range) ** 2), f32((K2 * data_range) ** 2)
+    NP = win_size ** 2
+    cov_norm = f32(NP / (NP - 1))
+    S = np.empty(im1.shape, f32)
+    for ch in range(im1.shape[0]):
+        x, y = im1[ch].astype(f32), im2[ch].astype(f32)
+        ux, uy = uniform_filter(x, size=win_size), uniform_filter(y, size=win_size)
+        uxx, uyy, uxy = uniform_filter(x * x, size=win_size), uniform_filter(y * y, size=win_size), uniform_filter(x * y, size=win_size)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        A1, A2, B1, B2 = 2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2
+        S[ch] = (A1 * A2) / (B1 * B2)
+    return S
+
+
+def project3d_grid(depth, inv_K, K, stereo_T):
+    """``BackprojectDepth`` + ``Project3D`` (depth/monodepth2/layers.py:141-192) in float32: the
+    sampling grid in [-1, 1] at which the reference warps the image (data_loader.py:362-363)."""
+    H, W = depth.shape
+    cam = backproject(depth.astype(f32), inv_K).reshape(-1, 3)              # (HW,3) float32
+    P = (np.asarray(K, f32) @ np.asarray(stereo_T, f32))[:3, :].astype(f32)
+    q = (cam[:, 0:1] * P[:, 0] + cam[:, 1:2] * P[:, 1] + cam[:, 2:3] * P[:, 2] + P[:, 3]).astype(f32)
+    den = (q[:, 2] + f32(1e-7)).astype(f32)
+    gx = ((q[:, 0] / den / f32(W - 1) - f32(0.5)) * f32(2)).astype(f32)
+    gy = ((q[:, 1] / den / f32(H - 1) - f32(0.5)) * f32(2)).astype(f32)
+    return gx.reshape(H, W), gy.reshape(H, W)
+
+
+def grid_sample_bilinear(img, gx, gy):
+    """``F.grid_sample(img, grid)`` defaults: bilinear, zeros padding, align_corners=False.
+    img (C,H,W) float32, grid in [-1,1]."""
+    C, H, W = img.shape
+    ix = (((gx + f32(1)) * f32(W) - f32(1)) / f32(2)).astype(f32)
+    iy = (((gy + f32(1)) * f32(H) - f32(1)) / f32(2)).astype(f32)
+    with np.errstate(invalid="ignore"):
+        x0, y0 = np.floor(ix), np.floor(iy)
+    wx1, wy1 = (ix - x0).astype(f32), (iy - y0).astype(f32)
+    wx0, wy0 = (f32(1) - wx1).astype(f32), (f32(1) - wy1).astype(f32)
+    out = np.zeros((C,) + gx.shape, f32)
+    bad = ~(np.isfinite(ix) & np.isfinite(iy))
+    for dy, wy in ((0, wy0), (1, wy1)):
+        for dx, wx in ((0, wx0), (1, wx1)):
+            xx = np.where(bad, -1, x0 + dx).astype(np.int64)
+            yy = np.where(bad, -1, y0 + dy).astype(np.int64)
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            v = img[:, np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+            out += np.where(ok, (wx * wy).astype(f32), f32(0))[None] * v
+    out[:, bad] = np.nan
+    return out
+
+
+def stereo_confidence(depth, K, inv_K, stereo_T, color):
+    """``inputs[("disp_conf",0)]`` (data_loader.py:359-373): SSIM between the image and its warp through
+    the stereo transform, mean over the colour channels.  (H,W) float32."""
+    gx, gy = project3d_grid(depth, inv_K, K, stereo_T)
+    warp = grid_sample_bilinear(np.asarray(color, f32), gx, gy)
+    return skimage_ssim_full(warp, np.asarray(color, f32)).mean(0).astype(f32)
+
+
+def depth_preprocessing(opt, depth, K, inv_K, color, divterm, seg=None, seg_conf=None, valid_mask=None,
+                        stereo_T=None):
     """Returns the fields of the reference's ``Data`` object as NumPy arrays (float64 where the
-    reference hands out float64)."""
+    reference hands out float64).  ``stereo_T`` (4,4) with ``opt.disable_ssim_conf == False``: the
+    confidence is blended with the stereo SSIM confidence (data_loader.py:477-479)."""
     H, W = depth.shape
     depth = depth.astype(f32).copy()
+    disp_conf = None
+    if hasattr(opt, "disable_ssim_conf") and not opt.disable_ssim_conf:
+        disp_conf = stereo_confidence(depth, K, inv_K, stereo_T, color)
     pcd = backproject(depth, inv_K)
     inval = invalid_map(opt, depth, seg, valid_mask)
     depth[inval] = np.nan
@@ -186,8 +259,13 @@ def depth_preprocessing(opt, depth, K, inv_K, color, divterm, seg=None, seg_conf
     a, b = (f32(2) * su - f32(1)).astype(f32), (f32(2) * sv - f32(1)).astype(f32)
     dc2 = ((a * a).astype(f32) + (b * b).astype(f32)).astype(f32)
     confs = np.exp((-dc2 * f32(divterm)).astype(f32)).astype(f32)
+    if disp_conf is not None:
+        sig = (f32(1) / (f32(1) + np.exp(-disp_conf).astype(f32))).astype(f32)
+        confs = (f32(0.5) * confs + f32(0.5) * sig).astype(f32)
     out = dict(points=pts, norms=nrm, colors=np.transpose(color, (1, 2, 0))[valid], radii=radii, confs=confs[valid],
                valid=valid.reshape(-1), index_map=index_map, valid_map=valid, inval=inval)
+    if disp_conf is not None:
+        out["disp_conf"] = disp_conf
     if seg is not None:
         sc = np.exp(seg_conf - seg_conf.max(0, keepdims=True))
         sc = (sc / sc.sum(0, keepdims=True)).transpose(1, 2, 0)

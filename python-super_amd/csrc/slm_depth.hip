@@ -9,6 +9,9 @@
 //   rocPRIM exclusive scan    index_map = running count of valid pixels (row-major)
 //   k_dp_gather               compacted points / normals / colours / radii / confidences / semantics
 //   k_dp_dist2edge            distance to the nearest class-boundary pixel (normalised image coords)
+//   k_dp_warp / k_dp_ssim     stereo confidence (default CLI setting): the image warped through K * stereo_T at
+//                             the back-projected depth (Project3D + grid_sample) and its 7x7-window SSIM against
+//                             the image itself (skimage.metrics.structural_similarity semantics), mean over channels
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -25,6 +28,8 @@ struct slm_depth {
   float* nrm = nullptr;                   // (H,W,3)
   int32_t *flag = nullptr, *idx = nullptr;   // valid flags (int) and their exclusive scan
   int32_t* total = nullptr;
+  float* warp = nullptr;                  // (3,H,W) warped image (stereo confidence)
+  float* ssim = nullptr;                  // (H,W) channel-mean SSIM
   void* tmp = nullptr;
   size_t cap_tmp = 0;
   SemScratch sem;
@@ -116,6 +121,100 @@ __global__ void __launch_bounds__(256) k_dp_points(slm_depth_config c, slm_depth
   }
 }
 
+// Project3D + F.grid_sample(bilinear, zeros, align_corners=False) of the image at the back-projected
+// raw depth (depth/monodepth2/layers.py:141-192, data_loader.py:362-366), float32 like the reference
+__global__ void __launch_bounds__(256) k_dp_warp(slm_depth_config c, slm_depth_inputs in, float* __restrict__ warp) {
+#pragma clang fp contract(off)
+  const int HW = c.H * c.W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int y = p / c.W, x = p % c.W;
+  const float d = in.depth[p];
+  const float u = (float)x, v = (float)y;
+  float cam[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float acc = c.inv_K[3 * i] * u;
+    acc = __builtin_fmaf(c.inv_K[3 * i + 1], v, acc);
+    acc = __builtin_fmaf(c.inv_K[3 * i + 2], 1.0f, acc);
+    cam[i] = d * acc;
+  }
+  float q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    q[i] = cam[0] * c.stereo_P[4 * i] + cam[1] * c.stereo_P[4 * i + 1] + cam[2] * c.stereo_P[4 * i + 2] + c.stereo_P[4 * i + 3];
+  const float den = q[2] + 1e-7f;
+  const float gx = (q[0] / den / (float)(c.W - 1) - 0.5f) * 2.0f;
+  const float gy = (q[1] / den / (float)(c.H - 1) - 0.5f) * 2.0f;
+  const float ix = ((gx + 1.0f) * (float)c.W - 1.0f) / 2.0f;
+  const float iy = ((gy + 1.0f) * (float)c.H - 1.0f) / 2.0f;
+  const float nanv = __int_as_float(0x7fc00000);
+  if (!(isfinite(ix) && isfinite(iy))) {
+    for (int k = 0; k < 3; ++k) warp[(size_t)k * HW + p] = nanv;
+    return;
+  }
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+  // coordinates far outside the image: every tap is padding
+  const bool far = fabsf(x0f) > 1e8f || fabsf(y0f) > 1e8f;
+  const int x0 = far ? -2 : (int)x0f, y0 = far ? -2 : (int)y0f;
+  float acc[3] = {0.0f, 0.0f, 0.0f};
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xx = x0 + dx, yy = y0 + dy;
+      if (xx < 0 || xx >= c.W || yy < 0 || yy >= c.H) continue;
+      const float w = (dx ? wx1 : wx0) * (dy ? wy1 : wy0);
+      for (int k = 0; k < 3; ++k) acc[k] += w * in.color[(size_t)k * HW + (size_t)yy * c.W + xx];
+    }
+  for (int k = 0; k < 3; ++k) warp[(size_t)k * HW + p] = acc[k];
+}
+
+// scipy.ndimage reflect: (d c b a | a b c d | d c b a)
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i - 1;
+  if (i >= n) i = 2 * n - 1 - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// skimage.metrics.structural_similarity(warp, image, channel_axis=0, full=True).mean(0): 7x7 uniform window
+// (separable, float32 after each pass like scipy.ndimage.uniform_filter), sample covariance, data_range 2
+__global__ void __launch_bounds__(256) k_dp_ssim(int H, int W, const float* __restrict__ warp, const float* __restrict__ img,
+                                                  float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int HW = H * W;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int y = p / W, x = p % W;
+  const float C1 = (float)((0.01 * 2.0) * (0.01 * 2.0)), C2 = (float)((0.03 * 2.0) * (0.03 * 2.0));
+  const float cov_norm = (float)(49.0 / 48.0);
+  float total = 0.0f;
+  for (int ch = 0; ch < 3; ++ch) {
+    const float* A = warp + (size_t)ch * HW;
+    const float* B = img + (size_t)ch * HW;
+    double s[5] = {0, 0, 0, 0, 0};          // horizontal pass over the float32 results of the vertical pass
+    for (int dx = -3; dx <= 3; ++dx) {
+      const int xx = reflect_idx(x + dx, W);
+      double v[5] = {0, 0, 0, 0, 0};
+      for (int dy = -3; dy <= 3; ++dy) {
+        const int yy = reflect_idx(y + dy, H);
+        const float a = A[(size_t)yy * W + xx], b = B[(size_t)yy * W + xx];
+        v[0] += (double)a;
+        v[1] += (double)b;
+        v[2] += (double)(a * a);
+        v[3] += (double)(b * b);
+        v[4] += (double)(a * b);
+      }
+      for (int k = 0; k < 5; ++k) s[k] += (double)(float)(v[k] / 7.0);
+    }
+    const float ux = (float)(s[0] / 7.0), uy = (float)(s[1] / 7.0), uxx = (float)(s[2] / 7.0), uyy = (float)(s[3] / 7.0),
+                uxy = (float)(s[4] / 7.0);
+    const float vx = cov_norm * (uxx - ux * ux), vy = cov_norm * (uyy - uy * uy), vxy = cov_norm * (uxy - ux * uy);
+    const float A1 = 2.0f * ux * uy + C1, A2 = 2.0f * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+    total += (A1 * A2) / (B1 * B2);
+  }
+  out[p] = total / 3.0f;
+}
+
 struct f3 {
   float x, y, z;
 };
@@ -197,7 +296,7 @@ __global__ void __launch_bounds__(256) k_dp_normals(int H, int W, int model, con
   flag[p] = ok ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(256) k_dp_gather(slm_depth_config c, slm_depth_inputs in, slm_depth_outputs o,
+__global__ void __launch_bounds__(256) k_dp_gather(slm_depth_config c, slm_depth_inputs in, slm_depth_outputs o, const float* __restrict__ ssim,
                                                     const float* __restrict__ pcd, const float* __restrict__ nrm,
                                                     const int32_t* __restrict__ flag, const int32_t* __restrict__ idx) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,7 +324,9 @@ __global__ void __launch_bounds__(256) k_dp_gather(slm_depth_config c, slm_depth
     const float su = (float)x / (float)c.W, sv = (float)y / (float)c.H;
     const float a = 2.0f * su - 1.0f, b = 2.0f * sv - 1.0f;
     const float dc2 = a * a + b * b;
-    o.confs[t] = expf(-dc2 * (float)c.divterm);
+    float conf = expf(-dc2 * (float)c.divterm);
+    if (ssim) conf = 0.5f * conf + 0.5f * (1.0f / (1.0f + expf(-ssim[p])));   // data_loader.py:477-479
+    o.confs[t] = conf;
   }
   if (in.seg && o.seg) o.seg[t] = in.seg[p];
   if (in.seg_conf && o.seg_conf) {
@@ -293,6 +394,8 @@ int slm_depth_create(int32_t H, int32_t W, slm_depth** out) {
   if (e == hipSuccess) e = dgrow(d->flag, n);
   if (e == hipSuccess) e = dgrow(d->idx, n);
   if (e == hipSuccess) e = dgrow(d->total, 2);
+  if (e == hipSuccess) e = dgrow(d->warp, 3 * n);
+  if (e == hipSuccess) e = dgrow(d->ssim, n);
   if (e != hipSuccess) {
     slm_set_error_text((std::string("slm_depth_create: ") + hipGetErrorString(e)).c_str());
     slm_depth_destroy(d);
@@ -304,7 +407,7 @@ int slm_depth_create(int32_t H, int32_t W, slm_depth** out) {
 
 int slm_depth_destroy(slm_depth* d) {
   if (!d) return SLM_OK;
-  void* ptrs[] = {d->m0, d->m1, d->pcd, d->nrm, d->flag, d->idx, d->total, d->tmp};
+  void* ptrs[] = {d->m0, d->m1, d->pcd, d->nrm, d->flag, d->idx, d->total, d->tmp, d->warp, d->ssim};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   sem_free(d->sem);
@@ -324,6 +427,14 @@ int slm_depth_preprocess(slm_depth* d, const slm_depth_config* cfg, const slm_de
   hipStream_t st = (hipStream_t)stream;
   const int H = d->H, W = d->W, HW = H * W;
   const dim3 grid((HW + 255) / 256), blk(256);
+  // 0. stereo confidence from the raw depth (before anything is invalidated)
+  const float* ssim = nullptr;
+  if (cfg->use_ssim_conf) {
+    hipLaunchKernelGGL(k_dp_warp, grid, blk, 0, st, *cfg, *in, d->warp);
+    hipLaunchKernelGGL(k_dp_ssim, grid, blk, 0, st, H, W, d->warp, in->color, d->ssim);
+    ssim = d->ssim;
+    if (out->disp_conf) DCHK(hipMemcpyAsync(out->disp_conf, d->ssim, sizeof(float) * (size_t)HW, hipMemcpyDeviceToDevice, st));
+  }
   // 1. invalid map
   int have_base = 0;
   uint8_t* m = d->m0;
@@ -357,7 +468,7 @@ int slm_depth_preprocess(slm_depth* d, const slm_depth_config* cfg, const slm_de
     d->cap_tmp = bytes;
   }
   DCHK(rocprim::exclusive_scan(d->tmp, bytes, d->flag, d->idx, 0, (size_t)HW, rocprim::plus<int32_t>(), st));
-  hipLaunchKernelGGL(k_dp_gather, grid, blk, 0, st, *cfg, *in, *out, d->pcd, d->nrm, d->flag, d->idx);
+  hipLaunchKernelGGL(k_dp_gather, grid, blk, 0, st, *cfg, *in, *out, ssim, d->pcd, d->nrm, d->flag, d->idx);
   int32_t last[2];
   DCHK(hipMemcpyAsync(&last[0], d->idx + HW - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   DCHK(hipMemcpyAsync(&last[1], d->flag + HW - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -77,7 +77,7 @@ class SlmDepthConfig(C.Structure):
                 ("num_classes", C.c_int32), ("n_del_classes", C.c_int32), ("del_classes", C.c_int32 * 3),
                 ("depth_width_range", C.c_float * 2), ("inv_K", C.c_float * 9),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
-                ("divterm", C.c_double)]
+                ("divterm", C.c_double), ("use_ssim_conf", C.c_int32), ("stereo_P", C.c_float * 12)]
 
 
 class SlmDepthInputs(C.Structure):
@@ -89,7 +89,7 @@ class SlmDepthOutputs(C.Structure):
     _fields_ = [("points", C.c_void_p), ("norms", C.c_void_p), ("colors", C.c_void_p),
                 ("radii", C.c_void_p), ("confs", C.c_void_p), ("index_map", C.c_void_p),
                 ("valid", C.c_void_p), ("seg", C.c_void_p), ("seg_conf", C.c_void_p),
-                ("dist2edge", C.c_void_p), ("inval", C.c_void_p)]
+                ("dist2edge", C.c_void_p), ("inval", C.c_void_p), ("disp_conf", C.c_void_p)]
 
 
 class SlmFuseConfig(C.Structure):

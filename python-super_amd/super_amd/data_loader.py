@@ -11,8 +11,13 @@ dilate_invalid_kernel,normal_model,del_seg_classes,num_classes,phase}``, and ret
 with the reference's field names and dtypes (points / norms float64, radii float64, confs float32,
 index_map int64, valid bool, ...).  Like the reference it NaNs ``inputs[("depth",0)]`` /
 ``inputs[("disp",0)]`` at the invalid pixels and stores ``inputs["valid_map"]`` (superv1).
-Not built: the SSIM confidence (``opt.disable_ssim_conf == False``), the ``opt.load_valid_mask`` file
-read (pass ``inputs["valid_mask"]`` (H,W) bool instead) and the bilateral ``pcd2norm`` branch.
+With ``opt.disable_ssim_conf == False`` (the CLI default) the stereo confidence is computed on the device
+too -- the image warped through ``K @ inputs["stereo_T"]`` at the back-projected depth and its 7x7-window
+SSIM against itself (``skimage.metrics.structural_similarity`` semantics of the 0.19 line, see
+``oracle/depth_oracle.py::skimage_ssim_full``) -- stored in ``inputs[("disp_conf",0)]`` and blended into
+``data.confs`` (``utils/data_loader.py:359-373,477-479``).
+Not built: the ``opt.load_valid_mask`` file read (pass ``inputs["valid_mask"]`` (H,W) bool instead) and
+the bilateral ``pcd2norm`` branch.
 """
 from __future__ import annotations
 
@@ -41,8 +46,7 @@ def depth_preprocessing(opt, models, inputs, return_valid_map=False):
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise _lib.SuperLMError("no HIP device visible: super_amd has no CPU fallback")
-    if hasattr(opt, "disable_ssim_conf") and not opt.disable_ssim_conf:
-        raise NotImplementedError("super_amd.depth_preprocessing: SSIM confidence is not supported")
+    use_ssim = hasattr(opt, "disable_ssim_conf") and not opt.disable_ssim_conf
     depth_t = inputs[("depth", 0)]
     dev = depth_t.device if depth_t.is_cuda else torch.device("cuda", torch.cuda.current_device())
     H, W = int(opt.height), int(opt.width)
@@ -71,6 +75,15 @@ def depth_preprocessing(opt, models, inputs, return_valid_map=False):
             cfg.inv_K[3 * i + j] = float(iK[i, j])
     cfg.fx, cfg.fy, cfg.cx, cfg.cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
     cfg.divterm = float(inputs["divterm"])
+    if use_ssim:
+        if "stereo_T" not in inputs:
+            raise KeyError('depth_preprocessing: inputs["stereo_T"] is needed for the SSIM confidence '
+                           "(opt.disable_ssim_conf is False)")
+        P = torch.matmul(inputs["K"].detach().cpu().float(), inputs["stereo_T"].detach().cpu().float())[0, :3, :]
+        cfg.use_ssim_conf = 1
+        for i in range(3):
+            for j in range(4):
+                cfg.stereo_P[4 * i + j] = float(P[i, j])
     keep = [depth, color]
     inp = SlmDepthInputs()
     inp.depth, inp.color = _dev_ptr(depth), _dev_ptr(color)
@@ -94,6 +107,8 @@ def depth_preprocessing(opt, models, inputs, return_valid_map=False):
              colors=torch.empty((n, 3), dtype=f32, device=dev), radii=torch.empty(n, dtype=torch.float64, device=dev),
              confs=torch.empty(n, dtype=f32, device=dev), index_map=torch.empty((H, W), dtype=torch.int32, device=dev),
              valid=torch.empty(n, dtype=torch.uint8, device=dev), inval=torch.empty(n, dtype=torch.uint8, device=dev))
+    if use_ssim:
+        o["disp_conf"] = torch.empty((H, W), dtype=f32, device=dev)
     if has_seg:
         o.update(seg=torch.empty(n, dtype=torch.int32, device=dev),
                  seg_conf=torch.empty((n, C_), dtype=torch.float64, device=dev),
@@ -117,6 +132,8 @@ def depth_preprocessing(opt, models, inputs, return_valid_map=False):
         data.seg_conf = o["seg_conf"][:T]
         data.dist2edge = o["dist2edge"][:T]
     # the reference's side effects on `inputs`
+    if use_ssim:
+        inputs[("disp_conf", 0)] = o["disp_conf"]
     nan = float("nan")
     if depth_t.is_floating_point():
         depth_t[0, 0][inval.to(depth_t.device)] = nan

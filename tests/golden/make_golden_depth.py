@@ -32,6 +32,8 @@ VARIANTS = {
     "v1seg": dict(data="superv1", use_seg=True, del_seg_classes=[2]),
     "v2": dict(data="superv2", load_depth=True),
     "v2range": dict(data="superv2", load_depth=False, depth_width_range=(0.1, 0.8)),
+    # stereo (SSIM) confidence blended in: confs = 0.5 * confs + 0.5 * sigmoid(inputs[("disp_conf", 0)])
+    "v2ssim": dict(data="superv2", load_depth=True, disable_ssim_conf=False),
 }
 
 
@@ -45,8 +47,14 @@ def make_inputs(H=60, W=80, seed=7):
     depth[5:9, 30:34] = 2.0                                    # beyond the 1.5 threshold
     color = rng.uniform(0, 255, (3, H, W)).astype(np.float32)
     logits = synth._f32(synth._box_mean(synth._class_logits(uu, vv, H, W, 3, 0.0), 5))
+    # stereo pair: right camera 5.5 mm to the right (units of the depth map), slight rotation; image in [0, 1]
+    r2 = np.random.default_rng(seed + 100)
+    img01 = (0.5 + 0.25 * np.sin(uu / 3.0)[None] * np.cos(vv / 4.0)[None] + r2.uniform(-0.2, 0.2, (3, H, W))).astype(np.float32)
+    a = 0.01
+    stereo_T = np.array([[np.cos(a), 0, np.sin(a), -0.0055], [0, 1, 0, 0.0002], [-np.sin(a), 0, np.cos(a), 0.0001],
+                         [0, 0, 0, 1]], np.float32)
     return dict(H=H, W=W, K=K, inv_K=inv_K, depth=depth, color=color, divterm=1.0 / (2.0 * 0.6 * 0.6),
-                seg_conf=logits, seg=np.argmax(logits, 0).astype(np.int64))
+                seg_conf=logits, seg=np.argmax(logits, 0).astype(np.int64), color01=img01, stereo_T=stereo_T)
 
 
 def run_reference(ref, base, okw):
@@ -62,6 +70,9 @@ def run_reference(ref, base, okw):
               "inv_K": torch.from_numpy(base["inv_K"])[None], "K": torch.from_numpy(base["K"])[None],
               ("color", 0): torch.from_numpy(base["color"].copy())[None], "divterm": base["divterm"],
               "filename": ["000001"]}
+    if hasattr(opt, "disable_ssim_conf"):
+        inputs["stereo_T"] = torch.from_numpy(base["stereo_T"].copy())[None]
+        inputs[("color", 0)] = torch.from_numpy(base["color01"].copy())[None]
     if use_seg:
         inputs[("seg", 0)] = torch.from_numpy(base["seg"])[None, None]
         inputs[("seg_conf", 0)] = torch.from_numpy(base["seg_conf"].astype(np.float64))[None]
@@ -70,6 +81,8 @@ def run_reference(ref, base, okw):
                valid=data.valid, index_map=data.index_map, valid_map=data.valid_map, inval=~not_inval[0, 0] if not_inval.dim() == 4 else ~not_inval[0])
     if use_seg:
         out.update(seg=data.seg, seg_conf=data.seg_conf, dist2edge=data.dist2edge)
+    if ("disp_conf", 0) in inputs:
+        out.update(disp_conf=inputs[("disp_conf", 0)])
     return {k: v.detach().cpu().numpy() for k, v in out.items()}
 
 

@@ -110,6 +110,21 @@ def install():
                            uutils=ref_uutils, deform_mesh=ref_dm)
 
 
+def _structural_similarity(im1, im2, channel_axis=None, full=False, **kw):
+    """scikit-image is not installed here (and not version-pinned by the reference): the restatement of
+    its published algorithm in ``oracle/depth_oracle.py::skimage_ssim_full`` stands in, so that the
+    reference's own warp (Project3D + grid_sample) and confidence blend run and get recorded.  The SSIM
+    values themselves are therefore NOT pinned by the reference (said so in the oracle and DESIGN.md)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import depth_oracle
+    assert channel_axis == 0 and full and not kw
+    S = depth_oracle.skimage_ssim_full(np.asarray(im1), np.asarray(im2))
+    return float(S.mean()), S
+
+
 def install_data_loader():
     """Additionally import the reference's ``utils.data_loader`` (for ``depth_preprocessing``,
     SURVEY.md 8f row f2): stubs for the image / network modules it imports at module level."""
@@ -126,7 +141,7 @@ def install_data_loader():
 
     sk = mod("skimage")
     sk.io = mod("skimage.io")
-    sk.metrics = mod("skimage.metrics", structural_similarity=None)
+    sk.metrics = mod("skimage.metrics", structural_similarity=_structural_similarity)
     pil = mod("PIL")
     pil.Image = mod("PIL.Image")
     mod("depth.raft_core")

@@ -31,8 +31,13 @@ def _run_gpu(base, okw):
     if use_seg:
         inputs[("seg", 0)] = torch.from_numpy(base["seg"])[None, None].cuda()
         inputs[("seg_conf", 0)] = torch.from_numpy(base["seg_conf"].astype(np.float64))[None].cuda()
+    if "disable_ssim_conf" in kw:
+        inputs["stereo_T"] = torch.from_numpy(base["stereo_T"].copy())[None]
+        inputs[("color", 0)] = torch.from_numpy(base["color01"].copy())[None].cuda()
     data, inputs, not_inval = depth_preprocessing(opt, None, inputs, return_valid_map=True)
     out = {k: v.cpu().numpy() for k, v in vars(data).items() if hasattr(v, "cpu")}
+    if ("disp_conf", 0) in inputs:
+        out["disp_conf"] = inputs[("disp_conf", 0)].cpu().numpy()
     out["inval"] = ~not_inval[0, 0].cpu().numpy()
     out["depth_after"] = inputs[("depth", 0)][0, 0].cpu().numpy()
     return out
@@ -46,7 +51,10 @@ def _check(out, ref, tag, exact_points=True):
     np.testing.assert_array_equal(out["colors"], ref[f"{tag}colors"])
     np.testing.assert_allclose(out["norms"], ref[f"{tag}norms"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(out["radii"], ref[f"{tag}radii"], rtol=1e-5)
-    np.testing.assert_allclose(out["confs"], ref[f"{tag}confs"], rtol=1e-6)
+    np.testing.assert_allclose(out["confs"], ref[f"{tag}confs"], rtol=1e-5 if f"{tag}disp_conf" in ref else 1e-6)
+    if f"{tag}disp_conf" in ref:
+        # warp + blend pinned by the reference; the SSIM kernel by the restated skimage algorithm
+        np.testing.assert_allclose(out["disp_conf"], ref[f"{tag}disp_conf"], rtol=0, atol=5e-5)
     if f"{tag}seg" in ref:
         np.testing.assert_array_equal(out["seg"], ref[f"{tag}seg"])
         np.testing.assert_allclose(out["seg_conf"], ref[f"{tag}seg_conf"], rtol=1e-6)   # float32 logits in HBM
@@ -60,6 +68,35 @@ def test_depth_preprocessing_matches_reference_goldens(tag):
     out = _run_gpu(base, VARIANTS[tag])
     _check(out, {k: g[k] for k in g.files}, tag + "_")
     assert np.isnan(out["depth_after"][out["inval"]]).all() and not np.isnan(out["depth_after"][~out["inval"]]).any()
+
+
+def test_stereo_confidence_full_size_matches_oracle():
+    """480x640, default CLI setting (SSIM confidence on): device warp + SSIM + blend against the oracle."""
+    from super_amd import synth
+    H, W = 480, 640
+    rng = np.random.default_rng(9)
+    K = synth.intrinsics()
+    inv_K = np.linalg.pinv(K)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    depth = (0.2 * synth._surface(uu, vv, H, W, 0.3)).astype(np.float32)
+    depth[rng.uniform(size=(H, W)) < 0.01] = 0.0
+    img = (0.5 + 0.25 * np.sin(uu / 5.0)[None] * np.cos(vv / 7.0)[None] + rng.uniform(-0.2, 0.2, (3, H, W))).astype(np.float32)
+    a = 0.004
+    T = np.array([[np.cos(a), 0, np.sin(a), -0.0055], [0, 1, 0, 1e-4], [-np.sin(a), 0, np.cos(a), 2e-4], [0, 0, 0, 1]],
+                 np.float32)
+    base = dict(H=H, W=W, K=K, inv_K=inv_K, depth=depth, color=img, color01=img, stereo_T=T, divterm=1.0 / (2 * 0.6 * 0.6))
+    okw = dict(data="superv2", load_depth=True, disable_ssim_conf=False)
+    out = _run_gpu(base, okw)
+    opt = dpo.default_opt(height=H, width=W, **okw)
+    ref = dpo.depth_preprocessing(opt, depth, K, inv_K, img, base["divterm"], stereo_T=T)
+    ok = np.isfinite(ref["disp_conf"])
+    assert ok.mean() > 0.99
+    np.testing.assert_allclose(out["disp_conf"][ok], ref["disp_conf"][ok], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(out["valid"], ref["valid"])
+    both = np.isfinite(ref["confs"]) & np.isfinite(out["confs"])
+    assert both.mean() > 0.99
+    np.testing.assert_allclose(out["confs"][both], ref["confs"][both], rtol=0, atol=3e-5)
+    assert float(np.nanstd(ref["disp_conf"])) > 0.01 and float(np.nanmax(np.abs(ref["disp_conf"]))) <= 1.0 + 1e-5
 
 
 @pytest.mark.parametrize("tag", ["v1seg", "v1n8"])
