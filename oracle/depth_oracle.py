@@ -12,6 +12,12 @@ Float32 arithmetic is reproduced operation by operation where the reference comp
 the 3x3 intrinsics here; point differences, cross products, normalisation), so points are
 bit-exact and normals agree to float32 rounding.  Pinned against the reference itself by
 ``tests/golden/make_golden_depth.py`` -> ``tests/golden/dp_*.npz``.  Only ``tests/`` import this.
+
+PARITY UNPINNED for one function: ``skimage_ssim_full`` restates the published algorithm of
+``skimage.metrics.structural_similarity`` (scikit-image, a dependency absent from the reference tree and
+from this image, and not version-pinned by the reference: ``resources/environment.yaml:28``); the stereo
+warp before it and the confidence blend after it ARE pinned by the reference (``v2ssim`` golden variant,
+recorded with this restatement standing in for the missing package).
 """
 from __future__ import annotations
 
