@@ -262,6 +262,7 @@ struct PrepBuffers {
   size_t cap_w = 0;
   void* tmp = nullptr;
   size_t cap_tmp = 0;
+  size_t q_n = 0, q_t = 0, q_e = 0;   // sizes the rocPRIM temporary-storage requirement was last queried for
   int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique
   int* scal_host = nullptr;   // pinned mirror
 };
@@ -303,6 +304,38 @@ static hipError_t ensure_tmp(PrepBuffers* p, size_t bytes) {
   return e;
 }
 
+// rocPRIM's size queries cost tens of microseconds of host time each (device-property look-ups) and
+// slm_bind_frame is host-bound, so the requirement is queried once per buffer capacity -- for N, the
+// tuple capacity and the entry capacity, which only change when a buffer grows -- and every call then
+// gets the whole scratch buffer (rocPRIM accepts more than it needs and reports too little as an error).
+static hipError_t ensure_tmp_for(PrepBuffers* p, size_t N, size_t cap_t, size_t cap_e, hipStream_t st) {
+  if (p->q_n == N && p->q_t == cap_t && p->q_e == cap_e && p->tmp) return hipSuccess;
+  size_t need = 0, b = 0;
+  auto upd = [&](hipError_t e) {
+    need = b > need ? b : need;
+    b = 0;
+    return e;
+  };
+  hipError_t e = hipSuccess;
+  unsigned long long* k64 = nullptr;
+  unsigned* k32 = nullptr;
+  int* v = nullptr;
+  if ((e = upd(rocprim::radix_sort_pairs(nullptr, b, k64, k64, v, v, N, 0, 64, st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::run_length_encode(nullptr, b, k64, N, k64, v, v, st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::exclusive_scan(nullptr, b, v, v, 0, cap_t, rocprim::plus<int>(), st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::radix_sort_pairs(nullptr, b, k32, k32, v, v, cap_e, 0, 32, st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::run_length_encode(nullptr, b, k32, cap_e, k32, v, v, st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::exclusive_scan(nullptr, b, v, v, 0, cap_e, rocprim::plus<int>(), st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::radix_sort_pairs(nullptr, b, k64, k64, v, v, cap_e, 0, 64, st))) != hipSuccess) return e;
+  if ((e = upd(rocprim::run_length_encode(nullptr, b, k64, cap_e, k64, v, v, st))) != hipSuccess) return e;
+  e = ensure_tmp(p, need + need / 4 + (1u << 20));
+  if (e != hipSuccess) return e;
+  p->q_n = N;
+  p->q_t = cap_t;
+  p->q_e = cap_e;
+  return hipSuccess;
+}
+
 void plan_free(V1Plan& plan) {
   void* ptrs[] = {plan.s_pts, plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes, plan.slab, plan.blk_key,
                   plan.blk_start, plan.blk_entry, plan.run_chunk, plan.wg_first, plan.wg_last, plan.run_lidx,
@@ -330,10 +363,8 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   }
   hipLaunchKernelGGL(k_tuple_keys, dim3((N + 255) / 256), dim3(256), 0, st, (int)N, f.sf_knn_idx,
                      p->keys, p->ids);
-  size_t b1 = 0, b2 = 0;
-  PCHK(rocprim::radix_sort_pairs(nullptr, b1, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
-  PCHK(rocprim::run_length_encode(nullptr, b2, p->skeys, N, p->tkeys, p->tcount, p->scal, st));
-  PCHK(ensure_tmp(p, b1 > b2 ? b1 : b2));
+  PCHK(ensure_tmp_for(p, N, p->cap_t ? p->cap_t : 1, p->cap_e ? p->cap_e : 1, st));
+  size_t b1 = p->cap_tmp, b2 = p->cap_tmp;
   PCHK(rocprim::radix_sort_pairs(p->tmp, b1, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
   PCHK(rocprim::run_length_encode(p->tmp, b2, p->skeys, N, p->tkeys, p->tcount, p->scal, st));
   PCHK(hipMemcpyAsync(p->scal_host, p->scal, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -376,9 +407,8 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
 
   const dim3 gt((nt + 255) / 256), blk(256);
   hipLaunchKernelGGL(k_padded_counts, gt, blk, 0, st, p->scal, p->tcount, p->pc);
-  size_t bs = 0;
-  PCHK(rocprim::exclusive_scan(nullptr, bs, p->tcount, p->tstart, 0, nt, rocprim::plus<int>(), st));
-  PCHK(ensure_tmp(p, bs));
+  PCHK(ensure_tmp_for(p, N, p->cap_t, p->cap_e, st));
+  size_t bs = p->cap_tmp;
   PCHK(rocprim::exclusive_scan(p->tmp, bs, p->tcount, p->tstart, 0, nt, rocprim::plus<int>(), st));
   PCHK(rocprim::exclusive_scan(p->tmp, bs, p->pc, p->pstart, 0, nt, rocprim::plus<int>(), st));
   hipLaunchKernelGGL(k_run_counts, gt, blk, 0, st, p->scal, p->pstart, p->pc, p->nruns);
@@ -389,15 +419,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
                      plan.s_idx, plan.s_w, plan.grp_run, plan.run_nodes, plan.run_chunk);
   hipLaunchKernelGGL(k_pairs, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
                      plan.run_nodes, p->pkeys, p->pvals);
-  size_t b3 = 0, b4 = 0, b5 = 0;
-  PCHK(rocprim::radix_sort_pairs(nullptr, b3, p->pkeys, p->spkeys, p->pvals, plan.blk_entry, n_entries, 0,
-                                 32, st));
-  PCHK(rocprim::run_length_encode(nullptr, b4, p->spkeys, n_entries, p->ukeys, p->bcount, p->scal + 4, st));
-  PCHK(rocprim::exclusive_scan(nullptr, b5, p->bcount, plan.blk_start, 0, n_entries,
-                               rocprim::plus<int>(), st));
-  size_t bm = b3 > b4 ? b3 : b4;
-  bm = bm > b5 ? bm : b5;
-  PCHK(ensure_tmp(p, bm));
+  size_t b3 = p->cap_tmp, b4 = p->cap_tmp, b5 = p->cap_tmp;
   PCHK(rocprim::radix_sort_pairs(p->tmp, b3, p->pkeys, p->spkeys, p->pvals, plan.blk_entry, n_entries, 0,
                                  32, st));
   PCHK(rocprim::run_length_encode(p->tmp, b4, p->spkeys, n_entries, p->ukeys, p->bcount, p->scal + 4, st));
@@ -438,14 +460,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   PCHK(hipMemsetAsync(plan.wg_last, 0xFF, n_wg * sizeof(int), st));   // -1
   hipLaunchKernelGGL(k_pairs2, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
                      plan.run_nodes, plan.run_chunk, p->wkeys, p->wvals);
-  size_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-  PCHK(rocprim::radix_sort_pairs(nullptr, c1, p->wkeys, p->swkeys, p->wvals, p->swvals, n_entries, 0, 64, st));
-  PCHK(rocprim::run_length_encode(nullptr, c2, p->swkeys, n_entries, p->uwkeys, p->wcount, p->scal + 5, st));
-  PCHK(rocprim::exclusive_scan(nullptr, c3, p->wcount, p->wstart, 0, n_entries, rocprim::plus<int>(), st));
-  PCHK(rocprim::radix_sort_pairs(nullptr, c4, p->pk2, p->spk2, p->pv2, plan.blk2_entry, n_entries, 0, 32, st));
-  PCHK(rocprim::run_length_encode(nullptr, c5, p->spk2, n_entries, p->upk2, p->b2count, p->scal + 4, st));
-  size_t cm = std::max(std::max(c1, c2), std::max(std::max(c3, c4), c5));
-  PCHK(ensure_tmp(p, cm));
+  size_t c1 = p->cap_tmp, c2 = p->cap_tmp, c3 = p->cap_tmp, c4 = p->cap_tmp, c5 = p->cap_tmp;
   PCHK(rocprim::radix_sort_pairs(p->tmp, c1, p->wkeys, p->swkeys, p->wvals, p->swvals, n_entries, 0, 64, st));
   PCHK(rocprim::run_length_encode(p->tmp, c2, p->swkeys, n_entries, p->uwkeys, p->wcount, p->scal + 5, st));
   PCHK(rocprim::exclusive_scan(p->tmp, c3, p->wcount, p->wstart, 0, n_entries, rocprim::plus<int>(), st));
