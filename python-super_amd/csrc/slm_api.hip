@@ -1,6 +1,7 @@
 // slm_api.hip -- the C ABI of libsuper_lm.so (include/super_lm.h): slot workspaces,
 // the on-device LM loop, parity entry points.  Host side only orchestrates launches.
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <cstdio>
 #include <cstring>
@@ -74,8 +75,18 @@ struct Slot {
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
   // nested-dissection plan: host copy + device mirrors (grow-only)
   NDPlanHost nd;
-  uint64_t nd_hash = 0;         // hash of the coupled-pair list + node KNN the cached plan was built from
+  uint64_t nd_hash = 0;         // hash of the coupled-pair list + node KNN of the frame bound last
+  uint64_t nd_knn_hash = 0;     // hash of (J, K_ED, node KNN) the cached plan was built for
   bool nd_valid = false;
+  // The plan is built for a SUPERSET of the frame's coupled node pairs (the union of the pair lists seen
+  // since the node graph last changed): surfels that appear / disappear change the list a little from
+  // frame to frame, and a frame whose pairs are all in the plan only needs its own pair -> destination
+  // table (a merge of two sorted lists), not a new symbolic analysis (1.7 ms at C2).
+  std::vector<uint32_t> plan_pairs;     // sorted keys the plan's block_dest is indexed by
+  std::vector<NDDest> cur_dest;         // destinations of the bound frame's pairs
+  NDDest* d_cur_dests = nullptr;
+  size_t cap_cur_dests = 0;
+  int cur_n_blocks = -1;
   std::vector<uint32_t> h_pairs;
   std::vector<int32_t> h_knn;
   std::vector<float> h_pts;
@@ -171,6 +182,7 @@ int slm_destroy(slm_solver* s) {
     if (sl.d_fronts) (void)hipFree(sl.d_fronts);
     if (sl.d_ints) (void)hipFree(sl.d_ints);
     if (sl.d_dests) (void)hipFree(sl.d_dests);
+    if (sl.d_cur_dests) (void)hipFree(sl.d_cur_dests);
     if (sl.ftiles) (void)hipFree(sl.ftiles);
     if (sl.fvec) (void)hipFree(sl.fvec);
     if (sl.flinv) (void)hipFree(sl.flinv);
@@ -341,12 +353,49 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     };
     const int32_t dims[2] = {f->J, f->K_ED};
     mix(dims, sizeof(dims));
-    mix(sl.h_pairs.data(), sizeof(uint32_t) * sl.h_pairs.size());
     mix(sl.h_knn.data(), sizeof(int32_t) * sl.h_knn.size());
-    if (sl.nd_valid && sl.nd_hash == hash && (int)sl.nd.block_dest.size() == h.n_blocks) {
-      h.nd_ready = 1;   // device mirrors of the plan are still in place (pointers kept in h)
-    } else if (nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), sl.h_pairs.data(), h.n_blocks, sl.nd)) {
+    const uint64_t knn_hash = hash;
+    mix(sl.h_pairs.data(), sizeof(uint32_t) * sl.h_pairs.size());
+    // pair -> destination table of this frame from the plan's (sorted) pair list; false when a pair is new
+    auto dests_from_plan = [&]() -> bool {
+      sl.cur_dest.resize(sl.h_pairs.size());
+      size_t j = 0;
+      for (size_t i = 0; i < sl.h_pairs.size(); ++i) {
+        while (j < sl.plan_pairs.size() && sl.plan_pairs[j] < sl.h_pairs[i]) ++j;
+        if (j == sl.plan_pairs.size() || sl.plan_pairs[j] != sl.h_pairs[i]) return false;
+        sl.cur_dest[i] = sl.nd.block_dest[j];
+      }
+      return true;
+    };
+    auto upload_cur_dests = [&]() -> hipError_t {
+      hipError_t e = grow(sl.d_cur_dests, sl.cap_cur_dests, sl.cur_dest.size() + 1);
+      if (e == hipSuccess && !sl.cur_dest.empty())
+        e = hipMemcpyAsync(sl.d_cur_dests, sl.cur_dest.data(), sizeof(NDDest) * sl.cur_dest.size(), hipMemcpyHostToDevice, st);
+      h.block_dest = sl.d_cur_dests;
+      sl.cur_n_blocks = h.n_blocks;
+      return e;
+    };
+    if (sl.nd_valid && sl.nd_knn_hash != knn_hash) {   // another node graph: nothing of the old plan applies
       sl.nd_valid = false;
+      sl.plan_pairs.clear();
+    }
+    std::vector<uint32_t> all_pairs;
+    if (sl.nd_valid && sl.nd_hash == hash && sl.cur_n_blocks == h.n_blocks) {
+      h.nd_ready = 1;   // device mirrors of the plan and of this pair list are still in place (pointers kept in h)
+    } else if (sl.nd_valid && dests_from_plan()) {
+      HIPCHK(upload_cur_dests());
+      h.nd_ready = 1;
+      sl.nd_hash = hash;
+    } else if ([&] {
+                 // new pairs: analyse the union of what the plan already covers and this frame's list
+                 all_pairs.resize(sl.plan_pairs.size() + sl.h_pairs.size());
+                 all_pairs.resize(std::set_union(sl.plan_pairs.begin(), sl.plan_pairs.end(), sl.h_pairs.begin(),
+                                                 sl.h_pairs.end(), all_pairs.begin()) - all_pairs.begin());
+                 return nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), all_pairs.data(),
+                                      (int)all_pairs.size(), sl.nd);
+               }()) {
+      sl.nd_valid = false;
+      sl.plan_pairs.swap(all_pairs);
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
                             nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size();
@@ -376,8 +425,9 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       if (!nd.block_dest.empty())
         HIPCHK(hipMemcpyAsync(sl.d_dests, nd.block_dest.data(), sizeof(NDDest) * nd.block_dest.size(), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(sl.d_dests + nd.block_dest.size(), nd.pair_dest.data(), sizeof(NDDest) * nd.pair_dest.size(), hipMemcpyHostToDevice, st));
-      h.block_dest = sl.d_dests;
       h.pair_dest = sl.d_dests + nd.block_dest.size();
+      if (!dests_from_plan()) return fail(SLM_ERR_INVALID, "slm_bind_frame: internal error (pair missing from its own plan)");
+      HIPCHK(upload_cur_dests());
       h.fronts = sl.d_fronts;
       h.n_fronts = (int)nd.fronts.size();
       h.n_levels = (int)nd.level_start.size() - 1;
@@ -386,9 +436,11 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.flinv = sl.flinv;
       h.nd_ready = 1;
       sl.nd_hash = hash;
+      sl.nd_knn_hash = knn_hash;
       sl.nd_valid = true;
     } else {
       sl.nd_valid = false;
+      sl.plan_pairs.clear();
     }
   }
   h.bound = 1;

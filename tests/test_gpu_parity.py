@@ -146,6 +146,35 @@ def test_batch_of_frames_matches_single():
     np.testing.assert_allclose(singles[0], ob, rtol=0, atol=TOL_BETA)
 
 
+def test_symbolic_plan_survives_a_changing_pair_list():
+    """Surfels come and go between frames (fusion), so the coupled node-pair list changes a little every
+    frame.  The solver keeps its symbolic plan for the union of the lists it has seen: frames solved one after
+    the other in the same slot give the same warp as each solved by a fresh solver, and match the oracle."""
+    import torch
+    from super_amd import synth
+    sc = synth.make_scene(N=20000, J=300, H=240, W=320, seed=21)
+    opt = orc.default_opt(num_optimize_iterations=3)
+    rng = np.random.default_rng(3)
+
+    def variant(keep):
+        sf, inputs, new_data = torch_frame(sc)
+        if keep is not None:
+            k = torch.from_numpy(keep).cuda()
+            sf.points, sf.norms, sf.knn_indices, sf.knn_w = sf.points[k], sf.norms[k], sf.knn_indices[k], sf.knn_w[k]
+            sf.isStable = sf.isStable[k]
+        return sf, inputs, new_data
+
+    keeps = [None] + [np.sort(rng.choice(sc.N, int(f * sc.N), replace=False)) for f in (0.9, 0.5, 0.95)] + [None]
+    lm = _solver(opt)
+    chained = [lm.LM(*variant(keep)).cpu().numpy() for keep in keeps]
+    for keep, got in zip(keeps, chained):
+        fresh = _solver(opt).LM(*variant(keep)).cpu().numpy()
+        np.testing.assert_allclose(got, fresh, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(chained[0], chained[-1], rtol=0, atol=1e-12)    # same frame, first and last
+    want = orc.lm(orc.Frame.from_scene(sc), opt)
+    np.testing.assert_allclose(chained[0], want, rtol=0, atol=TOL_BETA)
+
+
 @pytest.mark.parametrize("N,J", [(20000, 300), (50000, 512)])
 def test_mid_size_vs_oracle(N, J):
     """C1-sized parity against the NumPy oracle (seconds on CPU)."""
