@@ -1,0 +1,74 @@
+"""Diagnostic: end-to-end ms/frame of the driver mirror (super_amd.super.SuPer) at the SuPer image size:
+depth_preprocessing -> LM (10 iterations) -> Surfels.update -> fuseInputData -> swap, per stage."""
+import sys, os, time
+from types import SimpleNamespace
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-super_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from super_amd import synth, fusion, nodes
+from super_amd import super as drv
+from super_amd import data_loader
+
+H, W = 480, 640
+derived = "--gf" not in sys.argv
+step = 11
+K = synth.intrinsics()
+inv_K = np.linalg.pinv(K)
+vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+color = np.random.default_rng(2).uniform(0, 1, (3, H, W)).astype(np.float32)
+opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, depth_model="monodepth2",
+                      dilate_invalid_kernel=0, normal_model="naive", phase="test", method="super", load_depth=True,
+                      deform_udpate_method="super_edg", mesh_step_size=step, use_derived_gradient=derived,
+                      sf_point_plane=True, mesh_arap=True, mesh_rot=True, mesh_face=False, sf_point_plane_weight=1.0,
+                      mesh_arap_weight=10.0, mesh_rot_weight=1.0, mesh_face_weight=1.0, num_optimize_iterations=10,
+                      optimizer="Adam", learning_rate=2e-4, num_neighbors=4, num_ED_neighbors=4, th_dist=0.02,
+                      th_cosine_ang=0.4, th_time_steps=30, disable_merging_new_surfels=False,
+                      disable_merging_exist_surfels=False, disable_adding_new_surfels=False,
+                      disable_removing_unstable_surfels=False)
+model = drv.SuPer(opt)
+stages = {}
+
+
+def timed(name, fn):
+    def wrapper(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize()
+        stages.setdefault(name, []).append((time.perf_counter() - t0) * 1e3)
+        return r
+    return wrapper
+
+
+drv.depth_preprocessing = timed("depth_preprocessing", data_loader.depth_preprocessing)
+drv.Surfels.update = timed("update", nodes.update)
+drv.Surfels.fuseInputData = timed("fuseInputData", fusion.fuseInputData)
+drv.Surfels.prepareStableIndexNSwapAllModel = timed("swap", fusion.prepareStableIndexNSwapAllModel)
+if derived:
+    model.lm.LM = timed("LM", model.lm.LM)
+else:
+    model.graph_fit.forward = timed("GraphFit", model.graph_fit.forward)
+    model.graph_fit.__class__.__call__ = lambda self, *a, **k: self.forward(*a, **k)
+frames = 12
+tot = []
+if "--nogc" in sys.argv:
+    import gc
+    gc.disable()
+for k in range(frames):
+    depth = (0.2 * synth._surface(uu, vv, H, W, 0.3 + 0.01 * k)).astype(np.float32)
+    depth[:4] = 0.0
+    depth[:, :4] = 0.0
+    inputs = {("depth", 0): torch.from_numpy(depth)[None, None].cuda(), ("disp", 0): torch.zeros(1, 1, H, W).cuda(),
+              "inv_K": torch.from_numpy(inv_K)[None].cuda(), "K": torch.from_numpy(K)[None].cuda(),
+              ("color", 0): torch.from_numpy(color)[None].cuda(), "divterm": torch.tensor(1.0 / (2 * 0.6 * 0.6)),
+              "filename": ["%06d" % k], "time": k, "ID": torch.tensor([k])}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model(SimpleNamespace(), inputs)
+    torch.cuda.synchronize()
+    tot.append((time.perf_counter() - t0) * 1e3)
+print("surfels", int(model.sf.points.shape[0]), "nodes", model.sf.ED_nodes.num, "path", "LM" if derived else "GraphFit")
+print("ms/frame (frames 4..):", round(float(np.mean(tot[4:])), 2), "all:", [round(t, 1) for t in tot])
+for k, v in stages.items():
+    print(f"  {k:22s} {np.mean(v[3:]):7.2f} ms   per frame: {[round(x, 1) for x in v]}")
