@@ -52,6 +52,14 @@ def test_no_device_fails_loudly(lib):
     from oracle.lm_oracle import default_opt
     with pytest.raises(SuperLMError):
         LM_Solver(default_opt())
+    # the stages either side of the solve refuse as well
+    h = C.c_void_p()
+    assert lib.slm_fuse_create(48, 64, 1000, C.byref(h)) != 0 and b"no HIP device" in lib.slm_last_error()
+    assert lib.slm_depth_create(48, 64, C.byref(h)) != 0 and b"no HIP device" in lib.slm_last_error()
+    from super_amd.graph_encoder import DirectDeformGraph
+    from types import SimpleNamespace
+    with pytest.raises(SuperLMError):
+        DirectDeformGraph(SimpleNamespace(method="super"))
 
 
 def test_argument_validation(lib):
