@@ -537,6 +537,10 @@ int slm_graph_init_semantic(int32_t H, int32_t W, int32_t step, const uint8_t* v
                             int32_t prune_class_edges, const slm_graph_outputs* out, int32_t* node_seg,
                             double* node_seg_conf, int32_t* counts_host, void* stream);
 
+/* Diagnostics: {device buffer reallocations in the LM solver, bytes asked for, symbolic analyses,
+ * plan reuses with a changed pair list} since the library was loaded. */
+int slm_debug_counters(int64_t out[4]);
+
 #ifdef __cplusplus
 }
 #endif

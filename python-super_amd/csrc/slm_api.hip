@@ -115,9 +115,14 @@ struct slm_solver {
   int rank = 0, world = 1;      // surfel sharding of every frame (slm_set_shard)
 };
 
+// diagnostics (slm_debug_counters): device reallocations and symbolic analyses since the library was loaded
+static long long g_reallocs = 0, g_realloc_bytes = 0, g_plan_builds = 0, g_plan_reuses = 0;
+
 template <typename T>
 static hipError_t grow(T*& p, size_t& cap, size_t need) {
   if (need <= cap) return hipSuccess;
+  ++g_reallocs;
+  g_realloc_bytes += (long long)((need + need / 8) * sizeof(T));
   if (p) {
     hipError_t e = hipFree(p);
     if (e != hipSuccess) return e;
@@ -132,6 +137,15 @@ static hipError_t grow(T*& p, size_t& cap, size_t need) {
 extern "C" {
 
 const char* slm_last_error(void) { return g_err.c_str(); }
+
+int slm_debug_counters(int64_t out[4]) {
+  if (!out) return fail(SLM_ERR_INVALID, "slm_debug_counters: null output");
+  out[0] = g_reallocs;
+  out[1] = g_realloc_bytes;
+  out[2] = g_plan_builds;
+  out[3] = g_plan_reuses;
+  return SLM_OK;
+}
 
 int slm_device_count(void) {
   int n = 0;
@@ -383,6 +397,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     if (sl.nd_valid && sl.nd_hash == hash && sl.cur_n_blocks == h.n_blocks) {
       h.nd_ready = 1;   // device mirrors of the plan and of this pair list are still in place (pointers kept in h)
     } else if (sl.nd_valid && dests_from_plan()) {
+      ++g_plan_reuses;
       HIPCHK(upload_cur_dests());
       h.nd_ready = 1;
       sl.nd_hash = hash;
@@ -395,6 +410,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
                                       (int)all_pairs.size(), sl.nd);
                }()) {
       sl.nd_valid = false;
+      ++g_plan_builds;
       sl.plan_pairs.swap(all_pairs);
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +

@@ -5,7 +5,6 @@
 #include <cstdint>
 #include <functional>
 #include <numeric>
-#include <unordered_map>
 #include <vector>
 
 #include "slm_nd.h"
@@ -22,7 +21,7 @@ struct TreeNode {
 struct Builder {
   int J;
   const float* pts;
-  std::vector<std::vector<int>> adj;
+  std::vector<int> adj_start, adj;   // CSR adjacency (duplicates allowed: every use is a membership test)
   std::vector<TreeNode> tree;
   std::vector<char> side;   // scratch: 1 = A, 2 = B
 
@@ -34,7 +33,7 @@ struct Builder {
       tree[id].vars = nodes;
       return id;
     }
-    // widest coordinate axis, median split
+    // widest coordinate axis, median split (only the partition matters: nth_element, ties by node id)
     float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (int v : nodes)
       for (int a = 0; a < 3; ++a) {
@@ -44,10 +43,11 @@ struct Builder {
     int ax = 0;
     for (int a = 1; a < 3; ++a)
       if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
-    std::stable_sort(nodes.begin(), nodes.end(), [&](int x, int y) {
-      return pts[3 * x + ax] < pts[3 * y + ax];
-    });
     const size_t half = nodes.size() / 2;
+    std::nth_element(nodes.begin(), nodes.begin() + half, nodes.end(), [&](int x, int y) {
+      const float px = pts[3 * x + ax], py = pts[3 * y + ax];
+      return px < py || (px == py && x < y);
+    });
     for (size_t i = 0; i < nodes.size(); ++i) side[nodes[i]] = i < half ? 1 : 2;
     // vertex separator: the nodes of one side that touch the other side (smaller choice)
     std::vector<int> SA, SB;
@@ -55,13 +55,15 @@ struct Builder {
       const int v = nodes[i];
       const char other = side[v] == 1 ? 2 : 1;
       bool touches = false;
-      for (int w : adj[v])
-        if (side[w] == other) { touches = true; break; }
+      for (int e = adj_start[v]; e < adj_start[v + 1]; ++e)
+        if (side[adj[e]] == other) { touches = true; break; }
       if (touches) (side[v] == 1 ? SA : SB).push_back(v);
     }
     const std::vector<int>& S = SA.size() <= SB.size() ? SA : SB;
     for (int v : S) side[v] = 3;
     std::vector<int> A, B;
+    A.reserve(half + 1);
+    B.reserve(half + 1);
     for (int v : nodes) {
       if (side[v] == 1) A.push_back(v);
       else if (side[v] == 2) B.push_back(v);
@@ -94,19 +96,32 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   Builder b;
   b.J = J;
   b.pts = pts;
-  b.adj.assign(J, {});
   b.side.assign(J, 0);
-  auto add_edge = [&](int x, int y) {
-    if (x == y || x < 0 || y < 0 || x >= J || y >= J) return;
-    b.adj[x].push_back(y);
-    b.adj[y].push_back(x);
-  };
-  for (int i = 0; i < n_pairs; ++i) add_edge((int)(pairs[i] / (uint32_t)J), (int)(pairs[i] % (uint32_t)J));
+  // CSR adjacency in two counting passes over the pair list and the node KNN table
+  auto valid_edge = [&](int x, int y) { return x != y && x >= 0 && y >= 0 && x < J && y < J; };
+  b.adj_start.assign(J + 1, 0);
+  for (int i = 0; i < n_pairs; ++i) {
+    const int x = (int)(pairs[i] / (uint32_t)J), y = (int)(pairs[i] % (uint32_t)J);
+    if (valid_edge(x, y)) { b.adj_start[x + 1]++; b.adj_start[y + 1]++; }
+  }
   for (int j = 0; j < J; ++j)
-    for (int s = 0; s < K_ED; ++s) add_edge(j, ed_knn[j * K_ED + s]);
-  for (auto& a : b.adj) {
-    std::sort(a.begin(), a.end());
-    a.erase(std::unique(a.begin(), a.end()), a.end());
+    for (int k = 0; k < K_ED; ++k) {
+      const int y = ed_knn[j * K_ED + k];
+      if (valid_edge(j, y)) { b.adj_start[j + 1]++; b.adj_start[y + 1]++; }
+    }
+  for (int j = 0; j < J; ++j) b.adj_start[j + 1] += b.adj_start[j];
+  b.adj.resize(b.adj_start[J]);
+  {
+    std::vector<int> fill(b.adj_start.begin(), b.adj_start.end() - 1);
+    for (int i = 0; i < n_pairs; ++i) {
+      const int x = (int)(pairs[i] / (uint32_t)J), y = (int)(pairs[i] % (uint32_t)J);
+      if (valid_edge(x, y)) { b.adj[fill[x]++] = y; b.adj[fill[y]++] = x; }
+    }
+    for (int j = 0; j < J; ++j)
+      for (int k = 0; k < K_ED; ++k) {
+        const int y = ed_knn[j * K_ED + k];
+        if (valid_edge(j, y)) { b.adj[fill[j]++] = y; b.adj[fill[y]++] = j; }
+      }
   }
   // the graph may be disconnected: dissect() only needs the node list
   std::vector<int> all(J);
@@ -155,8 +170,8 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     int my_max = -1;
     for (int v : b.tree[id].vars) my_max = std::max(my_max, order[v]);
     for (int v : b.tree[id].vars)
-      for (int w : b.adj[v])
-        if (order[w] > my_max) push(w);
+      for (int e = b.adj_start[v]; e < b.adj_start[v + 1]; ++e)
+        if (order[b.adj[e]] > my_max) push(b.adj[e]);
     for (int c = 0; c < 2; ++c)
       if (b.tree[id].child[c] >= 0)
         for (int w : bnd[b.tree[id].child[c]])
@@ -188,7 +203,21 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   out.tile_doubles = out.vec_doubles = out.linv_doubles = 0;
   out.max_nt = out.max_npt = out.max_level_fronts = 0;
   out.flops = 0.0;
-  std::vector<std::unordered_map<int, int>> local_pos(T);   // node -> local position in its front
+  // local position of a node in a front: every node occurs in its own front and in the few descendants'
+  // fronts that have it on their boundary -> a short (tree id, position) list per node
+  std::vector<int> occ_start(J + 1, 0);
+  for (int id = 0; id < T; ++id) {
+    for (int v : b.tree[id].vars) occ_start[v + 1]++;
+    for (int v : bnd[id]) occ_start[v + 1]++;
+  }
+  for (int j = 0; j < J; ++j) occ_start[j + 1] += occ_start[j];
+  std::vector<std::pair<int, int>> occ(occ_start[J]);
+  std::vector<int> occ_fill(occ_start.begin(), occ_start.end() - 1);
+  auto pos_in = [&](int tid, int node) -> int {
+    for (int e = occ_start[node]; e < occ_fill[node]; ++e)
+      if (occ[e].first == tid) return occ[e].second;
+    return -1;
+  };
   for (int i = 0; i < T; ++i) {
     const int id = proc[i];
     TreeNode& t = b.tree[id];
@@ -212,11 +241,11 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       out.nodes.push_back(v);
       out.node_front[v] = i;
       out.node_pos[v] = p;
-      local_pos[id][v] = p++;
+      occ[occ_fill[v]++] = {id, p++};
     }
     for (int v : bnd[id]) {
       out.nodes.push_back(v);
-      local_pos[id][v] = p++;
+      occ[occ_fill[v]++] = {id, p++};
     }
     f.tile_off = out.tile_doubles;
     out.tile_doubles += (int64_t)f.nt * (f.nt + 1) / 2 * 4096;
@@ -270,11 +299,10 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       if (f.nb != 0) return false;   // the root cannot have a boundary
       continue;
     }
-    auto& lp = local_pos[b.tree[id].parent];
     for (int v : bnd[id]) {
-      auto it = lp.find(v);
-      if (it == lp.end()) return false;   // boundary must be covered by the parent front
-      out.eamap.push_back(it->second);
+      const int pp = pos_in(b.tree[id].parent, v);
+      if (pp < 0) return false;   // boundary must be covered by the parent front
+      out.eamap.push_back(pp);
     }
   }
 
@@ -283,12 +311,11 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     const int e = order[a] < order[bnode] ? a : bnode;          // earlier eliminated -> column
     const int l = (e == a) ? bnode : a;
     const int tid = node_tree[e];
-    auto& lp = local_pos[tid];
-    auto it = lp.find(l);
-    if (it == lp.end()) return false;
+    const int prow = pos_in(tid, l);
+    if (prow < 0) return false;
     d.front = front_of_tree[tid];
-    d.pcol = lp[e];
-    d.prow = it->second;
+    d.pcol = out.node_pos[e];
+    d.prow = prow;
     d.transpose = (e == a && a != bnode) ? 1 : 0;
     return true;
   };

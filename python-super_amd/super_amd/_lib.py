@@ -25,7 +25,7 @@ EXPORTS = [
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
-    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64", "slm_graph_init_semantic",
+    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64", "slm_graph_init_semantic", "slm_debug_counters",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -162,6 +162,7 @@ def load():
     sig = {
         "slm_create": [C.POINTER(SlmConfig), C.POINTER(vp)],
         "slm_destroy": [vp],
+        "slm_debug_counters": [C.POINTER(C.c_int64)],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],

@@ -50,13 +50,14 @@ if derived:
 else:
     model.graph_fit.forward = timed("GraphFit", model.graph_fit.forward)
     model.graph_fit.__class__.__call__ = lambda self, *a, **k: self.forward(*a, **k)
-frames = 12
+frames = int(os.environ.get("DRIVER_FRAMES", "12"))
 tot = []
+events = []
 if "--nogc" in sys.argv:
     import gc
     gc.disable()
 for k in range(frames):
-    depth = (0.2 * synth._surface(uu, vv, H, W, 0.3 + 0.01 * k)).astype(np.float32)
+    depth = (0.2 * synth._surface(uu, vv, H, W, 0.3 + 0.3 * np.sin(0.05 * k))).astype(np.float32)
     depth[:4] = 0.0
     depth[:, :4] = 0.0
     inputs = {("depth", 0): torch.from_numpy(depth)[None, None].cuda(), ("disp", 0): torch.zeros(1, 1, H, W).cuda(),
@@ -68,7 +69,19 @@ for k in range(frames):
     model(SimpleNamespace(), inputs)
     torch.cuda.synchronize()
     tot.append((time.perf_counter() - t0) * 1e3)
-print("surfels", int(model.sf.points.shape[0]), "nodes", model.sf.ED_nodes.num, "path", "LM" if derived else "GraphFit")
+    import ctypes
+    from super_amd import _lib
+    cnt = (ctypes.c_int64 * 4)()
+    _lib.load().slm_debug_counters(cnt)
+    events.append(tuple(cnt))
+print("surfels", int(model.sf.points.shape[0]), "nodes", model.sf.ED_nodes.num, "path", "LM" if derived else "GraphFit",
+      "| torch reserved MB", torch.cuda.memory_reserved() >> 20, "| device used MB",
+      (torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) >> 20)
 print("ms/frame (frames 4..):", round(float(np.mean(tot[4:])), 2), "all:", [round(t, 1) for t in tot])
+ev = np.array(events)
+d = np.diff(ev, axis=0)
+slow = [i + 1 for i in range(len(d)) if tot[i + 1] > 1.3 * np.median(tot)]
+print("slow frames:", [(i, round(tot[i], 1), "reallocs", int(d[i - 1][0]), "MB", int(d[i - 1][1]) >> 20, "plan builds", int(d[i - 1][2])) for i in slow[:25]])
+print("totals: reallocs", ev[-1][0], "plan builds", ev[-1][2], "plan reuses", ev[-1][3])
 for k, v in stages.items():
     print(f"  {k:22s} {np.mean(v[3:]):7.2f} ms   per frame: {[round(x, 1) for x in v]}")
