@@ -47,6 +47,20 @@ drv.Surfels.fuseInputData = timed("fuseInputData", fusion.fuseInputData)
 drv.Surfels.prepareStableIndexNSwapAllModel = timed("swap", fusion.prepareStableIndexNSwapAllModel)
 if derived:
     model.lm.LM = timed("LM", model.lm.LM)
+    if "--detail" in sys.argv:
+        from super_amd import LM as lm_mod
+        _bf = lm_mod.BoundFrame
+        lm_mod.BoundFrame = timed("LM.BoundFrame (conversions)", _bf)
+        _lib0 = model.lm.lib
+        class _Wrap:
+            def __init__(self, lib):
+                self._lib = lib
+            def __getattr__(self, name):
+                fn = getattr(self._lib, name)
+                if name in ("slm_bind_frame", "slm_run", "slm_get_beta", "slm_get_records"):
+                    return timed("C " + name, fn)
+                return fn
+        model.lm.lib = _Wrap(_lib0)
 else:
     model.graph_fit.forward = timed("GraphFit", model.graph_fit.forward)
     model.graph_fit.__class__.__call__ = lambda self, *a, **k: self.forward(*a, **k)
