@@ -1045,7 +1045,15 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     const NDLevelSched& s = lv[l];
     if (s.n_fronts <= 0) continue;
     const LevelRef lr{l, s.first, s.n_fronts};
-    const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= 16;
+    // One workgroup per front (k_fL11 + k_fL21) only pays when a level has enough fronts to fill the
+    // chip: with few fronts the per-column panel launches, which spread a front over its row tiles, have
+    // the shorter critical path (C2: 581 instead of 543 it/s at one frame per launch; the cross-over is
+    // around 128 fronts x frames).  SLM_COMPACT_MIN overrides the threshold for experiments.
+    static const long compact_min = [] {
+      const char* e = getenv("SLM_COMPACT_MIN");
+      return e ? atol(e) : 128L;
+    }();
+    const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= compact_min;
     if (compact) {
       hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, lr, u_override);
       if (s.max_n2p > 0) {
