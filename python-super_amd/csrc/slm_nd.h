@@ -13,7 +13,7 @@
 #include <stddef.h>
 #include <vector>
 
-#define SLM_ND_LEAF 32   // stop bisecting below this many nodes
+#define SLM_ND_LEAF 18   // stop bisecting at this many nodes (18 x 7 = 126 scalars: two 64-wide tiles)
 
 // One front, device + host view.  Local node positions: [0,nv) pivots (elimination order),
 // [nv, nv+nb) boundary (ancestor separator nodes, elimination order).  Scalar layout:

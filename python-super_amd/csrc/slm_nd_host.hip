@@ -2,6 +2,7 @@
 // solver (see slm_nd.h).  Runs once per frame inside slm_bind_frame on a node graph of
 // J ~ 10^3 vertices (milliseconds); everything numeric runs on the device.
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <functional>
 #include <numeric>
@@ -29,7 +30,11 @@ struct Builder {
     const int id = (int)tree.size();
     tree.emplace_back();
     tree[id].depth = depth;
-    if ((int)nodes.size() <= SLM_ND_LEAF) {
+    static const int leaf_max = [] {
+      const char* e = getenv("SLM_ND_LEAF");
+      return e ? atoi(e) : SLM_ND_LEAF;
+    }();
+    if ((int)nodes.size() <= leaf_max) {
       tree[id].vars = nodes;
       return id;
     }
