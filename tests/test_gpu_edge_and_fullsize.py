@@ -320,3 +320,35 @@ def test_c4_semantic_graphfit_matches_oracle():
     dv = gf(inputs, sf, new_data, None).cpu().numpy()
     ref = gfo.graphfit(gfo.Problem(sc), opt)
     np.testing.assert_allclose(dv, ref, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("env", [{"SLM_ND_LEAF": "8"}, {"SLM_ND_LEAF": "96"}, {"SLM_COMPACT_MIN": "1"},
+                                 {"SLM_COMPACT_MIN": "1000000"}, {"SLM_ND_LEAF": "40", "SLM_COMPACT_MIN": "4"}])
+def test_solver_tuning_overrides_keep_the_result(env):
+    """The plan / schedule knobs (leaf size of the dissection, compact-path threshold) change the elimination
+    order and the launch sequence, not the solution: LM on a mid-size frame against the oracle under each
+    override (read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'python-super_amd')!r}, {os.path.join(root, 'tests')!r}]\n"
+        "from helpers import ref_opt, torch_frame\n"
+        "from oracle import lm_oracle as orc\n"
+        "from super_amd import synth\n"
+        "from super_amd.LM import LM_Solver\n"
+        "sc = synth.make_scene(N=20000, J=300, H=240, W=320, seed=9)\n"
+        "opt = orc.default_opt(num_optimize_iterations=3)\n"
+        "lm = LM_Solver(ref_opt(opt), max_frames=2)\n"
+        "b1 = lm.LM(*torch_frame(sc)).cpu().numpy()\n"
+        "b2 = [b.cpu().numpy() for b in lm.LM_batch([torch_frame(sc), torch_frame(sc)])]\n"
+        "want = orc.lm(orc.Frame.from_scene(sc), opt)\n"
+        "print('ERR', float(np.abs(b1 - want).max()), float(np.abs(b2[0] - want).max()), float(np.abs(b2[1] - b2[0]).max()))\n")
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    errs = [float(x) for x in out.stdout.strip().splitlines()[-1].split()[1:]]
+    assert max(errs[:2]) < 1e-6 and errs[2] < 1e-12, (env, errs)   # (merged records add in arrival order)
