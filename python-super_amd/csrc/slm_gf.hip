@@ -10,7 +10,7 @@
 //   Rot          w_r sum_{rows 0..J} (1 - |q|^2)^2
 //   face         w_f sum_tri (area(V) - area0)^2,  area = 1/2 sqrt(|e1 x e2|^2 + 1e-13)
 // Gradient of the global row is divided by J before the step (deform_mesh.py:326).
-// One f64 atomic per gradient entry and surfel; the global row is reduced per block first.
+// Local rows: summed per workgroup in an LDS table, then one f64 atomic per entry and touched node; the global row is reduced per block first.
 #include <string>
 #include <vector>
 
@@ -28,11 +28,21 @@ __global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
 // seg_mode: 0 none, 1 hard, 2 soft semantic weight on the squared residual (loss.py:379-399);
 // pp_max > 0 (and no seg_mode): squared residuals >= pp_max are dropped (loss.py:369-370);
 // use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
+#define GF_TAB 128   // LDS gradient table: slots per workgroup (power of two)
 __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode,
                                                   double pp_max, int use_morph, double w_morph) {
   __shared__ double sm[16];
+  // The 256 surfels of a workgroup are neighbours on the image and share a few dozen ED nodes: their
+  // gradient rows are summed in an LDS table keyed by node (ds_add_f64) and flushed with one global
+  // atomic per entry and touched node -- about 20x fewer memory-side f64 atomics than one per surfel
+  // and entry.  A slot taken by another node (direct-mapped, node & 127) falls back to global atomics.
+  __shared__ int tkey[GF_TAB];
+  __shared__ double tval[GF_TAB * 7];
   GfSlot& s = slots[blockIdx.y];
   if (!s.bound) return;
+  for (int t = threadIdx.x; t < GF_TAB; t += blockDim.x) tkey[t] = -1;
+  for (int t = threadIdx.x; t < GF_TAB * 7; t += blockDim.x) tval[t] = 0.0;
+  __syncthreads();
   const slm_frame& f = s.f.base;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int J = f.J;
@@ -158,16 +168,25 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
       for (int a = 0; a < 4; ++a) {
         quat_jac_row(k.qw[a], k.qv[a], k.dk[a], cl, jq);
         const double wk = k.w[a];
-        double* gr = s.grad + 7 * k.id[a];
-        atomic_add_f64(gr + 0, wk * jq[0]);
-        atomic_add_f64(gr + 1, wk * jq[1]);
-        atomic_add_f64(gr + 2, wk * jq[2]);
-        atomic_add_f64(gr + 3, wk * jq[3]);
-        atomic_add_f64(gr + 4, wk * cl.x);
-        atomic_add_f64(gr + 5, wk * cl.y);
-        atomic_add_f64(gr + 6, wk * cl.z);
+        const double v[7] = {wk * jq[0], wk * jq[1], wk * jq[2], wk * jq[3], wk * cl.x, wk * cl.y, wk * cl.z};
+        const int node = k.id[a], slot = node & (GF_TAB - 1);
+        const int old = atomicCAS(&tkey[slot], -1, node);
+        if (old == -1 || old == node) {
+#pragma unroll
+          for (int e = 0; e < 7; ++e) unsafeAtomicAdd(&tval[7 * slot + e], v[e]);
+        } else {
+          double* gr = s.grad + 7 * node;
+#pragma unroll
+          for (int e = 0; e < 7; ++e) atomic_add_f64(gr + e, v[e]);
+        }
       }
     }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < GF_TAB * 7; t += blockDim.x) {
+    const int node = tkey[t / 7];
+    const double v = tval[t];
+    if (node >= 0 && v != 0.0) atomic_add_f64(s.grad + 7 * node + t % 7, v);
   }
   // global row, loss and count: block reduction, then one atomic each
   double vals[9] = {gq[0], gq[1], gq[2], gq[3], gb[0], gb[1], gb[2], loss, cnt};
