@@ -133,6 +133,35 @@ def cpu_baseline_autograd(dims, seed):
                       f"{sc.J}-node frame, PyTorch-CPU float64, {dt:.1f} s"}
 
 
+def graphfit_timing(dims, device):
+    """The device side of rows a18-a20 (GraphFit: 10 Adam iterations of point-plane + ARAP + Rot on one frame of
+    the bench workload) through the C ABI, beside cpu_baseline_autograd which times the same thing on the host."""
+    import torch
+    from oracle import graphfit_oracle as gfo
+    from super_amd import synth
+    from super_amd.deform_mesh import GraphFit
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import torch_frame
+    sc = synth.make_scene(seed=0, **dims)
+    sf, inputs, new_data = torch_frame(sc, device)
+    opt = gfo.default_opt(optimizer="Adam")
+    opt.deform_udpate_method = "super_edg"
+    gf = GraphFit(opt)
+    gf._bind(0, inputs, sf, new_data)
+    st = torch.cuda.current_stream(device).cuda_stream
+    for _ in range(2):
+        gf.lib.slm_gf_run(gf.h, 1, st)
+    torch.cuda.synchronize(device)
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gf.lib.slm_gf_run(gf.h, 1, st)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / n
+    return {"ms_per_frame": 1e3 * dt, "value": opt.num_optimize_iterations / dt, "unit": "Adam it/s",
+            "sample": f"10 Adam iterations per frame on one {sc.N}-surfel / {sc.J}-node frame, float64, C ABI"}
+
+
 def next_row_timings(device):
     """Untimed-region extras (rank 0, N=1): the widened rows of SURVEY.md 8(f), measured with torch
     events on the stream the kernels run on.  f2 = depth_preprocessing at the SuPer image size."""
@@ -397,6 +426,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, seed=0)
             out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)
+            out["graphfit_gpu"] = graphfit_timing(dims, device)
             out["next_rows"] = next_row_timings(device)
         print(json.dumps(out), flush=True)
     if world > 1:
