@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
     pz = fr.points[3 * (size_t)t + 2];
     if (by_class) cls = sm.new_seg[t];
   }
+  if (!__syncthreads_or(act ? 1 : 0)) return;   // no candidate pixel in this block (the common case once the model covers the scene)
   double bd[4] = {1e300, 1e300, 1e300, 1e300};
   int bi[4] = {-1, -1, -1, -1};
   for (int j0 = 0; j0 < m.J; j0 += FU_TILE) {
