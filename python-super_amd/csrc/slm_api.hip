@@ -116,7 +116,7 @@ struct slm_solver {
 };
 
 // diagnostics (slm_debug_counters): device reallocations and symbolic analyses since the library was loaded
-static long long g_reallocs = 0, g_realloc_bytes = 0, g_plan_builds = 0, g_plan_reuses = 0;
+static long long g_reallocs = 0, g_realloc_bytes = 0, g_plan_builds = 0, g_plan_reuses = 0, g_plan_fill_hits = 0;
 
 template <typename T>
 static hipError_t grow(T*& p, size_t& cap, size_t need) {
@@ -371,13 +371,16 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     const uint64_t knn_hash = hash;
     mix(sl.h_pairs.data(), sizeof(uint32_t) * sl.h_pairs.size());
     // pair -> destination table of this frame from the plan's (sorted) pair list; false when a pair is new
+    // A pair the plan was not built from still has a place in it when the later-eliminated node lies in the
+    // front of the earlier one (a fill position of the dense front): no new analysis then either.
     auto dests_from_plan = [&]() -> bool {
       sl.cur_dest.resize(sl.h_pairs.size());
       size_t j = 0;
       for (size_t i = 0; i < sl.h_pairs.size(); ++i) {
         while (j < sl.plan_pairs.size() && sl.plan_pairs[j] < sl.h_pairs[i]) ++j;
-        if (j == sl.plan_pairs.size() || sl.plan_pairs[j] != sl.h_pairs[i]) return false;
-        sl.cur_dest[i] = sl.nd.block_dest[j];
+        if (j < sl.plan_pairs.size() && sl.plan_pairs[j] == sl.h_pairs[i]) sl.cur_dest[i] = sl.nd.block_dest[j];
+        else if (!nd_dest_of(sl.nd, f->J, sl.h_pairs[i], sl.cur_dest[i])) return false;
+        else ++g_plan_fill_hits;
       }
       return true;
     };

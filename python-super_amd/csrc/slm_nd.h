@@ -11,6 +11,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <utility>
 #include <vector>
 
 #define SLM_ND_LEAF 18   // stop bisecting at this many nodes (18 x 7 = 126 scalars: two 64-wide tiles)
@@ -70,6 +71,10 @@ struct NDPlanHost {
   std::vector<int32_t> in_edge;       // ARAP edges e = j*K_ED + slot grouped by their TARGET node k, ascending e
   std::vector<NDDest> block_dest;     // per data-term block (order of blk_key)
   std::vector<NDDest> pair_dest;      // per (j, slot) ARAP pair, J*K_ED
+  // kept for nd_dest_of(): elimination position and tree node of every ED node, front of every tree node,
+  // and per node the (tree node, local position) pairs of the fronts it occurs in
+  std::vector<int32_t> order, node_tree, front_of_tree, occ_start;
+  std::vector<std::pair<int32_t, int32_t>> occ;
   int64_t tile_doubles = 0, vec_doubles = 0, linv_doubles = 0;
   int32_t max_nt = 0, max_npt = 0, max_level_fronts = 0;
   std::vector<NDLevelSched> sched;    // one entry per level
@@ -80,3 +85,8 @@ struct NDPlanHost {
 // term; ed_knn: (J,K_ED); pts: (J,3).  Returns false when the graph cannot be handled.
 bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, const uint32_t* pairs,
                    int n_pairs, NDPlanHost& out);
+
+// Destination of the 7x7 block of node pair key = a*J + b (a >= b) in an existing plan.  Also succeeds for
+// pairs the plan was NOT built from when the later-eliminated node lies in the front of the earlier one
+// (a fill position of the dense front): such a pair needs no new symbolic analysis.
+bool nd_dest_of(const NDPlanHost& plan, int J, uint32_t key, NDDest& d);

@@ -155,7 +155,10 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       }
     }
   }
-  std::vector<int> order(J, -1), node_tree(J, -1);
+  std::vector<int32_t>& order = out.order;
+  std::vector<int32_t>& node_tree = out.node_tree;
+  order.assign(J, -1);
+  node_tree.assign(J, -1);
   int cnt = 0;
   for (int id : post)
     for (int v : b.tree[id].vars) {
@@ -197,7 +200,8 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       if (b.tree[id].depth == d) proc.push_back(id);
   }
   out.level_start.push_back((int)proc.size());
-  std::vector<int> front_of_tree(T, -1);
+  std::vector<int32_t>& front_of_tree = out.front_of_tree;
+  front_of_tree.assign(T, -1);
   for (int i = 0; i < (int)proc.size(); ++i) front_of_tree[proc[i]] = i;
 
   out.fronts.assign(T, NDFront());
@@ -210,13 +214,15 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   out.flops = 0.0;
   // local position of a node in a front: every node occurs in its own front and in the few descendants'
   // fronts that have it on their boundary -> a short (tree id, position) list per node
-  std::vector<int> occ_start(J + 1, 0);
+  std::vector<int32_t>& occ_start = out.occ_start;
+  occ_start.assign(J + 1, 0);
   for (int id = 0; id < T; ++id) {
     for (int v : b.tree[id].vars) occ_start[v + 1]++;
     for (int v : bnd[id]) occ_start[v + 1]++;
   }
   for (int j = 0; j < J; ++j) occ_start[j + 1] += occ_start[j];
-  std::vector<std::pair<int, int>> occ(occ_start[J]);
+  std::vector<std::pair<int32_t, int32_t>>& occ = out.occ;
+  occ.assign(occ_start[J], {-1, -1});
   std::vector<int> occ_fill(occ_start.begin(), occ_start.end() - 1);
   auto pos_in = [&](int tid, int node) -> int {
     for (int e = occ_start[node]; e < occ_fill[node]; ++e)
@@ -352,5 +358,22 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       const int a = std::max(j, k), bb = std::min(j, k);
       if (!dest_of(a, bb, out.pair_dest[(size_t)j * K_ED + s])) return false;
     }
+  return true;
+}
+
+bool nd_dest_of(const NDPlanHost& p, int J, uint32_t key, NDDest& d) {
+  const int a = (int)(key / (uint32_t)J), b = (int)(key % (uint32_t)J);
+  if (a >= J || (int)p.order.size() != J) return false;
+  const int e = p.order[a] < p.order[b] ? a : b;   // earlier eliminated -> column
+  const int l = (e == a) ? b : a;
+  const int tid = p.node_tree[e];
+  int prow = -1;
+  for (int k = p.occ_start[l]; k < p.occ_start[l + 1]; ++k)
+    if (p.occ[k].first == tid) { prow = p.occ[k].second; break; }
+  if (prow < 0) return false;
+  d.front = p.front_of_tree[tid];
+  d.pcol = p.node_pos[e];
+  d.prow = prow;
+  d.transpose = (e == a && a != b) ? 1 : 0;
   return true;
 }
