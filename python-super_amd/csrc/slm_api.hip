@@ -375,12 +375,26 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     // front of the earlier one (a fill position of the dense front): no new analysis then either.
     auto dests_from_plan = [&]() -> bool {
       sl.cur_dest.resize(sl.h_pairs.size());
+      std::vector<size_t> fresh;   // pairs answered by nd_dest_of: remembered in the plan's list afterwards
       size_t j = 0;
       for (size_t i = 0; i < sl.h_pairs.size(); ++i) {
         while (j < sl.plan_pairs.size() && sl.plan_pairs[j] < sl.h_pairs[i]) ++j;
         if (j < sl.plan_pairs.size() && sl.plan_pairs[j] == sl.h_pairs[i]) sl.cur_dest[i] = sl.nd.block_dest[j];
         else if (!nd_dest_of(sl.nd, f->J, sl.h_pairs[i], sl.cur_dest[i])) return false;
-        else ++g_plan_fill_hits;
+        else fresh.push_back(i);
+      }
+      if (!fresh.empty()) {
+        g_plan_fill_hits += (long long)fresh.size();
+        std::vector<uint32_t> keys(sl.plan_pairs.size() + fresh.size());
+        std::vector<NDDest> dests(keys.size());
+        size_t a = 0, b = 0, o = 0;
+        while (a < sl.plan_pairs.size() || b < fresh.size()) {
+          const bool take_old = b == fresh.size() || (a < sl.plan_pairs.size() && sl.plan_pairs[a] < sl.h_pairs[fresh[b]]);
+          if (take_old) { keys[o] = sl.plan_pairs[a]; dests[o++] = sl.nd.block_dest[a++]; }
+          else { keys[o] = sl.h_pairs[fresh[b]]; dests[o++] = sl.cur_dest[fresh[b++]]; }
+        }
+        sl.plan_pairs.swap(keys);
+        sl.nd.block_dest.swap(dests);
       }
       return true;
     };
