@@ -16,8 +16,9 @@ too -- the image warped through ``K @ inputs["stereo_T"]`` at the back-projected
 SSIM against itself (``skimage.metrics.structural_similarity`` semantics of the 0.19 line, see
 ``oracle/depth_oracle.py::skimage_ssim_full``) -- stored in ``inputs[("disp_conf",0)]`` and blended into
 ``data.confs`` (``utils/data_loader.py:359-373,477-479``).
-Not built: the ``opt.load_valid_mask`` file read (pass ``inputs["valid_mask"]`` (H,W) bool instead) and
-the bilateral ``pcd2norm`` branch.
+``opt.load_valid_mask`` (superv1) reads the mask image like the reference (Pillow instead of OpenCV; an
+``inputs["valid_mask"]`` (H,W) tensor takes precedence).  The bilateral ``pcd2norm`` branch of the reference is
+unreachable (``inputs["pcd"]`` always exists by then) and is not built.
 """
 from __future__ import annotations
 
@@ -87,8 +88,22 @@ def depth_preprocessing(opt, models, inputs, return_valid_map=False):
     keep = [depth, color]
     inp = SlmDepthInputs()
     inp.depth, inp.color = _dev_ptr(depth), _dev_ptr(color)
-    if getattr(opt, "load_valid_mask", False) and "valid_mask" in inputs:
-        vm = _as(inputs["valid_mask"], torch.uint8, dev)
+    if getattr(opt, "load_valid_mask", False) and opt.data == "superv1":
+        if "valid_mask" in inputs:
+            vm = _as(inputs["valid_mask"], torch.uint8, dev)
+        else:
+            # the reference reads <data_dir>/<valid_mask_dir>/<filename>-left.png as a grey image
+            # (cv2.imread(..., 0), utils/data_loader.py:376-383); non-zero = valid
+            import os
+            import numpy as np
+            from PIL import Image
+            path = os.path.join(opt.data_dir, opt.valid_mask_dir, inputs["filename"][0] + "-left.png")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"depth_preprocessing: opt.load_valid_mask is set but {path} does not exist")
+            grey = np.asarray(Image.open(path).convert("L"))
+            if grey.shape != (H, W):
+                raise ValueError(f"depth_preprocessing: valid mask {path} is {grey.shape}, expected {(H, W)}")
+            vm = torch.from_numpy((grey != 0).astype(np.uint8)).to(dev)
         keep.append(vm)
         inp.valid_mask = _dev_ptr(vm)
     has_seg = ("seg", 0) in inputs

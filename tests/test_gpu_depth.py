@@ -125,3 +125,44 @@ def test_depth_preprocessing_full_size_matches_oracle(tag):
     T = int(out["valid"].sum())
     assert T == len(out["points"]) and T > 0.5 * H * W
     np.testing.assert_array_equal(out["index_map"].reshape(-1)[out["valid"]], np.arange(T))
+
+
+def test_valid_mask_file_is_read_like_the_reference(tmp_path):
+    """opt.load_valid_mask (superv1): <data_dir>/<valid_mask_dir>/<filename>-left.png, non-zero = valid; the result
+    equals passing the same mask as a tensor and the oracle with that mask; a missing file fails loudly."""
+    import torch
+    from PIL import Image
+    from super_amd.data_loader import depth_preprocessing
+    g = np.load(GOLD)
+    base = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    H, W = int(base["H"]), int(base["W"])
+    rng = np.random.default_rng(5)
+    mask = rng.uniform(size=(H, W)) > 0.2
+    mask[10:20, 15:40] = False
+    os.makedirs(tmp_path / "masks")
+    Image.fromarray((mask * 255).astype(np.uint8)).save(tmp_path / "masks" / "000001-left.png")
+
+    def run(**extra):
+        opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=True, depth_model="monodepth2",
+                              dilate_invalid_kernel=2, normal_model="naive", phase="test", load_depth=True,
+                              data_dir=str(tmp_path), valid_mask_dir="masks")
+        inputs = {("depth", 0): torch.from_numpy(base["depth"].copy())[None, None].cuda(),
+                  ("disp", 0): torch.zeros(1, 1, H, W).cuda(), "inv_K": torch.from_numpy(base["inv_K"])[None],
+                  "K": torch.from_numpy(base["K"])[None], ("color", 0): torch.from_numpy(base["color"].copy())[None].cuda(),
+                  "divterm": float(base["divterm"]), "filename": ["000001"]}
+        inputs.update(extra)
+        data, _ = depth_preprocessing(opt, None, inputs)[:2]
+        return data, opt
+
+    from_file, opt = run()
+    from_tensor, _ = run(valid_mask=torch.from_numpy(mask))
+    np.testing.assert_array_equal(from_file.valid.cpu().numpy(), from_tensor.valid.cpu().numpy())
+    np.testing.assert_array_equal(from_file.points.cpu().numpy(), from_tensor.points.cpu().numpy())
+    ref = dpo.depth_preprocessing(dpo.default_opt(height=H, width=W, data="superv1", load_valid_mask=True,
+                                                  dilate_invalid_kernel=2), base["depth"], base["K"], base["inv_K"],
+                                  base["color"], float(base["divterm"]), valid_mask=mask)
+    np.testing.assert_array_equal(from_file.valid.cpu().numpy(), ref["valid"])
+    assert not from_file.valid.view(H, W)[10:20, 15:40].any()
+    os.remove(tmp_path / "masks" / "000001-left.png")
+    with pytest.raises(FileNotFoundError):
+        run()
