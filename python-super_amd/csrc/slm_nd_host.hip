@@ -25,6 +25,14 @@ struct Builder {
   std::vector<int> adj_start, adj;   // CSR adjacency (duplicates allowed: every use is a membership test)
   std::vector<TreeNode> tree;
   std::vector<char> side;   // scratch: 1 = A, 2 = B
+  std::vector<int> idx_scratch;   // scratch: index of a node inside its boundary layer
+  static bool use_cover() {
+    static const bool on = [] {
+      const char* e = getenv("SLM_ND_COVER");
+      return e ? atoi(e) != 0 : true;
+    }();
+    return on;
+  }
 
   int dissect(std::vector<int>& nodes, int depth) {
     const int id = (int)tree.size();
@@ -64,7 +72,63 @@ struct Builder {
         if (side[adj[e]] == other) { touches = true; break; }
       if (touches) (side[v] == 1 ? SA : SB).push_back(v);
     }
-    const std::vector<int>& S = SA.size() <= SB.size() ? SA : SB;
+    // separator: a minimum vertex cover of the cut edges (Koenig's theorem on the bipartite graph
+    // between the two boundary layers) -- never larger than the smaller layer, and usually thinner
+    std::vector<int> cover;
+    if (use_cover()) {
+      const int na = (int)SA.size(), nb2 = (int)SB.size();
+      for (int i = 0; i < nb2; ++i) idx_scratch[SB[i]] = i;
+      std::vector<std::vector<int>> ed(na);
+      for (int i = 0; i < na; ++i)
+        for (int e = adj_start[SA[i]]; e < adj_start[SA[i] + 1]; ++e)
+          if (side[adj[e]] == 2) ed[i].push_back(idx_scratch[adj[e]]);
+      std::vector<int> matchA(na, -1), matchB(nb2, -1);
+      std::vector<char> seen;
+      std::function<bool(int)> aug = [&](int u) -> bool {
+        for (int v : ed[u]) {
+          if (seen[v]) continue;
+          seen[v] = 1;
+          if (matchB[v] < 0 || aug(matchB[v])) {
+            matchA[u] = v;
+            matchB[v] = u;
+            return true;
+          }
+        }
+        return false;
+      };
+      for (int u = 0; u < na; ++u) {
+        seen.assign(nb2, 0);
+        aug(u);
+      }
+      // Z = unmatched A vertices and everything reachable from them by alternating paths;
+      // cover = (A \ Z) + (B in Z)
+      std::vector<char> za(na, 0), zb(nb2, 0);
+      std::vector<int> stack;
+      for (int u = 0; u < na; ++u)
+        if (matchA[u] < 0) {
+          za[u] = 1;
+          stack.push_back(u);
+        }
+      while (!stack.empty()) {
+        const int u = stack.back();
+        stack.pop_back();
+        for (int v : ed[u])
+          if (!zb[v]) {
+            zb[v] = 1;
+            const int u2 = matchB[v];
+            if (u2 >= 0 && !za[u2]) {
+              za[u2] = 1;
+              stack.push_back(u2);
+            }
+          }
+      }
+      for (int u = 0; u < na; ++u)
+        if (!za[u]) cover.push_back(SA[u]);
+      for (int v = 0; v < nb2; ++v)
+        if (zb[v]) cover.push_back(SB[v]);
+    }
+    const std::vector<int>& S0 = SA.size() <= SB.size() ? SA : SB;
+    const std::vector<int>& S = (!cover.empty() && cover.size() < S0.size()) ? cover : S0;
     for (int v : S) side[v] = 3;
     std::vector<int> A, B;
     A.reserve(half + 1);
@@ -102,6 +166,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   b.J = J;
   b.pts = pts;
   b.side.assign(J, 0);
+  b.idx_scratch.assign(J, -1);
   // CSR adjacency in two counting passes over the pair list and the node KNN table
   auto valid_edge = [&](int x, int y) { return x != y && x >= 0 && y >= 0 && x < J && y < J; };
   b.adj_start.assign(J + 1, 0);
