@@ -19,8 +19,14 @@
  * Conventions
  *   - Every pointer marked "device" is a HIP device pointer owned by the caller;
  *     the library never frees or reallocates caller memory.
- *   - Streamed inputs are float32 / int32 in HBM; all arithmetic, the normal
- *     equations and the solve are float64 (the reference computes in float64).
+ *   - Indices are int32.  The MODEL STATE (surfel positions, skinning weights, node positions --
+ *     float64 tensors in the reference, true float64 values from the first Surfels.update on) is
+ *     read as float64 when slm_frame.state_f64 != 0 (what the Python mirror passes: the caller's
+ *     tensors are used in place, nothing is rounded) or as float32 (state_f64 == 0: the compact
+ *     layout of BASELINE.json's fp32 configs).  The per-frame target tables are float32: the
+ *     reference widens float32 back-projections to float64 (utils/data_loader.py:453-462), so
+ *     float32 holds them exactly.  All arithmetic, the normal equations and the solve are float64
+ *     (the reference computes in float64).
  *   - beta is (J,7) float64 row-major [qw,qx,qy,qz,bx,by,bz] (super/LM.py:85-88).
  *   - Every call returns an int status (SLM_OK == 0), never throws, and takes the
  *     hipStream_t (as void*) it enqueues on.  Only slm_bind_frame (one 4-byte
@@ -86,15 +92,18 @@ typedef struct slm_frame {
   int32_t K;                /* surfel->node neighbours (opt.num_neighbors); must be 4 */
   int32_t K_ED;             /* node->node neighbours (opt.num_ED_neighbors), 1..8 */
   float fx, fy, cx, cy;     /* inputs["K"][0] entries [0,0],[1,1],[0,2],[1,2] (float32 like the reference) */
-  const float* sf_points;     /* device (N,3)      sf.points */
+  const void* sf_points;      /* device (N,3)      sf.points            float32, or float64 with state_f64 */
   const int32_t* sf_knn_idx;  /* device (N,K)      sf.knn_indices */
-  const float* sf_knn_w;      /* device (N,K)      sf.knn_w */
-  const float* ed_points;     /* device (J,3)      sf.ED_nodes.points */
+  const void* sf_knn_w;       /* device (N,K)      sf.knn_w             float32 / float64 */
+  const void* ed_points;      /* device (J,3)      sf.ED_nodes.points   float32 / float64 */
   const int32_t* ed_knn_idx;  /* device (J,K_ED)   sf.ED_nodes.knn_indices */
   const float* tgt_points;    /* device (T,3)      new_data.points */
   const float* tgt_norms;     /* device (T,3)      new_data.norms */
   const int32_t* index_map;   /* device (H,W)      new_data.index_map, -1 = invalid */
   const uint8_t* tgt_valid;   /* device (H*W)      new_data.valid */
+  int32_t state_f64;          /* 0: sf_points / sf_knn_w / ed_points are float32; 1: float64 (the reference's
+                                 own dtype: no rounding of the model state between frames) */
+  int32_t pad;
 } slm_frame;
 
 typedef struct slm_iter_record {
@@ -213,6 +222,10 @@ int slm_data_residuals(slm_solver* s, int32_t slot, double* r_device, uint8_t* m
 int slm_apply_update(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
                      const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
                      float* ed_norms, const double* beta_device, void* stream);
+/* The same in place on float64 device arrays (the reference's dtype; nothing is rounded). */
+int slm_apply_update_f64(int32_t N, int32_t J, int32_t K, double* sf_points, double* sf_norms,
+                         const int32_t* sf_knn_idx, const double* sf_knn_w, double* ed_points,
+                         double* ed_norms, const double* beta_device, void* stream);
 
 /* -- KNN feeder --------------------------------------------------------------------- */
 /* K nearest `nodes` for every query point: squared L2 in float64, ascending, ties ->
@@ -280,9 +293,9 @@ typedef struct slm_gf_config {
 typedef struct slm_gf_frame {
   slm_frame base;                 /* same fields as the LM path (tgt_valid is not read here) */
   const uint8_t* sf_stable;       /* device (N) sf.isStable, or NULL = all stable */
-  const float* ed_knn_w;          /* device (J,K_ED) sf.ED_nodes.knn_w */
+  const void* ed_knn_w;           /* device (J,K_ED) sf.ED_nodes.knn_w   float32, or float64 with base.state_f64 */
   const int32_t* ed_triangles;    /* device (3,Tr) sf.ED_nodes.triangles, or NULL */
-  const float* ed_triangle_areas; /* device (Tr)   sf.ED_nodes.triangles_areas */
+  const void* ed_triangle_areas;  /* device (Tr)   sf.ED_nodes.triangles_areas   float32 / float64 */
   int32_t n_triangles;
   int32_t pad;
 } slm_gf_frame;
@@ -348,6 +361,9 @@ int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv_device, double* t
 int slm_apply_update_gf(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
                         const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
                         float* ed_norms, const double* deform_device, void* stream);
+int slm_apply_update_gf_f64(int32_t N, int32_t J, int32_t K, double* sf_points, double* sf_norms,
+                            const int32_t* sf_knn_idx, const double* sf_knn_w, double* ed_points,
+                            double* ed_norms, const double* deform_device, void* stream);
 
 /* ===================================================================================
  * "Next" row f2: depth map -> per-frame target `new_data`

@@ -38,6 +38,8 @@ void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
 void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
                    hipStream_t);
+void launch_update64(int, int, double*, double*, const int*, const double*, double*, double*, const double*,
+                     hipStream_t);
 void launch_knn(int, int, int, int, const float*, const float*, int*, float*, hipStream_t);
 void launch_knn64(int, int, int, int, const double*, const double*, const int*, const int*, int*, double*, int*,
                   hipStream_t);
@@ -90,6 +92,7 @@ struct Slot {
   std::vector<uint32_t> h_pairs;
   std::vector<int32_t> h_knn;
   std::vector<float> h_pts;
+  std::vector<double> h_pts64;
   NDFront* d_fronts = nullptr;
   int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos
   NDDest* d_dests = nullptr;    // block_dest | pair_dest
@@ -357,8 +360,16 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
     sl.h_pts.resize((size_t)f->J * 3);
     HIPCHK(hipMemcpyAsync(sl.h_pairs.data(), h.blk_key, sizeof(uint32_t) * h.n_blocks, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(sl.h_knn.data(), f->ed_knn_idx, sizeof(int32_t) * sl.h_knn.size(), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(sl.h_pts.data(), f->ed_points, sizeof(float) * sl.h_pts.size(), hipMemcpyDeviceToHost, st));
+    if (f->state_f64) {
+      sl.h_pts64.resize(sl.h_pts.size());
+      HIPCHK(hipMemcpyAsync(sl.h_pts64.data(), f->ed_points, sizeof(double) * sl.h_pts64.size(), hipMemcpyDeviceToHost, st));
+    } else {
+      HIPCHK(hipMemcpyAsync(sl.h_pts.data(), f->ed_points, sizeof(float) * sl.h_pts.size(), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
+    // the node positions only steer the geometric bisection of the symbolic plan: float32 is plenty
+    if (f->state_f64)
+      for (size_t i = 0; i < sl.h_pts.size(); ++i) sl.h_pts[i] = (float)sl.h_pts64[i];
     // the symbolic plan depends only on the coupling graph: reuse it while the graph is unchanged
     uint64_t hash = 1469598103934665603ull;
     auto mix = [&](const void* ptr, size_t bytes) {
@@ -1038,11 +1049,28 @@ int slm_apply_update(int32_t N, int32_t J, int32_t K, float* sf_points, float* s
   return SLM_OK;
 }
 
+int slm_apply_update_f64(int32_t N, int32_t J, int32_t K, double* sf_points, double* sf_norms,
+                         const int32_t* sf_knn_idx, const double* sf_knn_w, double* ed_points,
+                         double* ed_norms, const double* beta, void* stream) {
+  if (K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_f64: num_neighbors must be 4");
+  if (N < 0 || J < 1 || !ed_points || !ed_norms || !beta || (N > 0 && (!sf_points || !sf_norms ||
+      !sf_knn_idx || !sf_knn_w)))
+    return fail(SLM_ERR_INVALID, "slm_apply_update_f64: bad argument");
+  launch_update64(N, J, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, beta,
+                  (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
 int slm_knn(int32_t Nq, int32_t Nn, int32_t K, int32_t skip_self, const float* q, const float* nodes,
             int32_t* idx, float* dist, void* stream) {
   if (Nq < 0 || Nn < 1 || K < 1 || K + (skip_self ? 1 : 0) > 9 || !nodes || !idx || !dist ||
       (Nq > 0 && !q))
     return fail(SLM_ERR_INVALID, "slm_knn: bad argument (K + skip_self <= 9)");
+  // fewer nodes than neighbours asked for would leave index -1 / distance inf in the tables that
+  // slm_bind_frame, slm_knn_weights and slm_apply_update index with (the reference's knn_points fails too)
+  if (Nn < K + (skip_self ? 1 : 0))
+    return fail(SLM_ERR_INVALID, "slm_knn: fewer nodes than K (+ self)");
   launch_knn(Nq, Nn, K, skip_self, q, nodes, idx, dist, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return SLM_OK;
@@ -1062,6 +1090,7 @@ int slm_knn_f64(int32_t Nq, int32_t Nn, int32_t K, int32_t skip_self, const doub
   if (Nq < 0 || Nn < 1 || K < 1 || K + (skip_self ? 1 : 0) > 9 || !nodes || !idx || !dist || (Nq > 0 && !q) ||
       ((q_seg == nullptr) != (node_seg == nullptr)))
     return fail(SLM_ERR_INVALID, "slm_knn_f64: bad argument (K + skip_self <= 9; both class arrays or none)");
+  if (Nn < K + (skip_self ? 1 : 0)) return fail(SLM_ERR_INVALID, "slm_knn_f64: fewer nodes than K (+ self)");
   hipStream_t st = (hipStream_t)stream;
   int* counter = nullptr;
   if (q_seg) {

@@ -42,7 +42,7 @@ struct FrameDev {
   LMState* st;
   slm_iter_record* rec;  // (num_iterations)
   // packed gather tables of the per-surfel evaluation (16-byte loads instead of scalar ones)
-  double* node_pk;       // (J,10): beta[0..6], {g.x,g.y} as two floats, {g.z,0} as two floats, pad
+  double* node_pk;       // (J,10): beta[0..6], g.x, g.y, g.z (float64: exact for either state dtype)
   double* node_pk_try;   // same at the trial point beta + delta (loss pass of the LM loop)
   float4* tgt_pn;        // (T,2): target point xyz0, target normal xyz0
   unsigned long long* dbg;  // diagnostic builds only (-DSLM_STAMPS): in-kernel s_memtime stamps
@@ -53,9 +53,9 @@ struct FrameDev {
   int32_t n_runs;        // (tuple, 64-chunk) runs = slab entries
   int32_t n_blocks;      // distinct coupled node pairs (a >= b) of the data term
   int32_t pad3;
-  float* s_pts;          // (n_pos,3) surfel xyz in tuple-sorted, 4-padded order
+  void* s_pts;           // (n_pos,3) surfel xyz in tuple-sorted, 4-padded order (dtype of the state: f.state_f64)
   int32_t* s_idx;        // (n_pos,4) KNN ids (original order), -1 for padding positions
-  float* s_w;            // (n_pos,4) KNN weights
+  void* s_w;             // (n_pos,4) KNN weights (dtype of the state)
   int32_t* grp_run;      // (n_pos/4) run id of each group of 4 positions, -1 for padding
   int32_t* run_nodes;    // (n_runs,4) ascending node ids of each run's tuple
   double* slab;          // (n_runs, 768) per-run Gram tiles 00,10,11 (16x16 row-major each)
@@ -176,15 +176,42 @@ __device__ __forceinline__ double* band_entry(const FrameDev& fd, int i, int j) 
   return fd.band + tile * (SLM_NB * SLM_NB) + (i - tr * SLM_NB) + (size_t)(j - tc * SLM_NB) * SLM_NB;
 }
 
+// ---- model-state loads: float32 or float64 arrays (slm_frame.state_f64, uniform per slot) ----
+__device__ __forceinline__ d3 ld_state3(const void* p, size_t i, int f64) {
+  if (f64) {
+    const double* q = static_cast<const double*>(p) + 3 * i;
+    return {q[0], q[1], q[2]};
+  }
+  const float* q = static_cast<const float*>(p) + 3 * i;
+  return {(double)q[0], (double)q[1], (double)q[2]};
+}
+__device__ __forceinline__ void ld_state4(const void* p, size_t i, int f64, double w[4]) {
+  if (f64) {
+    const double2* q = reinterpret_cast<const double2*>(static_cast<const double*>(p) + 4 * i);
+    const double2 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(p) + 4 * i);
+    w[0] = (double)v.x; w[1] = (double)v.y; w[2] = (double)v.z; w[3] = (double)v.w;
+  }
+}
+__device__ __forceinline__ double ld_state1(const void* p, size_t i, int f64) {
+  return f64 ? static_cast<const double*>(p)[i] : (double)static_cast<const float*>(p)[i];
+}
+
 #define SLM_NPK 10   // doubles per node in node_pk
 
-__device__ __forceinline__ void pack_node(double* dst, const double bb[7], const float* g) {
+__device__ __forceinline__ void pack_node(double* dst, const double bb[7], d3 g) {
 #pragma unroll
   for (int c = 0; c < 7; ++c) dst[c] = bb[c];
-  float2 gxy = make_float2(g[0], g[1]), gz = make_float2(g[2], 0.f);
-  dst[7] = __builtin_bit_cast(double, gxy);
-  dst[8] = __builtin_bit_cast(double, gz);
-  dst[9] = 0.0;
+  dst[7] = g.x;
+  dst[8] = g.y;
+  dst[9] = g.z;
+}
+// node position from the packed table (what the per-iteration kernels read instead of f.ed_points)
+__device__ __forceinline__ d3 node_pos_pk(const double* npk, int j) {
+  const double* q = npk + (size_t)SLM_NPK * j + 7;
+  return {q[0], q[1], q[2]};
 }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {

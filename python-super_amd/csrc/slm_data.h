@@ -21,12 +21,10 @@ struct SurfelEval {
 // 4 target rows); the loads of each stage are issued together, and callers that can fetch the
 // surfel stream entries early pass them in (eval_surfel_core).
 template <bool GRAD>
-__device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, float px, float py, float pz, int4 ids, float4 wf,
+__device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p, int4 ids, const double w[4],
                                                  double lam, const double* __restrict__ npk, SurfelEval& out) {
   const slm_frame& f = fd.f;
-  const d3 p = {(double)px, (double)py, (double)pz};
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-  const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
 
   double qw[4];
   d3 qv[4], dk[4];
@@ -37,8 +35,7 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, float px, f
     const double2* nq = reinterpret_cast<const double2*>(npk + (size_t)SLM_NPK * id[k]);
     const double2 n0 = nq[0], n1 = nq[1], n2 = nq[2], n3 = nq[3], n4 = nq[4];
     const double bb[7] = {n0.x, n0.y, n1.x, n1.y, n2.x, n2.y, n3.x};
-    const float2 gxy = __builtin_bit_cast(float2, n3.y), gz = __builtin_bit_cast(float2, n4.x);
-    d3 g = {(double)gxy.x, (double)gxy.y, (double)gz.x};
+    const d3 g = {n3.y, n4.x, n4.y};
     qw[k] = bb[0];
     qv[k] = {bb[1], bb[2], bb[3]};
     dk[k] = p - g;
@@ -135,14 +132,15 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, float px, f
 }
 
 template <bool GRAD>
-__device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const float* __restrict__ sf_pts,
+__device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const void* __restrict__ sf_pts,
                                                const int* __restrict__ sf_idx,
-                                               const float* __restrict__ sf_w, double lam,
+                                               const void* __restrict__ sf_w, double lam,
                                                const double* __restrict__ npk, int i,
                                                SurfelEval& out) {
-  eval_surfel_core<GRAD>(fd, sf_pts[3 * i], sf_pts[3 * i + 1], sf_pts[3 * i + 2],
-                         *reinterpret_cast<const int4*>(sf_idx + 4 * i), *reinterpret_cast<const float4*>(sf_w + 4 * i),
-                         lam, npk, out);
+  double w[4];
+  ld_state4(sf_w, (size_t)i, fd.f.state_f64, w);
+  eval_surfel_core<GRAD>(fd, ld_state3(sf_pts, (size_t)i, fd.f.state_f64),
+                         *reinterpret_cast<const int4*>(sf_idx + 4 * (size_t)i), w, lam, npk, out);
 }
 
 template <bool GRAD>

@@ -58,15 +58,13 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   }
   int my_run = -1;
   int4 ids = {-1, -1, -1, -1};
-  float4 wf = {0, 0, 0, 0};
-  float px = 0, py = 0, pz = 0;
+  double wk[4] = {0, 0, 0, 0};
+  d3 pp = {0, 0, 0};
   if (wact) {
     my_run = fd.grp_run[(base >> 2) + lc];   // lane (l & 15) holds the run of group (l & 15)
     ids = *reinterpret_cast<const int4*>(fd.s_idx + 4 * (size_t)pos);
-    wf = *reinterpret_cast<const float4*>(fd.s_w + 4 * (size_t)pos);
-    px = fd.s_pts[3 * (size_t)pos];
-    py = fd.s_pts[3 * (size_t)pos + 1];
-    pz = fd.s_pts[3 * (size_t)pos + 2];
+    ld_state4(fd.s_w, (size_t)pos, fd.f.state_f64, wk);
+    pp = ld_state3(fd.s_pts, (size_t)pos, fd.f.state_f64);
   }
   // ---- stage 1: record numbers of the wave's runs (needs my_run), in flight with the node gathers ----
   uint8_t lv0 = 0, lv1 = 0, lv2 = 0;
@@ -94,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
 #else
   if (live)
 #endif
-    eval_surfel_core<true>(fd, px, py, pz, ids, wf, lam, fd.node_pk, ev);
+    eval_surfel_core<true>(fd, pp, ids, wk, lam, fd.node_pk, ev);
   if (MERGE && wact) {
     lidx[w][l] = lv0;
     lidx[w][l + 64] = lv1;

@@ -226,9 +226,7 @@ __device__ __forceinline__ void nd_rot_products32(const float q[4], float lam32,
 // ARAP residual of edge (j -> k) and the quaternion Jacobian of node k's part (reference
 // super/loss.py:408-455): r = lam [R(q_k) d + b_k - d - b_j], d = g_j - g_k
 __device__ __forceinline__ void nd_arap_edge(const FrameDev& fd, int j, int k, double lam_a, double r[3], double Jq[3][4]) {
-  const float* g = fd.f.ed_points;
-  const d3 d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
-                (double)g[3 * j + 2] - (double)g[3 * k + 2]};
+  const d3 d = node_pos_pk(fd.node_pk, j) - node_pos_pk(fd.node_pk, k);
   double bk[7], bj[7];
   nd_load_beta(fd.beta, k, bk);
   nd_load_beta(fd.beta, j, bj);

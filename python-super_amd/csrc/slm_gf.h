@@ -39,17 +39,15 @@ struct GfSkin {
 
 __device__ __forceinline__ void gf_skin(const GfSlot& s, int i, GfSkin& k) {
   const slm_frame& f = s.f.base;
-  const d3 p = {(double)f.sf_points[3 * i], (double)f.sf_points[3 * i + 1], (double)f.sf_points[3 * i + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
-  const float4 wf = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
+  const d3 p = ld_state3(f.sf_points, (size_t)i, f.state_f64);
+  const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * (size_t)i);
   k.id[0] = ids.x; k.id[1] = ids.y; k.id[2] = ids.z; k.id[3] = ids.w;
-  k.w[0] = (double)wf.x; k.w[1] = (double)wf.y; k.w[2] = (double)wf.z; k.w[3] = (double)wf.w;
+  ld_state4(f.sf_knn_w, (size_t)i, f.state_f64, k.w);
   k.T = {0, 0, 0};
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const double* b = s.dv + 7 * k.id[a];
-    const d3 g = {(double)f.ed_points[3 * k.id[a]], (double)f.ed_points[3 * k.id[a] + 1],
-                  (double)f.ed_points[3 * k.id[a] + 2]};
+    const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
     k.qw[a] = b[0];
     k.qv[a] = {b[1], b[2], b[3]};
     k.dk[a] = p - g;

@@ -215,16 +215,14 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0};   // global-row contributions of this thread
   if (use_arap && t < J * Ke) {
     const int j = t / Ke, k = f.ed_knn_idx[t];
-    const float* g = f.ed_points;
-    const d3 d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
-                  (double)g[3 * j + 2] - (double)g[3 * k + 2]};
+    const d3 d = ld_state3(f.ed_points, (size_t)j, f.state_f64) - ld_state3(f.ed_points, (size_t)k, f.state_f64);
     const d3 d32 = {(double)(float)d.x, (double)(float)d.y, (double)(float)d.z};
     const double* bk = s.dv + 7 * k;
     const double* bj = s.dv + 7 * j;
     const d3 qv = {bk[1], bk[2], bk[3]};
     const d3 tr = quat_apply(bk[0], qv, d);
     const d3 r = {tr.x + bk[4] - d32.x - bj[4], tr.y + bk[5] - d32.y - bj[5], tr.z + bk[6] - d32.z - bj[6]};
-    const double wjk = (double)s.f.ed_knn_w[t];
+    const double wjk = ld_state1(s.f.ed_knn_w, (size_t)t, f.state_f64);
     la = lam_a * wjk * dot(r, r);
     const double G = 2.0 * lam_a * wjk;
     double jq[4];
@@ -263,14 +261,14 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double* b = s.dv + 7 * iv[a];
-      loc[a] = {(double)f.ed_points[3 * iv[a]] + b[4], (double)f.ed_points[3 * iv[a] + 1] + b[5],
-                (double)f.ed_points[3 * iv[a] + 2] + b[6]};
+      const d3 gn = ld_state3(f.ed_points, (size_t)iv[a], f.state_f64);
+      loc[a] = {gn.x + b[4], gn.y + b[5], gn.z + b[6]};
       V[a] = quat_apply(gw, gv, loc[a]);   // + b_g cancels in the edge vectors
     }
     const d3 e1 = V[1] - V[0], e2 = V[2] - V[0];
     const d3 cr = cross(e1, e2);
     const double area = 0.5 * sqrt(dot(cr, cr) + 1e-13);
-    const double da = area - (double)s.f.ed_triangle_areas[t];
+    const double da = area - ld_state1(s.f.ed_triangle_areas, (size_t)t, f.state_f64);
     lf = lam_f * da * da;
     const double coef = 2.0 * lam_f * da / (4.0 * area);
     const d3 y = {coef * cr.x, coef * cr.y, coef * cr.z};     // dL/d(cr)
@@ -361,20 +359,23 @@ __global__ void __launch_bounds__(256) k_gf_init(GfSlot* __restrict__ slots, int
 
 // Surfels.update, autograd variant (super/nodes.py:193-223): T(p) + b_g (the global ROTATION is
 // applied to the normals only, exactly as the reference does), nodes += b_j + b_g.
-__global__ void __launch_bounds__(256) k_gf_update_surfels(int N, int J, float* __restrict__ pts,
-                                                            float* __restrict__ nrm,
+template <typename RT>
+__global__ void __launch_bounds__(256) k_gf_update_surfels(int N, int J, RT* __restrict__ pts_,
+                                                            RT* __restrict__ nrm_,
                                                             const int* __restrict__ knn_idx,
-                                                            const float* __restrict__ knn_w,
-                                                            const float* __restrict__ ed_pts,
+                                                            const RT* __restrict__ knn_w,
+                                                            const RT* __restrict__ ed_pts,
                                                             const double* __restrict__ dv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  RT* pts = pts_ + 3 * (size_t)i - 3 * i;   // 64-bit row offsets below go through these bases
+  RT* nrm = nrm_ + 3 * (size_t)i - 3 * i;
   const d3 p = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
   const d3 n0 = {(double)nrm[3 * i], (double)nrm[3 * i + 1], (double)nrm[3 * i + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(knn_idx + 4 * i);
-  const float4 wf = *reinterpret_cast<const float4*>(knn_w + 4 * i);
+  const int4 ids = *reinterpret_cast<const int4*>(knn_idx + 4 * (size_t)i);
+  const RT* wp = knn_w + 4 * (size_t)i;
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-  const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
+  const double w[4] = {(double)wp[0], (double)wp[1], (double)wp[2], (double)wp[3]};
   d3 T = {0, 0, 0}, Nn = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -391,16 +392,17 @@ __global__ void __launch_bounds__(256) k_gf_update_surfels(int N, int J, float* 
   const double* bgl = dv + 7 * J;
   Nn = quat_apply(bgl[0], {bgl[1], bgl[2], bgl[3]}, Nn);
   const double nl = fmax(sqrt(dot(Nn, Nn)), 1e-12);
-  pts[3 * i] = (float)(T.x + bgl[4]);
-  pts[3 * i + 1] = (float)(T.y + bgl[5]);
-  pts[3 * i + 2] = (float)(T.z + bgl[6]);
-  nrm[3 * i] = (float)(Nn.x / nl);
-  nrm[3 * i + 1] = (float)(Nn.y / nl);
-  nrm[3 * i + 2] = (float)(Nn.z / nl);
+  pts[3 * i] = (RT)(T.x + bgl[4]);
+  pts[3 * i + 1] = (RT)(T.y + bgl[5]);
+  pts[3 * i + 2] = (RT)(T.z + bgl[6]);
+  nrm[3 * i] = (RT)(Nn.x / nl);
+  nrm[3 * i + 1] = (RT)(Nn.y / nl);
+  nrm[3 * i + 2] = (RT)(Nn.z / nl);
 }
 
-__global__ void __launch_bounds__(256) k_gf_update_nodes(int J, float* __restrict__ ed_pts,
-                                                          float* __restrict__ ed_nrm,
+template <typename RT>
+__global__ void __launch_bounds__(256) k_gf_update_nodes(int J, RT* __restrict__ ed_pts,
+                                                          RT* __restrict__ ed_nrm,
                                                           const double* __restrict__ dv) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= J) return;
@@ -410,12 +412,12 @@ __global__ void __launch_bounds__(256) k_gf_update_nodes(int J, float* __restric
   d3 rn = quat_apply(b[0], {b[1], b[2], b[3]}, n0);
   rn = quat_apply(bgl[0], {bgl[1], bgl[2], bgl[3]}, rn);
   const double nl = fmax(sqrt(dot(rn, rn)), 1e-12);
-  ed_pts[3 * j] = (float)((double)ed_pts[3 * j] + b[4] + bgl[4]);
-  ed_pts[3 * j + 1] = (float)((double)ed_pts[3 * j + 1] + b[5] + bgl[5]);
-  ed_pts[3 * j + 2] = (float)((double)ed_pts[3 * j + 2] + b[6] + bgl[6]);
-  ed_nrm[3 * j] = (float)(rn.x / nl);
-  ed_nrm[3 * j + 1] = (float)(rn.y / nl);
-  ed_nrm[3 * j + 2] = (float)(rn.z / nl);
+  ed_pts[3 * j] = (RT)((double)ed_pts[3 * j] + b[4] + bgl[4]);
+  ed_pts[3 * j + 1] = (RT)((double)ed_pts[3 * j + 1] + b[5] + bgl[5]);
+  ed_pts[3 * j + 2] = (RT)((double)ed_pts[3 * j + 2] + b[6] + bgl[6]);
+  ed_nrm[3 * j] = (RT)(rn.x / nl);
+  ed_nrm[3 * j + 1] = (RT)(rn.y / nl);
+  ed_nrm[3 * j + 2] = (RT)(rn.z / nl);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -466,6 +468,23 @@ static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int max
 static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
   gf_enqueue_morph(g, slots, n, maxN, st);
   gf_enqueue_losses(g, slots, n, maxN, maxReg, st);
+}
+
+template <typename RT>
+static int apply_update_gf_t(int32_t N, int32_t J, int32_t K, RT* sf_points, RT* sf_norms,
+                             const int32_t* sf_knn_idx, const RT* sf_knn_w, RT* ed_points, RT* ed_norms,
+                             const double* deform, void* stream) {
+  if (K != SLM_K) return gf_fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_gf: num_neighbors must be 4");
+  if (N < 0 || J < 1 || !ed_points || !ed_norms || !deform ||
+      (N > 0 && (!sf_points || !sf_norms || !sf_knn_idx || !sf_knn_w)))
+    return gf_fail(SLM_ERR_INVALID, "slm_apply_update_gf: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 0)
+    hipLaunchKernelGGL(k_gf_update_surfels<RT>, dim3((N + 255) / 256), dim3(256), 0, st, N, J, sf_points, sf_norms,
+                       sf_knn_idx, sf_knn_w, (const RT*)ed_points, deform);
+  hipLaunchKernelGGL(k_gf_update_nodes<RT>, dim3((J + 255) / 256), dim3(256), 0, st, J, ed_points, ed_norms, deform);
+  GFCHK(hipGetLastError());
+  return SLM_OK;
 }
 
 extern "C" {
@@ -716,17 +735,13 @@ int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv, double* terms, d
 int slm_apply_update_gf(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
                         const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points, float* ed_norms,
                         const double* deform, void* stream) {
-  if (K != SLM_K) return gf_fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_gf: num_neighbors must be 4");
-  if (N < 0 || J < 1 || !ed_points || !ed_norms || !deform ||
-      (N > 0 && (!sf_points || !sf_norms || !sf_knn_idx || !sf_knn_w)))
-    return gf_fail(SLM_ERR_INVALID, "slm_apply_update_gf: bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  if (N > 0)
-    hipLaunchKernelGGL(k_gf_update_surfels, dim3((N + 255) / 256), dim3(256), 0, st, N, J, sf_points, sf_norms,
-                       sf_knn_idx, sf_knn_w, ed_points, deform);
-  hipLaunchKernelGGL(k_gf_update_nodes, dim3((J + 255) / 256), dim3(256), 0, st, J, ed_points, ed_norms, deform);
-  GFCHK(hipGetLastError());
-  return SLM_OK;
+  return apply_update_gf_t<float>(N, J, K, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, deform, stream);
+}
+
+int slm_apply_update_gf_f64(int32_t N, int32_t J, int32_t K, double* sf_points, double* sf_norms,
+                            const int32_t* sf_knn_idx, const double* sf_knn_w, double* ed_points, double* ed_norms,
+                            const double* deform, void* stream) {
+  return apply_update_gf_t<double>(N, J, K, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, deform, stream);
 }
 
 }  // extern "C"

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k_init_slot(const FrameDev* __restrict__ 
 #pragma unroll
     for (int c = 1; c < 7; ++c) b[c] = 0.0;
     const double ident[7] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    pack_node(fd.node_pk + (size_t)SLM_NPK * t, ident, fd.f.ed_points + 3 * t);
+    pack_node(fd.node_pk + (size_t)SLM_NPK * t, ident, ld_state3(fd.f.ed_points, (size_t)t, fd.f.state_f64));
   }
   if (t < num_iterations) {
     slm_iter_record r;
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_pack_nodes(const FrameDev* __restrict__
   double bb[7];
 #pragma unroll
   for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c];
-  pack_node(fd.node_pk + (size_t)SLM_NPK * j, bb, fd.f.ed_points + 3 * j);
+  pack_node(fd.node_pk + (size_t)SLM_NPK * j, bb, ld_state3(fd.f.ed_points, (size_t)j, fd.f.state_f64));
 }
 
 // node_pk_try <- beta + delta: the trial point of the loss pass; grid = (ceil(maxJ/256), n_frames)
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_make_trial(const FrameDev* __restrict__
   double bb[7];
 #pragma unroll
   for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c] + fd.delta[7 * j + c];
-  pack_node(fd.node_pk_try + (size_t)SLM_NPK * j, bb, fd.f.ed_points + 3 * j);
+  pack_node(fd.node_pk_try + (size_t)SLM_NPK * j, bb, ld_state3(fd.f.ed_points, (size_t)j, fd.f.state_f64));
 }
 
 // target points + normals -> interleaved float4 pairs; grid = (ceil(T/256))
@@ -194,23 +194,25 @@ __global__ void k_zero_reg_part(const FrameDev* __restrict__ frames, int n_reg_p
 }
 
 // ---------------------------------------------------------------------------------
-// Surfels.update, LM variant (reference super/nodes.py:193-223): in place, float32 storage.
-// Note the reference rotates the normals with the 7-wide beta, so the translation b_k is
-// ADDED to the rotated normal before blending and normalising (nodes.py:207-213).
-__global__ void __launch_bounds__(256) k_update_surfels(int N, float* __restrict__ pts,
-                                                         float* __restrict__ nrm,
+// Surfels.update, LM variant (reference super/nodes.py:193-223): in place, on float32 or float64
+// arrays (RT).  Note the reference rotates the normals with the 7-wide beta, so the translation b_k
+// is ADDED to the rotated normal before blending and normalising (nodes.py:207-213).
+template <typename RT>
+__global__ void __launch_bounds__(256) k_update_surfels(int N, RT* __restrict__ pts,
+                                                         RT* __restrict__ nrm,
                                                          const int* __restrict__ knn_idx,
-                                                         const float* __restrict__ knn_w,
-                                                         const float* __restrict__ ed_pts,
+                                                         const RT* __restrict__ knn_w,
+                                                         const RT* __restrict__ ed_pts,
                                                          const double* __restrict__ beta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const d3 p = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
-  const d3 n0 = {(double)nrm[3 * i], (double)nrm[3 * i + 1], (double)nrm[3 * i + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(knn_idx + 4 * i);
-  const float4 wf = *reinterpret_cast<const float4*>(knn_w + 4 * i);
+  const size_t i3 = 3 * (size_t)i;
+  const d3 p = {(double)pts[i3], (double)pts[i3 + 1], (double)pts[i3 + 2]};
+  const d3 n0 = {(double)nrm[i3], (double)nrm[i3 + 1], (double)nrm[i3 + 2]};
+  const int4 ids = *reinterpret_cast<const int4*>(knn_idx + 4 * (size_t)i);
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-  const double w[4] = {(double)wf.x, (double)wf.y, (double)wf.z, (double)wf.w};
+  const RT* wp = knn_w + 4 * (size_t)i;
+  const double w[4] = {(double)wp[0], (double)wp[1], (double)wp[2], (double)wp[3]};
   d3 T = {0, 0, 0}, Nn = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -226,17 +228,18 @@ __global__ void __launch_bounds__(256) k_update_surfels(int N, float* __restrict
     Nn = {Nn.x + w[k] * rn.x, Nn.y + w[k] * rn.y, Nn.z + w[k] * rn.z};
   }
   const double nl = fmax(sqrt(dot(Nn, Nn)), 1e-12);   // F.normalize eps
-  pts[3 * i] = (float)T.x;
-  pts[3 * i + 1] = (float)T.y;
-  pts[3 * i + 2] = (float)T.z;
-  nrm[3 * i] = (float)(Nn.x / nl);
-  nrm[3 * i + 1] = (float)(Nn.y / nl);
-  nrm[3 * i + 2] = (float)(Nn.z / nl);
+  pts[i3] = (RT)T.x;
+  pts[i3 + 1] = (RT)T.y;
+  pts[i3 + 2] = (RT)T.z;
+  nrm[i3] = (RT)(Nn.x / nl);
+  nrm[i3 + 1] = (RT)(Nn.y / nl);
+  nrm[i3 + 2] = (RT)(Nn.z / nl);
 }
 
 // must run AFTER k_update_surfels (which reads the old node positions)
-__global__ void __launch_bounds__(256) k_update_nodes(int J, float* __restrict__ ed_pts,
-                                                       float* __restrict__ ed_nrm,
+template <typename RT>
+__global__ void __launch_bounds__(256) k_update_nodes(int J, RT* __restrict__ ed_pts,
+                                                       RT* __restrict__ ed_nrm,
                                                        const double* __restrict__ beta) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= J) return;
@@ -244,12 +247,12 @@ __global__ void __launch_bounds__(256) k_update_nodes(int J, float* __restrict__
   const d3 n0 = {(double)ed_nrm[3 * j], (double)ed_nrm[3 * j + 1], (double)ed_nrm[3 * j + 2]};
   const d3 rn = quat_apply(b[0], {b[1], b[2], b[3]}, n0);
   const double nl = fmax(sqrt(dot(rn, rn)), 1e-12);
-  ed_pts[3 * j] = (float)((double)ed_pts[3 * j] + b[4]);
-  ed_pts[3 * j + 1] = (float)((double)ed_pts[3 * j + 1] + b[5]);
-  ed_pts[3 * j + 2] = (float)((double)ed_pts[3 * j + 2] + b[6]);
-  ed_nrm[3 * j] = (float)(rn.x / nl);
-  ed_nrm[3 * j + 1] = (float)(rn.y / nl);
-  ed_nrm[3 * j + 2] = (float)(rn.z / nl);
+  ed_pts[3 * j] = (RT)((double)ed_pts[3 * j] + b[4]);
+  ed_pts[3 * j + 1] = (RT)((double)ed_pts[3 * j + 1] + b[5]);
+  ed_pts[3 * j + 2] = (RT)((double)ed_pts[3 * j + 2] + b[6]);
+  ed_nrm[3 * j] = (RT)(rn.x / nl);
+  ed_nrm[3 * j + 1] = (RT)(rn.y / nl);
+  ed_nrm[3 * j + 2] = (RT)(rn.z / nl);
 }
 
 // ---------------------------------------------------------------------------------
@@ -499,14 +502,23 @@ void launch_zero_reg_part(const FrameDev* frames_dev, int n_frames, int n_reg_pa
   hipLaunchKernelGGL(k_zero_reg_part, dim3(1, n_frames), dim3(256), 0, st, frames_dev, n_reg_part);
 }
 
+template <typename RT>
+static void launch_update_t(int N, int J, RT* pts, RT* nrm, const int* knn_idx, const RT* knn_w,
+                            RT* ed_pts, RT* ed_nrm, const double* beta, hipStream_t st) {
+  if (N > 0)
+    hipLaunchKernelGGL(k_update_surfels<RT>, dim3((N + 255) / 256), dim3(256), 0, st, N, pts, nrm,
+                       knn_idx, knn_w, (const RT*)ed_pts, beta);
+  if (J > 0)
+    hipLaunchKernelGGL(k_update_nodes<RT>, dim3((J + 255) / 256), dim3(256), 0, st, J, ed_pts, ed_nrm,
+                       beta);
+}
 void launch_update(int N, int J, float* pts, float* nrm, const int* knn_idx, const float* knn_w,
                    float* ed_pts, float* ed_nrm, const double* beta, hipStream_t st) {
-  if (N > 0)
-    hipLaunchKernelGGL(k_update_surfels, dim3((N + 255) / 256), dim3(256), 0, st, N, pts, nrm,
-                       knn_idx, knn_w, ed_pts, beta);
-  if (J > 0)
-    hipLaunchKernelGGL(k_update_nodes, dim3((J + 255) / 256), dim3(256), 0, st, J, ed_pts, ed_nrm,
-                       beta);
+  launch_update_t<float>(N, J, pts, nrm, knn_idx, knn_w, ed_pts, ed_nrm, beta, st);
+}
+void launch_update64(int N, int J, double* pts, double* nrm, const int* knn_idx, const double* knn_w,
+                     double* ed_pts, double* ed_nrm, const double* beta, hipStream_t st) {
+  launch_update_t<double>(N, J, pts, nrm, knn_idx, knn_w, ed_pts, ed_nrm, beta, st);
 }
 
 void launch_knn(int Nq, int Nn, int K, int skip_self, const float* q, const float* nodes, int* idx,

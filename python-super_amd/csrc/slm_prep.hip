@@ -73,15 +73,15 @@ __global__ void __launch_bounds__(256) k_fill_sorted(
     int n_pos_bound, const int* __restrict__ scal, const slm_frame f,
     const unsigned long long* __restrict__ tkeys, const int* __restrict__ tcount,
     const int* __restrict__ tstart, const int* __restrict__ pstart, const int* __restrict__ rstart,
-    const int* __restrict__ sids, float* __restrict__ s_pts, int* __restrict__ s_idx,
-    float* __restrict__ s_w, int* __restrict__ grp_run, int* __restrict__ run_nodes,
+    const int* __restrict__ sids, void* __restrict__ s_pts, int* __restrict__ s_idx,
+    void* __restrict__ s_w, int* __restrict__ grp_run, int* __restrict__ run_nodes,
     int* __restrict__ run_chunk) {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= n_pos_bound) return;
   const int nt = scal[0], ptot = scal[1];
   int4 idv = make_int4(-1, -1, -1, -1);
-  float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-  float px = 0.f, py = 0.f, pz = 0.f;
+  double wv[4] = {0.0, 0.0, 0.0, 0.0};
+  d3 pp = {0.0, 0.0, 0.0};
   int run = -1;
   if (pos < ptot) {
     // tuple owning this position: last t with pstart[t] <= pos
@@ -95,10 +95,8 @@ __global__ void __launch_bounds__(256) k_fill_sorted(
     if (e < tcount[t]) {
       const int i = sids[tstart[t] + e];
       idv = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
-      wv = *reinterpret_cast<const float4*>(f.sf_knn_w + 4 * i);
-      px = f.sf_points[3 * i];
-      py = f.sf_points[3 * i + 1];
-      pz = f.sf_points[3 * i + 2];
+      ld_state4(f.sf_knn_w, (size_t)i, f.state_f64, wv);
+      pp = ld_state3(f.sf_points, (size_t)i, f.state_f64);
     }
     if (e == 0 || (pos & 63) == 0) {
       const unsigned long long k = tkeys[t];
@@ -109,10 +107,19 @@ __global__ void __launch_bounds__(256) k_fill_sorted(
     }
   }
   *reinterpret_cast<int4*>(s_idx + 4 * pos) = idv;
-  *reinterpret_cast<float4*>(s_w + 4 * pos) = wv;
-  s_pts[3 * pos] = px;
-  s_pts[3 * pos + 1] = py;
-  s_pts[3 * pos + 2] = pz;
+  // the sorted copies keep the dtype of the state (values are copied, never rounded)
+  if (f.state_f64) {
+    double* sw = static_cast<double*>(s_w) + 4 * (size_t)pos;
+    double* sp = static_cast<double*>(s_pts) + 3 * (size_t)pos;
+    *reinterpret_cast<double2*>(sw) = make_double2(wv[0], wv[1]);
+    *reinterpret_cast<double2*>(sw + 2) = make_double2(wv[2], wv[3]);
+    sp[0] = pp.x; sp[1] = pp.y; sp[2] = pp.z;
+  } else {
+    *reinterpret_cast<float4*>(static_cast<float*>(s_w) + 4 * (size_t)pos) =
+        make_float4((float)wv[0], (float)wv[1], (float)wv[2], (float)wv[3]);
+    float* sp = static_cast<float*>(s_pts) + 3 * (size_t)pos;
+    sp[0] = (float)pp.x; sp[1] = (float)pp.y; sp[2] = (float)pp.z;
+  }
   if ((pos & 3) == 0) grp_run[pos >> 2] = run;
 }
 
@@ -394,9 +401,11 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
     c = p->cap_e; PCHK(grow_raw(p->bcount, c, n_entries));
     p->cap_e = c;
   }
-  PCHK(grow_raw(plan.s_pts, plan.cap_pts, 3 * pos_bound));
+  // s_pts / s_w are sized in floats; a float64 state needs twice that
+  const size_t esz = f.state_f64 ? 2 : 1;
+  PCHK(grow_raw(plan.s_pts, plan.cap_pts, esz * 3 * pos_bound));
   PCHK(grow_raw(plan.s_idx, plan.cap_idx, 4 * pos_bound));
-  PCHK(grow_raw(plan.s_w, plan.cap_w, 4 * pos_bound));
+  PCHK(grow_raw(plan.s_w, plan.cap_w, esz * 4 * pos_bound));
   PCHK(grow_raw(plan.grp_run, plan.cap_grp, pos_bound / 4));
   PCHK(grow_raw(plan.run_nodes, plan.cap_runs, 4 * runs_bound));
   PCHK(grow_raw(plan.run_chunk, plan.cap_rchunk, runs_bound));

@@ -20,9 +20,7 @@ __device__ __forceinline__ void load_beta(const double* beta, const double* delt
 __device__ __forceinline__ void arap_residual(const FrameDev& fd, const double* beta,
                                               const double* delta, int j, int k, double lam,
                                               double r[3], double bk[7], d3& d) {
-  const float* g = fd.f.ed_points;
-  d = {(double)g[3 * j] - (double)g[3 * k], (double)g[3 * j + 1] - (double)g[3 * k + 1],
-       (double)g[3 * j + 2] - (double)g[3 * k + 2]};
+  d = node_pos_pk(fd.node_pk, j) - node_pos_pk(fd.node_pk, k);   // g_j - g_k (node_pk carries g in float64)
   double bj[7];
   load_beta(beta, delta, k, bk);
   load_beta(beta, delta, j, bj);

@@ -8,9 +8,13 @@ call it unchanged when ``--use_derived_gradient`` is set:
     self.lm = LM_Solver(self.opt)
     deform_param = self.lm.LM(self.sf, inputs, sfdata)        # (J,7) float64
 
-Everything numerical happens in the HIP library; this file only converts the caller's
-tensors to the storage layout of the C ABI (float32 / int32, contiguous), passes device
-pointers, and converts results back.  PyTorch is plumbing (device memory, streams).
+Everything numerical happens in the HIP library; this file only hands the caller's tensors to
+the C ABI (device pointers) and converts results back.  The model state (``sf.points``,
+``sf.knn_w``, ``ED_nodes.points``) is float64 in the reference and is passed AS IS (the library
+reads float64 state, ``slm_frame.state_f64``): nothing is rounded between frames.  float32
+state tensors are passed as float32 (the compact layout); indices become int32, the per-frame
+target tables float32 (exact: the reference widens float32 back-projections,
+``utils/data_loader.py:453-462``).  PyTorch is plumbing (device memory, streams).
 """
 from __future__ import annotations
 
@@ -36,21 +40,33 @@ def _as(t, dtype, device):
     return t.detach().to(device=device, dtype=dtype).contiguous()
 
 
+def state_dtype(sf, override=None):
+    """dtype the library reads the model state in: the dtype of ``sf.points`` (float64 in the
+    reference) unless ``override`` ("f32" / "f64", ``opt.slm_state_dtype``) forces one."""
+    if override in ("f32", "float32", torch.float32):
+        return torch.float32
+    if override in ("f64", "float64", torch.float64):
+        return torch.float64
+    return torch.float64 if sf.points.dtype == torch.float64 else torch.float32
+
+
 class BoundFrame:
-    """Device-resident, ABI-layout copy of what LM reads from ``sf`` / ``inputs`` /
+    """Device-resident, ABI-layout view of what LM reads from ``sf`` / ``inputs`` /
     ``new_data``.  Holds the tensors alive while the library uses them."""
 
-    def __init__(self, sf, inputs, new_data, device=None):
+    def __init__(self, sf, inputs, new_data, device=None, state=None):
         dev = device if device is not None else sf.points.device
         if dev.type != "cuda":
             raise _lib.SuperLMError("super_amd needs tensors on a HIP device (no CPU fallback)")
         ed = sf.ED_nodes
         f32, i32 = torch.float32, torch.int32
+        sdt = state_dtype(sf, state)
         self.device = dev
-        self.sf_points = _as(sf.points, f32, dev)
+        self.state_dtype = sdt
+        self.sf_points = _as(sf.points, sdt, dev)          # no copy when already float64 / contiguous
         self.sf_knn_idx = _as(sf.knn_indices, i32, dev)
-        self.sf_knn_w = _as(sf.knn_w, f32, dev)
-        self.ed_points = _as(ed.points, f32, dev)
+        self.sf_knn_w = _as(sf.knn_w, sdt, dev)
+        self.ed_points = _as(ed.points, sdt, dev)
         self.ed_knn_idx = _as(ed.knn_indices, i32, dev)
         self.tgt_points = _as(new_data.points, f32, dev)
         self.tgt_norms = _as(new_data.norms, f32, dev)
@@ -68,6 +84,7 @@ class BoundFrame:
         for name in ("sf_points", "sf_knn_idx", "sf_knn_w", "ed_points", "ed_knn_idx", "tgt_points",
                      "tgt_norms", "index_map", "tgt_valid"):
             setattr(fr, name, _dev_ptr(getattr(self, name)))
+        fr.state_f64 = 1 if sdt == torch.float64 else 0
         self.c = fr
 
 
@@ -143,7 +160,7 @@ class LM_Solver():
             pass
 
     def _bind(self, h, slot, sf, inputs, new_data):
-        bf = BoundFrame(sf, inputs, new_data)
+        bf = BoundFrame(sf, inputs, new_data, state=getattr(self.opt, "slm_state_dtype", None))
         _lib.check(self.lib.slm_bind_frame(h, slot, C.byref(bf.c), _stream_ptr(bf.device)),
                    "slm_bind_frame")
         self._bound[slot] = bf
@@ -154,7 +171,9 @@ class LM_Solver():
     def Solver(A, b, method="cholesky"):
         """(reference ``super/LM.py:37-51``) solve A x = b for SPD A on the device; raises
         ``RuntimeError`` when the factorisation fails, like ``torch.linalg.cholesky``."""
-        if method not in ("cholesky", "lu"):
+        if method == "lu":     # deprecated torch.lu path, never selected by any reference caller
+            raise NotImplementedError("super_amd.LM_Solver.Solver: method='lu' is not built (Cholesky only)")
+        if method != "cholesky":
             raise ValueError(method)
         lib = _lib.load()
         dev = A.device

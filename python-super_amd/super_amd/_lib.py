@@ -29,6 +29,7 @@ EXPORTS = [
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
+    "slm_apply_update_f64", "slm_apply_update_gf_f64",
 ]
 
 
@@ -46,7 +47,8 @@ class SlmFrame(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("sf_points", C.c_void_p), ("sf_knn_idx", C.c_void_p), ("sf_knn_w", C.c_void_p),
                 ("ed_points", C.c_void_p), ("ed_knn_idx", C.c_void_p), ("tgt_points", C.c_void_p),
-                ("tgt_norms", C.c_void_p), ("index_map", C.c_void_p), ("tgt_valid", C.c_void_p)]
+                ("tgt_norms", C.c_void_p), ("index_map", C.c_void_p), ("tgt_valid", C.c_void_p),
+                ("state_f64", C.c_int32), ("pad", C.c_int32)]
 
 
 class SlmGfConfig(C.Structure):
@@ -216,6 +218,8 @@ def load():
         "slm_gf_get_deform": [vp, i32, vp, vp],
         "slm_gf_loss_grad": [vp, i32, vp, vp, vp, vp],
         "slm_apply_update_gf": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "slm_apply_update_f64": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "slm_apply_update_gf_f64": [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

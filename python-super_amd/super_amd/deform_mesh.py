@@ -98,8 +98,9 @@ class GraphFit:
             trg.points, trg.norms, trg.index_map = new_data.points, new_data.norms, new_data.index_map
             trg.valid = torch.zeros(new_data.index_map.numel(), dtype=torch.bool,
                                     device=new_data.points.device)
-        bf = BoundFrame(src, inputs, trg)
+        bf = BoundFrame(src, inputs, trg, state=getattr(self.opt, "slm_state_dtype", None))
         dev = bf.device
+        sdt = bf.state_dtype       # ED_nodes.knn_w / triangle areas follow the dtype of the state
         ed = src.ED_nodes
         fr = SlmGfFrame()
         fr.base = bf.c
@@ -109,12 +110,12 @@ class GraphFit:
             st8 = _as(stable, torch.uint8, dev)
             keep.append(st8)
             fr.sf_stable = _dev_ptr(st8)
-        w = _as(ed.knn_w, torch.float32, dev)
+        w = _as(ed.knn_w, sdt, dev)
         keep.append(w)
         fr.ed_knn_w = _dev_ptr(w)
         if self.cfg.use_face:
             tri = _as(ed.triangles, torch.int32, dev)
-            area = _as(ed.triangles_areas, torch.float32, dev)
+            area = _as(ed.triangles_areas, sdt, dev)
             keep += [tri, area]
             fr.ed_triangles, fr.ed_triangle_areas = _dev_ptr(tri), _dev_ptr(area)
             fr.n_triangles = int(tri.shape[1])

@@ -19,12 +19,12 @@ class DeviceFrame:
     H: int
     W: int
     K: np.ndarray                   # (4,4) float32 intrinsics (host)
-    sf_points: torch.Tensor         # (N,3) f32
-    sf_norms: torch.Tensor          # (N,3) f32
+    sf_points: torch.Tensor         # (N,3) f32 | f64 (model state: one dtype for all six)
+    sf_norms: torch.Tensor          # (N,3)
     sf_knn_idx: torch.Tensor        # (N,4) i32
-    sf_knn_w: torch.Tensor          # (N,4) f32
-    ed_points: torch.Tensor         # (J,3) f32
-    ed_norms: torch.Tensor          # (J,3) f32
+    sf_knn_w: torch.Tensor          # (N,4)
+    ed_points: torch.Tensor         # (J,3)
+    ed_norms: torch.Tensor          # (J,3)
     ed_knn_idx: torch.Tensor        # (J,K_ED) i32
     tgt_points: torch.Tensor        # (T,3) f32
     tgt_norms: torch.Tensor         # (T,3) f32
@@ -32,13 +32,16 @@ class DeviceFrame:
     tgt_valid: torch.Tensor         # (H*W,) u8
 
     @staticmethod
-    def from_scene(sc, device) -> "DeviceFrame":
+    def from_scene(sc, device, state_f64=False) -> "DeviceFrame":
+        """``state_f64``: hold the model state (surfel / node positions and normals, skinning
+        weights) in float64 like the reference; default float32 (BASELINE's fp32 configs)."""
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)
         f32, i32 = torch.float32, torch.int32
-        return DeviceFrame(H=sc.H, W=sc.W, K=sc.K, sf_points=t(sc.sf_points, f32),
-                           sf_norms=t(sc.sf_norms, f32), sf_knn_idx=t(sc.sf_knn_idx, i32),
-                           sf_knn_w=t(sc.sf_knn_w, f32), ed_points=t(sc.ed_points, f32),
-                           ed_norms=t(sc.ed_norms, f32), ed_knn_idx=t(sc.ed_knn_idx, i32),
+        sd = torch.float64 if state_f64 else f32
+        return DeviceFrame(H=sc.H, W=sc.W, K=sc.K, sf_points=t(sc.sf_points, sd),
+                           sf_norms=t(sc.sf_norms, sd), sf_knn_idx=t(sc.sf_knn_idx, i32),
+                           sf_knn_w=t(sc.sf_knn_w, sd), ed_points=t(sc.ed_points, sd),
+                           ed_norms=t(sc.ed_norms, sd), ed_knn_idx=t(sc.ed_knn_idx, i32),
                            tgt_points=t(sc.tgt_points, f32), tgt_norms=t(sc.tgt_norms, f32),
                            index_map=t(sc.index_map, i32), tgt_valid=t(sc.valid, torch.uint8))
 
@@ -62,6 +65,8 @@ class DeviceFrame:
             t = getattr(self, name)
             assert t.is_cuda and t.is_contiguous()
             setattr(fr, name, t.data_ptr())
+        fr.state_f64 = 1 if self.sf_points.dtype == torch.float64 else 0
+        assert self.sf_knn_w.dtype == self.sf_points.dtype == self.ed_points.dtype
         return fr
 
 
@@ -117,7 +122,8 @@ class Engine:
     def apply_update(self, slot: int, beta: torch.Tensor):
         """``Surfels.update`` in place on the slot's frame tensors."""
         f = self._frames[slot]
-        _lib.check(self.lib.slm_apply_update(f.N, f.J, int(f.sf_knn_idx.shape[1]),
+        fn = self.lib.slm_apply_update_f64 if f.sf_points.dtype == torch.float64 else self.lib.slm_apply_update
+        _lib.check(fn(f.N, f.J, int(f.sf_knn_idx.shape[1]),
                                              f.sf_points.data_ptr(), f.sf_norms.data_ptr(),
                                              f.sf_knn_idx.data_ptr(), f.sf_knn_w.data_ptr(),
                                              f.ed_points.data_ptr(), f.ed_norms.data_ptr(),

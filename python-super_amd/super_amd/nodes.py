@@ -30,22 +30,28 @@ def find_knn(points1, points2, num_classes=-1, seg1=None, seg2=None, k=20, skip_
     assert)."""
     lib = _lib.load()
     dev = points1.device
-    if num_classes > 0:
+    if num_classes > 0 or points1.dtype == torch.float64 or points2.dtype == torch.float64:
+        # float64 like the reference's tensors (distances, and so the stability test
+        # dist <= radius and the weights, are not rounded)
         q = _as(points1, torch.float64, dev)
         n = _as(points2, torch.float64, dev)
-        s1, s2 = _as(seg1, torch.int32, dev), _as(seg2, torch.int32, dev)
+        s1 = s2 = None
+        if num_classes > 0:
+            s1, s2 = _as(seg1, torch.int32, dev), _as(seg2, torch.int32, dev)
         idx = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
         dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=dev)
-        _lib.check(lib.slm_knn_f64(q.shape[0], n.shape[0], k, int(skip_self), _dev_ptr(q), _dev_ptr(n), _dev_ptr(s1),
-                                   _dev_ptr(s2), _dev_ptr(idx), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn_f64")
+        _lib.check(lib.slm_knn_f64(q.shape[0], n.shape[0], k, int(skip_self), _dev_ptr(q), _dev_ptr(n),
+                                   _dev_ptr(s1) if s1 is not None else None, _dev_ptr(s2) if s2 is not None else None,
+                                   _dev_ptr(idx), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn_f64")
         return dist, idx.to(torch.int64)
+    # float32 state (the compact layout): float32 storage of the distances
     q = _as(points1, torch.float32, dev)
     n = _as(points2, torch.float32, dev)
     idx = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
     dist = torch.empty((q.shape[0], k), dtype=torch.float32, device=dev)
     _lib.check(lib.slm_knn(q.shape[0], n.shape[0], k, int(skip_self), _dev_ptr(q), _dev_ptr(n),
                            _dev_ptr(idx), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn")
-    return dist.to(torch.float64), idx.to(torch.int64)
+    return dist, idx.to(torch.int64)
 
 
 def _weights(idx, dist, radii, radius_mode, stable=None):
@@ -98,8 +104,11 @@ def update_ed(sf):
         ed.knn_w, ed.knn_indices = w, idx
         return
     dist, idx = find_knn(ed.points, ed.points, k=k, skip_self=True)
-    w, _ = _weights(idx, dist, ed.radii, 1)
-    ed.knn_w = w.to(torch.float64)
+    if dist.dtype == torch.float64:
+        w, _ = _weights64(idx, dist, ed.radii, 1)
+    else:
+        w, _ = _weights(idx, dist, ed.radii, 1)
+    ed.knn_w = w
     ed.knn_indices = idx
 
 
@@ -116,48 +125,47 @@ def update_sfed_knn(sf):
             dist, idx = find_knn(sf.points, ed.points, num_classes=int(sf.opt.num_classes), seg1=sf.seg, seg2=ed.seg, k=k)
         else:
             # float64 distances for the float64 weights
-            lib = _lib.load()
-            dev = sf.points.device
-            q, n = _as(sf.points, torch.float64, dev), _as(ed.points, torch.float64, dev)
-            idx32 = torch.empty((q.shape[0], k), dtype=torch.int32, device=dev)
-            dist = torch.empty((q.shape[0], k), dtype=torch.float64, device=dev)
-            _lib.check(lib.slm_knn_f64(q.shape[0], n.shape[0], k, 0, _dev_ptr(q), _dev_ptr(n), None, None,
-                                       _dev_ptr(idx32), _dev_ptr(dist), _stream_ptr(dev)), "slm_knn_f64")
-            idx = idx32.to(torch.int64)
+            dist, idx = find_knn(sf.points.to(torch.float64), ed.points, k=k)
         w, st8 = _weights64(idx, dist, ed.radii, 0, stable=sf.isStable,
                             q_conf=sf.seg_conf if soft else None, node_conf=ed.seg_conf if soft else None)
         sf.knn_indices, sf.knn_w, sf.isStable = idx, w, st8.to(torch.bool)
         return
     dist, idx = find_knn(sf.points, ed.points, k=k)
-    w, st8 = _weights(idx, dist, ed.radii, 0, stable=sf.isStable)
+    if dist.dtype == torch.float64:
+        w, st8 = _weights64(idx, dist, ed.radii, 0, stable=sf.isStable)
+    else:
+        w, st8 = _weights(idx, dist, ed.radii, 0, stable=sf.isStable)
     sf.knn_indices = idx
-    sf.knn_w = w.to(torch.float64)
+    sf.knn_w = w
     sf.isStable = st8.to(torch.bool)
 
 
 def update(sf, deform):
     """Apply the solved warp: skin surfel points, blend and normalise surfel normals, translate
     nodes, rotate node normals.  ``deform`` is (J,7) on the LM path
-    (``opt.use_derived_gradient``) and (J+1,7) with the global row T_g on the autograd path."""
+    (``opt.use_derived_gradient``) and (J+1,7) with the global row T_g on the autograd path.
+    The state keeps its dtype: float64 tensors (the reference's) are updated in float64, nothing
+    is rounded; float32 tensors stay float32."""
     if deform is None:
         return
     lib = _lib.load()
     dev = sf.points.device
     ed = sf.ED_nodes
-    f32 = torch.float32
-    pts, nrm = _as(sf.points, f32, dev).clone(), _as(sf.norms, f32, dev).clone()
-    epts, enrm = _as(ed.points, f32, dev).clone(), _as(ed.norms, f32, dev).clone()
+    sdt = torch.float64 if sf.points.dtype == torch.float64 else torch.float32
+    pts, nrm = _as(sf.points, sdt, dev).clone(), _as(sf.norms, sdt, dev).clone()
+    epts, enrm = _as(ed.points, sdt, dev).clone(), _as(ed.norms, sdt, dev).clone()
     idx = _as(sf.knn_indices, torch.int32, dev)
-    w = _as(sf.knn_w, f32, dev)
+    w = _as(sf.knn_w, sdt, dev)
     beta = _as(deform, torch.float64, dev)
-    fn = lib.slm_apply_update
+    f64 = sdt == torch.float64
+    fn = lib.slm_apply_update_f64 if f64 else lib.slm_apply_update
     if beta.shape[0] == epts.shape[0] + 1:
-        fn = lib.slm_apply_update_gf
+        fn = lib.slm_apply_update_gf_f64 if f64 else lib.slm_apply_update_gf
     elif beta.shape[0] != epts.shape[0]:
         raise ValueError("deform must have J or J+1 rows")
     _lib.check(fn(pts.shape[0], epts.shape[0], idx.shape[1], _dev_ptr(pts),
-                                    _dev_ptr(nrm), _dev_ptr(idx), _dev_ptr(w), _dev_ptr(epts),
-                                    _dev_ptr(enrm), _dev_ptr(beta), _stream_ptr(dev)),
+                  _dev_ptr(nrm), _dev_ptr(idx), _dev_ptr(w), _dev_ptr(epts),
+                  _dev_ptr(enrm), _dev_ptr(beta), _stream_ptr(dev)),
                "slm_apply_update")
     sf.points, sf.norms = pts.to(sf.points.dtype), nrm.to(sf.norms.dtype)
     ed.points, ed.norms = epts.to(ed.points.dtype), enrm.to(ed.norms.dtype)

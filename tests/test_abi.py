@@ -33,7 +33,7 @@ def test_struct_layouts_match_header(lib):
     from super_amd._lib import SlmGfConfig, SlmGfSemantic
     assert C.sizeof(SlmGfConfig) == 10 * 4 + 7 * 8
     assert C.sizeof(SlmGfSemantic) == 2 * 4 + 5 * 8
-    assert C.sizeof(SlmFrame) == 7 * 4 + 4 * 4 + 4 + 9 * 8   # 4 bytes padding before pointers
+    assert C.sizeof(SlmFrame) == 7 * 4 + 4 * 4 + 4 + 9 * 8 + 2 * 4   # 4 bytes padding before pointers; state_f64 + pad
 
 
 def test_no_device_fails_loudly(lib):

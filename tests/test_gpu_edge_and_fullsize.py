@@ -243,8 +243,8 @@ def test_three_frame_tracking_loop_matches_oracle_pipeline():
     targets = [synth.make_scene(N=3000, J=48, H=60, W=80, seed=51, src_border=6, tgt_border=3,
                                 dphi=0.05 * (k + 1)) for k in range(3)]
     opt = orc.default_opt(num_optimize_iterations=5)
-    # ---- oracle pipeline (f64, positions re-rounded to f32 after every update like the HIP path)
-    f32r = lambda a: a.astype(np.float32).astype(np.float64)
+    # ---- oracle pipeline: float64 state carried like the reference (nothing re-rounded; the HIP
+    #      mirrors keep float64 state too)
     P, Nn = base.f64("sf_points"), base.f64("sf_norms")
     G, Gn, R = base.f64("ed_points"), base.f64("ed_norms"), base.f64("ed_radii")
     idx, w = base.sf_knn_idx.copy(), base.f64("sf_knn_w")
@@ -258,10 +258,9 @@ def test_three_frame_tracking_loop_matches_oracle_pipeline():
                        tgt_points=tg.f64("tgt_points"), tgt_norms=tg.f64("tgt_norms"),
                        index_map=tg.index_map, valid=tg.valid, K=tg.K, H=tg.H, W=tg.W)
         beta_o = orc.lm(fr, opt)
-        P, Nn, G, Gn = (f32r(x) for x in orc.apply_update(P, Nn, idx, w, G, Gn, beta_o))
+        P, Nn, G, Gn = orc.apply_update(P, Nn, idx, w, G, Gn, beta_o)
         eidx, _, _ = orc.node_knn(G, R, 4)
         idx, w, _, _ = orc.surfel_knn(P, G, R, 4)
-        w = f32r(w)
 
         _, _, new_data = torch_frame(tg)
         beta_h = lm.LM(sf, inputs, new_data)
@@ -270,7 +269,8 @@ def test_three_frame_tracking_loop_matches_oracle_pipeline():
         nodes.update_ed(sf)
         nodes.update_sfed_knn(sf)
         sf.ED_nodes.num = base.J
-        np.testing.assert_allclose(sf.points.cpu().numpy(), P, rtol=0, atol=5e-6)
+        np.testing.assert_allclose(sf.points.cpu().numpy(), P, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(sf.knn_w.cpu().numpy(), w, rtol=0, atol=1e-8)
         np.testing.assert_array_equal(sf.knn_indices.cpu().numpy(), idx)
         np.testing.assert_array_equal(sf.ED_nodes.knn_indices.cpu().numpy(), eidx)
 

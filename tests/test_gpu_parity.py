@@ -87,32 +87,66 @@ def test_lm_matches_reference_golden(name):
     assert abs(np.sqrt(loss.min()) - np.sqrt(g["lm_loss"].min())) < 1e-4
 
 
+def _to_state32(sf):
+    """the compact float32 state layout (BASELINE's fp32 configs): same values, float32 tensors"""
+    for o, names in ((sf, ("points", "norms", "knn_w")), (sf.ED_nodes, ("points", "norms", "knn_w", "radii"))):
+        for k in names:
+            setattr(o, k, getattr(o, k).float())
+    return sf
+
+
+@pytest.mark.parametrize("state", ["f64", "f32"])
 @pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
-def test_update_matches_reference_golden(name):
+def test_update_matches_reference_golden(name, state):
     import torch
     from super_amd import nodes
     g, sc, opt = load_golden(name)
     sf, _, _ = torch_frame(sc)
+    if state == "f32":
+        _to_state32(sf)
     sf.opt = ref_opt(opt)
     nodes.update(sf, torch.from_numpy(g["lm_beta"]).cuda())
+    assert sf.points.dtype == (torch.float64 if state == "f64" else torch.float32)
+    tol = 1e-12 if state == "f64" else 2e-7      # float64 state like the reference / float32 storage
     for mine, key in ((sf.points, "upd_points"), (sf.norms, "upd_norms"),
                       (sf.ED_nodes.points, "upd_ed_points"), (sf.ED_nodes.norms, "upd_ed_norms")):
-        np.testing.assert_allclose(mine.cpu().numpy(), g[key], rtol=0, atol=2e-7)   # f32 storage
+        np.testing.assert_allclose(mine.cpu().numpy(), g[key], rtol=0, atol=tol)
 
 
+@pytest.mark.parametrize("state", ["f64", "f32"])
 @pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
-def test_knn_feeder_matches_reference_golden(name):
+def test_knn_feeder_matches_reference_golden(name, state):
     from super_amd import nodes
     g, sc, opt = load_golden(name)
     sf, _, _ = torch_frame(sc)
+    if state == "f32":
+        _to_state32(sf)
     sf.opt = ref_opt(opt)
     nodes.update_ed(sf)
     nodes.update_sfed_knn(sf)
     np.testing.assert_array_equal(sf.knn_indices.cpu().numpy(), g["knn_sf_idx"])   # bit-exact
     np.testing.assert_array_equal(sf.ED_nodes.knn_indices.cpu().numpy(), g["knn_ed_idx"])
-    np.testing.assert_allclose(sf.knn_w.cpu().numpy(), g["knn_sf_w"], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(sf.ED_nodes.knn_w.cpu().numpy(), g["knn_ed_w"], rtol=0, atol=1e-6)
+    tol = 1e-12 if state == "f64" else 1e-6
+    np.testing.assert_allclose(sf.knn_w.cpu().numpy(), g["knn_sf_w"], rtol=0, atol=tol)
+    np.testing.assert_allclose(sf.ED_nodes.knn_w.cpu().numpy(), g["knn_ed_w"], rtol=0, atol=tol)
     np.testing.assert_array_equal(sf.isStable.cpu().numpy(), g["knn_sf_stable"])
+
+
+def test_knn_exact_ties_take_the_lowest_index():
+    """pytorch3d's tie order is not pinned by the reference; the build's rule is lowest index
+    first, in both feeder kernels, with exact float ties (a query equidistant from mirrored nodes)."""
+    import torch
+    from super_amd import nodes
+    n = torch.tensor([[1.0, 0, 0], [-1.0, 0, 0], [0, 1.0, 0], [0, -1.0, 0], [0, 0, 1.0], [0, 0, -1.0], [2.0, 0, 0]],
+                     dtype=torch.float64).cuda()
+    q = torch.tensor([[0.0, 0, 0], [0.5, 0.5, 0.0]], dtype=torch.float64).cuda()
+    for dt in (torch.float64, torch.float32):
+        d, i = nodes.find_knn(q.to(dt), n.to(dt), k=4)
+        np.testing.assert_array_equal(i.cpu().numpy(), [[0, 1, 2, 3], [0, 2, 4, 5]])
+        np.testing.assert_allclose(d[0].cpu().numpy(), 1.0)
+    from super_amd import _lib
+    with pytest.raises(_lib.SuperLMError):          # fewer nodes than neighbours: refused, not index -1
+        nodes.find_knn(q, n[:3], k=4)
 
 
 def test_dense_solver_and_failure_status():
