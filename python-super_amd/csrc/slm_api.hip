@@ -23,6 +23,7 @@ void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hip
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
+void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t);
 void launch_reg_loss(const FrameDev*, int, int, int, double, int, double, int, hipStream_t);
 void launch_bandwidth(const slm_frame&, int*, hipStream_t);
 void launch_band_solve(const FrameDev*, int, int, int, double, hipStream_t);
@@ -94,7 +95,9 @@ struct Slot {
   std::vector<float> h_pts;
   std::vector<double> h_pts64;
   NDFront* d_fronts = nullptr;
-  int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos
+  int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos | ... | dag_tasks | front_nin
+  int32_t* d_dag_flags = nullptr;   // persistent task-graph solver: ticket, counters, per-tile / per-column flags
+  size_t cap_dag_flags = 0;
   NDDest* d_dests = nullptr;    // block_dest | pair_dest
   double *ftiles = nullptr, *fvec = nullptr, *flinv = nullptr;
   double* pairbuf = nullptr;   // sharded frames: per-pair sums to exchange
@@ -204,6 +207,7 @@ int slm_destroy(slm_solver* s) {
     if (sl.fvec) (void)hipFree(sl.fvec);
     if (sl.flinv) (void)hipFree(sl.flinv);
     if (sl.pairbuf) (void)hipFree(sl.pairbuf);
+    if (sl.d_dag_flags) (void)hipFree(sl.d_dag_flags);
   }
   prep_destroy(s->prep);
   for (auto& evs : s->ev_runs)
@@ -354,7 +358,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   }
   // nested-dissection plan (symbolic analysis on the host from the coupled-pair list)
   h.nd_ready = 0;
-  if (h.v1_ready && s->cfg.solver_path == 0) {
+  if (h.v1_ready && s->cfg.solver_path != 1) {
     sl.h_pairs.resize(h.n_blocks);
     sl.h_knn.resize((size_t)f->J * f->K_ED);
     sl.h_pts.resize((size_t)f->J * 3);
@@ -442,7 +446,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       sl.plan_pairs.swap(all_pairs);
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
-                            nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size();
+                            nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size() +
+                            nd.dag_tasks.size() + nd.front_nin.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
       HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
       HIPCHK(grow(sl.d_ints, sl.cap_ints, n_ints));
@@ -466,6 +471,14 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.in_edge = p;     HIPCHK(up(nd.in_edge));
       h.schur_items = p; HIPCHK(up(nd.schur_items));
       h.schur_off = p;   HIPCHK(up(nd.schur_off));
+      h.dag_tasks = p;   HIPCHK(up(nd.dag_tasks));
+      h.front_nin = p;   HIPCHK(up(nd.front_nin));
+      h.n_dag_tasks = (int32_t)(nd.dag_tasks.size() / 2);
+      h.dag_n_tiles = (int32_t)(nd.tile_doubles / (SLM_NB * SLM_NB));
+      h.dag_n_pcols = (int32_t)(nd.linv_doubles / (SLM_NB * SLM_NB));
+      h.dag_n_flags = 8 + 2 * (int32_t)nd.fronts.size() + h.dag_n_tiles + 2 * h.dag_n_pcols;
+      HIPCHK(grow(sl.d_dag_flags, sl.cap_dag_flags, (size_t)h.dag_n_flags));
+      h.dag_flags = sl.d_dag_flags;
       if (!nd.block_dest.empty())
         HIPCHK(hipMemcpyAsync(sl.d_dests, nd.block_dest.data(), sizeof(NDDest) * nd.block_dest.size(), hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(sl.d_dests + nd.block_dest.size(), nd.pair_dest.data(), sizeof(NDDest) * nd.pair_dest.size(), hipMemcpyHostToDevice, st));
@@ -517,6 +530,7 @@ struct BatchDims {
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
   int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
   bool nd = true;   // every slot of the batch has a nested-dissection plan
+  int max_tasks = 0;   // tasks of the persistent task-graph solver (maximum over the batch)
   std::vector<NDLevelSched> sched;   // per-level launch bounds over the batch
 };
 BatchDims dims_of(slm_solver* s, int first, int n) {
@@ -532,6 +546,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.v1 = d.v1 && h.v1_ready;
     if (h.v1_ready) d.gram_variants |= h.v2_ready ? 1 : 2;
     d.nd = d.nd && h.nd_ready;
+    d.max_tasks = std::max(d.max_tasks, h.nd_ready ? h.n_dag_tasks : 0);
     d.maxP = std::max(d.maxP, h.P);
   }
   if (d.nd) {
@@ -569,6 +584,13 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
   if (s->cfg.use_arap || s->cfg.use_rot)
     d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);
   return d;
+}
+
+// factor + substitutions of the assembled fronts: one persistent task-graph launch (solver_path 2) or the
+// per-level launches (solver_path 0)
+void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
+  if (s->cfg.solver_path == 2) launch_front_solve_dag(fr, n, d.max_tasks, u_override, st);
+  else launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
 }
 
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
@@ -628,8 +650,8 @@ static hipEvent_t take_event(slm_solver* s) {
 // ---- one frame sharded over several GPUs ----------------------------------------------------
 int slm_set_shard(slm_solver* s, int32_t rank, int32_t world) {
   if (!s || world < 1 || rank < 0 || rank >= world) return fail(SLM_ERR_INVALID, "slm_set_shard: bad rank/world");
-  if (world > 1 && (s->cfg.data_path != 0 || s->cfg.solver_path != 0))
-    return fail(SLM_ERR_UNSUPPORTED, "slm_set_shard: needs data_path 0 and solver_path 0");
+  if (world > 1 && (s->cfg.data_path != 0 || s->cfg.solver_path == 1))
+    return fail(SLM_ERR_UNSUPPORTED, "slm_set_shard: needs data_path 0 and a nested-dissection solver_path (0 or 2)");
   s->rank = rank;
   s->world = world;
   for (Slot& sl : s->slots) sl.h.bound = 0;   // the shares are fixed at bind time
@@ -676,7 +698,7 @@ int slm_lm_solve(slm_solver* s, int32_t n_frames, void* stream) {
   if (c.use_data) launch_pair_scatter(fr, n_frames, d.max_blocks, st);
   launch_reg_grad_nd(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
   launch_front_load_rhs(fr, n_frames, d.maxP, st);
-  launch_front_solve(fr, n_frames, d.sched.data(), (int)d.sched.size(), -1.0, st);
+  enqueue_front_solve(s, fr, n_frames, d, -1.0, st);
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -804,7 +826,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
       launch_reg_grad(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
     }
     mark();
-    if (d.nd) launch_front_solve(fr, n_frames, d.sched.data(), (int)d.sched.size(), -1.0, st);
+    if (d.nd) enqueue_front_solve(s, fr, n_frames, d, -1.0, st);
     else launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
     if (c.use_data) launch_make_trial(fr, n_frames, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
     mark();
@@ -972,7 +994,7 @@ int slm_solve(slm_solver* s, int32_t slot, double u, double* delta, int32_t* sta
   const FrameDev& h = s->slots[slot].h;
   if (d.nd) {
     HIPCHK(enqueue_assemble_nd(s, slot, 1, d, st));
-    launch_front_solve(s->frames_dev + slot, 1, d.sched.data(), (int)d.sched.size(), u, st);
+    enqueue_front_solve(s, s->frames_dev + slot, 1, d, u, st);
   } else {
     enqueue_assemble(s, s->frames_dev + slot, 1, d, st);
     launch_band_solve(s->frames_dev + slot, 1, d.nt_max, d.wb_cap, u, st);

@@ -1,0 +1,560 @@
+// slm_dag.hip -- the numeric phase of the nested-dissection multifrontal Cholesky (slm_nd.h) as ONE
+// persistent launch: factorisation of every front, forward substitution, extend-adds into the parents
+// and the back substitution run as tasks of a static task graph.
+//
+// Why: with one launch per (level, pivot tile column, phase) -- slm_front.hip, ~125 dependent launches
+// per LM iteration at C2 -- an iteration at one frame per launch is a chain of launch boundaries (each
+// 3-5 us of dispatch + a kernel prologue of dependent descriptor loads) around 33 sequential 64x64 tile
+// factorisations.  Here a dependent step costs one flag hand-off between two resident workgroups
+// (measured 1.8-1.9 us including a 32 KB tile written and re-read, tests/micro/launch_gap_mb.hip), tasks
+// of different fronts / levels / frames overlap freely, and nothing waits for a whole level.
+//
+// Scheduling.  The plan carries the task list in a topological order (sorted by modelled earliest start,
+// slm_nd_host.hip).  Workgroups take tickets (one agent-scope atomic add) and run the task of their ticket;
+// a task waits on flags of tasks with SMALLER tickets only, and a ticket is only ever held by a RUNNING
+// workgroup, so the earliest unfinished task can always finish: no deadlock whatever the residency.
+// Every spin is bounded; on a time-out the abort flag stops all workgroups and the solve reports failure.
+//
+// Tasks (left-looking: every tile is written by exactly ONE task, then read-only):
+//   POTRF(f,s)   A(s,s) - sum_{c<s} L(s,c) L(s,c)^T (+ u) -> Cholesky + inverse (slm_tile.h) -> flinv;
+//                y_s = L_ss^-1 (b_s - sum_{c<s} L(s,c) y_c)                                  (forward subst.)
+//   COL(f,r,s)   L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
+//   SCHUR(f,r,s) boundary tile: U = A(r,s) - sum_{c<npt} L(r,c) L(s,c)^T added into the parent front through the
+//                extend-add maps (child 0 before child 1: fixed summation order); diagonal tiles carry the
+//                vector rows  v_r = b_r - sum_c L(r,c) y_c
+//   BACKB(f,c)   y_c -= sum_{boundary r} L(r,c)^T x_r        (x of the boundary nodes from the global solution)
+//   BACK(f,c)    x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r), scattered into delta
+// All sums run in a fixed order: results are bitwise reproducible from run to run.
+//
+// Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): per-XCD L2s are not coherent and a CU's L1
+// is never refreshed, so EVERY byte that one task hands to another (tiles, vectors, inverses, the solution) is
+// stored with sc1 (write-through, agent scope) and loaded with sc1 (L1 bypass); a producer drains its stores
+// (s_waitcnt vmcnt(0) in every wave, then the workgroup barrier) before ONE lane publishes the flag / counter,
+// a consumer polls with relaxed agent-scope loads, then the workgroup barrier.  Descriptors (FrameDev, NDFront,
+// task list, maps) are written by the host before the launch and read with plain loads.
+#include <cstdlib>
+
+#include "slm_tile.h"
+
+namespace {
+
+#define DAG_SPIN_LIMIT (1 << 22)   // polls before a wait gives up (a few seconds)
+
+__device__ __forceinline__ double ld1(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st1(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ldf(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct DagFlags {
+  int* ticket;
+  int* abort_;
+  int* front_in;
+  int* child0;
+  int* tile;
+  int* pb;
+  int* px;
+};
+__device__ __forceinline__ DagFlags dag_flags_of(const FrameDev& fd) {
+  DagFlags g;
+  g.ticket = fd.dag_flags;
+  g.abort_ = fd.dag_flags + 1;
+  g.front_in = fd.dag_flags + 8;
+  g.child0 = g.front_in + fd.n_fronts;
+  g.tile = g.child0 + fd.n_fronts;
+  g.pb = g.tile + fd.dag_n_tiles;
+  g.px = g.pb + fd.dag_n_pcols;
+  return g;
+}
+
+__device__ __forceinline__ int tile_index(const NDFront& f, int r, int c) {
+  return (int)(f.tile_off / TILE) + c * f.nt - c * (c - 1) / 2 + (r - c);
+}
+__device__ __forceinline__ double* tile_ptr(const FrameDev& fd, const NDFront& f, int r, int c) {
+  const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
+  return fd.ftiles + f.tile_off + t * TILE;
+}
+__device__ __forceinline__ int dag_base(const NDFront& f, int p) {
+  return p < f.nv ? 7 * p : f.n1p + 7 * (p - f.nv);
+}
+
+// Wait until all `n` flags flag_of(i) (i < n) have reached `want`: the lanes of wave 0 poll one flag each
+// (n <= 64 per round).  Returns false when the solve was aborted.  Workgroup barrier inside.
+template <typename F>
+__device__ __forceinline__ bool dag_wait(int n, F flag_of, int want, int* abort_flag, int* s_abort) {
+  if (n > 0 && threadIdx.x < 64) {
+    int spins = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + threadIdx.x;
+      const int* fl = i < n ? flag_of(i) : nullptr;
+      for (;;) {
+        const bool ok = fl ? ldf(fl) >= want : true;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255) == 0) {
+          if (ldf(abort_flag) != 0 || spins > DAG_SPIN_LIMIT) {
+            if (threadIdx.x == 0) {
+              __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              *s_abort = 1;
+            }
+            base = n;
+            break;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  return *s_abort == 0;
+}
+
+// producer side of a hand-off: every wave drains its stores, barrier, one lane publishes
+__device__ __forceinline__ void dag_publish_begin() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+__device__ __forceinline__ void dag_set_flag(int* flag) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- sc1 forms of the fragment loads / stores of slm_tile.h ------------------------------------------
+__device__ __forceinline__ void load_a_frags1(const double* __restrict__ A, double areg[16]) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) areg[ks] = ld1(A + (16 * w + lr) + (size_t)(4 * ks + lk) * NB);
+}
+__device__ __forceinline__ void load_c_frags1(const double* __restrict__ Cg, double4_t acc[4]) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[ni][r] = ld1(Cg + (16 * w + lr) + (size_t)(16 * ni + lk + 4 * r) * NB);
+}
+__device__ __forceinline__ void store_c_frags1(double* __restrict__ Cg, const double4_t acc[4]) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st1(Cg + (16 * w + lr) + (size_t)(16 * ni + lk + 4 * r) * NB, acc[ni][r]);
+}
+__device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, double breg[16]) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) breg[e] = ld1(T + threadIdx.x + 256 * e);
+}
+
+// acc -= sum_{c in [c0,c1)} L(ra,c) L(rb,c)^T.  Both operand tiles pass through LDS (Bl <- L(rb,c), Al <- L(ra,c);
+// one tile when ra == rb) with tile-linear, fully coalesced sc1 loads, and the next column's tiles are in
+// flight (registers) under the MFMAs.  VEC (needs ra == rb): also tsum += (L(ra,c) y_c)[row threadIdx.x & 63] over
+// the 16 inner columns of this thread's quarter; y_c is read from the front's vector.
+template <bool VEC>
+__device__ __forceinline__ void dag_accumulate(const FrameDev& fd, const NDFront& f, int ra, int rb, int c0, int c1,
+                                               double4_t acc[4], double* Bl, double* Al, double* yv, double& tsum) {
+  if (c0 >= c1) return;
+  const bool two = ra != rb;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  double breg[16], areg[16];
+  load_tile_regs1(tile_ptr(fd, f, rb, c0), breg);
+  if (two) load_tile_regs1(tile_ptr(fd, f, ra, c0), areg);
+  double ynext = 0.0;
+  if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)c0 * NB + threadIdx.x);
+  const double* Ar = two ? Al : Bl;
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();   // earlier readers of Bl / Al / yv are done
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+    if (two) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Al[threadIdx.x + 256 * e] = areg[e];
+    }
+    if (VEC && threadIdx.x < NB) yv[threadIdx.x] = ynext;
+    if (c + 1 < c1) {
+      load_tile_regs1(tile_ptr(fd, f, rb, c + 1), breg);
+      if (two) load_tile_regs1(tile_ptr(fd, f, ra, c + 1), areg);
+      if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const double a = -Ar[(16 * w + lr) + (4 * ks + lk) * LD];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const double bv = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
+        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, a, acc[ni], 0, 0, 0);
+      }
+    }
+    if (VEC) {
+      const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 16 * q; k < 16 * q + 16; ++k) tsum += Bl[i + k * LD] * yv[k];
+    }
+  }
+}
+
+// sum of the four quarter partials of dag_accumulate<true>: result for row i in every thread with (threadIdx.x & 63) == i
+__device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4 * NB */) {
+  const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+  __syncthreads();
+  part[q * NB + i] = tsum;
+  __syncthreads();
+  return part[i] + part[NB + i] + part[2 * NB + i] + part[3 * NB + i];
+}
+
+// S, M, the four diagonal-block inverses, three 16x16 scratch blocks, two vectors, a few ints: 80 960 B -> two
+// workgroups per CU.  `part` (row partials) shares the scratch blocks and the extend-add maps share the
+// diagonal-block inverses: neither is live while a tile is being factored.
+#define DAG_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 8)
+
+// Tile factorisation + inverse as a real call: inlined into the task loop it raises the register demand of the
+// whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
+// base inside the function, so their address space stays known.
+extern __shared__ double dag_lds[];
+__device__ __noinline__ bool dag_factor_tile(const FrameDev* fd) {
+  double* S = dag_lds;
+  double* M = dag_lds + TILE;
+  double* dinv = dag_lds + 2 * TILE;
+  double* wt = dinv + 4 * 256;
+  int* s_ok = reinterpret_cast<int*>(wt + 3 * 256 + 2 * NB);
+  const bool ok = potrf64(S, dinv, wt, s_ok, *fd, false);
+  inverse_assemble64(S, M, dinv, wt);
+  return ok;
+}
+
+}  // namespace
+
+// grid = persistent (2 workgroups per CU), 256 threads
+__global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
+                                                 double u_override) {
+  double* lds = dag_lds;
+  double* S = lds;                 // tile being factored / B operand staging
+  double* M = lds + TILE;          // inverse of the factored tile / second staging tile
+  double* dinv = lds + 2 * TILE;   // 4 x 256
+  double* wt = dinv + 4 * 256;     // 3 x 256 scratch
+  double* vec = wt + 3 * 256;      // NB
+  double* yv = vec + NB;           // NB
+  double* part = wt;               // 4 * NB row partials (not live during potrf64 / inverse_assemble64)
+  int* s_ok = reinterpret_cast<int*>(yv + NB);
+  int* s_task = s_ok + 1;
+  int* s_abort = s_ok + 2;
+  int* rmap = reinterpret_cast<int*>(dinv);   // NB + NB ints: extend-add maps (SCHUR tasks only)
+  int* cmap = rmap + NB;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  const FrameDev& fd0 = frames[0];
+  if (!fd0.bound || !fd0.nd_ready) return;
+  int* ticket = fd0.dag_flags;
+  int* abort_flag = fd0.dag_flags + 1;
+  if (threadIdx.x == 0) *s_abort = 0;
+  __syncthreads();
+  const int total = n_frames * max_tasks;
+
+  for (;;) {
+    if (threadIdx.x == 0) *s_task = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int tk = *s_task;
+    __syncthreads();
+    if (tk >= total || *s_abort) break;
+    const int slot = tk % n_frames, ti = tk / n_frames;
+    const FrameDev& fd = frames[slot];
+    if (!fd.bound || !fd.nd_ready || ti >= fd.n_dag_tasks) continue;
+    const int w0 = fd.dag_tasks[2 * ti], w1 = fd.dag_tasks[2 * ti + 1];
+    const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
+    const NDFront& f = fd.fronts[fi];
+    const DagFlags g = dag_flags_of(fd);
+    double* vecs = fd.fvec + f.vec_off;
+    const int nin = fd.front_nin[2 * fi];
+
+    if (type == ND_T_POTRF || type == ND_T_COL) {
+      // ================= POTRF(f,s) / COL(f,r,s) ==================================================
+      const int r = tr_, s = ts_;
+      const bool diag = type == ND_T_POTRF;
+      // stage 0: the front's own tile is complete (children's extend-adds) + all but the last operand column
+      {
+        const int n0 = s > 0 ? (diag ? s - 1 : 2 * (s - 1)) : 0;
+        auto fl = [&](int i) -> const int* {
+          if (diag) return g.tile + tile_index(f, s, i);
+          return g.tile + tile_index(f, (i & 1) ? s : r, i >> 1);
+        };
+        // front_in counts up to nin; tile flags are 0/1: two calls (different targets)
+        if (nin > 0 && !dag_wait(1, [&](int) { return (const int*)(g.front_in + fi); }, nin, abort_flag, s_abort)) break;
+        if (n0 > 0 && !dag_wait(n0, fl, 1, abort_flag, s_abort)) break;
+      }
+      double4_t acc[4];
+      load_c_frags1(tile_ptr(fd, f, r, s), acc);
+      double bvec = 0.0, tsum = 0.0;
+      if (diag && threadIdx.x < NB) bvec = ld1(vecs + (size_t)s * NB + threadIdx.x);
+      if (diag) dag_accumulate<true>(fd, f, s, s, 0, s - 1, acc, S, M, yv, tsum);
+      else dag_accumulate<false>(fd, f, r, s, 0, s - 1, acc, S, M, yv, tsum);
+      if (s > 0) {
+        // stage 1: the last operand column (the critical one)
+        auto fl = [&](int i) -> const int* { return g.tile + tile_index(f, (i & 1) ? s : r, s - 1); };
+        if (!dag_wait(diag ? 1 : 2, fl, 1, abort_flag, s_abort)) break;
+        if (diag) dag_accumulate<true>(fd, f, s, s, s - 1, s, acc, S, M, yv, tsum);
+        else dag_accumulate<false>(fd, f, r, s, s - 1, s, acc, S, M, yv, tsum);
+      }
+      if (diag) {
+        const double u = (u_override >= 0.0) ? u_override : fd.st->u;
+        const double t = dag_reduce_rows(tsum, part);      // (sum_c L(s,c) y_c)[row threadIdx.x & 63]
+        if (threadIdx.x < NB) vec[threadIdx.x] = bvec - t;
+        // updated tile -> S: lower triangle, damping on real pivots, identity on the padding rows
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int i = 16 * w + lr, k = 16 * ni + lk + 4 * rr;
+            double x = (i >= k) ? acc[ni][rr] : 0.0;
+            if (i == k) x = (s * NB + i < f.n1) ? x + u : 1.0;
+            S[i + k * LD] = x;
+          }
+        __syncthreads();
+        const bool ok = dag_factor_tile(&fd);
+        if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
+        double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st1(linv + threadIdx.x + 256 * e, M[threadIdx.x + 256 * e]);
+        if (threadIdx.x < NB) {
+          const int i = threadIdx.x;
+          double a = 0.0;
+          for (int k = 0; k <= i; ++k) a += M[i + k * LD] * vec[k];
+          st1(vecs + (size_t)s * NB + i, a);     // y_s
+        }
+        dag_publish_begin();
+        dag_set_flag(g.tile + tile_index(f, s, s));
+      } else {
+        // wait for the factor of the diagonal tile, then X = acc L_ss^-T as one tile product with L_ss^-1
+        if (!dag_wait(1, [&](int) { return (const int*)(g.tile + tile_index(f, s, s)); }, 1, abort_flag, s_abort)) break;
+        const double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
+        double breg[16];
+        load_tile_regs1(linv, breg);
+        // (dag_wait's barrier came after the last MFMA that read M as an operand buffer)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
+        __syncthreads();
+        double areg[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) areg[4 * ni + rr] = acc[ni][rr];
+        double4_t xa[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+        tile_ABt_regs<false>(areg, M, xa);
+        store_c_frags1(tile_ptr(fd, f, r, s), xa);
+        dag_publish_begin();
+        dag_set_flag(g.tile + tile_index(f, r, s));
+      }
+    } else if (type == ND_T_SCHUR) {
+      // ================= SCHUR(f,r,s): boundary tile -> parent ======================================
+      const int r = tr_, sc = ts_, tr = r - f.npt, tc = sc - f.npt;
+      const NDFront& pf = fd.fronts[f.parent];
+      if (threadIdx.x < 2 * NB) {
+        const int* em = fd.nd_eamap + f.eamap_off;
+        const bool is_row = threadIdx.x < NB;
+        const int i = (is_row ? tr : tc) * NB + (threadIdx.x & 63);
+        const int m = (i < 7 * f.nb) ? dag_base(pf, em[i / 7]) + i % 7 : -1;
+        if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
+      }
+      if (nin > 0 && !dag_wait(1, [&](int) { return (const int*)(g.front_in + fi); }, nin, abort_flag, s_abort)) break;
+      const bool dg = tr == tc;
+      {
+        const int n0 = f.npt > 1 ? (dg ? f.npt - 1 : 2 * (f.npt - 1)) : 0;
+        auto fl = [&](int i) -> const int* {
+          if (dg) return g.tile + tile_index(f, r, i);
+          return g.tile + tile_index(f, (i & 1) ? sc : r, i >> 1);
+        };
+        if (n0 > 0 && !dag_wait(n0, fl, 1, abort_flag, s_abort)) break;
+      }
+      double4_t acc[4];
+      load_c_frags1(tile_ptr(fd, f, r, sc), acc);
+      double bvec = 0.0, tsum = 0.0;
+      if (dg && threadIdx.x < NB) bvec = ld1(vecs + (size_t)r * NB + threadIdx.x);
+      if (dg) dag_accumulate<true>(fd, f, r, r, 0, f.npt - 1, acc, S, M, yv, tsum);
+      else dag_accumulate<false>(fd, f, r, sc, 0, f.npt - 1, acc, S, M, yv, tsum);
+      if (f.npt > 0) {
+        auto fl = [&](int i) -> const int* { return g.tile + tile_index(f, (i & 1) ? sc : r, f.npt - 1); };
+        if (!dag_wait(dg ? 1 : 2, fl, 1, abort_flag, s_abort)) break;
+        if (dg) dag_accumulate<true>(fd, f, r, r, f.npt - 1, f.npt, acc, S, M, yv, tsum);
+        else dag_accumulate<false>(fd, f, r, sc, f.npt - 1, f.npt, acc, S, M, yv, tsum);
+      }
+      double tvec = 0.0;
+      if (dg) tvec = dag_reduce_rows(tsum, part);
+      // child 1 adds after child 0 (fixed order of the two contributions to every parent entry)
+      if (f.which_child == 1) {
+        const int nin0 = fd.front_nin[2 * f.parent + 1];
+        if (nin0 > 0 && !dag_wait(1, [&](int) { return (const int*)(g.child0 + f.parent); }, nin0, abort_flag, s_abort)) break;
+      }
+      __syncthreads();     // all waves done with S as the operand buffer; maps visible
+      store_c_frags(S, acc);
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        double* dst[8];
+        double cur[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int idx = threadIdx.x + 256 * (8 * h + e);
+          const int i = idx & 63, j = idx >> 6;
+          const int pr = rmap[i], pc = cmap[j];
+          double* p = nullptr;
+          if (pr >= 0 && pc >= 0 && (tr > tc || i >= j)) {
+            const size_t t = (size_t)(pc >> 6) * pf.nt - (size_t)(pc >> 6) * ((pc >> 6) - 1) / 2 + (size_t)((pr >> 6) - (pc >> 6));
+            p = fd.ftiles + pf.tile_off + t * TILE + (pr & 63) + (size_t)(pc & 63) * NB;
+          }
+          dst[e] = p;
+        }
+        // all loads of a chunk before its first store: the destinations are distinct but the compiler cannot know
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cur[e] = dst[e] ? ld1(dst[e]) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (dst[e]) st1(dst[e], cur[e] + S[threadIdx.x + 256 * (8 * h + e)]);
+      }
+      if (dg && threadIdx.x < NB) {
+        const int pr = rmap[threadIdx.x];
+        if (pr >= 0) {
+          double* pv = fd.fvec + pf.vec_off + pr;
+          st1(pv, ld1(pv) + (bvec - tvec));
+        }
+      }
+      dag_publish_begin();
+      if (threadIdx.x == 0) {
+        if (f.which_child == 0) atomicAdd(g.child0 + f.parent, 1);
+        atomicAdd(g.front_in + f.parent, 1);
+      }
+    } else if (type == ND_T_BACKB) {
+      // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================
+      const int c = ts_;
+      const NDFront& pf = fd.fronts[f.parent];
+      // the parent's pivots (and with them all ancestors') are solved once its column 0 is
+      if (!dag_wait(1, [&](int) { return (const int*)(g.px + (int)(pf.linv_off / TILE)); }, 1, abort_flag, s_abort)) break;
+      double* xb = S;   // n2p doubles
+      const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
+      for (int i = threadIdx.x; i < f.n2p; i += blockDim.x) xb[i] = (i < 7 * f.nb) ? ld1(fd.delta + 7 * nodes[i / 7] + i % 7) : 0.0;
+      __syncthreads();
+      const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
+      double a = 0.0;
+      for (int r = f.npt; r < f.nt; ++r) {
+        const double* Lt = tile_ptr(fd, f, r, c);
+        const double* xr = xb + (size_t)(r - f.npt) * NB;
+        double lv[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) lv[m] = ld1(Lt + 16 * q + m + n * NB);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) a += lv[m] * xr[16 * q + m];
+      }
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      if (q == 0) {
+        double* pv = vecs + (size_t)c * NB + n;
+        st1(pv, ld1(pv) - a);
+      }
+      dag_publish_begin();
+      dag_set_flag(g.pb + (int)(f.linv_off / TILE) + c);
+    } else if (type == ND_T_BACK) {
+      // ================= BACK(f,c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r) ===============
+      const int c = ts_;
+      const int pc0 = (int)(f.linv_off / TILE);
+      {
+        // y_c final: factored (always) and the boundary part subtracted (fronts with a boundary)
+        auto fl = [&](int i) -> const int* { return i == 0 ? g.tile + tile_index(f, c, c) : g.pb + pc0 + c; };
+        if (!dag_wait(f.nb > 0 ? 2 : 1, fl, 1, abort_flag, s_abort)) break;
+      }
+      {
+        const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
+        double breg[16];
+        load_tile_regs1(linv, breg);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
+        if (threadIdx.x < NB) vec[threadIdx.x] = ld1(vecs + (size_t)c * NB + threadIdx.x);
+      }
+      const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
+      double a = 0.0;
+      double lv[16];
+      if (c + 1 < f.npt) {
+        const double* Lt = tile_ptr(fd, f, f.npt - 1, c);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) lv[m] = ld1(Lt + 16 * q + m + n * NB);
+      }
+      for (int r = f.npt - 1; r > c; --r) {
+        // x_r: the solution of pivot column r of this front (the chain); the tile L(r,c) is already in registers
+        if (!dag_wait(1, [&](int) { return (const int*)(g.px + pc0 + r); }, 1, abort_flag, s_abort)) goto done;
+        if (threadIdx.x < NB) yv[threadIdx.x] = ld1(vecs + (size_t)r * NB + threadIdx.x);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) a += lv[m] * yv[16 * q + m];
+        if (r - 1 > c) {   // next tile: requested before the next wait, lands during it
+          const double* Lt = tile_ptr(fd, f, r - 1, c);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) lv[m] = ld1(Lt + 16 * q + m + n * NB);
+        }
+        __syncthreads();   // yv is rewritten by the next round
+      }
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      __syncthreads();     // M / vec staged
+      if (q == 0) vec[n] -= a;
+      __syncthreads();
+      {
+        // x[k] = sum_i Linv[i][k] y[i]
+        const int k = threadIdx.x & 63, qq = threadIdx.x >> 6;
+        double p = 0.0;
+#pragma unroll
+        for (int i = 16 * qq; i < 16 * qq + 16; ++i) p += M[i + k * LD] * vec[i];
+        part[qq * NB + k] = p;
+        __syncthreads();
+        if (threadIdx.x < NB) {
+          const double x = part[k] + part[NB + k] + part[2 * NB + k] + part[3 * NB + k];
+          st1(vecs + (size_t)c * NB + k, x);
+          const int i = c * NB + k;
+          if (i < f.n1) {
+            const int node = fd.nd_nodes[f.nodes_off + i / 7];
+            st1(fd.delta + 7 * node + i % 7, x);
+          }
+        }
+      }
+      dag_publish_begin();
+      dag_set_flag(g.px + pc0 + c);
+    }
+  }
+done:
+  return;
+}
+
+// zero the flags of slots [0, n_frames) (ticket, abort, counters, tile / column flags); grid = (blocks, n_frames)
+__global__ void __launch_bounds__(256) k_dag_reset(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.nd_ready || !fd.dag_flags) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fd.dag_n_flags; i += gridDim.x * blockDim.x) fd.dag_flags[i] = 0;
+}
+
+// a timed-out solve is reported like a failed factorisation (the LM loop stops, beta is kept)
+__global__ void k_dag_check(const FrameDev* __restrict__ frames, int n_frames) {
+  const FrameDev& fd0 = frames[0];
+  if (!fd0.bound || !fd0.nd_ready) return;
+  if (fd0.dag_flags[1] != 0 && threadIdx.x < n_frames) {
+    const FrameDev& fd = frames[threadIdx.x];
+    if (fd.bound) fd.st->chol_fail = 1;
+  }
+}
+
+void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st) {
+  if (max_tasks <= 0) return;
+  const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
+  static int n_wg = 0;
+  if (n_wg == 0) {
+    (void)hipFuncSetAttribute((const void*)k_fdag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* e = getenv("SLM_DAG_WG_PER_CU");
+    const int per_cu = e ? atoi(e) : 2;
+    n_wg = cus * (per_cu > 0 ? per_cu : 2);
+  }
+  hipLaunchKernelGGL(k_dag_reset, dim3(8, n_frames), dim3(256), 0, st, fr);
+  const long total = (long)n_frames * max_tasks;
+  const int grid = (int)(total < n_wg ? total : n_wg);
+  hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override);
+  hipLaunchKernelGGL(k_dag_check, dim3(1), dim3(64), 0, st, fr, n_frames);
+}

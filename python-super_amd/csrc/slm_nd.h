@@ -56,6 +56,17 @@ struct NDLevelSched {
   int32_t schur_at[2]; // their offset in schur_items when all slots of the batch agree, else -1
 };
 
+// ---- persistent task-graph form of the numeric phase (slm_dag.hip) ------------------------------
+// One launch runs the whole factorisation + substitutions: workgroups take tasks from a list in
+// ticket order and wait on per-tile flags.  Task word 0 = type << 24 | front, word 1 = r << 8 | s.
+enum {
+  ND_T_POTRF = 0,   // (f, s, s): left-looking update of the diagonal tile of pivot column s, factor, inverse, y_s
+  ND_T_COL = 1,     // (f, r, s), r > s: L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
+  ND_T_SCHUR = 2,   // (f, r, s) boundary tiles: Schur complement tile extend-added into the parent (+ vector rows)
+  ND_T_BACKB = 3,   // (f, c): y_c -= sum over boundary tiles L(r,c)^T x_r
+  ND_T_BACK = 4     // (f, c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r)
+};
+
 struct NDPlanHost {
   std::vector<NDFront> fronts;        // processing order: deepest level first
   std::vector<int32_t> level_start;   // fronts[level_start[l] .. level_start[l+1]) are independent
@@ -79,6 +90,11 @@ struct NDPlanHost {
   int32_t max_nt = 0, max_npt = 0, max_level_fronts = 0;
   std::vector<NDLevelSched> sched;    // one entry per level
   double flops = 0.0;
+  // task list of the persistent kernel, sorted by earliest possible start (a topological order: every task
+  // comes after the tasks it waits for), and per front {tasks that extend-add into it, those of its child 0}
+  std::vector<int32_t> dag_tasks;     // 2 words per task
+  std::vector<int32_t> front_nin;     // 2 per front
+  double dag_critical_us = 0.0;       // modelled critical path (diagnostic)
 };
 
 // Host symbolic analysis.  pairs: unique coupled node pairs key = a*J + b (a >= b) of the data

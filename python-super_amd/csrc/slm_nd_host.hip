@@ -366,6 +366,87 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       out.sched[l].schur_at[w] = out.schur_off[out.schur_off.size() - 2];
       out.sched[l].n_schur[w] = out.schur_off.back() - out.sched[l].schur_at[w];
     }
+  // ---- task list of the persistent kernel (slm_dag.hip) -----------------------------------------
+  // Earliest start times from a duration model (microseconds; only the ORDER matters): tasks sorted by
+  // them are in a topological order, and workgroups that take tasks in that order find them ready
+  // about when they get to them.
+  {
+    struct Task { double start; int32_t w0, w1; };
+    std::vector<Task> tasks;
+    const double HOP = 2.0;   // flag + payload hand-off between workgroups
+    auto d_potrf = [](int s) { return 13.0 + 0.6 * s; };
+    auto d_col = [](int s) { return 3.5 + 0.6 * s; };
+    auto d_schur = [](int npt) { return 4.0 + 1.0 * npt; };
+    std::vector<double> ready(T, 0.0);             // front assembled (children's Schur complements in)
+    std::vector<double> ready0(T, 0.0);            // ... of child 0 only
+    std::vector<double> fact_done(T, 0.0);
+    out.front_nin.assign(2 * (size_t)T, 0);
+    std::vector<double> done;                      // per tile of the current front
+    for (int i = 0; i < T; ++i) {                  // processing order: children before parents
+      const NDFront& f = out.fronts[i];
+      auto tix = [&](int r, int c) { return (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c); };
+      done.assign((size_t)f.nt * (f.nt + 1) / 2, 0.0);
+      for (int s = 0; s < f.npt; ++s) {
+        double st = ready[i];
+        for (int c = 0; c < s; ++c) st = std::max(st, done[tix(s, c)] + HOP);
+        tasks.push_back({st, (ND_T_POTRF << 24) | i, (s << 8) | s});
+        done[tix(s, s)] = st + d_potrf(s);
+        for (int r = s + 1; r < f.nt; ++r) {
+          double sr = ready[i];
+          for (int c = 0; c < s; ++c) sr = std::max(sr, std::max(done[tix(r, c)], done[tix(s, c)]) + HOP);
+          const double fin = std::max(sr + 1.0 + 0.6 * s, done[tix(s, s)] + HOP) + 2.5;
+          tasks.push_back({sr, (ND_T_COL << 24) | i, (r << 8) | s});
+          done[tix(r, s)] = fin;
+          (void)d_col;
+        }
+      }
+      double fd_ = ready[i];
+      for (int s = 0; s < f.npt; ++s) fd_ = std::max(fd_, done[tix(s, s)]);
+      fact_done[i] = fd_;
+      if (f.parent >= 0) {
+        const int nbt = f.nt - f.npt;
+        for (int tr = 0; tr < nbt; ++tr)
+          for (int tc = 0; tc <= tr; ++tc) {
+            double st = ready[i];
+            for (int c = 0; c < f.npt; ++c)
+              st = std::max(st, std::max(done[tix(f.npt + tr, c)], done[tix(f.npt + tc, c)]) + HOP);
+            if (f.which_child == 1) st = std::max(st, ready0[f.parent]);   // child 0's extend-adds come first
+            tasks.push_back({st, (ND_T_SCHUR << 24) | i, ((f.npt + tr) << 8) | (f.npt + tc)});
+            const double fin = st + d_schur(f.npt);
+            ready[f.parent] = std::max(ready[f.parent], fin + HOP);
+            if (f.which_child == 0) ready0[f.parent] = std::max(ready0[f.parent], fin + HOP);
+            out.front_nin[2 * (size_t)f.parent] += 1;
+            if (f.which_child == 0) out.front_nin[2 * (size_t)f.parent + 1] += 1;
+          }
+      }
+    }
+    // back substitution, root first (fronts are stored deepest level first)
+    std::vector<double> back_done(T, 0.0);
+    double t_end = 0.0;
+    for (int i = T - 1; i >= 0; --i) {
+      const NDFront& f = out.fronts[i];
+      double st0 = fact_done[i];
+      if (f.parent >= 0) st0 = std::max(st0, back_done[f.parent] + HOP);
+      else for (int k = 0; k < T; ++k) st0 = std::max(st0, fact_done[k]);   // the root starts when everything is factored
+      double prev = st0;
+      for (int c = f.npt - 1; c >= 0; --c) {
+        if (f.nb > 0) tasks.push_back({st0, (ND_T_BACKB << 24) | i, (c << 8) | c});
+        const double st = std::max(prev, st0 + (f.nb > 0 ? 2.0 + 0.3 * (f.nt - f.npt) : 0.0));
+        tasks.push_back({st, (ND_T_BACK << 24) | i, (c << 8) | c});
+        prev = st + 2.5;
+      }
+      back_done[i] = prev;
+      t_end = std::max(t_end, prev);
+    }
+    out.dag_critical_us = t_end;
+    std::stable_sort(tasks.begin(), tasks.end(), [](const Task& a, const Task& b) { return a.start < b.start; });
+    out.dag_tasks.resize(2 * tasks.size());
+    for (size_t k = 0; k < tasks.size(); ++k) {
+      out.dag_tasks[2 * k] = tasks[k].w0;
+      out.dag_tasks[2 * k + 1] = tasks[k].w1;
+    }
+    if (T >= (1 << 24) || out.max_nt > 255) return false;
+  }
   // extend-add maps: boundary index of a child -> local node position in the parent
   for (int i = 0; i < T; ++i) {
     const int id = proc[i];

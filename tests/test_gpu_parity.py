@@ -259,7 +259,7 @@ def test_nd_multifrontal_solve_matches_band_and_numpy(name):
     beta = torch.from_numpy(g["b1_beta"]).cuda()
     P = 7 * sc.J
     sols = {}
-    for path in (0, 1):
+    for path in (0, 1, 2):     # per-level launches, band, persistent task graph
         o = ref_opt(opt)
         o.slm_solver_path = path
         lm = LM_Solver(o)
@@ -275,6 +275,7 @@ def test_nd_multifrontal_solve_matches_band_and_numpy(name):
         ref = np.linalg.solve(A, jtl.cpu().numpy().reshape(-1))
         np.testing.assert_allclose(sols[path], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
     np.testing.assert_allclose(sols[0], sols[1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sols[0], sols[2], rtol=0, atol=1e-11)
 
 
 @pytest.mark.parametrize("name,world", [("s60x80_j48", 2), ("s120x160_j108", 3), ("s60x80_j48_reject", 4)])
