@@ -558,6 +558,11 @@ int slm_graph_init_semantic(int32_t H, int32_t W, int32_t step, const uint8_t* v
 /* Diagnostics: {device buffer reallocations in the LM solver, bytes asked for, symbolic analyses,
  * plan reuses with a changed pair list} since the library was loaded. */
 int slm_debug_counters(int64_t out[4]);
+/* Diagnostics: copies a solver work buffer of the slot to HOST memory (synchronises `stream`): what = 0 front
+ * tiles, 1 front vectors, 2 inverses of the diagonal factor blocks, 3 delta.  *n_doubles receives the buffer's
+ * length; at most max_doubles are copied. */
+int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, int64_t max_doubles,
+                   int64_t* n_doubles, void* stream);
 
 #ifdef __cplusplus
 }

@@ -153,6 +153,27 @@ int slm_debug_counters(int64_t out[4]) {
   return SLM_OK;
 }
 
+int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, int64_t max_doubles,
+                   int64_t* n_doubles, void* stream) {
+  if (!s || slot < 0 || slot >= (int)s->slots.size() || !n_doubles) return fail(SLM_ERR_INVALID, "slm_debug_read: bad argument");
+  const Slot& sl = s->slots[slot];
+  if (!sl.h.bound) return fail(SLM_ERR_UNBOUND, "slm_debug_read: slot used before slm_bind_frame");
+  const double* src = nullptr;
+  int64_t n = 0;
+  switch (what) {
+    case 0: src = sl.ftiles; n = sl.h.nd_ready ? sl.nd.tile_doubles : 0; break;
+    case 1: src = sl.fvec; n = sl.h.nd_ready ? sl.nd.vec_doubles : 0; break;
+    case 2: src = sl.flinv; n = sl.h.nd_ready ? sl.nd.linv_doubles : 0; break;
+    case 3: src = sl.h.delta; n = sl.h.P; break;
+    default: return fail(SLM_ERR_INVALID, "slm_debug_read: unknown buffer");
+  }
+  *n_doubles = n;
+  const int64_t m = n < max_doubles ? n : max_doubles;
+  if (m > 0 && host_out && src) HIPCHK(hipMemcpyAsync(host_out, src, sizeof(double) * m, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return SLM_OK;
+}
+
 int slm_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

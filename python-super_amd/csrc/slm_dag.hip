@@ -40,14 +40,25 @@ namespace {
 
 #define DAG_SPIN_LIMIT (1 << 22)   // polls before a wait gives up (a few seconds)
 
+// Every hand-off access is a GLOBAL-segment instruction with sc1 (global_load / global_store ... sc1): pointers read
+// from the slot descriptor are generic, and a flat_ access is not a valid hand-off form (MI355X_MICROARCH.md), so
+// they are cast to the global address space explicitly.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) int gint;
 __device__ __forceinline__ double ld1(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load((const gdouble*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st1(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ int ldf(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load((const gint*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stf(int* p, int v) {
+  __hip_atomic_store((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int addf(int* p, int v) {
+  return __hip_atomic_fetch_add((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct DagFlags {
@@ -98,7 +109,7 @@ __device__ __forceinline__ bool dag_wait(int n, F flag_of, int want, int* abort_
         if ((++spins & 255) == 0) {
           if (ldf(abort_flag) != 0 || spins > DAG_SPIN_LIMIT) {
             if (threadIdx.x == 0) {
-              __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              stf(abort_flag, 1);
               *s_abort = 1;
             }
             base = n;
@@ -118,7 +129,7 @@ __device__ __forceinline__ void dag_publish_begin() {
   __syncthreads();
 }
 __device__ __forceinline__ void dag_set_flag(int* flag) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) stf(flag, 1);
 }
 
 // ---- sc1 forms of the fragment loads / stores of slm_tile.h ------------------------------------------
@@ -251,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
   const int total = n_frames * max_tasks;
 
   for (;;) {
-    if (threadIdx.x == 0) *s_task = atomicAdd(ticket, 1);
+    if (threadIdx.x == 0) *s_task = addf(ticket, 1);
     __syncthreads();
     const int tk = *s_task;
     __syncthreads();
@@ -420,8 +431,8 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       }
       dag_publish_begin();
       if (threadIdx.x == 0) {
-        if (f.which_child == 0) atomicAdd(g.child0 + f.parent, 1);
-        atomicAdd(g.front_in + f.parent, 1);
+        if (f.which_child == 0) addf(g.child0 + f.parent, 1);
+        addf(g.front_in + f.parent, 1);
       }
     } else if (type == ND_T_BACKB) {
       // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================
@@ -457,9 +468,16 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       const int c = ts_;
       const int pc0 = (int)(f.linv_off / TILE);
       {
-        // y_c final: factored (always) and the boundary part subtracted (fronts with a boundary)
-        auto fl = [&](int i) -> const int* { return i == 0 ? g.tile + tile_index(f, c, c) : g.pb + pc0 + c; };
-        if (!dag_wait(f.nb > 0 ? 2 : 1, fl, 1, abort_flag, s_abort)) break;
+        // y_c final: factored (always) and the boundary part subtracted (fronts with a boundary); the tiles
+        // L(r,c), c < r < npt, that are fetched ahead of the x_r they multiply must be final too (a root front
+        // gets here while its factorisation is still running)
+        const int nb_flags = f.nb > 0 ? 2 : 1;
+        auto fl = [&](int i) -> const int* {
+          if (i == 0) return g.tile + tile_index(f, c, c);
+          if (i < nb_flags) return g.pb + pc0 + c;
+          return g.tile + tile_index(f, c + 1 + (i - nb_flags), c);
+        };
+        if (!dag_wait(nb_flags + (f.npt - 1 - c), fl, 1, abort_flag, s_abort)) break;
       }
       {
         const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
