@@ -96,6 +96,8 @@ struct Slot {
   std::vector<double> h_pts64;
   NDFront* d_fronts = nullptr;
   int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos | ... | dag_tasks | front_nin
+  long long* d_dag_trace = nullptr; // diagnostics
+  size_t cap_dag_trace = 0;
   int32_t* d_dag_flags = nullptr;   // persistent task-graph solver: ticket, counters, per-tile / per-column flags
   size_t cap_dag_flags = 0;
   NDDest* d_dests = nullptr;    // block_dest | pair_dest
@@ -153,6 +155,21 @@ int slm_debug_counters(int64_t out[4]) {
   return SLM_OK;
 }
 
+int slm_debug_dag_trace(slm_solver* s, int32_t slot, int32_t on, void* stream) {
+  if (!s || slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_debug_dag_trace: bad argument");
+  Slot& sl = s->slots[slot];
+  if (!sl.h.bound || !sl.h.nd_ready) return fail(SLM_ERR_UNBOUND, "slm_debug_dag_trace: no nested-dissection plan bound");
+  hipStream_t st = (hipStream_t)stream;
+  if (on) {
+    HIPCHK(grow(sl.d_dag_trace, sl.cap_dag_trace, (size_t)8 * sl.h.n_dag_tasks + 8));
+    HIPCHK(hipMemsetAsync(sl.d_dag_trace, 0, sizeof(long long) * 8 * (size_t)sl.h.n_dag_tasks, st));
+  }
+  sl.h.dag_trace = on ? sl.d_dag_trace : nullptr;
+  HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &sl.h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return SLM_OK;
+}
+
 int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, int64_t max_doubles,
                    int64_t* n_doubles, void* stream) {
   if (!s || slot < 0 || slot >= (int)s->slots.size() || !n_doubles) return fail(SLM_ERR_INVALID, "slm_debug_read: bad argument");
@@ -165,6 +182,8 @@ int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, 
     case 1: src = sl.fvec; n = sl.h.nd_ready ? sl.nd.vec_doubles : 0; break;
     case 2: src = sl.flinv; n = sl.h.nd_ready ? sl.nd.linv_doubles : 0; break;
     case 3: src = sl.h.delta; n = sl.h.P; break;
+    case 4: src = reinterpret_cast<const double*>(sl.h.dag_trace); n = sl.h.dag_trace ? 8 * (int64_t)sl.h.n_dag_tasks : 0; break;
+    case 5: src = reinterpret_cast<const double*>(sl.h.dag_tasks); n = sl.h.nd_ready ? sl.h.n_dag_tasks : 0; break;
     default: return fail(SLM_ERR_INVALID, "slm_debug_read: unknown buffer");
   }
   *n_doubles = n;
@@ -229,6 +248,7 @@ int slm_destroy(slm_solver* s) {
     if (sl.flinv) (void)hipFree(sl.flinv);
     if (sl.pairbuf) (void)hipFree(sl.pairbuf);
     if (sl.d_dag_flags) (void)hipFree(sl.d_dag_flags);
+    if (sl.d_dag_trace) (void)hipFree(sl.d_dag_trace);
   }
   prep_destroy(s->prep);
   for (auto& evs : s->ev_runs)
@@ -285,6 +305,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   // (solver_path 1, a frame without an ND plan, slm_assemble): ensure_band() fills them in on demand
   int wb = 0;
   sl.band_ready = false;
+  h.dag_trace = nullptr;   // a trace buffer is sized for the plan it was enabled on
   h.f = *f;
   h.P = P;
   h.nt = nt;
@@ -497,7 +518,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.n_dag_tasks = (int32_t)(nd.dag_tasks.size() / 2);
       h.dag_n_tiles = (int32_t)(nd.tile_doubles / (SLM_NB * SLM_NB));
       h.dag_n_pcols = (int32_t)(nd.linv_doubles / (SLM_NB * SLM_NB));
-      h.dag_n_flags = 8 + 2 * (int32_t)nd.fronts.size() + h.dag_n_tiles + 2 * h.dag_n_pcols;
+      h.dag_n_flags = 8 + 2 * (int32_t)nd.fronts.size() + h.dag_n_tiles + 3 * h.dag_n_pcols;
       HIPCHK(grow(sl.d_dag_flags, sl.cap_dag_flags, (size_t)h.dag_n_flags));
       h.dag_flags = sl.d_dag_flags;
       if (!nd.block_dest.empty())

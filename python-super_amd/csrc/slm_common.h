@@ -102,11 +102,12 @@ struct FrameDev {
   // ---- persistent task-graph solver (slm_dag.hip): task list of the plan + per-iteration flags ----
   const int32_t* dag_tasks;    // (n_dag_tasks, 2) task words (slm_nd.h), in a topological order
   const int32_t* front_nin;    // (n_fronts, 2) extend-add tasks that feed the front {all, those of child 0}
-  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per front {in, child0}, per tile done, per pivot column {b, x}
+  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per front {in, child0}, per tile done, per pivot column {b, x, y}
   int32_t n_dag_tasks;
   int32_t dag_n_tiles;         // tiles of all fronts
   int32_t dag_n_pcols;         // pivot tile columns of all fronts
   int32_t dag_n_flags;         // ints in dag_flags
+  long long* dag_trace;        // diagnostics (slm_debug_dag_trace): per task {start, ready, end} in 10 ns ticks + workgroup; else null
 };
 #define SLM_SLAB_STRIDE 768
 #define SLM_WREC 56          // doubles per (workgroup, pair) record

@@ -61,6 +61,40 @@ __device__ __forceinline__ int addf(int* p, int v) {
   return __hip_atomic_fetch_add((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Values read through pointers that were themselves read from memory are "divergent" for the compiler even
+// when every lane reads the same address: whole descriptors would live in VGPRs (and spill).  The task loop
+// therefore takes a scalar snapshot (v_readfirstlane) of everything it uses from the slot and the front.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long long uni64(long long x) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned)(x & 0xFFFFFFFFll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+  return ((long long)hi << 32) | (unsigned)lo;
+}
+template <typename T>
+__device__ __forceinline__ T* unip(T* p) { return reinterpret_cast<T*>(uni64(reinterpret_cast<long long>(p))); }
+
+struct FS {   // scalar snapshot of an NDFront
+  int nt, npt, nv, nb, n1, n1p, n2p, parent, which_child, nodes_off, eamap_off;
+  int tile0, pcol0;      // first tile / first pivot tile column of the front in the slot's flag arrays
+  long long tile_off, vec_off, linv_off;
+};
+__device__ __forceinline__ FS front_snapshot(const NDFront& f) {
+  FS o;
+  o.nt = uni(f.nt); o.npt = uni(f.npt); o.nv = uni(f.nv); o.nb = uni(f.nb); o.n1 = uni(f.n1); o.n1p = uni(f.n1p);
+  o.n2p = uni(f.n2p); o.parent = uni(f.parent); o.which_child = uni(f.which_child);
+  o.nodes_off = uni(f.nodes_off); o.eamap_off = uni(f.eamap_off);
+  o.tile_off = uni64(f.tile_off); o.vec_off = uni64(f.vec_off); o.linv_off = uni64(f.linv_off);
+  o.tile0 = (int)(o.tile_off / TILE);
+  o.pcol0 = (int)(o.linv_off / TILE);
+  return o;
+}
+struct SS {   // scalar snapshot of the slot's buffers
+  double *ftiles, *fvec, *flinv, *delta;
+  const int32_t *nd_nodes, *nd_eamap, *front_nin;
+  const NDFront* fronts;
+  int n_fronts;
+};
+
 struct DagFlags {
   int* ticket;
   int* abort_;
@@ -69,27 +103,31 @@ struct DagFlags {
   int* tile;
   int* pb;
   int* px;
+  int* py;
 };
 __device__ __forceinline__ DagFlags dag_flags_of(const FrameDev& fd) {
   DagFlags g;
-  g.ticket = fd.dag_flags;
-  g.abort_ = fd.dag_flags + 1;
-  g.front_in = fd.dag_flags + 8;
-  g.child0 = g.front_in + fd.n_fronts;
-  g.tile = g.child0 + fd.n_fronts;
-  g.pb = g.tile + fd.dag_n_tiles;
-  g.px = g.pb + fd.dag_n_pcols;
+  int* base = unip(fd.dag_flags);
+  const int nf = uni(fd.n_fronts), nt = uni(fd.dag_n_tiles), np = uni(fd.dag_n_pcols);
+  g.ticket = base;
+  g.abort_ = base + 1;
+  g.front_in = base + 8;
+  g.child0 = g.front_in + nf;
+  g.tile = g.child0 + nf;
+  g.pb = g.tile + nt;
+  g.px = g.pb + np;
+  g.py = g.px + np;
   return g;
 }
 
-__device__ __forceinline__ int tile_index(const NDFront& f, int r, int c) {
-  return (int)(f.tile_off / TILE) + c * f.nt - c * (c - 1) / 2 + (r - c);
+__device__ __forceinline__ int tile_index(const FS& f, int r, int c) {
+  return f.tile0 + c * f.nt - c * (c - 1) / 2 + (r - c);
 }
-__device__ __forceinline__ double* tile_ptr(const FrameDev& fd, const NDFront& f, int r, int c) {
+__device__ __forceinline__ double* tile_ptr(const SS& fd, const FS& f, int r, int c) {
   const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
   return fd.ftiles + f.tile_off + t * TILE;
 }
-__device__ __forceinline__ int dag_base(const NDFront& f, int p) {
+__device__ __forceinline__ int dag_base(const FS& f, int p) {
   return p < f.nv ? 7 * p : f.n1p + 7 * (p - f.nv);
 }
 
@@ -162,7 +200,7 @@ __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, do
 // flight (registers) under the MFMAs.  VEC (needs ra == rb): also tsum += (L(ra,c) y_c)[row threadIdx.x & 63] over
 // the 16 inner columns of this thread's quarter; y_c is read from the front's vector.
 template <bool VEC>
-__device__ __forceinline__ void dag_accumulate(const FrameDev& fd, const NDFront& f, int ra, int rb, int c0, int c1,
+__device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra, int rb, int c0, int c1,
                                                double4_t acc[4], double* Bl, double* Al, double* yv, double& tsum) {
   if (c0 >= c1) return;
   const bool two = ra != rb;
@@ -217,27 +255,27 @@ __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4
 // S, M, the four diagonal-block inverses, three 16x16 scratch blocks, two vectors, a few ints: 80 960 B -> two
 // workgroups per CU.  `part` (row partials) shares the scratch blocks and the extend-add maps share the
 // diagonal-block inverses: neither is live while a tile is being factored.
-#define DAG_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 8)
+#define DAG_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 16)
 
 // Tile factorisation + inverse as a real call: inlined into the task loop it raises the register demand of the
 // whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
 // base inside the function, so their address space stays known.
 extern __shared__ double dag_lds[];
-__device__ __noinline__ bool dag_factor_tile(const FrameDev* fd) {
+__device__ __forceinline__ bool dag_factor_tile() {
   double* S = dag_lds;
   double* M = dag_lds + TILE;
   double* dinv = dag_lds + 2 * TILE;
   double* wt = dinv + 4 * 256;
-  int* s_ok = reinterpret_cast<int*>(wt + 3 * 256 + 2 * NB);
-  const bool ok = potrf64(S, dinv, wt, s_ok, *fd, false);
-  inverse_assemble64(S, M, dinv, wt);
-  return ok;
+  double* xch = wt + 3 * 256;                   // vec | yv: not live while a tile is being factored
+  int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
+  int* pf = s_ok + 16;                          // 16 hand-off flags of the trailing waves
+  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf);
 }
 
 }  // namespace
 
 // grid = persistent (2 workgroups per CU), 256 threads
-__global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
+__global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
                                                  double u_override) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
@@ -264,18 +302,33 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
   for (;;) {
     if (threadIdx.x == 0) *s_task = addf(ticket, 1);
     __syncthreads();
-    const int tk = *s_task;
+    const int tk = __builtin_amdgcn_readfirstlane(*s_task);   // provably uniform: descriptors stay in SGPRs
     __syncthreads();
     if (tk >= total || *s_abort) break;
     const int slot = tk % n_frames, ti = tk / n_frames;
-    const FrameDev& fd = frames[slot];
-    if (!fd.bound || !fd.nd_ready || ti >= fd.n_dag_tasks) continue;
-    const int w0 = fd.dag_tasks[2 * ti], w1 = fd.dag_tasks[2 * ti + 1];
+    const FrameDev& fdr = frames[slot];
+    if (!uni(fdr.bound) || !uni(fdr.nd_ready) || ti >= uni(fdr.n_dag_tasks)) continue;
+    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
-    const NDFront& f = fd.fronts[fi];
-    const DagFlags g = dag_flags_of(fd);
+    SS fd;
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.nd_nodes = unip(fdr.nd_nodes); fd.nd_eamap = unip(fdr.nd_eamap); fd.front_nin = unip(fdr.front_nin);
+    fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
+    const FS f = front_snapshot(fd.fronts[fi]);
+    const DagFlags g = dag_flags_of(fdr);
     double* vecs = fd.fvec + f.vec_off;
-    const int nin = fd.front_nin[2 * fi];
+    const int nin = uni(fd.front_nin[2 * fi]);
+    LMState* lmst = unip(fdr.st);
+    long long* trc_base = unip(fdr.dag_trace);
+    long long* trc = trc_base ? trc_base + 8 * (size_t)ti : nullptr;
+    if (trc && threadIdx.x == 0) {
+      trc[0] = wall_clock64();
+      trc[3] = blockIdx.x;
+    }
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
 
     if (type == ND_T_POTRF || type == ND_T_COL) {
       // ================= POTRF(f,s) / COL(f,r,s) ==================================================
@@ -283,9 +336,11 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       const bool diag = type == ND_T_POTRF;
       // stage 0: the front's own tile is complete (children's extend-adds) + all but the last operand column
       {
-        const int n0 = s > 0 ? (diag ? s - 1 : 2 * (s - 1)) : 0;
+        // operands of columns c < s-1: COL waits for L(r,c) and L(s,c); POTRF for L(s,c) and y_c
+        const int pcy = f.pcol0;
+        const int n0 = s > 0 ? 2 * (s - 1) : 0;
         auto fl = [&](int i) -> const int* {
-          if (diag) return g.tile + tile_index(f, s, i);
+          if (diag) return (i & 1) ? g.py + pcy + (i >> 1) : g.tile + tile_index(f, s, i >> 1);
           return g.tile + tile_index(f, (i & 1) ? s : r, i >> 1);
         };
         // front_in counts up to nin; tile flags are 0/1: two calls (different targets)
@@ -300,15 +355,20 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       else dag_accumulate<false>(fd, f, r, s, 0, s - 1, acc, S, M, yv, tsum);
       if (s > 0) {
         // stage 1: the last operand column (the critical one)
-        auto fl = [&](int i) -> const int* { return g.tile + tile_index(f, (i & 1) ? s : r, s - 1); };
-        if (!dag_wait(diag ? 1 : 2, fl, 1, abort_flag, s_abort)) break;
+        auto fl = [&](int i) -> const int* {
+          if (diag && (i & 1)) return g.py + f.pcol0 + s - 1;
+          return g.tile + tile_index(f, (i & 1) ? s : r, s - 1);
+        };
+        if (!dag_wait(2, fl, 1, abort_flag, s_abort)) break;
+        if (diag) DAG_READY();
         if (diag) dag_accumulate<true>(fd, f, s, s, s - 1, s, acc, S, M, yv, tsum);
         else dag_accumulate<false>(fd, f, r, s, s - 1, s, acc, S, M, yv, tsum);
       }
       if (diag) {
-        const double u = (u_override >= 0.0) ? u_override : fd.st->u;
+        const double u = (u_override >= 0.0) ? u_override : lmst->u;
+        DAG_MARK(4);
         const double t = dag_reduce_rows(tsum, part);      // (sum_c L(s,c) y_c)[row threadIdx.x & 63]
-        if (threadIdx.x < NB) vec[threadIdx.x] = bvec - t;
+        const double bt = bvec - t;                        // threads < NB: right-hand side of row threadIdx.x
         // updated tile -> S: lower triangle, damping on real pivots, identity on the padding rows
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -320,22 +380,35 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
             S[i + k * LD] = x;
           }
         __syncthreads();
-        const bool ok = dag_factor_tile(&fd);
-        if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
+        DAG_MARK(5);
+        const bool ok = dag_factor_tile();
+        DAG_MARK(6);
+        if (!ok && threadIdx.x == 0) lmst->chol_fail = 1;
         double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st1(linv + threadIdx.x + 256 * e, M[threadIdx.x + 256 * e]);
-        if (threadIdx.x < NB) {
-          const int i = threadIdx.x;
+        if (threadIdx.x < NB) vec[threadIdx.x] = bt;
+        dag_publish_begin();                               // (also makes vec visible)
+        dag_set_flag(g.tile + tile_index(f, s, s));        // the factor is out: the column's row solves can start
+        DAG_MARK(7);
+        {
+          // y_s = L_ss^-1 (b_s - t), off the factorisation's critical path; published under its own flag
+          const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
           double a = 0.0;
-          for (int k = 0; k <= i; ++k) a += M[i + k * LD] * vec[k];
-          st1(vecs + (size_t)s * NB + i, a);     // y_s
+#pragma unroll
+          for (int k = 16 * q; k < 16 * q + 16; ++k) a += M[i + k * LD] * vec[k];
+          part[q * NB + i] = a;
+          __syncthreads();
+          if (threadIdx.x < NB) st1(vecs + (size_t)s * NB + i, part[i] + part[NB + i] + part[2 * NB + i] + part[3 * NB + i]);
         }
         dag_publish_begin();
-        dag_set_flag(g.tile + tile_index(f, s, s));
+        dag_set_flag(g.py + f.pcol0 + s);
+        if (s == 0) DAG_READY();
+        DAG_END();
       } else {
         // wait for the factor of the diagonal tile, then X = acc L_ss^-T as one tile product with L_ss^-1
         if (!dag_wait(1, [&](int) { return (const int*)(g.tile + tile_index(f, s, s)); }, 1, abort_flag, s_abort)) break;
+        DAG_READY();
         const double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
         double breg[16];
         load_tile_regs1(linv, breg);
@@ -355,11 +428,12 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
         store_c_frags1(tile_ptr(fd, f, r, s), xa);
         dag_publish_begin();
         dag_set_flag(g.tile + tile_index(f, r, s));
+        DAG_END();
       }
     } else if (type == ND_T_SCHUR) {
       // ================= SCHUR(f,r,s): boundary tile -> parent ======================================
       const int r = tr_, sc = ts_, tr = r - f.npt, tc = sc - f.npt;
-      const NDFront& pf = fd.fronts[f.parent];
+      const FS pf = front_snapshot(fd.fronts[f.parent]);
       if (threadIdx.x < 2 * NB) {
         const int* em = fd.nd_eamap + f.eamap_off;
         const bool is_row = threadIdx.x < NB;
@@ -370,9 +444,9 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       if (nin > 0 && !dag_wait(1, [&](int) { return (const int*)(g.front_in + fi); }, nin, abort_flag, s_abort)) break;
       const bool dg = tr == tc;
       {
-        const int n0 = f.npt > 1 ? (dg ? f.npt - 1 : 2 * (f.npt - 1)) : 0;
+        const int n0 = f.npt > 1 ? 2 * (f.npt - 1) : 0;
         auto fl = [&](int i) -> const int* {
-          if (dg) return g.tile + tile_index(f, r, i);
+          if (dg) return (i & 1) ? g.py + f.pcol0 + (i >> 1) : g.tile + tile_index(f, r, i >> 1);
           return g.tile + tile_index(f, (i & 1) ? sc : r, i >> 1);
         };
         if (n0 > 0 && !dag_wait(n0, fl, 1, abort_flag, s_abort)) break;
@@ -384,8 +458,12 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       if (dg) dag_accumulate<true>(fd, f, r, r, 0, f.npt - 1, acc, S, M, yv, tsum);
       else dag_accumulate<false>(fd, f, r, sc, 0, f.npt - 1, acc, S, M, yv, tsum);
       if (f.npt > 0) {
-        auto fl = [&](int i) -> const int* { return g.tile + tile_index(f, (i & 1) ? sc : r, f.npt - 1); };
-        if (!dag_wait(dg ? 1 : 2, fl, 1, abort_flag, s_abort)) break;
+        auto fl = [&](int i) -> const int* {
+          if (dg && (i & 1)) return g.py + f.pcol0 + f.npt - 1;
+          return g.tile + tile_index(f, (i & 1) ? sc : r, f.npt - 1);
+        };
+        if (!dag_wait(2, fl, 1, abort_flag, s_abort)) break;
+        DAG_READY();
         if (dg) dag_accumulate<true>(fd, f, r, r, f.npt - 1, f.npt, acc, S, M, yv, tsum);
         else dag_accumulate<false>(fd, f, r, sc, f.npt - 1, f.npt, acc, S, M, yv, tsum);
       }
@@ -393,7 +471,7 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       if (dg) tvec = dag_reduce_rows(tsum, part);
       // child 1 adds after child 0 (fixed order of the two contributions to every parent entry)
       if (f.which_child == 1) {
-        const int nin0 = fd.front_nin[2 * f.parent + 1];
+        const int nin0 = uni(fd.front_nin[2 * f.parent + 1]);
         if (nin0 > 0 && !dag_wait(1, [&](int) { return (const int*)(g.child0 + f.parent); }, nin0, abort_flag, s_abort)) break;
       }
       __syncthreads();     // all waves done with S as the operand buffer; maps visible
@@ -434,12 +512,14 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
         if (f.which_child == 0) addf(g.child0 + f.parent, 1);
         addf(g.front_in + f.parent, 1);
       }
+      DAG_END();
     } else if (type == ND_T_BACKB) {
       // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================
       const int c = ts_;
-      const NDFront& pf = fd.fronts[f.parent];
+      const FS pf = front_snapshot(fd.fronts[f.parent]);
       // the parent's pivots (and with them all ancestors') are solved once its column 0 is
-      if (!dag_wait(1, [&](int) { return (const int*)(g.px + (int)(pf.linv_off / TILE)); }, 1, abort_flag, s_abort)) break;
+      if (!dag_wait(1, [&](int) { return (const int*)(g.px + pf.pcol0); }, 1, abort_flag, s_abort)) break;
+      DAG_READY();
       double* xb = S;   // n2p doubles
       const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
       for (int i = threadIdx.x; i < f.n2p; i += blockDim.x) xb[i] = (i < 7 * f.nb) ? ld1(fd.delta + 7 * nodes[i / 7] + i % 7) : 0.0;
@@ -462,22 +542,24 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
         st1(pv, ld1(pv) - a);
       }
       dag_publish_begin();
-      dag_set_flag(g.pb + (int)(f.linv_off / TILE) + c);
+      dag_set_flag(g.pb + f.pcol0 + c);
+      DAG_END();
     } else if (type == ND_T_BACK) {
       // ================= BACK(f,c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r) ===============
       const int c = ts_;
-      const int pc0 = (int)(f.linv_off / TILE);
+      const int pc0 = f.pcol0;
       {
         // y_c final: factored (always) and the boundary part subtracted (fronts with a boundary); the tiles
         // L(r,c), c < r < npt, that are fetched ahead of the x_r they multiply must be final too (a root front
         // gets here while its factorisation is still running)
         const int nb_flags = f.nb > 0 ? 2 : 1;
         auto fl = [&](int i) -> const int* {
-          if (i == 0) return g.tile + tile_index(f, c, c);
+          if (i == 0) return g.py + pc0 + c;           // factor, inverse and y_c
           if (i < nb_flags) return g.pb + pc0 + c;
           return g.tile + tile_index(f, c + 1 + (i - nb_flags), c);
         };
         if (!dag_wait(nb_flags + (f.npt - 1 - c), fl, 1, abort_flag, s_abort)) break;
+        DAG_READY();
       }
       {
         const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
@@ -498,6 +580,7 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       for (int r = f.npt - 1; r > c; --r) {
         // x_r: the solution of pivot column r of this front (the chain); the tile L(r,c) is already in registers
         if (!dag_wait(1, [&](int) { return (const int*)(g.px + pc0 + r); }, 1, abort_flag, s_abort)) goto done;
+        DAG_READY();
         if (threadIdx.x < NB) yv[threadIdx.x] = ld1(vecs + (size_t)r * NB + threadIdx.x);
         __syncthreads();
 #pragma unroll
@@ -534,6 +617,7 @@ __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ fr
       }
       dag_publish_begin();
       dag_set_flag(g.px + pc0 + c);
+      DAG_END();
     }
   }
 done:
@@ -567,8 +651,8 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("SLM_DAG_WG_PER_CU");
-    const int per_cu = e ? atoi(e) : 2;
-    n_wg = cus * (per_cu > 0 ? per_cu : 2);
+    const int per_cu = e ? atoi(e) : 1;
+    n_wg = cus * (per_cu > 0 ? per_cu : 1);
   }
   hipLaunchKernelGGL(k_dag_reset, dim3(8, n_frames), dim3(256), 0, st, fr);
   const long total = (long)n_frames * max_tasks;

@@ -228,6 +228,130 @@ __device__ __forceinline__ void inverse_assemble64(const double* S, double* M, c
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Pipelined form of potrf64 + inverse_assemble64 for the latency-critical callers (slm_dag.hip): wave 0 runs
+// the pivot chain -- diag16(kb), its own panel block (kb+1,kb), the update of the NEXT diagonal block, diag16(kb+1)
+// -- with one workgroup barrier per 16 pivots and nothing else on its path; waves 1..3 trail it: the other panel
+// blocks, the other trailing updates (one round behind, while wave 0 is inside the next diag16) and the blocks of
+// L^-1 as soon as their operands exist.  After the last diagonal block only one 16x16 product per wave remains.
+// The waves hand the panel blocks of a round to each other through LDS flags (pf, 16 ints), not barriers.
+//   S   in: SPD tile, lower triangle (+ damping) ; out: L (lower, zeros above inside the diagonal blocks)
+//   M   out: L^-1 (full 64x64, zeros above)
+//   dinv 4 x 256 (inverses of the diagonal blocks), wt 3 x 256 (one scratch block per trailing wave),
+//   xch 128 doubles (wave 0's exchange buffer for diag16)
+__device__ __forceinline__ void lds_signal(volatile int* f) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) *f = 1;
+}
+__device__ __forceinline__ void lds_wait_all(volatile int* f, int n) {
+  for (int i = 0; i < n; ++i)
+    while (f[i] == 0) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// W = A B (16x16 blocks); A = L block of S (row stride 1, column stride LD); B = a diagonal-block inverse
+// (b_dinv: 16x16 column-major ld 16) or a block of M (column-major ld LD); accumulates into acc
+__device__ __forceinline__ double4_t blk_LM(double4_t acc, const double* Lblk, const double* B, bool b_dinv) {
+  return blk_mma<false>(acc, Lblk, 1, LD, B, 1, b_dinv ? 16 : LD);
+}
+// M(ib,jb) = -Dinv_ib W, with W taken from the wave's scratch block (16x16 column-major ld 16)
+__device__ __forceinline__ void blk_neg_dinv_store(double* Mblk, const double* dinv_ib, double* Wscr, double4_t w) {
+  blk_store(Wscr, 1, 16, w);
+  wave_sync();
+  double4_t m2 = {0.0, 0.0, 0.0, 0.0};
+  m2 = blk_mma<true>(m2, dinv_ib, 1, 16, Wscr, 1, 16);
+  blk_store(Mblk, 1, LD, m2);
+  wave_sync();
+}
+__device__ __forceinline__ void blk_trail(double* S, int ib, int jb, int kb) {
+  double* Cb = S + ib * 16 + jb * 16 * LD;
+  double4_t acc = blk_load(Cb, 1, LD);
+  acc = blk_mma<true>(acc, S + ib * 16 + kb * 16 * LD, 1, LD, S + jb * 16 + kb * 16 * LD, LD, 1);
+  blk_store(Cb, 1, LD, acc);
+}
+
+__device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* dinv, double* wt, double* xch,
+                                                  int* s_ok, int* pf) {
+  const int w = threadIdx.x >> 6;
+  const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+  if (threadIdx.x < 16) pf[threadIdx.x] = 0;
+  if (threadIdx.x == 0) *s_ok = 1;
+  __syncthreads();
+  double* Wscr = wt + (w > 0 ? w - 1 : 0) * 256;
+  volatile int* vpf = pf;
+#pragma unroll 1   // one copy of diag16: the unrolled form needs ~250 VGPRs and spills on the critical path
+  for (int kb = 0; kb < 4; ++kb) {
+    if (w == 0) {
+      const bool ok = diag16(S + kb * 16 * (LD + 1), dinv + kb * 256, xch);
+      if (!ok && (threadIdx.x & 63) == 0) *s_ok = 0;
+    } else if (kb == 0) {
+      for (int e = threadIdx.x - 64; e < TILE; e += 192) M[e] = 0.0;   // blocks above the diagonal stay zero
+    } else if (kb == 1) {
+      lds_wait_all(vpf + 0, 3);                    // panel blocks (1,0) (2,0) (3,0)
+      if (w == 1) { blk_trail(S, 2, 1, 0); blk_trail(S, 3, 2, 0); }
+      else if (w == 2) { blk_trail(S, 2, 2, 0); blk_trail(S, 3, 3, 0); }
+      else blk_trail(S, 3, 1, 0);
+    } else if (kb == 2) {
+      lds_wait_all(vpf + 4, 2);                    // panel blocks (2,1) (3,1)
+      if (w == 1) blk_trail(S, 3, 2, 1);
+      else if (w == 2) blk_trail(S, 3, 3, 1);
+      else {                                       // M10 = -Dinv_1 (L10 Dinv_0)
+        const double4_t t = blk_LM(z4, S + 16, dinv, true);
+        blk_neg_dinv_store(M + 16, dinv + 256, Wscr, t);
+      }
+    } else {
+      lds_wait_all(vpf + 8, 1);                    // panel block (3,2)
+      if (w == 3) {                                // M21 = -Dinv_2 (L21 Dinv_1);  T1 = L31 Dinv_1 + L32 M21
+        double4_t t = blk_LM(z4, S + 32 + 16 * LD, dinv + 256, true);
+        blk_neg_dinv_store(M + 32 + 16 * LD, dinv + 512, Wscr, t);
+        t = blk_LM(z4, S + 48 + 16 * LD, dinv + 256, true);
+        t = blk_LM(t, S + 48 + 32 * LD, M + 32 + 16 * LD, false);
+        blk_store(Wscr, 1, 16, t);
+      } else if (w == 1) {                         // M20 = -Dinv_2 (L20 Dinv_0 + L21 M10);  T0 = L30 Dinv_0 + L31 M10 + L32 M20
+        double4_t t = blk_LM(z4, S + 32, dinv, true);
+        t = blk_LM(t, S + 32 + 16 * LD, M + 16, false);
+        blk_neg_dinv_store(M + 32, dinv + 512, Wscr, t);
+        t = blk_LM(z4, S + 48, dinv, true);
+        t = blk_LM(t, S + 48 + 16 * LD, M + 16, false);
+        t = blk_LM(t, S + 48 + 32 * LD, M + 32, false);
+        blk_store(Wscr, 1, 16, t);
+      } else {                                     // T2 = L32 Dinv_2
+        const double4_t t = blk_LM(z4, S + 48 + 32 * LD, dinv + 512, true);
+        blk_store(Wscr, 1, 16, t);
+      }
+      wave_sync();
+    }
+    __syncthreads();   // Dinv_kb and L(kb,kb) visible; the trailing work of the previous round is complete
+    if (kb == 3) break;
+    if (w < 3 - kb) {
+      // panel: S[ib,kb] = S[ib,kb] Dinv_kb^T
+      const int ib = kb + 1 + w;
+      double* Xb = S + ib * 16 + kb * 16 * LD;
+      double4_t acc = blk_mma<false>(z4, Xb, 1, LD, dinv + kb * 256, 16, 1);
+      blk_store(Xb, 1, LD, acc);
+      wave_sync();
+      lds_signal(vpf + 4 * kb + w);
+    }
+    if (w == 0) {      // the next diagonal block, from this wave's own panel block
+      blk_trail(S, kb + 1, kb + 1, kb);
+      wave_sync();
+    }
+  }
+  // row 3 of the inverse needs Dinv_3: one product per trailing wave; wave 0 copies the diagonal blocks
+  if (w >= 1) {
+    const int j = (w == 1) ? 0 : (w == 2 ? 2 : 1);
+    double4_t m2 = blk_mma<true>(z4, dinv + 768, 1, 16, Wscr, 1, 16);
+    blk_store(M + 48 + j * 16 * LD, 1, LD, m2);
+  } else {
+    for (int e = threadIdx.x; e < 1024; e += 64) {
+      const int b = e >> 8, i = e & 15, k = (e >> 4) & 15;
+      M[(16 * b + i) + (16 * b + k) * LD] = dinv[b * 256 + i + 16 * k];
+    }
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
 // C(64x64) = Cinit + sign * A B^T with B staged in LDS (Bl, ld LD) and the A fragments /
 // C tile of this wave's 16 rows already in registers (loaded by the caller so that the
 // global loads overlap whatever precedes).  Wave w owns rows [16w, 16w+16).

@@ -29,7 +29,7 @@ EXPORTS = [
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
-    "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read",
+    "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read", "slm_debug_dag_trace",
 ]
 
 
@@ -166,6 +166,7 @@ def load():
         "slm_destroy": [vp],
         "slm_debug_counters": [C.POINTER(C.c_int64)],
         "slm_debug_read": [vp, i32, i32, vp, C.c_int64, C.POINTER(C.c_int64), vp],
+        "slm_debug_dag_trace": [vp, i32, i32, vp],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],

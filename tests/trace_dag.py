@@ -1,0 +1,65 @@
+"""Diagnostic: per-task timeline of the task-graph solver (solver_path 2) for one damped solve.
+    python tests/trace_dag.py [workload] [frames]"""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-super_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from super_amd import _lib, synth
+from super_amd.engine import DeviceFrame, Engine
+dev = torch.device("cuda", 0)
+wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+e = Engine(dev, solver_path=2, max_frames=B)
+for i in range(B):
+    e.bind(i, DeviceFrame.from_scene(synth.make_scene(seed=i, **synth.WORKLOADS[wl]), dev))
+e.run(B)
+torch.cuda.synchronize()
+_lib.check(e.lib.slm_debug_dag_trace(e.h, 0, 1, e.stream), "trace on")
+e.run(B)
+torch.cuda.synchronize()
+
+
+def read(what, dtype):
+    n = C.c_int64(0)
+    _lib.check(e.lib.slm_debug_read(e.h, 0, what, None, 0, C.byref(n), e.stream), "dbg")
+    a = np.zeros(n.value)
+    _lib.check(e.lib.slm_debug_read(e.h, 0, what, a.ctypes.data_as(C.c_void_p), n.value, C.byref(n), e.stream), "dbg")
+    return a.view(dtype)
+
+
+tr = read(4, np.int64).reshape(-1, 8)
+tk = read(5, np.int32).reshape(-1, 2)
+typ, front, r, s = tk[:, 0] >> 24, tk[:, 0] & 0xFFFFFF, tk[:, 1] >> 8, tk[:, 1] & 255
+t0 = tr[:, 0].min()
+st, rd, en = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0   # microseconds
+names = ["POTRF", "COL", "SCHUR", "BACKB", "BACK"]
+print(f"{wl} B={B}: {len(tk)} tasks (slot 0), span {en.max():.1f} us, workgroups used {len(np.unique(tr[:, 3]))}")
+for t in range(5):
+    m = typ == t
+    if m.any():
+        print(f"  {names[t]:6s} x{m.sum():5d}: start..end mean {np.mean(en[m] - st[m]):7.2f} us, waiting {np.mean(rd[m] - st[m]):7.2f}, "
+              f"after last dependency {np.mean(en[m] - rd[m]):6.2f} (max {np.max(en[m] - rd[m]):6.2f}); busy sum {np.sum(en[m] - rd[m]) / 1e3:.2f} ms")
+fact_end = en[typ <= 2].max()
+print(f"  factorisation + forward done at {fact_end:.1f} us; back substitution takes {en.max() - fact_end:.1f} us")
+# the chain of the root front
+root = front.max()
+print("root front timeline (us):")
+for i in np.argsort(st):
+    if front[i] == root and typ[i] in (0, 4) or (front[i] == root and typ[i] == 1 and r[i] == s[i] + 1):
+        print(f"   {names[typ[i]]:6s} r={r[i]:2d} s={s[i]:2d}  start {st[i]:8.1f}  ready {rd[i]:8.1f}  end {en[i]:8.1f}  wg {tr[i, 3]}")
+m = (typ == 0) & (front == root) & (s > 0)
+if m.any():
+    sub = (tr[m][:, [1, 4, 5, 6, 7, 2]] - tr[m][:, [1]]) / 100.0
+    print("root POTRF sub-steps after the last dependency (us): accumulate, reduce + tile to LDS, factor + inverse, stores + y, publish:")
+    print("   ", np.round(np.diff(sub, axis=1).mean(0), 2))
+# per level: when does the first / last POTRF of each depth finish
+order = np.argsort(en)
+lvl_front = {}
+for i in order:
+    if typ[i] == 0:
+        lvl_front.setdefault(front[i], []).append((s[i], rd[i], en[i]))
+ends = sorted((max(x[2] for x in v), f, len(v)) for f, v in lvl_front.items())
+print("last 12 fronts to finish factoring (end us, front, npt):", [(round(a, 1), int(b), c) for a, b, c in ends[-12:]])
