@@ -489,7 +489,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
                             nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size() +
-                            nd.dag_tasks.size() + nd.front_nin.size();
+                            nd.dag_tasks.size() + nd.front_kids.size() + nd.pull_off.size() + nd.pullmap.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
       HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
       HIPCHK(grow(sl.d_ints, sl.cap_ints, n_ints));
@@ -514,11 +514,13 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.schur_items = p; HIPCHK(up(nd.schur_items));
       h.schur_off = p;   HIPCHK(up(nd.schur_off));
       h.dag_tasks = p;   HIPCHK(up(nd.dag_tasks));
-      h.front_nin = p;   HIPCHK(up(nd.front_nin));
+      h.front_kids = p;  HIPCHK(up(nd.front_kids));
+      h.pull_off = p;    HIPCHK(up(nd.pull_off));
+      h.pullmap = p;     HIPCHK(up(nd.pullmap));
       h.n_dag_tasks = (int32_t)(nd.dag_tasks.size() / 2);
       h.dag_n_tiles = (int32_t)(nd.tile_doubles / (SLM_NB * SLM_NB));
       h.dag_n_pcols = (int32_t)(nd.linv_doubles / (SLM_NB * SLM_NB));
-      h.dag_n_flags = 8 + 2 * (int32_t)nd.fronts.size() + h.dag_n_tiles + 3 * h.dag_n_pcols;
+      h.dag_n_flags = 8 + h.dag_n_tiles + 3 * h.dag_n_pcols;
       HIPCHK(grow(sl.d_dag_flags, sl.cap_dag_flags, (size_t)h.dag_n_flags));
       h.dag_flags = sl.d_dag_flags;
       if (!nd.block_dest.empty())

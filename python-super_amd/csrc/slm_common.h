@@ -101,8 +101,10 @@ struct FrameDev {
   double* flinv;               // inverses of the diagonal Cholesky blocks of the fronts
   // ---- persistent task-graph solver (slm_dag.hip): task list of the plan + per-iteration flags ----
   const int32_t* dag_tasks;    // (n_dag_tasks, 2) task words (slm_nd.h), in a topological order
-  const int32_t* front_nin;    // (n_fronts, 2) extend-add tasks that feed the front {all, those of child 0}
-  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per front {in, child0}, per tile done, per pivot column {b, x, y}
+  const int32_t* front_kids;   // (n_fronts, 2) children with a boundary (front index or -1)
+  const int32_t* pull_off;     // (n_fronts) offset of the front's pull map in pullmap (-1: none)
+  const int32_t* pullmap;      // per child: parent scalar index -> boundary scalar index of the child, -1
+  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per tile done, per pivot column {b, x, y}
   int32_t n_dag_tasks;
   int32_t dag_n_tiles;         // tiles of all fronts
   int32_t dag_n_pcols;         // pivot tile columns of all fronts

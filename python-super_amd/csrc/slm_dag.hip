@@ -90,7 +90,7 @@ __device__ __forceinline__ FS front_snapshot(const NDFront& f) {
 }
 struct SS {   // scalar snapshot of the slot's buffers
   double *ftiles, *fvec, *flinv, *delta;
-  const int32_t *nd_nodes, *nd_eamap, *front_nin;
+  const int32_t *nd_nodes, *front_kids, *pull_off, *pullmap;
   const NDFront* fronts;
   int n_fronts;
 };
@@ -98,8 +98,6 @@ struct SS {   // scalar snapshot of the slot's buffers
 struct DagFlags {
   int* ticket;
   int* abort_;
-  int* front_in;
-  int* child0;
   int* tile;
   int* pb;
   int* px;
@@ -108,12 +106,10 @@ struct DagFlags {
 __device__ __forceinline__ DagFlags dag_flags_of(const FrameDev& fd) {
   DagFlags g;
   int* base = unip(fd.dag_flags);
-  const int nf = uni(fd.n_fronts), nt = uni(fd.dag_n_tiles), np = uni(fd.dag_n_pcols);
+  const int nt = uni(fd.dag_n_tiles), np = uni(fd.dag_n_pcols);
   g.ticket = base;
   g.abort_ = base + 1;
-  g.front_in = base + 8;
-  g.child0 = g.front_in + nf;
-  g.tile = g.child0 + nf;
+  g.tile = base + 8;
   g.pb = g.tile + nt;
   g.px = g.pb + np;
   g.py = g.px + np;
@@ -193,6 +189,75 @@ __device__ __forceinline__ void store_c_frags1(double* __restrict__ Cg, const do
 __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, double breg[16]) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) breg[e] = ld1(T + threadIdx.x + 256 * e);
+}
+
+// Gather (pull) form of the extend-add: acc (tile (r,s) of front fi in accumulator layout) += the entries of the
+// children's update tiles that map into it -- child 0 first, then child 1: a fixed order, so the sum does not
+// depend on which workgroup ran when.  The task waits only for the child tiles it actually reads.  VEC (diagonal
+// tiles): bvec (threads < NB, row threadIdx.x of tile row r) += the children's vector rows.
+// maps: 128 ints of LDS (rows | columns), rng: 4 ints.  Returns false when the solve was aborted.
+template <bool VEC>
+__device__ __forceinline__ bool dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec,
+                                         const DagFlags& g, int* maps, int* rng, int* abort_flag, int* s_abort) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  for (int k = 0; k < 2; ++k) {
+    const int ch = uni(fd.front_kids[2 * fi + k]);
+    if (ch < 0) continue;
+    const FS cf = front_snapshot(fd.fronts[ch]);
+    const int32_t* pm = fd.pullmap + uni(fd.pull_off[ch]);
+    __syncthreads();   // earlier readers of maps / rng are done
+    if (threadIdx.x < 128) {
+      const int m = pm[64 * (w == 0 ? r : s) + l];
+      maps[threadIdx.x] = m;
+      int lo = m >= 0 ? (m >> 6) : (1 << 20), hi = m >= 0 ? (m >> 6) : -1;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+      }
+      if (l == 0) {
+        rng[2 * w] = lo;
+        rng[2 * w + 1] = hi;
+      }
+    }
+    __syncthreads();
+    const int r0 = uni(rng[0]), r1 = uni(rng[1]), c0 = uni(rng[2]), c1 = uni(rng[3]);
+    if (r1 < 0 || c1 < 0) continue;   // nothing of this child lands in the tile
+    {
+      const int nc = c1 - c0 + 1, n = (r1 - r0 + 1) * nc;
+      auto fl = [&](int i) -> const int* {
+        const int cr = r0 + i / nc;
+        int cc = c0 + i % nc;
+        if (cc > cr) cc = cr;            // lower triangle only (a duplicate flag in the list is harmless)
+        return g.tile + tile_index(cf, cf.npt + cr, cf.npt + cc);
+      };
+      if (!dag_wait(n, fl, 1, abort_flag, s_abort)) return false;
+    }
+    const double* ct = fd.ftiles + cf.tile_off;
+    double v[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int ci = maps[16 * w + lr], cj = maps[64 + 16 * ni + lk + 4 * rr];
+        double x = 0.0;
+        if (ci >= 0 && cj >= 0 && ci >= cj) {
+          const int tr = cf.npt + (ci >> 6), tc = cf.npt + (cj >> 6);
+          const size_t t = (size_t)tc * cf.nt - (size_t)tc * (tc - 1) / 2 + (size_t)(tr - tc);
+          x = ld1(ct + t * TILE + (ci & 63) + (size_t)(cj & 63) * NB);
+        }
+        v[4 * ni + rr] = x;
+      }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[ni][rr] += v[4 * ni + rr];
+    if (VEC && threadIdx.x < NB) {
+      const int ci = maps[threadIdx.x];
+      if (ci >= 0) bvec += ld1(fd.fvec + cf.vec_off + (size_t)cf.npt * NB + ci);
+    }
+  }
+  return true;
 }
 
 // acc -= sum_{c in [c0,c1)} L(ra,c) L(rb,c)^T.  Both operand tiles pass through LDS (Bl <- L(rb,c), Al <- L(ra,c);
@@ -288,8 +353,8 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
   int* s_ok = reinterpret_cast<int*>(yv + NB);
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
-  int* rmap = reinterpret_cast<int*>(dinv);   // NB + NB ints: extend-add maps (SCHUR tasks only)
-  int* cmap = rmap + NB;
+  int* maps = reinterpret_cast<int*>(dinv);   // 128 + 4 ints: pull maps of the tile being loaded (not live in a factorisation)
+  int* rng = maps + 128;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   const FrameDev& fd0 = frames[0];
   if (!fd0.bound || !fd0.nd_ready) return;
@@ -313,12 +378,12 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
-    fd.nd_nodes = unip(fdr.nd_nodes); fd.nd_eamap = unip(fdr.nd_eamap); fd.front_nin = unip(fdr.front_nin);
+    fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
+    fd.pullmap = unip(fdr.pullmap);
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
     const FS f = front_snapshot(fd.fronts[fi]);
     const DagFlags g = dag_flags_of(fdr);
     double* vecs = fd.fvec + f.vec_off;
-    const int nin = uni(fd.front_nin[2 * fi]);
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
     long long* trc = trc_base ? trc_base + 8 * (size_t)ti : nullptr;
@@ -343,14 +408,15 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           if (diag) return (i & 1) ? g.py + pcy + (i >> 1) : g.tile + tile_index(f, s, i >> 1);
           return g.tile + tile_index(f, (i & 1) ? s : r, i >> 1);
         };
-        // front_in counts up to nin; tile flags are 0/1: two calls (different targets)
-        if (nin > 0 && !dag_wait(1, [&](int) { return (const int*)(g.front_in + fi); }, nin, abort_flag, s_abort)) break;
         if (n0 > 0 && !dag_wait(n0, fl, 1, abort_flag, s_abort)) break;
       }
       double4_t acc[4];
       load_c_frags1(tile_ptr(fd, f, r, s), acc);
       double bvec = 0.0, tsum = 0.0;
       if (diag && threadIdx.x < NB) bvec = ld1(vecs + (size_t)s * NB + threadIdx.x);
+      // the children's contributions to this tile (and to the vector rows of a diagonal tile)
+      if (diag) { if (!dag_pull<true>(fd, fi, r, s, acc, bvec, g, maps, rng, abort_flag, s_abort)) break; }
+      else if (!dag_pull<false>(fd, fi, r, s, acc, bvec, g, maps, rng, abort_flag, s_abort)) break;
       if (diag) dag_accumulate<true>(fd, f, s, s, 0, s - 1, acc, S, M, yv, tsum);
       else dag_accumulate<false>(fd, f, r, s, 0, s - 1, acc, S, M, yv, tsum);
       if (s > 0) {
@@ -431,18 +497,9 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
         DAG_END();
       }
     } else if (type == ND_T_SCHUR) {
-      // ================= SCHUR(f,r,s): boundary tile -> parent ======================================
-      const int r = tr_, sc = ts_, tr = r - f.npt, tc = sc - f.npt;
-      const FS pf = front_snapshot(fd.fronts[f.parent]);
-      if (threadIdx.x < 2 * NB) {
-        const int* em = fd.nd_eamap + f.eamap_off;
-        const bool is_row = threadIdx.x < NB;
-        const int i = (is_row ? tr : tc) * NB + (threadIdx.x & 63);
-        const int m = (i < 7 * f.nb) ? dag_base(pf, em[i / 7]) + i % 7 : -1;
-        if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
-      }
-      if (nin > 0 && !dag_wait(1, [&](int) { return (const int*)(g.front_in + fi); }, nin, abort_flag, s_abort)) break;
-      const bool dg = tr == tc;
+      // ================= SCHUR(f,r,s): update tile of the boundary block, stored in place =============
+      const int r = tr_, sc = ts_;
+      const bool dg = r == sc;
       {
         const int n0 = f.npt > 1 ? 2 * (f.npt - 1) : 0;
         auto fl = [&](int i) -> const int* {
@@ -455,9 +512,11 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       load_c_frags1(tile_ptr(fd, f, r, sc), acc);
       double bvec = 0.0, tsum = 0.0;
       if (dg && threadIdx.x < NB) bvec = ld1(vecs + (size_t)r * NB + threadIdx.x);
+      if (dg) { if (!dag_pull<true>(fd, fi, r, sc, acc, bvec, g, maps, rng, abort_flag, s_abort)) break; }
+      else if (!dag_pull<false>(fd, fi, r, sc, acc, bvec, g, maps, rng, abort_flag, s_abort)) break;
       if (dg) dag_accumulate<true>(fd, f, r, r, 0, f.npt - 1, acc, S, M, yv, tsum);
       else dag_accumulate<false>(fd, f, r, sc, 0, f.npt - 1, acc, S, M, yv, tsum);
-      if (f.npt > 0) {
+      {
         auto fl = [&](int i) -> const int* {
           if (dg && (i & 1)) return g.py + f.pcol0 + f.npt - 1;
           return g.tile + tile_index(f, (i & 1) ? sc : r, f.npt - 1);
@@ -467,51 +526,15 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
         if (dg) dag_accumulate<true>(fd, f, r, r, f.npt - 1, f.npt, acc, S, M, yv, tsum);
         else dag_accumulate<false>(fd, f, r, sc, f.npt - 1, f.npt, acc, S, M, yv, tsum);
       }
-      double tvec = 0.0;
-      if (dg) tvec = dag_reduce_rows(tsum, part);
-      // child 1 adds after child 0 (fixed order of the two contributions to every parent entry)
-      if (f.which_child == 1) {
-        const int nin0 = uni(fd.front_nin[2 * f.parent + 1]);
-        if (nin0 > 0 && !dag_wait(1, [&](int) { return (const int*)(g.child0 + f.parent); }, nin0, abort_flag, s_abort)) break;
-      }
-      __syncthreads();     // all waves done with S as the operand buffer; maps visible
-      store_c_frags(S, acc);
-      __syncthreads();
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        double* dst[8];
-        double cur[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int idx = threadIdx.x + 256 * (8 * h + e);
-          const int i = idx & 63, j = idx >> 6;
-          const int pr = rmap[i], pc = cmap[j];
-          double* p = nullptr;
-          if (pr >= 0 && pc >= 0 && (tr > tc || i >= j)) {
-            const size_t t = (size_t)(pc >> 6) * pf.nt - (size_t)(pc >> 6) * ((pc >> 6) - 1) / 2 + (size_t)((pr >> 6) - (pc >> 6));
-            p = fd.ftiles + pf.tile_off + t * TILE + (pr & 63) + (size_t)(pc & 63) * NB;
-          }
-          dst[e] = p;
-        }
-        // all loads of a chunk before its first store: the destinations are distinct but the compiler cannot know
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cur[e] = dst[e] ? ld1(dst[e]) : 0.0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (dst[e]) st1(dst[e], cur[e] + S[threadIdx.x + 256 * (8 * h + e)]);
-      }
-      if (dg && threadIdx.x < NB) {
-        const int pr = rmap[threadIdx.x];
-        if (pr >= 0) {
-          double* pv = fd.fvec + pf.vec_off + pr;
-          st1(pv, ld1(pv) + (bvec - tvec));
-        }
+      // the update tile replaces the assembled one (the parent's tasks gather from it); diagonal tiles carry
+      // the vector rows v_r = b_r - sum_c L(r,c) y_c
+      store_c_frags1(tile_ptr(fd, f, r, sc), acc);
+      if (dg) {
+        const double tvec = dag_reduce_rows(tsum, part);
+        if (threadIdx.x < NB) st1(vecs + (size_t)r * NB + threadIdx.x, bvec - tvec);
       }
       dag_publish_begin();
-      if (threadIdx.x == 0) {
-        if (f.which_child == 0) addf(g.child0 + f.parent, 1);
-        addf(g.front_in + f.parent, 1);
-      }
+      dag_set_flag(g.tile + tile_index(f, r, sc));
       DAG_END();
     } else if (type == ND_T_BACKB) {
       // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================

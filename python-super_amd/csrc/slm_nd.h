@@ -62,7 +62,7 @@ struct NDLevelSched {
 enum {
   ND_T_POTRF = 0,   // (f, s, s): left-looking update of the diagonal tile of pivot column s, factor, inverse, y_s
   ND_T_COL = 1,     // (f, r, s), r > s: L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
-  ND_T_SCHUR = 2,   // (f, r, s) boundary tiles: Schur complement tile extend-added into the parent (+ vector rows)
+  ND_T_SCHUR = 2,   // (f, r, s) boundary tiles: Schur complement (update) tile, stored in place; the parent gathers it
   ND_T_BACKB = 3,   // (f, c): y_c -= sum over boundary tiles L(r,c)^T x_r
   ND_T_BACK = 4     // (f, c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r)
 };
@@ -93,7 +93,9 @@ struct NDPlanHost {
   // task list of the persistent kernel, sorted by earliest possible start (a topological order: every task
   // comes after the tasks it waits for), and per front {tasks that extend-add into it, those of its child 0}
   std::vector<int32_t> dag_tasks;     // 2 words per task
-  std::vector<int32_t> front_nin;     // 2 per front
+  std::vector<int32_t> front_kids;    // 2 per front: its children with a boundary (front index or -1)
+  std::vector<int32_t> pull_off;      // per front: offset of its pull map (as a child) in pullmap, or -1
+  std::vector<int32_t> pullmap;       // per child front: parent scalar index -> boundary scalar index of the child, -1
   double dag_critical_us = 0.0;       // modelled critical path (diagnostic)
 };
 

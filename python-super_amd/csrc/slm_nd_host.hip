@@ -366,57 +366,104 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       out.sched[l].schur_at[w] = out.schur_off[out.schur_off.size() - 2];
       out.sched[l].n_schur[w] = out.schur_off.back() - out.sched[l].schur_at[w];
     }
+  // extend-add maps: boundary index of a child -> local node position in the parent
+  for (int i = 0; i < T; ++i) {
+    const int id = proc[i];
+    NDFront& f = out.fronts[i];
+    f.eamap_off = (int)out.eamap.size();
+    if (b.tree[id].parent < 0) {
+      if (f.nb != 0) return false;   // the root cannot have a boundary
+      continue;
+    }
+    for (int v : bnd[id]) {
+      const int pp = pos_in(b.tree[id].parent, v);
+      if (pp < 0) return false;   // boundary must be covered by the parent front
+      out.eamap.push_back(pp);
+    }
+  }
+
   // ---- task list of the persistent kernel (slm_dag.hip) -----------------------------------------
+  // Pull maps: the children do not scatter their Schur complements into the parent; every task of the parent
+  // GATHERS the entries of its own tile from the children's update tiles (fixed order: own, child 0, child 1).
+  // pullmap[pull_off[c] + parent scalar index] = boundary scalar index of child c, or -1.
+  out.front_kids.assign(2 * (size_t)T, -1);
+  out.pull_off.assign((size_t)T, -1);
+  out.pullmap.clear();
+  for (int i = 0; i < T; ++i) {
+    const NDFront& f = out.fronts[i];
+    if (f.parent < 0 || f.nb == 0) continue;
+    const NDFront& pf = out.fronts[f.parent];
+    out.front_kids[2 * (size_t)f.parent + f.which_child] = i;
+    out.pull_off[i] = (int32_t)out.pullmap.size();
+    out.pullmap.resize(out.pullmap.size() + (size_t)pf.nt * 64, -1);
+    int32_t* pm = out.pullmap.data() + out.pull_off[i];
+    for (int bq = 0; bq < f.nb; ++bq) {
+      const int pp = out.eamap[f.eamap_off + bq];
+      const int base = pp < pf.nv ? 7 * pp : pf.n1p + 7 * (pp - pf.nv);
+      for (int k = 0; k < 7; ++k) pm[base + k] = 7 * bq + k;
+    }
+  }
   // Earliest start times from a duration model (microseconds; only the ORDER matters): tasks sorted by
   // them are in a topological order, and workgroups that take tasks in that order find them ready
   // about when they get to them.
   {
     struct Task { double start; int32_t w0, w1; };
     std::vector<Task> tasks;
-    const double HOP = 2.0;   // flag + payload hand-off between workgroups
-    auto d_potrf = [](int s) { return 13.0 + 0.6 * s; };
-    auto d_col = [](int s) { return 3.5 + 0.6 * s; };
-    auto d_schur = [](int npt) { return 4.0 + 1.0 * npt; };
-    std::vector<double> ready(T, 0.0);             // front assembled (children's Schur complements in)
-    std::vector<double> ready0(T, 0.0);            // ... of child 0 only
+    const double HOP = 1.0;   // flag + payload hand-off between workgroups
+    auto d_potrf = [](int s) { return 15.0 + 0.6 * s; };
+    auto d_schur = [](int npt) { return 3.0 + 1.5 * npt; };
+    std::vector<std::vector<double>> done_all(T);   // per front, per tile: when its final content is published
     std::vector<double> fact_done(T, 0.0);
-    out.front_nin.assign(2 * (size_t)T, 0);
-    std::vector<double> done;                      // per tile of the current front
     for (int i = 0; i < T; ++i) {                  // processing order: children before parents
       const NDFront& f = out.fronts[i];
       auto tix = [&](int r, int c) { return (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c); };
+      std::vector<double>& done = done_all[i];
       done.assign((size_t)f.nt * (f.nt + 1) / 2, 0.0);
+      // when are the children's update tiles that tile (r,s) of this front gathers from complete?
+      auto pulled = [&](int r, int s) {
+        double t = 0.0;
+        for (int k = 0; k < 2; ++k) {
+          const int ch = out.front_kids[2 * (size_t)i + k];
+          if (ch < 0) continue;
+          const NDFront& cf = out.fronts[ch];
+          const int32_t* pm = out.pullmap.data() + out.pull_off[ch];
+          int r0 = 1 << 30, r1 = -1, c0 = 1 << 30, c1 = -1;
+          for (int e = 0; e < 64; ++e) {
+            const int a = pm[64 * r + e], bb = pm[64 * s + e];
+            if (a >= 0) { r0 = std::min(r0, a >> 6); r1 = std::max(r1, a >> 6); }
+            if (bb >= 0) { c0 = std::min(c0, bb >> 6); c1 = std::max(c1, bb >> 6); }
+          }
+          for (int cr = r0; cr <= r1; ++cr)
+            for (int cc = c0; cc <= std::min(c1, cr); ++cc) {
+              const size_t ti = (size_t)(cf.npt + cc) * cf.nt - (size_t)(cf.npt + cc) * (cf.npt + cc - 1) / 2 + (size_t)(cr - cc);
+              t = std::max(t, done_all[ch][ti] + HOP);
+            }
+        }
+        return t;
+      };
       for (int s = 0; s < f.npt; ++s) {
-        double st = ready[i];
+        double st = pulled(s, s);
         for (int c = 0; c < s; ++c) st = std::max(st, done[tix(s, c)] + HOP);
         tasks.push_back({st, (ND_T_POTRF << 24) | i, (s << 8) | s});
         done[tix(s, s)] = st + d_potrf(s);
         for (int r = s + 1; r < f.nt; ++r) {
-          double sr = ready[i];
+          double sr = pulled(r, s);
           for (int c = 0; c < s; ++c) sr = std::max(sr, std::max(done[tix(r, c)], done[tix(s, c)]) + HOP);
-          const double fin = std::max(sr + 1.0 + 0.6 * s, done[tix(s, s)] + HOP) + 2.5;
+          const double fin = std::max(sr + 1.5 + 0.8 * s, done[tix(s, s)] + HOP) + 2.5;
           tasks.push_back({sr, (ND_T_COL << 24) | i, (r << 8) | s});
           done[tix(r, s)] = fin;
-          (void)d_col;
         }
       }
-      double fd_ = ready[i];
+      double fd_ = 0.0;
       for (int s = 0; s < f.npt; ++s) fd_ = std::max(fd_, done[tix(s, s)]);
       fact_done[i] = fd_;
       if (f.parent >= 0) {
-        const int nbt = f.nt - f.npt;
-        for (int tr = 0; tr < nbt; ++tr)
-          for (int tc = 0; tc <= tr; ++tc) {
-            double st = ready[i];
-            for (int c = 0; c < f.npt; ++c)
-              st = std::max(st, std::max(done[tix(f.npt + tr, c)], done[tix(f.npt + tc, c)]) + HOP);
-            if (f.which_child == 1) st = std::max(st, ready0[f.parent]);   // child 0's extend-adds come first
-            tasks.push_back({st, (ND_T_SCHUR << 24) | i, ((f.npt + tr) << 8) | (f.npt + tc)});
-            const double fin = st + d_schur(f.npt);
-            ready[f.parent] = std::max(ready[f.parent], fin + HOP);
-            if (f.which_child == 0) ready0[f.parent] = std::max(ready0[f.parent], fin + HOP);
-            out.front_nin[2 * (size_t)f.parent] += 1;
-            if (f.which_child == 0) out.front_nin[2 * (size_t)f.parent + 1] += 1;
+        for (int r = f.npt; r < f.nt; ++r)
+          for (int sc = f.npt; sc <= r; ++sc) {
+            double st = pulled(r, sc);
+            for (int c = 0; c < f.npt; ++c) st = std::max(st, std::max(done[tix(r, c)], done[tix(sc, c)]) + HOP);
+            tasks.push_back({st, (ND_T_SCHUR << 24) | i, (r << 8) | sc});
+            done[tix(r, sc)] = st + d_schur(f.npt);
           }
       }
     }
@@ -447,22 +494,6 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     }
     if (T >= (1 << 24) || out.max_nt > 255) return false;
   }
-  // extend-add maps: boundary index of a child -> local node position in the parent
-  for (int i = 0; i < T; ++i) {
-    const int id = proc[i];
-    NDFront& f = out.fronts[i];
-    f.eamap_off = (int)out.eamap.size();
-    if (b.tree[id].parent < 0) {
-      if (f.nb != 0) return false;   // the root cannot have a boundary
-      continue;
-    }
-    for (int v : bnd[id]) {
-      const int pp = pos_in(b.tree[id].parent, v);
-      if (pp < 0) return false;   // boundary must be covered by the parent front
-      out.eamap.push_back(pp);
-    }
-  }
-
   // ---- destinations of the assembled blocks -------------------------------------------------
   auto dest_of = [&](int a, int bnode, NDDest& d) -> bool {   // block given as (a,b), a >= b by id
     const int e = order[a] < order[bnode] ? a : bnode;          // earlier eliminated -> column
