@@ -73,10 +73,11 @@ typedef struct slm_config {
   int32_t data_path;        /* 0 = tuple-sorted MFMA assembly, node-pair blocks merged per workgroup in
                                LDS (default); 1 = per-entry f64 atomics (simple cross-check path, also
                                used when J >= 65536); 2 = MFMA assembly with one Gram per run in HBM */
-  int32_t solver_path;      /* 0 = nested-dissection multifrontal Cholesky, one launch per level / tile column / phase
-                               (needs data_path 0); 1 = block-banded Cholesky; 2 = the same nested-dissection
-                               factorisation as ONE persistent launch over a static task graph (per-tile flags instead
-                               of launch boundaries) */
+  int32_t solver_path;      /* 0 = nested-dissection multifrontal Cholesky (default, needs data_path 0); its numeric
+                               phase runs as ONE persistent launch over a static task graph (per-tile flags instead
+                               of launch boundaries: the latency form) for one or two frames per launch, and as one
+                               launch per level / tile column / phase for larger batches (the throughput form);
+                               2 / 3 force the task-graph / the per-level form; 1 = block-banded Cholesky */
   double w_data;            /* opt.sf_point_plane_weight (1.0) */
   double w_arap;            /* opt.mesh_arap_weight (10.0) */
   double w_rot;             /* opt.mesh_rot_weight (1.0) */

@@ -489,7 +489,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
                             nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size() +
-                            nd.dag_tasks.size() + nd.front_kids.size() + nd.pull_off.size() + nd.pullmap.size();
+                            nd.dag_tasks.size() + nd.front_kids.size() + nd.pull_off.size() + nd.pullmap.size() + nd.prng_off.size() +
+                            nd.prng.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
       HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
       HIPCHK(grow(sl.d_ints, sl.cap_ints, n_ints));
@@ -517,6 +518,8 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.front_kids = p;  HIPCHK(up(nd.front_kids));
       h.pull_off = p;    HIPCHK(up(nd.pull_off));
       h.pullmap = p;     HIPCHK(up(nd.pullmap));
+      h.prng_off = p;    HIPCHK(up(nd.prng_off));
+      h.prng = p;        HIPCHK(up(nd.prng));
       h.n_dag_tasks = (int32_t)(nd.dag_tasks.size() / 2);
       h.dag_n_tiles = (int32_t)(nd.tile_doubles / (SLM_NB * SLM_NB));
       h.dag_n_pcols = (int32_t)(nd.linv_doubles / (SLM_NB * SLM_NB));
@@ -633,7 +636,10 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
 // factor + substitutions of the assembled fronts: one persistent task-graph launch (solver_path 2) or the
 // per-level launches (solver_path 0)
 void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
-  if (s->cfg.solver_path == 2) launch_front_solve_dag(fr, n, d.max_tasks, u_override, st);
+  // solver_path 0 picks by batch size: the task graph is a latency scheduler (one or two frames per launch: the
+  // drop-in case, one frame at a time); larger batches are throughput-bound and run the per-level launches
+  const bool dag = s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && n <= 2);
+  if (dag) launch_front_solve_dag(fr, n, d.max_tasks, u_override, st);
   else launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
 }
 

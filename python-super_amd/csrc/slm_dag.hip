@@ -90,7 +90,7 @@ __device__ __forceinline__ FS front_snapshot(const NDFront& f) {
 }
 struct SS {   // scalar snapshot of the slot's buffers
   double *ftiles, *fvec, *flinv, *delta;
-  const int32_t *nd_nodes, *front_kids, *pull_off, *pullmap;
+  const int32_t *nd_nodes, *front_kids, *pull_off, *pullmap, *prng_off, *prng;
   const NDFront* fronts;
   int n_fronts;
 };
@@ -191,48 +191,110 @@ __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, do
   for (int e = 0; e < 16; ++e) breg[e] = ld1(T + threadIdx.x + 256 * e);
 }
 
+// ---- the dependency list of a task ---------------------------------------------------------------------
+// POTRF / COL / SCHUR of tile (r,s):  [update tiles of child 0 it gathers from][... of child 1]
+//                                     [per operand column c < kc: two flags][COL only: the diagonal factor (s,s)]
+//   kc = s (POTRF, COL) or npt (SCHUR); the two flags of column c are
+//   POTRF: L(s,c), y_c    COL: L(r,c), L(s,c)    SCHUR: L(r,c) and L(s,c), or y_c on diagonal tiles.
+//   Stage 0 = everything but the last operand column (and the diagonal factor): what the task needs to START.
+// BACKB(f,c): [x of the parent's column 0]
+// BACK(f,c):  [y_c][boundary part subtracted (fronts with a boundary)][L(r,c), c < r < npt] | chain: x_r, r = npt-1 .. c+1
+struct TD {
+  int type, r, s, kc, diag;
+  int np[2], pr0[2], pc0[2], pnc[2];     // gathered child tiles: count, first tile row / column, columns
+  int ctile0[2], cnt[2], cnpt[2];        // the children's tile numbering
+  int n0, n;                             // flags needed to start / all flags
+  int pcol_self, pcol_parent, nb, npt, c;
+};
+__device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int type, int r, int s) {
+  TD d;
+  d.type = type; d.r = r; d.s = s; d.diag = (r == s); d.npt = f.npt; d.nb = f.nb; d.c = s;
+  d.pcol_self = f.pcol0;
+  d.pcol_parent = 0;
+  d.np[0] = d.np[1] = 0;
+  d.kc = 0;
+  if (type <= ND_T_SCHUR) {
+    const int32_t* pr = fd.prng + uni(fd.prng_off[fi]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int ch = uni(fd.front_kids[2 * fi + k]);
+      const int rr = ch >= 0 ? uni(pr[2 * r + k]) : -1, cc = ch >= 0 ? uni(pr[2 * s + k]) : -1;
+      d.pr0[k] = d.pc0[k] = 0; d.pnc[k] = 1; d.ctile0[k] = d.cnt[k] = d.cnpt[k] = 0;
+      if (rr >= 0 && cc >= 0) {
+        const NDFront& cf = fd.fronts[ch];
+        d.ctile0[k] = (int)(uni64(cf.tile_off) / TILE); d.cnt[k] = uni(cf.nt); d.cnpt[k] = uni(cf.npt);
+        d.pr0[k] = rr & 255; d.pc0[k] = cc & 255;
+        d.pnc[k] = (cc >> 8) - (cc & 255) + 1;
+        d.np[k] = ((rr >> 8) - (rr & 255) + 1) * d.pnc[k];
+      }
+    }
+    d.kc = type == ND_T_SCHUR ? f.npt : s;
+    d.n = d.np[0] + d.np[1] + 2 * d.kc + (type == ND_T_COL ? 1 : 0);
+    d.n0 = d.np[0] + d.np[1] + 2 * (d.kc > 0 ? d.kc - 1 : 0);
+  } else if (type == ND_T_BACKB) {
+    d.pcol_parent = (int)(uni64(fd.fronts[f.parent].linv_off) / TILE);
+    d.n0 = d.n = 1;
+  } else {
+    d.n0 = 1 + (f.nb > 0 ? 1 : 0) + (f.npt - 1 - s);
+    d.n = d.n0 + (f.npt - 1 - s);
+  }
+  return d;
+}
+__device__ __forceinline__ const int* dep_flag(const TD& d, const FS& f, const DagFlags& g, int i) {
+  if (d.type <= ND_T_SCHUR) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (i < d.np[k]) {
+        const int cr = d.cnpt[k] + d.pr0[k] + i / d.pnc[k];
+        int cc = d.cnpt[k] + d.pc0[k] + i % d.pnc[k];
+        if (cc > cr) cc = cr;            // lower triangle only (a duplicate flag in the list is harmless)
+        return g.tile + d.ctile0[k] + cc * d.cnt[k] - cc * (cc - 1) / 2 + (cr - cc);
+      }
+      i -= d.np[k];
+    }
+    if (i < 2 * d.kc) {
+      const int c = i >> 1, odd = i & 1;
+      if (d.type == ND_T_POTRF) return odd ? g.py + f.pcol0 + c : g.tile + tile_index(f, d.s, c);
+      if (d.type == ND_T_COL) return g.tile + tile_index(f, odd ? d.s : d.r, c);
+      if (d.diag) return odd ? g.py + f.pcol0 + c : g.tile + tile_index(f, d.r, c);
+      return g.tile + tile_index(f, odd ? d.s : d.r, c);
+    }
+    return g.tile + tile_index(f, d.s, d.s);
+  }
+  if (d.type == ND_T_BACKB) return g.px + d.pcol_parent;
+  // BACK
+  const int c = d.c;
+  if (i == 0) return g.py + f.pcol0 + c;
+  const int nbf = d.nb > 0 ? 1 : 0;
+  if (i <= nbf && nbf) return g.pb + f.pcol0 + c;
+  i -= 1 + nbf;
+  const int m = d.npt - 1 - c;
+  if (i < m) return g.tile + tile_index(f, c + 1 + i, c);
+  return g.px + f.pcol0 + (d.npt - 1 - (i - m));
+}
+// blocking wait for the flags [a, b) of the list
+__device__ __forceinline__ bool dag_wait_deps(const TD& d, const FS& f, const DagFlags& g, int a, int b, int* abort_flag,
+                                              int* s_abort) {
+  if (b <= a) return true;
+  return dag_wait(b - a, [&](int i) { return dep_flag(d, f, g, a + i); }, 1, abort_flag, s_abort);
+}
 // Gather (pull) form of the extend-add: acc (tile (r,s) of front fi in accumulator layout) += the entries of the
 // children's update tiles that map into it -- child 0 first, then child 1: a fixed order, so the sum does not
-// depend on which workgroup ran when.  The task waits only for the child tiles it actually reads.  VEC (diagonal
-// tiles): bvec (threads < NB, row threadIdx.x of tile row r) += the children's vector rows.
-// maps: 128 ints of LDS (rows | columns), rng: 4 ints.  Returns false when the solve was aborted.
+// depend on which workgroup ran when.  (The update tiles are complete: their flags are part of the task's stage 0.)
+// VEC (diagonal tiles): bvec (threads < NB, row threadIdx.x of tile row r) += the children's vector rows.
+// maps: 128 ints of LDS (rows | columns).
 template <bool VEC>
-__device__ __forceinline__ bool dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec,
-                                         const DagFlags& g, int* maps, int* rng, int* abort_flag, int* s_abort) {
+__device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const TD& d,
+                                         int* maps) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   for (int k = 0; k < 2; ++k) {
+    if (d.np[k] == 0) continue;
     const int ch = uni(fd.front_kids[2 * fi + k]);
-    if (ch < 0) continue;
     const FS cf = front_snapshot(fd.fronts[ch]);
     const int32_t* pm = fd.pullmap + uni(fd.pull_off[ch]);
-    __syncthreads();   // earlier readers of maps / rng are done
-    if (threadIdx.x < 128) {
-      const int m = pm[64 * (w == 0 ? r : s) + l];
-      maps[threadIdx.x] = m;
-      int lo = m >= 0 ? (m >> 6) : (1 << 20), hi = m >= 0 ? (m >> 6) : -1;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, __shfl_xor(lo, o, 64));
-        hi = max(hi, __shfl_xor(hi, o, 64));
-      }
-      if (l == 0) {
-        rng[2 * w] = lo;
-        rng[2 * w + 1] = hi;
-      }
-    }
+    __syncthreads();   // earlier readers of maps are done
+    if (threadIdx.x < 128) maps[threadIdx.x] = pm[64 * (w == 0 ? r : s) + l];
     __syncthreads();
-    const int r0 = uni(rng[0]), r1 = uni(rng[1]), c0 = uni(rng[2]), c1 = uni(rng[3]);
-    if (r1 < 0 || c1 < 0) continue;   // nothing of this child lands in the tile
-    {
-      const int nc = c1 - c0 + 1, n = (r1 - r0 + 1) * nc;
-      auto fl = [&](int i) -> const int* {
-        const int cr = r0 + i / nc;
-        int cc = c0 + i % nc;
-        if (cc > cr) cc = cr;            // lower triangle only (a duplicate flag in the list is harmless)
-        return g.tile + tile_index(cf, cf.npt + cr, cf.npt + cc);
-      };
-      if (!dag_wait(n, fl, 1, abort_flag, s_abort)) return false;
-    }
     const double* ct = fd.ftiles + cf.tile_off;
     double v[16];
 #pragma unroll
@@ -257,7 +319,6 @@ __device__ __forceinline__ bool dag_pull(const SS& fd, int fi, int r, int s, dou
       if (ci >= 0) bvec += ld1(fd.fvec + cf.vec_off + (size_t)cf.npt * NB + ci);
     }
   }
-  return true;
 }
 
 // acc -= sum_{c in [c0,c1)} L(ra,c) L(rb,c)^T.  Both operand tiles pass through LDS (Bl <- L(rb,c), Al <- L(ra,c);
@@ -320,7 +381,7 @@ __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4
 // S, M, the four diagonal-block inverses, three 16x16 scratch blocks, two vectors, a few ints: 80 960 B -> two
 // workgroups per CU.  `part` (row partials) shares the scratch blocks and the extend-add maps share the
 // diagonal-block inverses: neither is live while a tile is being factored.
-#define DAG_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 16)
+#define DAG_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 24)
 
 // Tile factorisation + inverse as a real call: inlined into the task loop it raises the register demand of the
 // whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
@@ -339,7 +400,17 @@ __device__ __forceinline__ bool dag_factor_tile() {
 
 }  // namespace
 
-// grid = persistent (2 workgroups per CU), 256 threads
+// grid = persistent (one workgroup per CU), 256 threads
+//
+// Scheduling.  One ticket stream over all slots (ticket -> slot = ticket % n_frames, task = ticket / n_frames, the
+// frames of a batch advance side by side).  A workgroup takes a ticket, waits until the task can START (stage 0 of
+// its dependency list), and inside the task waits again for the last operand column / the diagonal factor ("start
+// early, wait late": the earlier columns are accumulated meanwhile).  A task only ever waits for smaller tickets
+// and a ticket is only held by a running workgroup, so the smallest unfinished ticket can always finish.
+// This is a LATENCY scheduler (one or two frames per launch: the drop-in case): workgroups that hold tickets of
+// the narrow top of the tree idle until their turn, and every operand tile is fetched from L2 / MALL by the task
+// that needs it.  Larger batches are bandwidth- and occupancy-bound and run the per-level launches of
+// slm_front.hip (XCD-aware work lists, operands shared through L2) -- slm_api.hip picks.
 __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
                                                  double u_override) {
   double* lds = dag_lds;
@@ -349,17 +420,16 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
   double* wt = dinv + 4 * 256;     // 3 x 256 scratch
   double* vec = wt + 3 * 256;      // NB
   double* yv = vec + NB;           // NB
-  double* part = wt;               // 4 * NB row partials (not live during potrf64 / inverse_assemble64)
+  double* part = wt;               // 4 * NB row partials (not live during a tile factorisation)
   int* s_ok = reinterpret_cast<int*>(yv + NB);
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
-  int* maps = reinterpret_cast<int*>(dinv);   // 128 + 4 ints: pull maps of the tile being loaded (not live in a factorisation)
-  int* rng = maps + 128;
+  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   const FrameDev& fd0 = frames[0];
   if (!fd0.bound || !fd0.nd_ready) return;
-  int* ticket = fd0.dag_flags;
-  int* abort_flag = fd0.dag_flags + 1;
+  int* ticket = unip(fd0.dag_flags);
+  int* abort_flag = ticket + 1;
   if (threadIdx.x == 0) *s_abort = 0;
   __syncthreads();
   const int total = n_frames * max_tasks;
@@ -367,22 +437,26 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
   for (;;) {
     if (threadIdx.x == 0) *s_task = addf(ticket, 1);
     __syncthreads();
-    const int tk = __builtin_amdgcn_readfirstlane(*s_task);   // provably uniform: descriptors stay in SGPRs
+    const int tk = uni(*s_task);   // provably uniform: descriptors stay in SGPRs
     __syncthreads();
-    if (tk >= total || *s_abort) break;
+    if (tk >= total || uni(*s_abort)) break;
+    {
+      const FrameDev& fq = frames[tk % n_frames];
+      if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(fq.n_dag_tasks)) continue;
+    }
     const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
-    if (!uni(fdr.bound) || !uni(fdr.nd_ready) || ti >= uni(fdr.n_dag_tasks)) continue;
     const int32_t* tasks = unip(fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
-    fd.pullmap = unip(fdr.pullmap);
+    fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
     const FS f = front_snapshot(fd.fronts[fi]);
     const DagFlags g = dag_flags_of(fdr);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
     double* vecs = fd.fvec + f.vec_off;
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
@@ -394,38 +468,26 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
 #define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
 #define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // stage 0: what the task needs to start
+    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) break;
 
     if (type == ND_T_POTRF || type == ND_T_COL) {
       // ================= POTRF(f,s) / COL(f,r,s) ==================================================
       const int r = tr_, s = ts_;
       const bool diag = type == ND_T_POTRF;
-      // stage 0: the front's own tile is complete (children's extend-adds) + all but the last operand column
-      {
-        // operands of columns c < s-1: COL waits for L(r,c) and L(s,c); POTRF for L(s,c) and y_c
-        const int pcy = f.pcol0;
-        const int n0 = s > 0 ? 2 * (s - 1) : 0;
-        auto fl = [&](int i) -> const int* {
-          if (diag) return (i & 1) ? g.py + pcy + (i >> 1) : g.tile + tile_index(f, s, i >> 1);
-          return g.tile + tile_index(f, (i & 1) ? s : r, i >> 1);
-        };
-        if (n0 > 0 && !dag_wait(n0, fl, 1, abort_flag, s_abort)) break;
-      }
+      // (stage 0: the children's update tiles and the operand columns c < s-1)
       double4_t acc[4];
       load_c_frags1(tile_ptr(fd, f, r, s), acc);
       double bvec = 0.0, tsum = 0.0;
       if (diag && threadIdx.x < NB) bvec = ld1(vecs + (size_t)s * NB + threadIdx.x);
       // the children's contributions to this tile (and to the vector rows of a diagonal tile)
-      if (diag) { if (!dag_pull<true>(fd, fi, r, s, acc, bvec, g, maps, rng, abort_flag, s_abort)) break; }
-      else if (!dag_pull<false>(fd, fi, r, s, acc, bvec, g, maps, rng, abort_flag, s_abort)) break;
+      if (diag) dag_pull<true>(fd, fi, r, s, acc, bvec, d, maps);
+      else dag_pull<false>(fd, fi, r, s, acc, bvec, d, maps);
       if (diag) dag_accumulate<true>(fd, f, s, s, 0, s - 1, acc, S, M, yv, tsum);
       else dag_accumulate<false>(fd, f, r, s, 0, s - 1, acc, S, M, yv, tsum);
       if (s > 0) {
         // stage 1: the last operand column (the critical one)
-        auto fl = [&](int i) -> const int* {
-          if (diag && (i & 1)) return g.py + f.pcol0 + s - 1;
-          return g.tile + tile_index(f, (i & 1) ? s : r, s - 1);
-        };
-        if (!dag_wait(2, fl, 1, abort_flag, s_abort)) break;
+        if (!dag_wait_deps(d, f, g, d.n0, d.n0 + 2, abort_flag, s_abort)) break;
         if (diag) DAG_READY();
         if (diag) dag_accumulate<true>(fd, f, s, s, s - 1, s, acc, S, M, yv, tsum);
         else dag_accumulate<false>(fd, f, r, s, s - 1, s, acc, S, M, yv, tsum);
@@ -472,13 +534,13 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
         if (s == 0) DAG_READY();
         DAG_END();
       } else {
-        // wait for the factor of the diagonal tile, then X = acc L_ss^-T as one tile product with L_ss^-1
-        if (!dag_wait(1, [&](int) { return (const int*)(g.tile + tile_index(f, s, s)); }, 1, abort_flag, s_abort)) break;
+        // stage 2: the factor of the diagonal tile, then X = acc L_ss^-T as one tile product with L_ss^-1
+        if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) break;
         DAG_READY();
         const double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
         double breg[16];
         load_tile_regs1(linv, breg);
-        // (dag_wait's barrier came after the last MFMA that read M as an operand buffer)
+        // (the wait's barrier came after the last MFMA that read M as an operand buffer)
 #pragma unroll
         for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
         __syncthreads();
@@ -500,32 +562,18 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       // ================= SCHUR(f,r,s): update tile of the boundary block, stored in place =============
       const int r = tr_, sc = ts_;
       const bool dg = r == sc;
-      {
-        const int n0 = f.npt > 1 ? 2 * (f.npt - 1) : 0;
-        auto fl = [&](int i) -> const int* {
-          if (dg) return (i & 1) ? g.py + f.pcol0 + (i >> 1) : g.tile + tile_index(f, r, i >> 1);
-          return g.tile + tile_index(f, (i & 1) ? sc : r, i >> 1);
-        };
-        if (n0 > 0 && !dag_wait(n0, fl, 1, abort_flag, s_abort)) break;
-      }
       double4_t acc[4];
       load_c_frags1(tile_ptr(fd, f, r, sc), acc);
       double bvec = 0.0, tsum = 0.0;
       if (dg && threadIdx.x < NB) bvec = ld1(vecs + (size_t)r * NB + threadIdx.x);
-      if (dg) { if (!dag_pull<true>(fd, fi, r, sc, acc, bvec, g, maps, rng, abort_flag, s_abort)) break; }
-      else if (!dag_pull<false>(fd, fi, r, sc, acc, bvec, g, maps, rng, abort_flag, s_abort)) break;
+      if (dg) dag_pull<true>(fd, fi, r, sc, acc, bvec, d, maps);
+      else dag_pull<false>(fd, fi, r, sc, acc, bvec, d, maps);
       if (dg) dag_accumulate<true>(fd, f, r, r, 0, f.npt - 1, acc, S, M, yv, tsum);
       else dag_accumulate<false>(fd, f, r, sc, 0, f.npt - 1, acc, S, M, yv, tsum);
-      {
-        auto fl = [&](int i) -> const int* {
-          if (dg && (i & 1)) return g.py + f.pcol0 + f.npt - 1;
-          return g.tile + tile_index(f, (i & 1) ? sc : r, f.npt - 1);
-        };
-        if (!dag_wait(2, fl, 1, abort_flag, s_abort)) break;
-        DAG_READY();
-        if (dg) dag_accumulate<true>(fd, f, r, r, f.npt - 1, f.npt, acc, S, M, yv, tsum);
-        else dag_accumulate<false>(fd, f, r, sc, f.npt - 1, f.npt, acc, S, M, yv, tsum);
-      }
+      if (!dag_wait_deps(d, f, g, d.n0, d.n, abort_flag, s_abort)) break;
+      DAG_READY();
+      if (dg) dag_accumulate<true>(fd, f, r, r, f.npt - 1, f.npt, acc, S, M, yv, tsum);
+      else dag_accumulate<false>(fd, f, r, sc, f.npt - 1, f.npt, acc, S, M, yv, tsum);
       // the update tile replaces the assembled one (the parent's tasks gather from it); diagonal tiles carry
       // the vector rows v_r = b_r - sum_c L(r,c) y_c
       store_c_frags1(tile_ptr(fd, f, r, sc), acc);
@@ -538,10 +586,8 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       DAG_END();
     } else if (type == ND_T_BACKB) {
       // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================
+      // (the parent's pivots -- and with them all ancestors' -- are solved: stage 0)
       const int c = ts_;
-      const FS pf = front_snapshot(fd.fronts[f.parent]);
-      // the parent's pivots (and with them all ancestors') are solved once its column 0 is
-      if (!dag_wait(1, [&](int) { return (const int*)(g.px + pf.pcol0); }, 1, abort_flag, s_abort)) break;
       DAG_READY();
       double* xb = S;   // n2p doubles
       const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
@@ -569,21 +615,11 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       DAG_END();
     } else if (type == ND_T_BACK) {
       // ================= BACK(f,c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r) ===============
+      // stage 0: y_c final (factored, boundary part subtracted) and the tiles L(r,c), c < r < npt, that are
+      // fetched ahead of the x_r they multiply (a root front gets here while its factorisation still runs)
       const int c = ts_;
       const int pc0 = f.pcol0;
-      {
-        // y_c final: factored (always) and the boundary part subtracted (fronts with a boundary); the tiles
-        // L(r,c), c < r < npt, that are fetched ahead of the x_r they multiply must be final too (a root front
-        // gets here while its factorisation is still running)
-        const int nb_flags = f.nb > 0 ? 2 : 1;
-        auto fl = [&](int i) -> const int* {
-          if (i == 0) return g.py + pc0 + c;           // factor, inverse and y_c
-          if (i < nb_flags) return g.pb + pc0 + c;
-          return g.tile + tile_index(f, c + 1 + (i - nb_flags), c);
-        };
-        if (!dag_wait(nb_flags + (f.npt - 1 - c), fl, 1, abort_flag, s_abort)) break;
-        DAG_READY();
-      }
+      DAG_READY();
       {
         const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
         double breg[16];
@@ -602,7 +638,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       }
       for (int r = f.npt - 1; r > c; --r) {
         // x_r: the solution of pivot column r of this front (the chain); the tile L(r,c) is already in registers
-        if (!dag_wait(1, [&](int) { return (const int*)(g.px + pc0 + r); }, 1, abort_flag, s_abort)) goto done;
+        if (!dag_wait_deps(d, f, g, d.n0 + (f.npt - 1 - r), d.n0 + (f.npt - 1 - r) + 1, abort_flag, s_abort)) goto done;
         DAG_READY();
         if (threadIdx.x < NB) yv[threadIdx.x] = ld1(vecs + (size_t)r * NB + threadIdx.x);
         __syncthreads();
@@ -657,7 +693,7 @@ __global__ void __launch_bounds__(256) k_dag_reset(const FrameDev* __restrict__ 
 // a timed-out solve is reported like a failed factorisation (the LM loop stops, beta is kept)
 __global__ void k_dag_check(const FrameDev* __restrict__ frames, int n_frames) {
   const FrameDev& fd0 = frames[0];
-  if (!fd0.bound || !fd0.nd_ready) return;
+  if (!fd0.bound || !fd0.nd_ready || !fd0.dag_flags) return;
   if (fd0.dag_flags[1] != 0 && threadIdx.x < n_frames) {
     const FrameDev& fd = frames[threadIdx.x];
     if (fd.bound) fd.st->chol_fail = 1;

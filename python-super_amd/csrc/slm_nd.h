@@ -95,6 +95,8 @@ struct NDPlanHost {
   std::vector<int32_t> dag_tasks;     // 2 words per task
   std::vector<int32_t> front_kids;    // 2 per front: its children with a boundary (front index or -1)
   std::vector<int32_t> pull_off;      // per front: offset of its pull map (as a child) in pullmap, or -1
+  std::vector<int32_t> prng_off;      // per front: offset into prng
+  std::vector<int32_t> prng;          // per front, tile row, child k: child boundary tile rows lo | hi << 8 gathered from, -1 none
   std::vector<int32_t> pullmap;       // per child front: parent scalar index -> boundary scalar index of the child, -1
   double dag_critical_us = 0.0;       // modelled critical path (diagnostic)
 };

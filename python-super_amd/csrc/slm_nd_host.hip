@@ -403,6 +403,27 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       for (int k = 0; k < 7; ++k) pm[base + k] = 7 * bq + k;
     }
   }
+  // per (front, child, tile row of the front): range of the child's boundary tile rows that map into it,
+  // lo | hi << 8, or -1: which update tiles of the children a task of the front has to wait for
+  out.prng_off.assign((size_t)T, 0);
+  out.prng.clear();
+  for (int i = 0; i < T; ++i) {
+    const NDFront& f = out.fronts[i];
+    out.prng_off[i] = (int32_t)out.prng.size();
+    for (int t = 0; t < f.nt; ++t)
+      for (int k = 0; k < 2; ++k) {
+        const int ch = out.front_kids[2 * (size_t)i + k];
+        int lo = 1 << 20, hi = -1;
+        if (ch >= 0) {
+          const int32_t* pm = out.pullmap.data() + out.pull_off[ch];
+          for (int e = 0; e < 64; ++e) {
+            const int a = pm[64 * t + e];
+            if (a >= 0) { lo = std::min(lo, a >> 6); hi = std::max(hi, a >> 6); }
+          }
+        }
+        out.prng.push_back(hi >= 0 ? (lo | (hi << 8)) : -1);
+      }
+  }
   // Earliest start times from a duration model (microseconds; only the ORDER matters): tasks sorted by
   // them are in a topological order, and workgroups that take tasks in that order find them ready
   // about when they get to them.
@@ -447,7 +468,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
         tasks.push_back({st, (ND_T_POTRF << 24) | i, (s << 8) | s});
         done[tix(s, s)] = st + d_potrf(s);
         for (int r = s + 1; r < f.nt; ++r) {
-          double sr = pulled(r, s);
+          double sr = std::max(pulled(r, s), st);   // never listed before the POTRF it waits for
           for (int c = 0; c < s; ++c) sr = std::max(sr, std::max(done[tix(r, c)], done[tix(s, c)]) + HOP);
           const double fin = std::max(sr + 1.5 + 0.8 * s, done[tix(s, s)] + HOP) + 2.5;
           tasks.push_back({sr, (ND_T_COL << 24) | i, (r << 8) | s});

@@ -1,5 +1,5 @@
 """The nested-dissection factorisation as ONE persistent launch over a static task graph (solver_path 2,
-csrc/slm_dag.hip) against the reference's goldens, against the per-level launch form (solver_path 0), for
+csrc/slm_dag.hip) against the reference's goldens, against the per-level launch form (solver_path 3), for
 batches of frames with different plans, for reproducibility and for the failure path.  Through the C ABI."""
 import numpy as np
 import pytest
@@ -45,14 +45,14 @@ def test_task_graph_equals_level_launches_on_a_batch_of_different_plans():
               synth.make_scene(N=2500, J=48, H=60, W=80, seed=62, src_border=5, tgt_border=3),
               synth.make_scene(N=6000, J=140, H=120, W=160, seed=63, src_border=6, tgt_border=4, dphi=0.4)]
     out = {}
-    for sp in (0, 2):
+    for sp in (3, 2):
         e = _engine(max_frames=3, solver_path=sp)
         for i, sc in enumerate(scenes):
             e.bind(i, _dframe(sc))
         e.run(3)
         out[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(3)]
     for i in range(3):
-        b0, r0 = out[0][i]
+        b0, r0 = out[3][i]
         b2, r2 = out[2][i]
         assert all(r["status"] == 0 for r in r2)
         np.testing.assert_allclose([r["loss"] for r in r2], [r["loss"] for r in r0], rtol=1e-10)
@@ -95,11 +95,11 @@ def test_c2_full_size_task_graph_solver():
     from super_amd import synth
     sc = synth.make_scene(seed=0, **synth.WORKLOADS["C2"])
     res = {}
-    for sp in (0, 2):
+    for sp in (3, 2):
         e = _engine(solver_path=sp)
         e.bind(0, _dframe(sc, state_f64=(sp == 2)))
         e.run(1)
         res[sp] = (e.beta(0).cpu().numpy(), e.records(0))
     assert all(r["status"] == 0 for r in res[2][1])
-    np.testing.assert_allclose([r["loss"] for r in res[2][1]], [r["loss"] for r in res[0][1]], rtol=1e-9)
-    np.testing.assert_allclose(res[2][0], res[0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose([r["loss"] for r in res[2][1]], [r["loss"] for r in res[3][1]], rtol=1e-9)
+    np.testing.assert_allclose(res[2][0], res[3][0], rtol=0, atol=1e-9)

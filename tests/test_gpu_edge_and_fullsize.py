@@ -163,7 +163,7 @@ def test_c2_lm_properties(c2):
     # normal-equation residual of one damped solve at the final beta, multifrontal vs band
     P = 7 * c2.J
     sols = []
-    for sp in (0, 1, 2):
+    for sp in (3, 1, 2):
         e2 = _engine(solver_path=sp)
         e2.bind(0, _dframe(c2))
         beta = eng.beta(0)
@@ -174,7 +174,7 @@ def test_c2_lm_properties(c2):
         assert int(s.item()) == 0
         sols.append(d.cpu().numpy())
     np.testing.assert_allclose(sols[0], sols[1], rtol=0, atol=1e-8 * max(1.0, np.abs(sols[1]).max()))
-    np.testing.assert_allclose(sols[0], sols[2], rtol=0, atol=1e-10 * max(1.0, np.abs(sols[0]).max()))
+    np.testing.assert_allclose(sols[0], sols[2], rtol=0, atol=1e-10 * max(1.0, np.abs(sols[0]).max()))   # [0]: path 3
 
 
 def test_c2_assembly_paths_agree_and_match_oracle_terms(c2):

@@ -13,7 +13,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 Bs = [int(x) for x in sys.argv[2:]] or [1, 8]
 for B in Bs:
     frames = [DeviceFrame.from_scene(synth.make_scene(seed=s, **synth.WORKLOADS[wl]), dev) for s in range(B)]
-    for sp in (0, 2):
+    for sp in (3, 2):
         eng = Engine(dev, max_frames=B, solver_path=sp)
         for i, fr in enumerate(frames):
             eng.bind(i, fr)
