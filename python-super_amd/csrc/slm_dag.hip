@@ -202,6 +202,7 @@ __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, do
 struct TD {
   int type, r, s, kc, diag;
   int np[2], pr0[2], pc0[2], pnc[2];     // gathered child tiles: count, first tile row / column, columns
+  int np2[2], pc2[2], pnc2[2];           // POTRF(s > 0): the same for its second tile (s, s-1) (same tile rows)
   int ctile0[2], cnt[2], cnpt[2];        // the children's tile numbering
   int n0, n;                             // flags needed to start / all flags
   int pcol_self, pcol_parent, nb, npt, c;
@@ -213,24 +214,32 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
   d.pcol_parent = 0;
   d.np[0] = d.np[1] = 0;
   d.kc = 0;
+  d.np2[0] = d.np2[1] = 0;
   if (type <= ND_T_SCHUR) {
     const int32_t* pr = fd.prng + uni(fd.prng_off[fi]);
+    const bool two = type == ND_T_POTRF && s > 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int ch = uni(fd.front_kids[2 * fi + k]);
       const int rr = ch >= 0 ? uni(pr[2 * r + k]) : -1, cc = ch >= 0 ? uni(pr[2 * s + k]) : -1;
-      d.pr0[k] = d.pc0[k] = 0; d.pnc[k] = 1; d.ctile0[k] = d.cnt[k] = d.cnpt[k] = 0;
-      if (rr >= 0 && cc >= 0) {
+      const int c2 = (ch >= 0 && two) ? uni(pr[2 * (s - 1) + k]) : -1;
+      d.pr0[k] = d.pc0[k] = d.pc2[k] = 0; d.pnc[k] = d.pnc2[k] = 1; d.ctile0[k] = d.cnt[k] = d.cnpt[k] = 0;
+      if (rr >= 0 && (cc >= 0 || c2 >= 0)) {
         const NDFront& cf = fd.fronts[ch];
         d.ctile0[k] = (int)(uni64(cf.tile_off) / TILE); d.cnt[k] = uni(cf.nt); d.cnpt[k] = uni(cf.npt);
-        d.pr0[k] = rr & 255; d.pc0[k] = cc & 255;
-        d.pnc[k] = (cc >> 8) - (cc & 255) + 1;
-        d.np[k] = ((rr >> 8) - (rr & 255) + 1) * d.pnc[k];
+        d.pr0[k] = rr & 255;
+        const int nr = (rr >> 8) - (rr & 255) + 1;
+        if (cc >= 0) { d.pc0[k] = cc & 255; d.pnc[k] = (cc >> 8) - (cc & 255) + 1; d.np[k] = nr * d.pnc[k]; }
+        if (c2 >= 0) { d.pc2[k] = c2 & 255; d.pnc2[k] = (c2 >> 8) - (c2 & 255) + 1; d.np2[k] = nr * d.pnc2[k]; }
       }
     }
     d.kc = type == ND_T_SCHUR ? f.npt : s;
-    d.n = d.np[0] + d.np[1] + 2 * d.kc + (type == ND_T_COL ? 1 : 0);
-    d.n0 = d.np[0] + d.np[1] + 2 * (d.kc > 0 ? d.kc - 1 : 0);
+    const int npull = d.np[0] + d.np[1] + d.np2[0] + d.np2[1];
+    d.n0 = npull;                 // to start: the children's update tiles; the operand columns are consumed as they come
+    if (type == ND_T_POTRF)       // per column c < s-1: L(s,c), y_c, L(s-1,c); then the factor and y of column s-1
+      d.n = npull + 3 * (s > 0 ? s - 1 : 0) + (s > 0 ? 2 : 0);
+    else
+      d.n = npull + 2 * d.kc + (type == ND_T_COL ? 1 : 0);
   } else if (type == ND_T_BACKB) {
     d.pcol_parent = (int)(uni64(fd.fronts[f.parent].linv_off) / TILE);
     d.n0 = d.n = 1;
@@ -252,9 +261,27 @@ __device__ __forceinline__ const int* dep_flag(const TD& d, const FS& f, const D
       }
       i -= d.np[k];
     }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (i < d.np2[k]) {
+        const int cr = d.cnpt[k] + d.pr0[k] + i / d.pnc2[k];
+        int cc = d.cnpt[k] + d.pc2[k] + i % d.pnc2[k];
+        if (cc > cr) cc = cr;
+        return g.tile + d.ctile0[k] + cc * d.cnt[k] - cc * (cc - 1) / 2 + (cr - cc);
+      }
+      i -= d.np2[k];
+    }
+    if (d.type == ND_T_POTRF) {
+      const int s = d.s;
+      if (i < 3 * (s - 1)) {
+        const int c = i / 3, j = i % 3;
+        return j == 0 ? g.tile + tile_index(f, s, c) : (j == 1 ? g.py + f.pcol0 + c : g.tile + tile_index(f, s - 1, c));
+      }
+      i -= 3 * (s - 1);
+      return i == 0 ? g.tile + tile_index(f, s - 1, s - 1) : g.py + f.pcol0 + s - 1;
+    }
     if (i < 2 * d.kc) {
       const int c = i >> 1, odd = i & 1;
-      if (d.type == ND_T_POTRF) return odd ? g.py + f.pcol0 + c : g.tile + tile_index(f, d.s, c);
       if (d.type == ND_T_COL) return g.tile + tile_index(f, odd ? d.s : d.r, c);
       if (d.diag) return odd ? g.py + f.pcol0 + c : g.tile + tile_index(f, d.r, c);
       return g.tile + tile_index(f, odd ? d.s : d.r, c);
@@ -278,17 +305,49 @@ __device__ __forceinline__ bool dag_wait_deps(const TD& d, const FS& f, const Da
   if (b <= a) return true;
   return dag_wait(b - a, [&](int i) { return dep_flag(d, f, g, a + i); }, 1, abort_flag, s_abort);
 }
+// How many leading groups (of `per` flags each) of the flags [a, b) are set?  Waits until at least one group is
+// (returns 0 only when the solve was aborted); looks at up to 64 flags per call.  The operand columns of a task are
+// consumed in order AS THEY BECOME AVAILABLE: old columns cost one look, and only the newest one is ever waited for.
+__device__ __forceinline__ int dag_wait_prefix(const TD& d, const FS& f, const DagFlags& g, int a, int b, int per,
+                                               int* abort_flag, int* s_abort, int* s_cnt) {
+  const int nfl = min(b - a, 64 / per * per);
+  if (threadIdx.x < 64) {
+    int spins = 0;
+    for (;;) {
+      const bool ok = (int)threadIdx.x < nfl ? ldf(dep_flag(d, f, g, a + threadIdx.x)) >= 1 : true;
+      const unsigned long long m = __ballot(ok);
+      const int lead = (m == ~0ull) ? 64 : (__ffsll((long long)~m) - 1);
+      const int groups = min(lead, nfl) / per;
+      if (groups > 0) {
+        if (threadIdx.x == 0) *s_cnt = groups;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255) == 0 && (ldf(abort_flag) != 0 || spins > DAG_SPIN_LIMIT)) {
+        if (threadIdx.x == 0) {
+          stf(abort_flag, 1);
+          *s_abort = 1;
+          *s_cnt = 0;
+        }
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return uni(*s_cnt);
+}
+
 // Gather (pull) form of the extend-add: acc (tile (r,s) of front fi in accumulator layout) += the entries of the
 // children's update tiles that map into it -- child 0 first, then child 1: a fixed order, so the sum does not
 // depend on which workgroup ran when.  (The update tiles are complete: their flags are part of the task's stage 0.)
 // VEC (diagonal tiles): bvec (threads < NB, row threadIdx.x of tile row r) += the children's vector rows.
 // maps: 128 ints of LDS (rows | columns).
 template <bool VEC>
-__device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const TD& d,
+__device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const int np[2],
                                          int* maps) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   for (int k = 0; k < 2; ++k) {
-    if (d.np[k] == 0) continue;
+    if (np[k] == 0) continue;
     const int ch = uni(fd.front_kids[2 * fi + k]);
     const FS cf = front_snapshot(fd.fronts[ch]);
     const int32_t* pm = fd.pullmap + uni(fd.pull_off[ch]);
@@ -369,6 +428,49 @@ __device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra
   }
 }
 
+// POTRF(s), s > 0, columns c in [c0, c1): acc_d (tile (s,s)) -= L(s,c) L(s,c)^T, acc_l (tile (s,s-1)) -= L(s,c) L(s-1,c)^T,
+// tsum += (L(s,c) y_c)[row]; L(s,c) is staged in Bl, L(s-1,c) in Al.
+__device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s, int c0, int c1, double4_t acc_d[4],
+                                                double4_t acc_l[4], double* Bl, double* Al, double* yv, double& tsum) {
+  if (c0 >= c1) return;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  double breg[16], areg[16];
+  load_tile_regs1(tile_ptr(fd, f, s, c0), breg);
+  load_tile_regs1(tile_ptr(fd, f, s - 1, c0), areg);
+  double ynext = 0.0;
+  if (threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)c0 * NB + threadIdx.x);
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Al[threadIdx.x + 256 * e] = areg[e];
+    if (threadIdx.x < NB) yv[threadIdx.x] = ynext;
+    if (c + 1 < c1) {
+      load_tile_regs1(tile_ptr(fd, f, s, c + 1), breg);
+      load_tile_regs1(tile_ptr(fd, f, s - 1, c + 1), areg);
+      if (threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const double a = -Bl[(16 * w + lr) + (4 * ks + lk) * LD];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const double bd = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
+        const double bl = Al[(16 * ni + lr) + (4 * ks + lk) * LD];
+        acc_d[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bd, a, acc_d[ni], 0, 0, 0);
+        acc_l[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bl, a, acc_l[ni], 0, 0, 0);
+      }
+    }
+    {
+      const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+#pragma unroll
+      for (int k = 16 * q; k < 16 * q + 16; ++k) tsum += Bl[i + k * LD] * yv[k];
+    }
+  }
+}
+
 // sum of the four quarter partials of dag_accumulate<true>: result for row i in every thread with (threadIdx.x & 63) == i
 __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4 * NB */) {
   const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -424,6 +526,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
   int* s_ok = reinterpret_cast<int*>(yv + NB);
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
+  int* s_cnt = s_ok + 3;
   int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   const FrameDev& fd0 = frames[0];
@@ -481,16 +584,70 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       double bvec = 0.0, tsum = 0.0;
       if (diag && threadIdx.x < NB) bvec = ld1(vecs + (size_t)s * NB + threadIdx.x);
       // the children's contributions to this tile (and to the vector rows of a diagonal tile)
-      if (diag) dag_pull<true>(fd, fi, r, s, acc, bvec, d, maps);
-      else dag_pull<false>(fd, fi, r, s, acc, bvec, d, maps);
-      if (diag) dag_accumulate<true>(fd, f, s, s, 0, s - 1, acc, S, M, yv, tsum);
-      else dag_accumulate<false>(fd, f, r, s, 0, s - 1, acc, S, M, yv, tsum);
-      if (s > 0) {
-        // stage 1: the last operand column (the critical one)
-        if (!dag_wait_deps(d, f, g, d.n0, d.n0 + 2, abort_flag, s_abort)) break;
-        if (diag) DAG_READY();
-        if (diag) dag_accumulate<true>(fd, f, s, s, s - 1, s, acc, S, M, yv, tsum);
-        else dag_accumulate<false>(fd, f, r, s, s - 1, s, acc, S, M, yv, tsum);
+      if (diag) dag_pull<true>(fd, fi, r, s, acc, bvec, d.np, maps);
+      else dag_pull<false>(fd, fi, r, s, acc, bvec, d.np, maps);
+      if (diag && s > 0) {
+        // POTRF(s) owns the tile (s, s-1) too: L(s,s-1) = (A(s,s-1) - sum_{c<s-1} L(s,c) L(s-1,c)^T) L_{s-1,s-1}^-T is
+        // formed here as soon as the factor of column s-1 is out, and goes into the update of (s,s) from LDS
+        double4_t accl[4];
+        load_c_frags1(tile_ptr(fd, f, s, s - 1), accl);
+        double dummy = 0.0;
+        dag_pull<false>(fd, fi, s, s - 1, accl, dummy, d.np2, maps);
+        {
+          int c = 0, m = 1;
+          while (c < s - 1 && m > 0) {
+            m = dag_wait_prefix(d, f, g, d.n0 + 3 * c, d.n0 + 3 * (s - 1), 3, abort_flag, s_abort, s_cnt);
+            dag_accumulate2(fd, f, s, c, c + m, acc, accl, S, M, yv, tsum);
+            c += m;
+          }
+          if (m == 0) break;
+        }
+        if (!dag_wait_deps(d, f, g, d.n - 2, d.n, abort_flag, s_abort)) break;   // factor + y of column s-1
+        DAG_READY();
+        {
+          const double* linv = fd.flinv + f.linv_off + (size_t)(s - 1) * TILE;
+          double breg[16];
+          load_tile_regs1(linv, breg);
+          const double yl = threadIdx.x < NB ? ld1(vecs + (size_t)(s - 1) * NB + threadIdx.x) : 0.0;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
+          if (threadIdx.x < NB) yv[threadIdx.x] = yl;
+        }
+        __syncthreads();
+        double areg[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) areg[4 * ni + rr] = accl[ni][rr];
+        double4_t xa[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+        tile_ABt_regs<false>(areg, M, xa);                      // X = L(s, s-1)
+        store_c_frags1(tile_ptr(fd, f, s, s - 1), xa);           // for the other tasks (in flight under the update below)
+        store_c_frags(S, xa);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const double a = -S[(16 * w + lr) + (4 * ks + lk) * LD];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
+        }
+        {
+          const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+#pragma unroll
+          for (int k = 16 * q; k < 16 * q + 16; ++k) tsum += S[i + k * LD] * yv[k];
+        }
+        dag_publish_begin();
+        dag_set_flag(g.tile + tile_index(f, s, s - 1));
+      } else if (!diag) {
+        int c = 0, m = 1;
+        while (c < s && m > 0) {
+          m = dag_wait_prefix(d, f, g, d.n0 + 2 * c, d.n0 + 2 * s, 2, abort_flag, s_abort, s_cnt);
+          dag_accumulate<false>(fd, f, r, s, c, c + m, acc, S, M, yv, tsum);
+          c += m;
+        }
+        if (m == 0) break;
       }
       if (diag) {
         const double u = (u_override >= 0.0) ? u_override : lmst->u;
@@ -566,14 +723,19 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       load_c_frags1(tile_ptr(fd, f, r, sc), acc);
       double bvec = 0.0, tsum = 0.0;
       if (dg && threadIdx.x < NB) bvec = ld1(vecs + (size_t)r * NB + threadIdx.x);
-      if (dg) dag_pull<true>(fd, fi, r, sc, acc, bvec, d, maps);
-      else dag_pull<false>(fd, fi, r, sc, acc, bvec, d, maps);
-      if (dg) dag_accumulate<true>(fd, f, r, r, 0, f.npt - 1, acc, S, M, yv, tsum);
-      else dag_accumulate<false>(fd, f, r, sc, 0, f.npt - 1, acc, S, M, yv, tsum);
-      if (!dag_wait_deps(d, f, g, d.n0, d.n, abort_flag, s_abort)) break;
-      DAG_READY();
-      if (dg) dag_accumulate<true>(fd, f, r, r, f.npt - 1, f.npt, acc, S, M, yv, tsum);
-      else dag_accumulate<false>(fd, f, r, sc, f.npt - 1, f.npt, acc, S, M, yv, tsum);
+      if (dg) dag_pull<true>(fd, fi, r, sc, acc, bvec, d.np, maps);
+      else dag_pull<false>(fd, fi, r, sc, acc, bvec, d.np, maps);
+      {
+        int c = 0, m = 1;
+        while (c < f.npt && m > 0) {
+          m = dag_wait_prefix(d, f, g, d.n0 + 2 * c, d.n0 + 2 * f.npt, 2, abort_flag, s_abort, s_cnt);
+          if (c + m == f.npt) DAG_READY();
+          if (dg) dag_accumulate<true>(fd, f, r, r, c, c + m, acc, S, M, yv, tsum);
+          else dag_accumulate<false>(fd, f, r, sc, c, c + m, acc, S, M, yv, tsum);
+          c += m;
+        }
+        if (m == 0) break;
+      }
       // the update tile replaces the assembled one (the parent's tasks gather from it); diagonal tiles carry
       // the vector rows v_r = b_r - sum_c L(r,c) y_c
       store_c_frags1(tile_ptr(fd, f, r, sc), acc);

@@ -462,12 +462,23 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
         }
         return t;
       };
+      double st_prev = 0.0;
       for (int s = 0; s < f.npt; ++s) {
-        double st = pulled(s, s);
-        for (int c = 0; c < s; ++c) st = std::max(st, done[tix(s, c)] + HOP);
+        // POTRF(s) also owns the tile (s, s-1) left of the diagonal one: its row solve needs nothing but the
+        // factor of column s-1, and its result feeds the update of (s,s) without leaving the workgroup
+        double st = std::max(pulled(s, s), st_prev);
+        if (s > 0) st = std::max(st, pulled(s, s - 1));
+        for (int c = 0; c + 1 < s; ++c) st = std::max(st, std::max(done[tix(s, c)], done[tix(s - 1, c)]) + HOP);
         tasks.push_back({st, (ND_T_POTRF << 24) | i, (s << 8) | s});
-        done[tix(s, s)] = st + d_potrf(s);
+        st_prev = st;
+        double ready_at = st + 1.5 + 0.8 * s;
+        if (s > 0) {
+          ready_at = std::max(ready_at, done[tix(s - 1, s - 1)] + HOP) + 4.0;
+          done[tix(s, s - 1)] = ready_at;
+        }
+        done[tix(s, s)] = ready_at + d_potrf(0);
         for (int r = s + 1; r < f.nt; ++r) {
+          if (r == s + 1 && r < f.npt) continue;             // tile (s+1, s) belongs to POTRF(s+1)
           double sr = std::max(pulled(r, s), st);   // never listed before the POTRF it waits for
           for (int c = 0; c < s; ++c) sr = std::max(sr, std::max(done[tix(r, c)], done[tix(s, c)]) + HOP);
           const double fin = std::max(sr + 1.5 + 0.8 * s, done[tix(s, s)] + HOP) + 2.5;
