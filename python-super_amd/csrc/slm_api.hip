@@ -161,8 +161,8 @@ int slm_debug_dag_trace(slm_solver* s, int32_t slot, int32_t on, void* stream) {
   if (!sl.h.bound || !sl.h.nd_ready) return fail(SLM_ERR_UNBOUND, "slm_debug_dag_trace: no nested-dissection plan bound");
   hipStream_t st = (hipStream_t)stream;
   if (on) {
-    HIPCHK(grow(sl.d_dag_trace, sl.cap_dag_trace, (size_t)8 * sl.h.n_dag_tasks + 8));
-    HIPCHK(hipMemsetAsync(sl.d_dag_trace, 0, sizeof(long long) * 8 * (size_t)sl.h.n_dag_tasks, st));
+    HIPCHK(grow(sl.d_dag_trace, sl.cap_dag_trace, (size_t)24 * sl.h.n_dag_tasks + 8));
+    HIPCHK(hipMemsetAsync(sl.d_dag_trace, 0, sizeof(long long) * 24 * (size_t)sl.h.n_dag_tasks, st));
   }
   sl.h.dag_trace = on ? sl.d_dag_trace : nullptr;
   HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &sl.h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
@@ -182,7 +182,7 @@ int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, 
     case 1: src = sl.fvec; n = sl.h.nd_ready ? sl.nd.vec_doubles : 0; break;
     case 2: src = sl.flinv; n = sl.h.nd_ready ? sl.nd.linv_doubles : 0; break;
     case 3: src = sl.h.delta; n = sl.h.P; break;
-    case 4: src = reinterpret_cast<const double*>(sl.h.dag_trace); n = sl.h.dag_trace ? 8 * (int64_t)sl.h.n_dag_tasks : 0; break;
+    case 4: src = reinterpret_cast<const double*>(sl.h.dag_trace); n = sl.h.dag_trace ? 24 * (int64_t)sl.h.n_dag_tasks : 0; break;
     case 5: src = reinterpret_cast<const double*>(sl.h.dag_tasks); n = sl.h.nd_ready ? sl.h.n_dag_tasks : 0; break;
     default: return fail(SLM_ERR_INVALID, "slm_debug_read: unknown buffer");
   }
@@ -523,7 +523,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
       h.n_dag_tasks = (int32_t)(nd.dag_tasks.size() / 2);
       h.dag_n_tiles = (int32_t)(nd.tile_doubles / (SLM_NB * SLM_NB));
       h.dag_n_pcols = (int32_t)(nd.linv_doubles / (SLM_NB * SLM_NB));
-      h.dag_n_flags = 8 + h.dag_n_tiles + 3 * h.dag_n_pcols;
+      h.dag_n_flags = 8 + h.dag_n_tiles + 7 * h.dag_n_pcols;
       HIPCHK(grow(sl.d_dag_flags, sl.cap_dag_flags, (size_t)h.dag_n_flags));
       h.dag_flags = sl.d_dag_flags;
       if (!nd.block_dest.empty())

@@ -106,7 +106,7 @@ struct FrameDev {
   const int32_t* pullmap;      // per child: parent scalar index -> boundary scalar index of the child, -1
   const int32_t* prng_off;     // (n_fronts) offset into prng
   const int32_t* prng;         // per front, tile row, child: child boundary tile rows lo | hi << 8 it gathers from, -1 none
-  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per tile done, per pivot column {b, x, y}
+  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per tile done, per pivot column {b, x, y, 4 x 16 pivots out}
   int32_t n_dag_tasks;
   int32_t dag_n_tiles;         // tiles of all fronts
   int32_t dag_n_pcols;         // pivot tile columns of all fronts

@@ -102,6 +102,7 @@ struct DagFlags {
   int* pb;
   int* px;
   int* py;
+  int* pk;   // 4 per pivot tile column: 16, 32, 48, 64 pivots of its diagonal tile are out (streamed row solves)
 };
 __device__ __forceinline__ DagFlags dag_flags_of(const FrameDev& fd) {
   DagFlags g;
@@ -113,6 +114,7 @@ __device__ __forceinline__ DagFlags dag_flags_of(const FrameDev& fd) {
   g.pb = g.tile + nt;
   g.px = g.pb + np;
   g.py = g.px + np;
+  g.pk = g.py + np;
   return g;
 }
 
@@ -236,8 +238,8 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
     d.kc = type == ND_T_SCHUR ? f.npt : s;
     const int npull = d.np[0] + d.np[1] + d.np2[0] + d.np2[1];
     d.n0 = npull;                 // to start: the children's update tiles; the operand columns are consumed as they come
-    if (type == ND_T_POTRF)       // per column c < s-1: L(s,c), y_c, L(s-1,c); then the factor and y of column s-1
-      d.n = npull + 3 * (s > 0 ? s - 1 : 0) + (s > 0 ? 2 : 0);
+    if (type == ND_T_POTRF)       // per column c < s-1: L(s,c), y_c, L(s-1,c); then 4 x 16 pivots of (s-1,s-1), then y_{s-1}
+      d.n = npull + 3 * (s > 0 ? s - 1 : 0) + (s > 0 ? 5 : 0);
     else
       d.n = npull + 2 * d.kc + (type == ND_T_COL ? 1 : 0);
   } else if (type == ND_T_BACKB) {
@@ -278,7 +280,7 @@ __device__ __forceinline__ const int* dep_flag(const TD& d, const FS& f, const D
         return j == 0 ? g.tile + tile_index(f, s, c) : (j == 1 ? g.py + f.pcol0 + c : g.tile + tile_index(f, s - 1, c));
       }
       i -= 3 * (s - 1);
-      return i == 0 ? g.tile + tile_index(f, s - 1, s - 1) : g.py + f.pcol0 + s - 1;
+      return i < 4 ? g.pk + 4 * (f.pcol0 + s - 1) + i : g.py + f.pcol0 + s - 1;
     }
     if (i < 2 * d.kc) {
       const int c = i >> 1, odd = i & 1;
@@ -489,7 +491,7 @@ __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4
 // whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
 // base inside the function, so their address space stays known.
 extern __shared__ double dag_lds[];
-__device__ __forceinline__ bool dag_factor_tile() {
+__device__ __forceinline__ bool dag_factor_tile(double* g_linv, double* g_ltile, int* g_flag, int* g_early, long long* trc) {
   double* S = dag_lds;
   double* M = dag_lds + TILE;
   double* dinv = dag_lds + 2 * TILE;
@@ -497,7 +499,7 @@ __device__ __forceinline__ bool dag_factor_tile() {
   double* xch = wt + 3 * 256;                   // vec | yv: not live while a tile is being factored
   int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
   int* pf = s_ok + 16;                          // 16 hand-off flags of the trailing waves
-  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf);
+  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_linv, g_ltile, g_flag, g_early, trc);
 }
 
 }  // namespace
@@ -563,7 +565,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
     double* vecs = fd.fvec + f.vec_off;
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
-    long long* trc = trc_base ? trc_base + 8 * (size_t)ti : nullptr;
+    long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
     if (trc && threadIdx.x == 0) {
       trc[0] = wall_clock64();
       trc[3] = blockIdx.x;
@@ -578,6 +580,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       // ================= POTRF(f,s) / COL(f,r,s) ==================================================
       const int r = tr_, s = ts_;
       const bool diag = type == ND_T_POTRF;
+      const double u = (u_override >= 0.0 || !diag) ? u_override : lmst->u;   // requested now, used after the updates
       // (stage 0: the children's update tiles and the operand columns c < s-1)
       double4_t acc[4];
       load_c_frags1(tile_ptr(fd, f, r, s), acc);
@@ -586,6 +589,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       // the children's contributions to this tile (and to the vector rows of a diagonal tile)
       if (diag) dag_pull<true>(fd, fi, r, s, acc, bvec, d.np, maps);
       else dag_pull<false>(fd, fi, r, s, acc, bvec, d.np, maps);
+      double4_t xl[4];   // POTRF(s > 0): L(s, s-1), rows of this wave (for its product with y_{s-1} after the factorisation)
       if (diag && s > 0) {
         // POTRF(s) owns the tile (s, s-1) too: L(s,s-1) = (A(s,s-1) - sum_{c<s-1} L(s,c) L(s-1,c)^T) L_{s-1,s-1}^-T is
         // formed here as soon as the factor of column s-1 is out, and goes into the update of (s,s) from LDS
@@ -602,44 +606,59 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           }
           if (m == 0) break;
         }
-        if (!dag_wait_deps(d, f, g, d.n - 2, d.n, abort_flag, s_abort)) break;   // factor + y of column s-1
-        DAG_READY();
+        // ---- streamed row solve against column s-1 and update of (s,s), 16 pivots at a time: the producer
+        // (POTRF(s-1), still inside its factorisation) publishes every finished diagonal-block inverse and row
+        // block of L; this task trails it by one block, so that (s,s) is fully updated shortly after the
+        // producer's last pivot -- not a whole inverse assembly + publish + reload + 64x64 products later.
         {
-          const double* linv = fd.flinv + f.linv_off + (size_t)(s - 1) * TILE;
-          double breg[16];
-          load_tile_regs1(linv, breg);
-          const double yl = threadIdx.x < NB ? ld1(vecs + (size_t)(s - 1) * NB + threadIdx.x) : 0.0;
+          const double* gl = fd.flinv + f.linv_off + (size_t)(s - 1) * TILE;
+          const double* gt = tile_ptr(fd, f, s - 1, s - 1);
+          double* Lst = M;     // row block kb of L(s-1,s-1), at its place in a 64 x 64 tile
+          double* Xs = S;      // X(:, 16 kb .. 16 kb + 15) of all 64 rows, column-major ld 64
+          const int pkb = d.n - 5;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
-          if (threadIdx.x < NB) yv[threadIdx.x] = yl;
+          for (int kb = 0; kb < 4; ++kb) {
+            if (!dag_wait_deps(d, f, g, pkb + kb, pkb + kb + 1, abort_flag, s_abort)) goto done;
+            if (kb == 3) DAG_READY();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j > kb) break;
+              const int e = threadIdx.x, i = e & 15, k = e >> 4;
+              if (j == 0) dinv[kb * 256 + i + 16 * k] = ld1(gl + (16 * kb + i) + (size_t)(16 * kb + k) * NB);
+              else Lst[(16 * kb + i) + (16 * (j - 1) + k) * LD] = ld1(gt + (16 * kb + i) + (size_t)(16 * (j - 1) + k) * NB);
+            }
+            __syncthreads();
+            double4_t t4 = accl[kb];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (t >= kb) break;
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                const double y = Lst[(16 * kb + lr) + (16 * t + 4 * ks + lk) * LD];
+                t4 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, -accl[t][ks], t4, 0, 0, 0);
+              }
+            }
+            double4_t x4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double y = dinv[kb * 256 + lr + 16 * (4 * ks + lk)];   // Y[p][n] = Dinv[n][p]
+              x4 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, t4[ks], x4, 0, 0, 0);
+            }
+            accl[kb] = x4;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) Xs[(16 * w + lr) + (lk + 4 * rr) * LD] = x4[rr];
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double a = -Xs[(16 * w + lr) + (4 * ks + lk) * LD];
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni)
+                acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
+            }
+          }
         }
-        __syncthreads();
-        double areg[16];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) areg[4 * ni + rr] = accl[ni][rr];
-        double4_t xa[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-        tile_ABt_regs<false>(areg, M, xa);                      // X = L(s, s-1)
-        store_c_frags1(tile_ptr(fd, f, s, s - 1), xa);           // for the other tasks (in flight under the update below)
-        store_c_frags(S, xa);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const double a = -S[(16 * w + lr) + (4 * ks + lk) * LD];
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(S[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
-        }
-        {
-          const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
-#pragma unroll
-          for (int k = 16 * q; k < 16 * q + 16; ++k) tsum += S[i + k * LD] * yv[k];
-        }
-        dag_publish_begin();
-        dag_set_flag(g.tile + tile_index(f, s, s - 1));
+        store_c_frags1(tile_ptr(fd, f, s, s - 1), accl);         // L(s, s-1) for the other tasks; published below
+        xl[0] = accl[0]; xl[1] = accl[1]; xl[2] = accl[2]; xl[3] = accl[3];
       } else if (!diag) {
         int c = 0, m = 1;
         while (c < s && m > 0) {
@@ -650,10 +669,9 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
         if (m == 0) break;
       }
       if (diag) {
-        const double u = (u_override >= 0.0) ? u_override : lmst->u;
         DAG_MARK(4);
-        const double t = dag_reduce_rows(tsum, part);      // (sum_c L(s,c) y_c)[row threadIdx.x & 63]
-        const double bt = bvec - t;                        // threads < NB: right-hand side of row threadIdx.x
+        const double t = dag_reduce_rows(tsum, part);      // (sum_{c<s-1} L(s,c) y_c)[row threadIdx.x & 63]
+        const double bt = bvec - t;                        // threads < NB: right-hand side of row threadIdx.x (minus L(s,s-1) y_{s-1}, below)
         // updated tile -> S: lower triangle, damping on real pivots, identity on the padding rows
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -666,18 +684,39 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           }
         __syncthreads();
         DAG_MARK(5);
-        const bool ok = dag_factor_tile();
+        const bool stream = s + 1 < f.npt;                 // POTRF(s+1) follows the factorisation 16 pivots at a time
+        double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
+        const bool ok = dag_factor_tile(linv, tile_ptr(fd, f, s, s), stream ? g.pk + 4 * (f.pcol0 + s) : nullptr,
+                                       s > 0 ? g.tile + tile_index(f, s, s - 1) : nullptr,    // L(s, s-1) goes out during the first 16 pivots
+                                       trc ? trc + 8 : nullptr);
         DAG_MARK(6);
         if (!ok && threadIdx.x == 0) lmst->chol_fail = 1;
-        double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st1(linv + threadIdx.x + 256 * e, M[threadIdx.x + 256 * e]);
-        if (threadIdx.x < NB) vec[threadIdx.x] = bt;
-        dag_publish_begin();                               // (also makes vec visible)
-        dag_set_flag(g.tile + tile_index(f, s, s));        // the factor is out: the column's row solves can start
+        dag_publish_begin();
+        dag_set_flag(g.tile + tile_index(f, s, s));        // the whole inverse is out: the column's other row solves can start
         DAG_MARK(7);
         {
-          // y_s = L_ss^-1 (b_s - t), off the factorisation's critical path; published under its own flag
+          // y_s = L_ss^-1 (b_s - sum_{c<s} L(s,c) y_c), off the factorisation's critical path, under its own flag
+          double xy = 0.0;
+          if (s > 0) {
+            if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) break;   // y_{s-1}
+            if (threadIdx.x < NB) yv[threadIdx.x] = ld1(vecs + (size_t)(s - 1) * NB + threadIdx.x);
+            __syncthreads();
+            double p = 0.0;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) p += xl[kb][rr] * yv[16 * kb + lk + 4 * rr];
+            p += __shfl_xor(p, 16, 64);
+            p += __shfl_xor(p, 32, 64);
+            if (lk == 0) part[16 * w + lr] = p;            // (L(s,s-1) y_{s-1})[row 16 w + lr]
+            __syncthreads();
+            if (threadIdx.x < NB) xy = part[threadIdx.x];
+            __syncthreads();
+          }
+          if (threadIdx.x < NB) vec[threadIdx.x] = bt - xy;
+          __syncthreads();
           const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
           double a = 0.0;
 #pragma unroll

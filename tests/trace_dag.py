@@ -30,7 +30,7 @@ def read(what, dtype):
     return a.view(dtype)
 
 
-tr = read(4, np.int64).reshape(-1, 8)
+tr = read(4, np.int64).reshape(-1, 24)
 tk = read(5, np.int32).reshape(-1, 2)
 typ, front, r, s = tk[:, 0] >> 24, tk[:, 0] & 0xFFFFFF, tk[:, 1] >> 8, tk[:, 1] & 255
 t0 = tr[:, 0].min()
@@ -55,6 +55,9 @@ if m.any():
     sub = (tr[m][:, [1, 4, 5, 6, 7, 2]] - tr[m][:, [1]]) / 100.0
     print("root POTRF sub-steps after the last dependency (us): accumulate, reduce + tile to LDS, factor + inverse, stores + y, publish:")
     print("   ", np.round(np.diff(sub, axis=1).mean(0), 2))
+    ft = (tr[m][:, 8:21] - tr[m][:, [8]]) / 100.0
+    print("inside the factorisation (us from its start): per 16 pivots [start, diag16 done, barrier passed] x 4, end:")
+    print("   ", np.round(ft.mean(0), 2))
 # per level: when does the first / last POTRF of each depth finish
 order = np.argsort(en)
 lvl_front = {}
