@@ -246,8 +246,8 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
     d.pcol_parent = (int)(uni64(fd.fronts[f.parent].linv_off) / TILE);
     d.n0 = d.n = 1;
   } else {
-    d.n0 = 1 + (f.nb > 0 ? 1 : 0) + (f.npt - 1 - s);
-    d.n = d.n0 + (f.npt - 1 - s);
+    // BACK(f): y_c (and its boundary part) of every column, and every tile L(r,c), c < r < npt
+    d.n0 = d.n = f.npt * (1 + (f.nb > 0 ? 1 : 0)) + f.npt * (f.npt - 1) / 2;
   }
   return d;
 }
@@ -291,15 +291,17 @@ __device__ __forceinline__ const int* dep_flag(const TD& d, const FS& f, const D
     return g.tile + tile_index(f, d.s, d.s);
   }
   if (d.type == ND_T_BACKB) return g.px + d.pcol_parent;
-  // BACK
-  const int c = d.c;
-  if (i == 0) return g.py + f.pcol0 + c;
-  const int nbf = d.nb > 0 ? 1 : 0;
-  if (i <= nbf && nbf) return g.pb + f.pcol0 + c;
-  i -= 1 + nbf;
-  const int m = d.npt - 1 - c;
-  if (i < m) return g.tile + tile_index(f, c + 1 + i, c);
-  return g.px + f.pcol0 + (d.npt - 1 - (i - m));
+  // BACK(f)
+  if (i < d.npt) return g.py + f.pcol0 + i;
+  i -= d.npt;
+  if (d.nb > 0) {
+    if (i < d.npt) return g.pb + f.pcol0 + i;
+    i -= d.npt;
+  }
+  // tiles (r, c), c < r < npt, row by row: i = r (r - 1) / 2 + c
+  int r = 1;
+  while ((r + 1) * r / 2 <= i) ++r;
+  return g.tile + tile_index(f, r, i - r * (r - 1) / 2);
 }
 // blocking wait for the flags [a, b) of the list
 __device__ __forceinline__ bool dag_wait_deps(const TD& d, const FS& f, const DagFlags& g, int a, int b, int* abort_flag,
@@ -473,6 +475,31 @@ __device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s
   }
 }
 
+// Transposed matrix-vector product with a tile held tile-linear in registers (lv[e] = T[threadIdx.x + 256 e], i.e.
+// row m = lane, column n = wave + 4 e; loaded with fully coalesced instructions): the caller forms
+// v[e] = lv[e] * x[lane]; this butterfly then sums every column over the 64 lanes with 17 shuffles (halving the
+// number of live values at each of the first four steps).  Returns, in the lanes with (lane & 3) == 0, the sum
+// of column n = wave + 4 * ((lane >> 2) & 15).
+__device__ __forceinline__ double col_reduce16(double v[16]) {
+  const int l = threadIdx.x & 63;
+#define CR_STEP(CNT, O)                                                         \
+  _Pragma("unroll") for (int i = 0; i < (CNT); ++i) {                           \
+    const bool up = (l & (O)) != 0;                                             \
+    const double send = up ? v[i] : v[i + (CNT)];                               \
+    const double keep = up ? v[i + (CNT)] : v[i];                               \
+    v[i] = keep + __shfl_xor(send, (O), 64);                                    \
+  }
+  CR_STEP(8, 32)
+  CR_STEP(4, 16)
+  CR_STEP(2, 8)
+  CR_STEP(1, 4)
+#undef CR_STEP
+  double r = v[0];
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
 // sum of the four quarter partials of dag_accumulate<true>: result for row i in every thread with (threadIdx.x & 63) == i
 __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4 * NB */) {
   const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -515,8 +542,10 @@ __device__ __forceinline__ bool dag_factor_tile(double* g_linv, double* g_ltile,
 // the narrow top of the tree idle until their turn, and every operand tile is fetched from L2 / MALL by the task
 // that needs it.  Larger batches are bandwidth- and occupancy-bound and run the per-level launches of
 // slm_front.hip (XCD-aware work lists, operands shared through L2) -- slm_api.hip picks.
-__global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
-                                                 double u_override) {
+// ---- the tasks.  Each kind is a function of its own (a real call): inlined into one loop, every path pays the
+// register demand of all of them, and the tile factorisation -- the critical path -- ends up spilling.
+// A task re-derives its descriptors from (ticket) itself; LDS regions come from the dynamic LDS base.
+__device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -531,24 +560,8 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
   int* s_cnt = s_ok + 3;
   int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
-  const FrameDev& fd0 = frames[0];
-  if (!fd0.bound || !fd0.nd_ready) return;
-  int* ticket = unip(fd0.dag_flags);
-  int* abort_flag = ticket + 1;
-  if (threadIdx.x == 0) *s_abort = 0;
-  __syncthreads();
-  const int total = n_frames * max_tasks;
-
-  for (;;) {
-    if (threadIdx.x == 0) *s_task = addf(ticket, 1);
-    __syncthreads();
-    const int tk = uni(*s_task);   // provably uniform: descriptors stay in SGPRs
-    __syncthreads();
-    if (tk >= total || uni(*s_abort)) break;
-    {
-      const FrameDev& fq = frames[tk % n_frames];
-      if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(fq.n_dag_tasks)) continue;
-    }
+  int* abort_flag = unip(frames[0].dag_flags) + 1;
+  (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
     const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
     const int32_t* tasks = unip(fdr.dag_tasks);
@@ -574,9 +587,9 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
 #define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
     // stage 0: what the task needs to start
-    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) break;
+    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
 
-    if (type == ND_T_POTRF || type == ND_T_COL) {
+  {
       // ================= POTRF(f,s) / COL(f,r,s) ==================================================
       const int r = tr_, s = ts_;
       const bool diag = type == ND_T_POTRF;
@@ -604,7 +617,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
             dag_accumulate2(fd, f, s, c, c + m, acc, accl, S, M, yv, tsum);
             c += m;
           }
-          if (m == 0) break;
+          if (m == 0) return;
         }
         // ---- streamed row solve against column s-1 and update of (s,s), 16 pivots at a time: the producer
         // (POTRF(s-1), still inside its factorisation) publishes every finished diagonal-block inverse and row
@@ -618,7 +631,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           const int pkb = d.n - 5;
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
-            if (!dag_wait_deps(d, f, g, pkb + kb, pkb + kb + 1, abort_flag, s_abort)) goto done;
+            if (!dag_wait_deps(d, f, g, pkb + kb, pkb + kb + 1, abort_flag, s_abort)) return;
             if (kb == 3) DAG_READY();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -666,7 +679,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           dag_accumulate<false>(fd, f, r, s, c, c + m, acc, S, M, yv, tsum);
           c += m;
         }
-        if (m == 0) break;
+        if (m == 0) return;
       }
       if (diag) {
         DAG_MARK(4);
@@ -700,7 +713,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           // y_s = L_ss^-1 (b_s - sum_{c<s} L(s,c) y_c), off the factorisation's critical path, under its own flag
           double xy = 0.0;
           if (s > 0) {
-            if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) break;   // y_{s-1}
+            if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) return;   // y_{s-1}
             if (threadIdx.x < NB) yv[threadIdx.x] = ld1(vecs + (size_t)(s - 1) * NB + threadIdx.x);
             __syncthreads();
             double p = 0.0;
@@ -731,7 +744,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
         DAG_END();
       } else {
         // stage 2: the factor of the diagonal tile, then X = acc L_ss^-T as one tile product with L_ss^-1
-        if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) break;
+        if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) return;
         DAG_READY();
         const double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
         double breg[16];
@@ -754,7 +767,54 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
         dag_set_flag(g.tile + tile_index(f, r, s));
         DAG_END();
       }
-    } else if (type == ND_T_SCHUR) {
+  }
+}
+
+__device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+  double* lds = dag_lds;
+  double* S = lds;                 // tile being factored / B operand staging
+  double* M = lds + TILE;          // inverse of the factored tile / second staging tile
+  double* dinv = lds + 2 * TILE;   // 4 x 256
+  double* wt = dinv + 4 * 256;     // 3 x 256 scratch
+  double* vec = wt + 3 * 256;      // NB
+  double* yv = vec + NB;           // NB
+  double* part = wt;               // 4 * NB row partials (not live during a tile factorisation)
+  int* s_ok = reinterpret_cast<int*>(yv + NB);
+  int* s_task = s_ok + 1;
+  int* s_abort = s_ok + 2;
+  int* s_cnt = s_ok + 3;
+  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  int* abort_flag = unip(frames[0].dag_flags) + 1;
+  (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
+    const int slot = tk % n_frames, ti = tk / n_frames;
+    const FrameDev& fdr = frames[slot];
+    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
+    const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
+    SS fd;
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
+    fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
+    fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
+    const FS f = front_snapshot(fd.fronts[fi]);
+    const DagFlags g = dag_flags_of(fdr);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    double* vecs = fd.fvec + f.vec_off;
+    LMState* lmst = unip(fdr.st);
+    long long* trc_base = unip(fdr.dag_trace);
+    long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
+    if (trc && threadIdx.x == 0) {
+      trc[0] = wall_clock64();
+      trc[3] = blockIdx.x;
+    }
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // stage 0: what the task needs to start
+    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
+
+  {
       // ================= SCHUR(f,r,s): update tile of the boundary block, stored in place =============
       const int r = tr_, sc = ts_;
       const bool dg = r == sc;
@@ -773,7 +833,7 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
           else dag_accumulate<false>(fd, f, r, sc, c, c + m, acc, S, M, yv, tsum);
           c += m;
         }
-        if (m == 0) break;
+        if (m == 0) return;
       }
       // the update tile replaces the assembled one (the parent's tasks gather from it); diagonal tiles carry
       // the vector rows v_r = b_r - sum_c L(r,c) y_c
@@ -785,7 +845,54 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       dag_publish_begin();
       dag_set_flag(g.tile + tile_index(f, r, sc));
       DAG_END();
-    } else if (type == ND_T_BACKB) {
+  }
+}
+
+__device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+  double* lds = dag_lds;
+  double* S = lds;                 // tile being factored / B operand staging
+  double* M = lds + TILE;          // inverse of the factored tile / second staging tile
+  double* dinv = lds + 2 * TILE;   // 4 x 256
+  double* wt = dinv + 4 * 256;     // 3 x 256 scratch
+  double* vec = wt + 3 * 256;      // NB
+  double* yv = vec + NB;           // NB
+  double* part = wt;               // 4 * NB row partials (not live during a tile factorisation)
+  int* s_ok = reinterpret_cast<int*>(yv + NB);
+  int* s_task = s_ok + 1;
+  int* s_abort = s_ok + 2;
+  int* s_cnt = s_ok + 3;
+  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  int* abort_flag = unip(frames[0].dag_flags) + 1;
+  (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
+    const int slot = tk % n_frames, ti = tk / n_frames;
+    const FrameDev& fdr = frames[slot];
+    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
+    const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
+    SS fd;
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
+    fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
+    fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
+    const FS f = front_snapshot(fd.fronts[fi]);
+    const DagFlags g = dag_flags_of(fdr);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    double* vecs = fd.fvec + f.vec_off;
+    LMState* lmst = unip(fdr.st);
+    long long* trc_base = unip(fdr.dag_trace);
+    long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
+    if (trc && threadIdx.x == 0) {
+      trc[0] = wall_clock64();
+      trc[3] = blockIdx.x;
+    }
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // stage 0: what the task needs to start
+    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
+
+  {
       // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================
       // (the parent's pivots -- and with them all ancestors' -- are solved: stage 0)
       const int c = ts_;
@@ -794,94 +901,173 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
       const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
       for (int i = threadIdx.x; i < f.n2p; i += blockDim.x) xb[i] = (i < 7 * f.nb) ? ld1(fd.delta + 7 * nodes[i / 7] + i % 7) : 0.0;
       __syncthreads();
-      const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
-      double a = 0.0;
-      for (int r = f.npt; r < f.nt; ++r) {
-        const double* Lt = tile_ptr(fd, f, r, c);
-        const double* xr = xb + (size_t)(r - f.npt) * NB;
-        double lv[16];
+      // tile-linear (coalesced) loads, two boundary tiles in flight; the partial products of all tiles are summed
+      // per thread first, one butterfly over the lanes at the end
+      double acc16[16];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) lv[m] = ld1(Lt + 16 * q + m + n * NB);
+      for (int e = 0; e < 16; ++e) acc16[e] = 0.0;
+      for (int r = f.npt; r < f.nt; r += 2) {
+        double l0[16], l1[16];
+        const bool h1 = r + 1 < f.nt;
+        load_tile_regs1(tile_ptr(fd, f, r, c), l0);
+        if (h1) load_tile_regs1(tile_ptr(fd, f, r + 1, c), l1);
+        const double x0 = xb[(size_t)(r - f.npt) * NB + l];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) a += lv[m] * xr[16 * q + m];
+        for (int e = 0; e < 16; ++e) acc16[e] += l0[e] * x0;
+        if (h1) {
+          const double x1 = xb[(size_t)(r + 1 - f.npt) * NB + l];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc16[e] += l1[e] * x1;
+        }
       }
-      a += __shfl_xor(a, 1, 64);
-      a += __shfl_xor(a, 2, 64);
-      if (q == 0) {
-        double* pv = vecs + (size_t)c * NB + n;
+      const double a = col_reduce16(acc16);
+      if ((l & 3) == 0) {
+        double* pv = vecs + (size_t)c * NB + w + 4 * ((l >> 2) & 15);
         st1(pv, ld1(pv) - a);
       }
       dag_publish_begin();
       dag_set_flag(g.pb + f.pcol0 + c);
       DAG_END();
-    } else if (type == ND_T_BACK) {
-      // ================= BACK(f,c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r) ===============
-      // stage 0: y_c final (factored, boundary part subtracted) and the tiles L(r,c), c < r < npt, that are
-      // fetched ahead of the x_r they multiply (a root front gets here while its factorisation still runs)
-      const int c = ts_;
-      const int pc0 = f.pcol0;
+  }
+}
+
+__device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+  double* lds = dag_lds;
+  double* S = lds;                 // tile being factored / B operand staging
+  double* M = lds + TILE;          // inverse of the factored tile / second staging tile
+  double* dinv = lds + 2 * TILE;   // 4 x 256
+  double* wt = dinv + 4 * 256;     // 3 x 256 scratch
+  double* vec = wt + 3 * 256;      // NB
+  double* yv = vec + NB;           // NB
+  double* part = wt;               // 4 * NB row partials (not live during a tile factorisation)
+  int* s_ok = reinterpret_cast<int*>(yv + NB);
+  int* s_task = s_ok + 1;
+  int* s_abort = s_ok + 2;
+  int* s_cnt = s_ok + 3;
+  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  int* abort_flag = unip(frames[0].dag_flags) + 1;
+  (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
+    const int slot = tk % n_frames, ti = tk / n_frames;
+    const FrameDev& fdr = frames[slot];
+    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
+    const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
+    SS fd;
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
+    fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
+    fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
+    const FS f = front_snapshot(fd.fronts[fi]);
+    const DagFlags g = dag_flags_of(fdr);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    double* vecs = fd.fvec + f.vec_off;
+    LMState* lmst = unip(fdr.st);
+    long long* trc_base = unip(fdr.dag_trace);
+    long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
+    if (trc && threadIdx.x == 0) {
+      trc[0] = wall_clock64();
+      trc[3] = blockIdx.x;
+    }
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // stage 0: what the task needs to start
+    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
+
+  {
+      // ================= BACK(f): the chain over the front's pivot columns =========================
+      // for r = npt-1 .. 0:  x_r = L_rr^-T y_r,  then  y_c -= L(r,c)^T x_r  for c < r.  y / x stay in LDS, the tiles
+      // (the inverses of the diagonal factors and the L tiles, in the order they are used) stream through
+      // registers three ahead: their addresses do not depend on x, so the chain never waits for memory.
+      // (stage 0: every y_c -- boundary part subtracted --, every tile L(r,c) of the pivot block)
       DAG_READY();
-      {
-        const double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
-        double breg[16];
-        load_tile_regs1(linv, breg);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
-        if (threadIdx.x < NB) vec[threadIdx.x] = ld1(vecs + (size_t)c * NB + threadIdx.x);
+      double* ya = S;                  // npt * NB: y, overwritten by x column by column
+      for (int i = threadIdx.x; i < f.npt * NB; i += blockDim.x) ya[i] = ld1(vecs + i);
+      const int nops = f.npt * (f.npt + 1) / 2;      // op k: row r, then the inverse (j = 0) or tile (r, r - j) (j = 1 .. r)
+      auto op_tile = [&](int k, int& r, int& j) -> const double* {
+        r = f.npt - 1;
+        while (k > r) { k -= r + 1; --r; }
+        j = k;
+        return j == 0 ? fd.flinv + f.linv_off + (size_t)r * TILE : tile_ptr(fd, f, r, r - j);
+      };
+      double l0[16], l1[16], l2[16];
+#define BACK_LOAD(LV, K)                                                                  \
+  do {                                                                                    \
+    if ((K) < nops) {                                                                     \
+      int r_, j_;                                                                         \
+      load_tile_regs1(op_tile((K), r_, j_), LV);                                          \
+    }                                                                                     \
+  } while (0)
+      // out[n] = sum_m T[m][n] v[m]: the inverse acts on y_r (giving x_r in place), a tile on x_r (subtracted from y_c)
+#define BACK_OP(LV, K)                                                                    \
+  do {                                                                                    \
+    if ((K) < nops) {                                                                     \
+      int r_, j_;                                                                         \
+      (void)op_tile((K), r_, j_);                                                         \
+      const double xm_ = ya[(size_t)r_ * NB + l];                                         \
+      double pv_[16];                                                                     \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) pv_[e] = LV[e] * xm_;                \
+      BACK_LOAD(LV, (K) + 3);      /* refill this slot: three operations ahead */         \
+      const double a_ = col_reduce16(pv_);                                                \
+      if (j_ == 0) __syncthreads(); /* everybody has read y_r */                          \
+      if ((l & 3) == 0) {                                                                 \
+        const int n_ = w + 4 * ((l >> 2) & 15);                                           \
+        if (j_ == 0) ya[(size_t)r_ * NB + n_] = a_;                                       \
+        else ya[(size_t)(r_ - j_) * NB + n_] -= a_;                                       \
+      }                                                                                   \
+      /* the tiles of one row update different y_c: no barrier between them */            \
+      if (j_ == 0 || j_ == r_) __syncthreads();                                           \
+    }                                                                                     \
+  } while (0)
+      BACK_LOAD(l0, 0);
+      BACK_LOAD(l1, 1);
+      BACK_LOAD(l2, 2);
+      __syncthreads();                 // ya complete
+      for (int k0 = 0; k0 < nops; k0 += 3) {
+        BACK_OP(l0, k0);
+        BACK_OP(l1, k0 + 1);
+        BACK_OP(l2, k0 + 2);
       }
-      const int n = threadIdx.x >> 2, q = threadIdx.x & 3;
-      double a = 0.0;
-      double lv[16];
-      if (c + 1 < f.npt) {
-        const double* Lt = tile_ptr(fd, f, f.npt - 1, c);
-#pragma unroll
-        for (int m = 0; m < 16; ++m) lv[m] = ld1(Lt + 16 * q + m + n * NB);
-      }
-      for (int r = f.npt - 1; r > c; --r) {
-        // x_r: the solution of pivot column r of this front (the chain); the tile L(r,c) is already in registers
-        if (!dag_wait_deps(d, f, g, d.n0 + (f.npt - 1 - r), d.n0 + (f.npt - 1 - r) + 1, abort_flag, s_abort)) goto done;
-        DAG_READY();
-        if (threadIdx.x < NB) yv[threadIdx.x] = ld1(vecs + (size_t)r * NB + threadIdx.x);
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 16; ++m) a += lv[m] * yv[16 * q + m];
-        if (r - 1 > c) {   // next tile: requested before the next wait, lands during it
-          const double* Lt = tile_ptr(fd, f, r - 1, c);
-#pragma unroll
-          for (int m = 0; m < 16; ++m) lv[m] = ld1(Lt + 16 * q + m + n * NB);
-        }
-        __syncthreads();   // yv is rewritten by the next round
-      }
-      a += __shfl_xor(a, 1, 64);
-      a += __shfl_xor(a, 2, 64);
-      __syncthreads();     // M / vec staged
-      if (q == 0) vec[n] -= a;
-      __syncthreads();
-      {
-        // x[k] = sum_i Linv[i][k] y[i]
-        const int k = threadIdx.x & 63, qq = threadIdx.x >> 6;
-        double p = 0.0;
-#pragma unroll
-        for (int i = 16 * qq; i < 16 * qq + 16; ++i) p += M[i + k * LD] * vec[i];
-        part[qq * NB + k] = p;
-        __syncthreads();
-        if (threadIdx.x < NB) {
-          const double x = part[k] + part[NB + k] + part[2 * NB + k] + part[3 * NB + k];
-          st1(vecs + (size_t)c * NB + k, x);
-          const int i = c * NB + k;
-          if (i < f.n1) {
-            const int node = fd.nd_nodes[f.nodes_off + i / 7];
-            st1(fd.delta + 7 * node + i % 7, x);
-          }
-        }
+#undef BACK_OP
+#undef BACK_LOAD
+      // x -> the front's vector and the global solution
+      for (int i = threadIdx.x; i < f.npt * NB; i += blockDim.x) {
+        const double x = ya[i];
+        st1(vecs + i, x);
+        if (i < f.n1) st1(fd.delta + 7 * fd.nd_nodes[f.nodes_off + i / 7] + i % 7, x);
       }
       dag_publish_begin();
-      dag_set_flag(g.px + pc0 + c);
+      dag_set_flag(g.px + f.pcol0);    // (column 0 stands for the whole front: what the children's BACKB wait for)
       DAG_END();
     }
+}
+
+__global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
+                                                 double u_override) {
+  int* s_ok = reinterpret_cast<int*>(dag_lds + 2 * TILE + 7 * 256 + 2 * NB);
+  int* s_task = s_ok + 1;
+  int* s_abort = s_ok + 2;
+  const FrameDev& fd0 = frames[0];
+  if (!fd0.bound || !fd0.nd_ready) return;
+  int* ticket = unip(fd0.dag_flags);
+  if (threadIdx.x == 0) *s_abort = 0;
+  __syncthreads();
+  const int total = n_frames * max_tasks;
+  for (;;) {
+    if (threadIdx.x == 0) *s_task = addf(ticket, 1);
+    __syncthreads();
+    const int tk = uni(*s_task);   // provably uniform: descriptors stay in SGPRs
+    __syncthreads();
+    if (tk >= total || uni(*s_abort)) break;
+    const FrameDev& fq = frames[tk % n_frames];
+    if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(fq.n_dag_tasks)) continue;
+    const int type = uni(unip(fq.dag_tasks)[2 * (tk / n_frames)]) >> 24;
+    if (type <= ND_T_COL) dag_task_factor(frames, n_frames, tk, u_override);
+    else if (type == ND_T_SCHUR) dag_task_schur(frames, n_frames, tk, u_override);
+    else if (type == ND_T_BACKB) dag_task_backb(frames, n_frames, tk, u_override);
+    else dag_task_back(frames, n_frames, tk, u_override);
   }
-done:
-  return;
 }
 
 // zero the flags of slots [0, n_frames) (ticket, abort, counters, tile / column flags); grid = (blocks, n_frames)

@@ -64,7 +64,7 @@ enum {
   ND_T_COL = 1,     // (f, r, s), r > s: L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
   ND_T_SCHUR = 2,   // (f, r, s) boundary tiles: Schur complement (update) tile, stored in place; the parent gathers it
   ND_T_BACKB = 3,   // (f, c): y_c -= sum over boundary tiles L(r,c)^T x_r
-  ND_T_BACK = 4     // (f, c): x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r)
+  ND_T_BACK = 4     // (f): the chain over the front's pivot columns, x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r), c = npt-1 .. 0
 };
 
 struct NDPlanHost {

@@ -507,13 +507,12 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       double st0 = fact_done[i];
       if (f.parent >= 0) st0 = std::max(st0, back_done[f.parent] + HOP);
       else for (int k = 0; k < T; ++k) st0 = std::max(st0, fact_done[k]);   // the root starts when everything is factored
-      double prev = st0;
-      for (int c = f.npt - 1; c >= 0; --c) {
+      // BACKB(f,c) for every pivot column in parallel, then ONE task per front for the chain over its columns
+      for (int c = f.npt - 1; c >= 0; --c)
         if (f.nb > 0) tasks.push_back({st0, (ND_T_BACKB << 24) | i, (c << 8) | c});
-        const double st = std::max(prev, st0 + (f.nb > 0 ? 2.0 + 0.3 * (f.nt - f.npt) : 0.0));
-        tasks.push_back({st, (ND_T_BACK << 24) | i, (c << 8) | c});
-        prev = st + 2.5;
-      }
+      const double stc = st0 + (f.nb > 0 ? 2.0 + 0.5 * (f.nt - f.npt) : 0.0);
+      tasks.push_back({stc, (ND_T_BACK << 24) | i, 0});
+      double prev = stc + 2.0 + 0.25 * f.npt * (f.npt + 1) / 2;
       back_done[i] = prev;
       t_end = std::max(t_end, prev);
     }
