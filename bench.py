@@ -11,10 +11,14 @@ before the timed region starts.  N > 1: one process per GPU (torchrun), frames s
 across ranks (weak scaling, B frames per GPU), end-of-frame RCCL all-gather of beta
 (SURVEY.md section 8e); rank 0 prints ONE JSON line.
 
-`value` = whole-job LM iterations per second; `roofline` = the fused data-term Jacobian
-pass (one kernel launch per LM iteration), timed with HIP events on its launch stream
-inside the timed region; `cpu_baseline` = the NumPy oracle (a port of the reference
-algorithm) timed on this box's host cores on a bounded sample.
+`value` = whole-job LM iterations per second.  `roofline` = the TIME-DOMINANT phase, the float64
+multifrontal factor + substitutions (f64-MFMA bound; FLOPs from the plan, padded and unpadded),
+timed with HIP events on its launch stream inside the timed region; `roofline_data` = the fused
+data-term Jacobian pass (one launch per LM iteration, HBM bound); `whole_step_hbm_frac` = the
+algorithmic bytes of the whole step against the HBM peak (the path is latency-bound: an exact
+float64 solve is a chain of dependent tile factorisations); `latency_b1` = the same workload at
+ONE frame per launch -- what a sequential tracker (run_super.py) sees; `cpu_baseline` = the NumPy
+oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
 
@@ -54,12 +58,24 @@ def workload_dims(name):
     return dict(synth.WORKLOADS[name])
 
 
+def lib_sha16():
+    import hashlib
+    from super_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel, workload, frames_per_gpu):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
     (profiles/*pmc_traffic.json, made by profiles/make_traffic.py from separate FETCH_SIZE /
-    WRITE_SIZE passes with the gfx950 corrections), or None when no summary matches."""
+    WRITE_SIZE passes with the gfx950 corrections).  Returns (bytes or None, provenance): a summary
+    is only used when it was collected for THIS workload / batch; the provenance names the file and
+    says whether the library it profiled is byte-identical to the one running now (`stale` otherwise:
+    the figure then describes an older build of the kernel and is reported as null)."""
     import glob
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
         try:
             d = json.load(open(path))
@@ -68,7 +84,68 @@ def pmc_traffic(kernel, workload, frames_per_gpu):
         if d.get("workload") == workload and d.get("frames_per_gpu") == frames_per_gpu \
                 and kernel in d.get("kernels", {}):
             best = d["kernels"][kernel]["traffic_bytes_per_launch"]
-    return best
+            src = {"file": os.path.relpath(path, ROOT), "lib_sha16": d.get("lib_sha16"),
+                   "stale": d.get("lib_sha16") != lib_sha16()}
+    if src is not None and src["stale"]:
+        best = None
+    return best, src
+
+
+def host_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count()}
+
+
+def latency_b1(dims, device, iters, steps=6):
+    """The same workload at ONE frame per launch (what `run_super.py` hits: one sequential frame at a
+    time): bind + 10 LM iterations + Surfels.update, timed like the main loop, with the phase split."""
+    import torch
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+    sc = synth.make_scene(seed=0, **dims)
+    pristine, work = DeviceFrame.from_scene(sc, device), DeviceFrame.from_scene(sc, device)
+    eng = Engine(device, max_frames=1, num_iterations=iters)
+    beta = torch.empty((sc.J, 7), dtype=torch.float64, device=device)
+
+    def step():
+        work.sf_points.copy_(pristine.sf_points)
+        work.sf_norms.copy_(pristine.sf_norms)
+        work.ed_points.copy_(pristine.ed_points)
+        work.ed_norms.copy_(pristine.ed_norms)
+        eng.bind(0, work)
+        eng.run(1)
+        eng.beta(0, beta)
+        eng.apply_update(0, beta)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(device)
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    prof = eng.profile_read()
+    eng.profile(False)
+    info = eng.plan_info(0)
+    phases = {k: v["ms"] / max(v["count"], 1) for k, v in prof.items()}
+    solve_s = phases["solve"] * 1e-3
+    out = {"value": iters / dt, "unit": "LM it/s", "ms_per_frame": 1e3 * dt, "frames_per_launch": 1,
+           "phase_ms_per_iteration": phases,
+           "solver_form": "task graph (one persistent launch)" if info["solver_tasks"] > 0 else "per-level launches",
+           "solver_tflops_padded": info["factor_flops"] / solve_s / 1e12 if solve_s > 0 else 0.0,
+           "solver_frac_of_f64_mfma_peak": info["factor_flops"] / solve_s / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_s > 0 else 0.0,
+           "sample": f"{steps} steps of one {sc.N}-surfel / {sc.J}-node frame"}
+    eng.close()
+    return out
 
 
 def cpu_baseline(dims, seed):
@@ -78,7 +155,7 @@ def cpu_baseline(dims, seed):
     import numpy as np  # noqa: F401
     from oracle import lm_oracle as orc
     from super_amd import synth
-    try:
+    try:                       # threads of the BLAS / LAPACK pool NumPy and SciPy run the oracle on
         from threadpoolctl import threadpool_info
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
@@ -92,7 +169,8 @@ def cpu_baseline(dims, seed):
     dt = time.perf_counter() - t0
     return {"value": n_it / dt, "unit": "LM it/s", "cores": int(cores), "kind": "port",
             "sample": f"{n_it} LM iterations (of 10) of one {sc.N}-surfel / {sc.J}-node frame, "
-                      f"NumPy/SciPy float64 oracle incl. dense Cholesky, {dt:.1f} s",
+                      f"NumPy/SciPy float64 oracle incl. dense Cholesky, {dt:.1f} s; `cores` = BLAS pool threads "
+                      "(the dense Cholesky dominates and is the only multi-threaded part)",
             "seconds": dt}
 
 
@@ -394,35 +472,55 @@ def main():
                                    f"Surfels.update per frame",
                        "frames_per_gpu": B, "streams_per_gpu": S, "global_frames": world * B,
                        "image": [dims["H"], dims["W"]],
-                       "storage": "f32/i32 in HBM, f64 arithmetic and solve",
+                       "storage": "f32/i32 state in HBM (BASELINE's fp32 configs; the drop-in mirror passes the "
+                                  "reference's float64 state in place), f64 arithmetic and solve",
                        "parallelism": f"frames sharded over {world} GPU(s), beta all-gather"},
             "lm_iterations_ok_frame0": n_ok,
             "final_loss_frame0": final_loss[-1] if final_loss else None,
         }
         if prof is not None:
+            info = eng.plan_info(0)
+            flops = Bs * info["factor_flops"]          # padded dense-front FLOPs of one factorisation (what the MFMAs execute)
+            flops_exact = Bs * info["factor_flops_unpadded"]
+            sp = prof["solve"]
+            savg = sp["ms"] / max(sp["count"], 1) * 1e-3
+            tf = flops / savg / 1e12 if savg > 0 else 0.0
+            # the time-dominant phase: the float64 multifrontal factor + substitutions of all frames of a launch
+            out["roofline"] = {"kernel": "solve phase: " + info["solver"] + " Cholesky factor + substitutions ("
+                                         + ("k_fdag, one persistent launch" if Bs <= 2 and info["solver_tasks"] > 0
+                                            else "k_fpanel / k_ftrail / k_fschur / k_fbacksub ..., all launches of one LM iteration") + ")",
+                               "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "achieved_unpadded": flops_exact / savg / 1e12 if savg > 0 else 0.0,
+                               "frac_unpadded": flops_exact / savg / 1e12 / F64_MFMA_PEAK_TFLOPS if savg > 0 else 0.0,
+                               "avg_phase_ms": savg * 1e3, "share_of_iteration": None,
+                               "factor_gflop_per_frame": info["factor_flops"] / 1e9,
+                               "factor_gflop_per_frame_unpadded": info["factor_flops_unpadded"] / 1e9,
+                               "fronts": int(info["fronts"]), "levels": int(info["levels"]),
+                               "note": "latency-bound: a chain of dependent 64x64 float64 tile factorisations "
+                                       "(33 at C2) bounds the phase, not the MFMA rate"}
             g = prof["data_grad"]
             per_launch_bytes = Bs * (72.0 * N + 3165.0 * J)    # grad pass, f32/i32
             avg_s = g["ms"] / max(g["count"], 1) * 1e-3
             ach = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-            out["roofline"] = {"kernel": "k_data_gram", "bound": "hbm", "achieved": ach,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic("k_data_gram", a.workload, Bs),
-                               "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
-                               "algorithmic_bytes_per_launch": per_launch_bytes}
-            info = eng.plan_info(0)
-            flops = Bs * info["factor_flops"]          # padded dense-front FLOPs of one factorisation
-            s = prof["solve"]
-            savg = s["ms"] / max(s["count"], 1) * 1e-3
-            tf = flops / savg / 1e12 if savg > 0 else 0.0
-            out["roofline_solver"] = {"phase": f"{info['solver']} Cholesky factor + substitutions "
-                                               "(all launches of one LM iteration)",
-                                      "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS,
-                                      "avg_phase_ms": savg * 1e3, "factor_gflop_per_frame": info["factor_flops"] / 1e9,
-                                      "fronts": int(info["fronts"]), "levels": int(info["levels"])}
-            out["plan"] = {k: (int(v) if isinstance(v, float) and k not in ("factor_flops", "factor_bytes") else v)
+            traffic, tsrc = pmc_traffic("k_data_gram", a.workload, Bs)
+            out["roofline_data"] = {"kernel": "k_data_gram", "bound": "hbm", "achieved": ach,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                    "traffic": traffic, "traffic_source": tsrc,
+                                    "avg_launch_ms": avg_s * 1e3, "launches": g["count"],
+                                    "algorithmic_bytes_per_launch": per_launch_bytes}
+            out["plan"] = {k: (int(v) if isinstance(v, float) and k not in ("factor_flops", "factor_bytes", "factor_flops_unpadded") else v)
                            for k, v in info.items()}
-            out["phase_ms_per_iteration"] = {k: v["ms"] / max(v["count"], 1) for k, v in prof.items()}
+            phases = {k: v["ms"] / max(v["count"], 1) for k, v in prof.items()}
+            out["phase_ms_per_iteration"] = phases
+            tot = sum(phases.values())
+            out["roofline"]["share_of_iteration"] = phases["solve"] / tot if tot > 0 else None
+            # whole step against the HBM peak: algorithmic bytes of one LM iteration x iterations x frames
+            step_bytes = world * B * iters * (144.0 * N + 3205.0 * J)
+            out["whole_step_hbm_frac"] = step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS
+        if world == 1 and not a.no_profile:
+            out["latency_b1"] = latency_b1(dims, device, iters)
+        out["host"] = host_info()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, seed=0)
             out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)

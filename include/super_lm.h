@@ -143,11 +143,12 @@ int slm_set_beta(slm_solver* s, int32_t slot, const double* beta_in_device, void
 int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int32_t max_records,
                     void* stream);
 
-/* Host-side facts about the slot's per-frame plan (after slm_bind_frame), info_out[10]:
+/* Host-side facts about the slot's per-frame plan (after slm_bind_frame), info_out[12]:
  * [0] solver in use (0 nested dissection, 1 band), [1] fronts, [2] tree levels,
  * [3] FLOPs of one factorisation (padded dense fronts, or P*w^2 for the band),
  * [4] factor storage bytes, [5] distinct KNN tuples, [6] Gram runs, [7] coupled node pairs,
- * [8] workgroup-merged (workgroup, pair) records (0: one Gram per run in HBM), [9] padded positions. */
+ * [8] workgroup-merged (workgroup, pair) records (0: one Gram per run in HBM), [9] padded positions,
+ * [10] FLOPs of one factorisation without the padding of the fronts to 64, [11] tasks of the task-graph solver. */
 int slm_get_plan_info(slm_solver* s, int32_t slot, double* info_out);
 
 /* -- one LARGE frame sharded over the GPUs of a node ----------------

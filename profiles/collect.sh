@@ -14,4 +14,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1 < /dev/null
   find $R/gpurun_out/${TAG}_pmc_$c -name '*kernel_trace.csv' -delete
 done
+# one frame per launch (the drop-in case): kernel stats of the task-graph solver
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
+find $R/gpurun_out/${TAG}_stats_b1 -name '*kernel_trace.csv' -delete
+# per-kernel HBM traffic summary, tagged with the library that was profiled
+F=$(find $R/gpurun_out/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+W=$(find $R/gpurun_out/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+python3 $R/profiles/make_traffic.py $F $W --workload C2 --frames-per-gpu 8 --lib $R/python-super_amd/lib/libsuper_lm.so --out $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
 ls $R/gpurun_out/${TAG}_stats/* $R/gpurun_out/${TAG}_pmc_FETCH_SIZE/* < /dev/null

@@ -30,9 +30,15 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--lib", default=None, help="libsuper_lm.so that was profiled (its sha256[:16] is recorded so that "
+                                                "bench.py can tell a summary of an older build from a current one)")
     a = ap.parse_args()
     f, w = means(a.fetch_csv), means(a.write_csv)
-    out = {"workload": a.workload, "frames_per_gpu": a.frames_per_gpu, "kernels": {}}
+    sha = None
+    if a.lib:
+        import hashlib
+        sha = hashlib.sha256(open(a.lib, "rb").read()).hexdigest()[:16]
+    out = {"workload": a.workload, "frames_per_gpu": a.frames_per_gpu, "lib_sha16": sha, "kernels": {}}
     for k in sorted(set(f) & set(w)):
         fetch_kib, n = f[k]
         write_kib, _ = w[k]

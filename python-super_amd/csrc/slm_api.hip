@@ -897,12 +897,14 @@ int slm_get_plan_info(slm_solver* s, int32_t slot, double* out) {
   if (!out) return fail(SLM_ERR_INVALID, "slm_get_plan_info: null output");
   const Slot& sl = s->slots[slot];
   const FrameDev& h = sl.h;
-  for (int i = 0; i < 10; ++i) out[i] = 0.0;
+  for (int i = 0; i < 12; ++i) out[i] = 0.0;
   if (h.nd_ready) {
     out[0] = 0.0;
     out[1] = (double)sl.nd.fronts.size();
     out[2] = (double)sl.nd.level_start.size() - 1.0;
     out[3] = sl.nd.flops;
+    out[10] = sl.nd.flops_exact;
+    out[11] = (double)sl.nd.dag_tasks.size() / 2.0;
     out[4] = 8.0 * (double)sl.nd.tile_doubles;
   } else {
     out[0] = 1.0;

@@ -89,7 +89,8 @@ struct NDPlanHost {
   int64_t tile_doubles = 0, vec_doubles = 0, linv_doubles = 0;
   int32_t max_nt = 0, max_npt = 0, max_level_fronts = 0;
   std::vector<NDLevelSched> sched;    // one entry per level
-  double flops = 0.0;
+  double flops = 0.0;          // factorisation FLOPs of the 64-padded dense fronts (what the kernels execute)
+  double flops_exact = 0.0;    // the same with the true pivot / boundary sizes (no padding)
   // task list of the persistent kernel, sorted by earliest possible start (a topological order: every task
   // comes after the tasks it waits for), and per front {tasks that extend-add into it, those of its child 0}
   std::vector<int32_t> dag_tasks;     // 2 words per task

@@ -276,7 +276,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   out.node_pos.assign(J, -1);
   out.tile_doubles = out.vec_doubles = out.linv_doubles = 0;
   out.max_nt = out.max_npt = out.max_level_fronts = 0;
-  out.flops = 0.0;
+  out.flops = out.flops_exact = 0.0;
   // local position of a node in a front: every node occurs in its own front and in the few descendants'
   // fronts that have it on their boundary -> a short (tree id, position) list per node
   std::vector<int32_t>& occ_start = out.occ_start;
@@ -333,6 +333,8 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     out.max_npt = std::max(out.max_npt, f.npt);
     const double n1 = f.n1p, n2 = f.n2p;
     out.flops += n1 * n1 * n1 / 3.0 + n1 * n1 * n2 + n1 * n2 * n2;
+    const double e1 = f.n1, e2 = 7.0 * f.nb;
+    out.flops_exact += e1 * e1 * e1 / 3.0 + e1 * e1 * e2 + e1 * e2 * e2;
   }
   out.sched.clear();
   for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {

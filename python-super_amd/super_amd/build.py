@@ -39,16 +39,16 @@ def _stale(out, deps):
 def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
     """``stamps=True`` builds the DIAGNOSTIC variant (in-kernel s_memtime stamps, printed by
     slm_get_records); never ship or time that build."""
-    global OBJ_DIR, LIB_PATH
+    obj_dir, lib_path = OBJ_DIR, LIB_PATH          # (locals: a stamps build must not redirect later normal builds)
     if stamps:
-        OBJ_DIR = os.path.join(PKG_ROOT, "build", "stamps")
-        LIB_PATH = os.path.join(LIB_DIR, "libsuper_lm_stamps.so")
+        obj_dir = os.path.join(PKG_ROOT, "build", "stamps")
+        lib_path = os.path.join(LIB_DIR, "libsuper_lm_stamps.so")
     os.makedirs(LIB_DIR, exist_ok=True)
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(REPO_ROOT, "include", "super_lm.h"))
     srcs = sources()
-    objs = [os.path.join(OBJ_DIR, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    objs = [os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o") for s in srcs]
 
     def compile_one(pair):
         src, obj = pair
@@ -64,8 +64,8 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> s
 
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         logs = list(ex.map(compile_one, zip(srcs, objs)))
-    if force or _stale(LIB_PATH, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if force or _stale(lib_path, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> s
         for lg in logs:
             if lg:
                 print(lg)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
