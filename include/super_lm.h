@@ -175,6 +175,9 @@ int slm_lm_solve(slm_solver* s, int32_t n_frames, void* stream);
 int slm_lm_loss_local(slm_solver* s, int32_t n_frames, void* stream);
 int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream);
 int slm_lm_exchange_size(slm_solver* s, int32_t slot, int32_t what, int64_t* n_doubles);
+/* The library's own exchange buffer (device pointer, n_doubles long): a caller whose collective can run on foreign
+ * device memory reduces IN PLACE on it (no get / set copies).  Valid until the slot is bound again. */
+int slm_lm_exchange_ptr(slm_solver* s, int32_t slot, int32_t what, double** device_ptr_out, int64_t* n_doubles);
 int slm_lm_exchange_get(slm_solver* s, int32_t slot, int32_t what, double* out_device, void* stream);
 int slm_lm_exchange_set(slm_solver* s, int32_t slot, int32_t what, const double* in_device, void* stream);
 

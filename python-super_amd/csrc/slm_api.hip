@@ -807,6 +807,11 @@ int slm_lm_exchange_size(slm_solver* s, int32_t slot, int32_t what, int64_t* n_d
   return exchange_buf(s, slot, what, &p, n_doubles);
 }
 
+int slm_lm_exchange_ptr(slm_solver* s, int32_t slot, int32_t what, double** ptr_out, int64_t* n_doubles) {
+  if (!ptr_out || !n_doubles) return fail(SLM_ERR_INVALID, "slm_lm_exchange_ptr: null output");
+  return exchange_buf(s, slot, what, ptr_out, n_doubles);
+}
+
 int slm_lm_exchange_get(slm_solver* s, int32_t slot, int32_t what, double* out, void* stream) {
   double* p;
   int64_t n;

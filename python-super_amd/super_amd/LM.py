@@ -117,10 +117,11 @@ class LM_Solver():
             if world is None:
                 world, rank = dist.get_world_size(), dist.get_rank()
             self.rank, self.world = int(rank), int(world)
-            if self._all_reduce is None:
-                self._all_reduce = lambda t: dist.all_reduce(t)          # sum, in place
-            if self._broadcast is None:
-                self._broadcast = lambda t: dist.broadcast(t, src=0)
+            if self._all_reduce is None or self._broadcast is None:
+                from .dist import default_collectives
+                ar, bc = default_collectives()
+                self._all_reduce = self._all_reduce or ar                # sum, in place
+                self._broadcast = self._broadcast or bc
 
     # ---- library handle --------------------------------------------------------------
     def _config(self, u, v, minimal_loss):
@@ -242,20 +243,25 @@ class LM_Solver():
         _lib.check(self.lib.slm_lm_exchange_size(h, slot, what, C.byref(n)), "slm_lm_exchange_size")
         return torch.empty(n.value, dtype=torch.float64, device=dev)
 
+    def exchange_view(self, h, slot, what, dev):
+        """The library's exchange buffer itself as a tensor (aliased, not copied)."""
+        from .dist import device_view
+        ptr, n = C.c_void_p(), C.c_int64(0)
+        _lib.check(self.lib.slm_lm_exchange_ptr(h, slot, what, C.byref(ptr), C.byref(n)), "slm_lm_exchange_ptr")
+        return device_view(ptr.value, n.value, dev)
+
     def _exchange(self, h, n, what, op, bufs):
-        st = _stream_ptr(bufs[0].device)
+        # the collective runs in place on the library's buffer (kernels and collective share the current stream)
         for i in range(n):
-            _lib.check(self.lib.slm_lm_exchange_get(h, i, what, _dev_ptr(bufs[i]), st), "slm_lm_exchange_get")
             op(bufs[i])
-            _lib.check(self.lib.slm_lm_exchange_set(h, i, what, _dev_ptr(bufs[i]), st), "slm_lm_exchange_set")
 
     def _run_sharded(self, h, n, dev):
         """The LM loop with the three exchanges per iteration (see include/super_lm.h)."""
         st = _stream_ptr(dev)
         lib = self.lib
-        pair = [self.exchange_buffer(h, i, _lib.SLM_X_PAIR_BLOCKS, dev) for i in range(n)]
-        delta = [self.exchange_buffer(h, i, _lib.SLM_X_DELTA, dev) for i in range(n)]
-        loss = [self.exchange_buffer(h, i, _lib.SLM_X_DATA_LOSS, dev) for i in range(n)]
+        pair = [self.exchange_view(h, i, _lib.SLM_X_PAIR_BLOCKS, dev) for i in range(n)] if self.opt.sf_point_plane else []
+        delta = [self.exchange_view(h, i, _lib.SLM_X_DELTA, dev) for i in range(n)]
+        loss = [self.exchange_view(h, i, _lib.SLM_X_DATA_LOSS, dev) for i in range(n)] if self.opt.sf_point_plane else []
         for _ in range(int(self.opt.num_optimize_iterations)):
             _lib.check(lib.slm_lm_grad_local(h, n, st), "slm_lm_grad_local")
             if self.opt.sf_point_plane:

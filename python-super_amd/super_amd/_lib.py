@@ -27,7 +27,7 @@ EXPORTS = [
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
     "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64", "slm_graph_init_semantic", "slm_debug_counters",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
-    "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set",
+    "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set", "slm_lm_exchange_ptr",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
     "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read", "slm_debug_dag_trace",
 ]
@@ -203,6 +203,7 @@ def load():
         "slm_lm_loss_local": [vp, i32, vp],
         "slm_lm_accept": [vp, i32, vp],
         "slm_lm_exchange_size": [vp, i32, i32, C.POINTER(C.c_int64)],
+        "slm_lm_exchange_ptr": [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_int64)],
         "slm_lm_exchange_get": [vp, i32, i32, vp, vp],
         "slm_lm_exchange_set": [vp, i32, i32, vp, vp],
         "slm_graph_init": [i32, i32, i32, vp, vp, vp, vp, C.POINTER(SlmGraphOutputs), C.POINTER(C.c_int32), vp],

@@ -81,7 +81,8 @@ class GraphFit:
                 world, rank = dist.get_world_size(), dist.get_rank()
             self.rank, self.world = int(rank), int(world)
             if self._all_reduce is None:
-                self._all_reduce = lambda t: dist.all_reduce(t)     # sum, in place (RCCL on the GPU box)
+                from .dist import default_collectives
+                self._all_reduce = default_collectives()[0]         # sum, in place (RCCL on the GPU box; host-staged under gloo)
             _lib.check(self.lib.slm_gf_set_shard(self.h, self.rank, self.world), "slm_gf_set_shard")
 
     def __del__(self):

@@ -43,3 +43,33 @@ def all_gather_betas(local_betas: torch.Tensor, n_frames: int, group=None) -> to
         a, b = shard_range(n_frames, world, r)
         parts.append(out[r * n_max: r * n_max + (b - a)])
     return torch.cat(parts, dim=0)
+
+
+class _DeviceView:
+    """A raw device buffer owned by libsuper_lm.so, exposed through ``__cuda_array_interface__`` so that
+    ``torch.as_tensor`` aliases it (no copy): the collective then runs in place on the library's memory."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr: int, n: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DeviceView(ptr, n), device=device)
+
+
+def default_collectives(group=None):
+    """(all_reduce_sum, broadcast_from_0) for float64 device tensors over ``torch.distributed``.  Backend "nccl"
+    (RCCL over xGMI on the GPU box) works on the device tensor in place; "gloo" (CPU tests, or several ranks
+    sharing one GPU) stages through host memory."""
+    if dist.get_backend(group) == "gloo":
+        def all_reduce(t):
+            h = t.cpu()
+            dist.all_reduce(h, group=group)
+            t.copy_(h)
+
+        def broadcast(t):
+            h = t.cpu()
+            dist.broadcast(h, src=0, group=group)
+            t.copy_(h)
+        return all_reduce, broadcast
+    return (lambda t: dist.all_reduce(t, group=group)), (lambda t: dist.broadcast(t, src=0, group=group))
