@@ -288,14 +288,17 @@ typedef struct slm_gf_config {
                               2 opt.sf_soft_seg_point_plane (either implies the point-plane term,
                               super/deform_mesh.py:76-92; needs slm_gf_bind_semantic) */
   int32_t use_bn_morph;    /* opt.sf_bn_morph (needs slm_gf_bind_semantic) */
-  int32_t reserved;
+  int32_t corr_mode;       /* opt.sf_corr: 0 off, 1 opt.sf_corr_loss_type 'point-point', 2 'point-plane'
+                              (super/deform_mesh.py:100-109; needs slm_gf_bind_flow) */
   double w_data, w_arap, w_rot, w_face; /* opt.*_weight */
   double lr;               /* opt.learning_rate (5e-5) */
   double w_bn_morph;       /* opt.sf_bn_morph_weight (0.1) */
   double pp_max;           /* > 0: drop squared point-plane residuals >= pp_max (2e-5 when
                               opt.depth_model == "raft_stereo", super/deform_mesh.py:97;
                               ignored with seg_mode != 0 like the reference) */
+  double w_corr;           /* opt.sf_corr_weight (0.001) */
 } slm_gf_config;
+#define SLM_GF_NTERMS 10   /* doubles in the loss-term block of slm_gf_loss_grad / slm_gf_get_partial */
 
 typedef struct slm_gf_frame {
   slm_frame base;                 /* same fields as the LM path (tgt_valid is not read here) */
@@ -329,6 +332,13 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* frame, void* 
  * NULL, receives num_classes counts (synchronises `stream`). */
 int slm_gf_bind_semantic(slm_gf* g, int32_t slot, const slm_gf_semantic* sem, int32_t* edge_counts_host,
                          void* stream);
+/* After slm_gf_bind_frame: binds the optical flow of the frame for the surfel-correspondence term (corr_mode):
+ * flow_device is (2,H,W) float32, channel 0 the x (u) and channel 1 the y (v) displacement in pixels -- the output
+ * of the reference's models.optical_flow(src.rgb, inputs[("color",0)]) (super/deform_mesh.py:286-320), which stays
+ * with the caller.  The term samples it at each surfel's unrounded projection exactly like
+ * F.grid_sample(flow, grid.float()) (bilinear, zero padding, align_corners=False; super/loss.py:318-323), moves
+ * the projection by it and evaluates the 4-tap residual there; the gradient includes d(flow)/d(u,v). */
+int slm_gf_bind_flow(slm_gf* g, int32_t slot, const float* flow_device, void* stream);
 /* Copies the slot's boundary pixels of `class_id` ((x,y) float pairs, row-major pixel order) to
  * device memory `xy_out_device` (capacity max_points pairs). */
 int slm_gf_get_edge_points(slm_gf* g, int32_t slot, int32_t class_id, float* xy_out_device,
@@ -344,7 +354,7 @@ int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream);
  *                            global kept count scales the back-propagation)
  *     slm_gf_eval_losses  -> all-reduce(sum) of the partial state   (gradient + loss terms)
  *     slm_gf_step
- * on every rank; the partial state is [(J+1)*7 gradient | 8 terms] doubles, moved with
+ * on every rank; the partial state is [(J+1)*7 gradient | SLM_GF_NTERMS terms] doubles, moved with
  * slm_gf_get_partial / slm_gf_set_partial (device to device) so that the collective runs on the
  * caller's own buffer (torch.distributed all_reduce = RCCL over xGMI). */
 int slm_gf_set_shard(slm_gf* g, int32_t rank, int32_t world);
@@ -355,11 +365,12 @@ int slm_gf_get_partial(slm_gf* g, int32_t slot, double* out_device, void* stream
 int slm_gf_set_partial(slm_gf* g, int32_t slot, const double* in_device, void* stream);
 /* Copies deform_verts ((J+1)*7 doubles) of the slot into caller device memory. */
 int slm_gf_get_deform(slm_gf* g, int32_t slot, double* out_device, void* stream);
-/* One loss + gradient evaluation at dv_device ((J+1)*7): terms_device[8]: [0..3] = face, arap,
+/* One loss + gradient evaluation at dv_device ((J+1)*7): terms_device[SLM_GF_NTERMS]: [0..3] = face, arap,
  * rot, point_plane losses (already weighted), [4] = point-plane residuals kept, [5] = boundary
  * morphing loss (weighted; NaN when candidates exist but none passes the > 15 test, like the
  * reference's mean over an empty tensor), [6] = surfels kept by the morphing term,
- * [7] = 1 when some class contributed to it (the loss key exists in the reference);
+ * [7] = 1 when some class contributed to it (the loss key exists in the reference),
+ * [8] = flow-correspondence loss (weighted), [9] = its residuals kept;
  * grad_device ((J+1)*7) = d(sum)/d(dv) with the global row divided by J like the reference. */
 int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv_device, double* terms_device,
                      double* grad_device, void* stream);

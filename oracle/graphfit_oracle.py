@@ -3,7 +3,7 @@
 A float64 PyTorch-CPU restatement of the reference's DEFAULT per-frame optimiser, the
 autograd path ``GraphFit`` (``super/deform_mesh.py:198-230,251-379`` with the loss terms of
 ``super/loss.py:293-401,458-473,502-505``): skin the stable surfels with the local warps,
-apply the global row T_g, evaluate face / ARAP / Rot / point-to-plane losses, backprop,
+apply the global row T_g, evaluate face / ARAP / Rot / point-to-plane / flow-correspondence losses, backprop,
 scale the global row's gradient by 1/J, step SGD(momentum 0.9) or Adam; plus the
 Semantic-SuPer terms of the same function: the hard / soft segmentation weight on the
 point-to-plane residuals (``loss.py:346-399``), the optional ``max`` clip (``loss.py:369-370``)
@@ -14,7 +14,7 @@ the host cores, and it is the parity reference for the hand-derived-gradient HIP
 Pinned against the reference itself by ``tests/golden/make_golden.py`` (``gf_*`` arrays in
 the fixtures): per-term losses and d(loss)/d(deform_verts) at iteration 0, and the final
 ``deform_verts`` after 10 iterations of SGD and of Adam; ``s60x80_j48_semantic`` pins the
-semantic terms the same way.  Only ``tests/`` and ``bench.py``'s
+semantic terms the same way and ``s60x80_j48_corr`` (make_golden_corr.py) the flow-correspondence term.  Only ``tests/`` and ``bench.py``'s
 ``cpu_baseline`` leg import this module.
 """
 from __future__ import annotations
@@ -68,6 +68,8 @@ class Problem:
             self.img_seg_conf = _t(sc.img_seg_conf)[None]          # inputs[("seg_conf",0)] (1,C,H,W)
             self.img_seg = _t(sc.img_seg, torch.long)              # inputs[("seg",0)][0,0]
             self.edge_pts = None
+        fl = getattr(sc, "flow", None)                             # models.optical_flow(src.rgb, color) (1,2,H,W) f32
+        self.flow = None if fl is None else torch.from_numpy(np.ascontiguousarray(fl, dtype=np.float32))
 
 
 def deform(pb: Problem, dv):
@@ -130,6 +132,43 @@ def point_plane(pb: Problem, sf, seg_mode=None, pp_max=None):
         losses = losses * wgt[tap_ok]
     elif pp_max is not None:
         losses = losses[losses < pp_max]
+    return losses.sum(), int(losses.numel())
+
+
+def corr_term(pb: Problem, sf, loss_type="point-point"):
+    """``DataLoss.autograd_forward(..., flow=flow, loss_type=opt.sf_corr_loss_type)`` (loss.py:293-345,401 as
+    called at deform_mesh.py:100-109): the UNROUNDED projections are shifted by the optical flow sampled at
+    them -- ``F.grid_sample`` on a float32 grid, bilinear, zero padding, align_corners=False, differentiable
+    through the grid -- validity is margin 1 on the shifted FLOAT coordinates, then the same 4-tap gather;
+    'point-point' sums |p - o|^2, 'point-plane' (n.(p - o))^2."""
+    Z = sf[:, 2] + 1e-8
+    u_ = sf[:, 0] * pb.fx / Z + pb.cx
+    v_ = sf[:, 1] * pb.fy / Z + pb.cy
+    grid = torch.stack([u_ * 2 / pb.W - 1, v_ * 2 / pb.H - 1], dim=1).view(1, -1, 1, 2).float()
+    loc = F.grid_sample(pb.flow, grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0, :, :, 0]
+    u_ = u_ + loc[0]
+    v_ = v_ + loc[1]
+    ok = (v_ >= 1) & (v_ < pb.H - 2) & (u_ >= 1) & (u_ < pb.W - 2)
+    u, v, P = u_[ok], v_[ok], sf[ok]
+    fv, cv, fu, cu = torch.floor(v), torch.ceil(v), torch.floor(u), torch.ceil(u)
+    nb = torch.stack([fv, fv, cv, cv], -1)
+    mb = torch.stack([fu, cu, fu, cu], -1)
+    rows = pb.index_map[nb.long(), mb.long()]
+    tap_ok = (rows >= 0).all(-1)
+    feat = torch.cat([pb.o, pb.n], -1)
+    U = torch.zeros(rows.shape + (6,), dtype=F64)
+    U[rows >= 0] = feat[rows[rows >= 0]]
+    an = torch.clamp(1 - torch.abs(nb - v[:, None]), min=0)[..., None]
+    am = torch.clamp(1 - torch.abs(mb - u[:, None]), min=0)[..., None]
+    out = (U * an * am).sum(-2)
+    o, n = out[:, 0:3], out[:, 3:6]
+    d = P[tap_ok] - o[tap_ok]
+    if loss_type == "point-point":
+        losses = (d ** 2).sum(-1)
+    elif loss_type == "point-plane":
+        losses = (n[tap_ok] * d).sum(-1) ** 2
+    else:
+        raise ValueError(loss_type)
     return losses.sum(), int(losses.numel())
 
 
@@ -218,7 +257,8 @@ def default_opt(**kw):
                         mesh_arap_weight=10.0, mesh_rot=True, mesh_rot_weight=1.0, mesh_face=False,
                         mesh_face_weight=1.0, num_optimize_iterations=10, optimizer="SGD",
                         learning_rate=5e-5, sf_soft_seg_point_plane=False, sf_hard_seg_point_plane=False,
-                        sf_bn_morph=False, sf_bn_morph_weight=1.0, depth_model="monodepth2")
+                        sf_bn_morph=False, sf_bn_morph_weight=1.0, depth_model="monodepth2", sf_corr=False,
+                        sf_corr_weight=0.001, sf_corr_loss_type="point-point")
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -242,6 +282,10 @@ def total_loss(pb: Problem, dv, opt):
         pp, m = point_plane(pb, sf, seg_mode, pp_max)
         terms["point_plane_loss"] = opt.sf_point_plane_weight * pp
         terms["_matched"] = m
+    if getattr(opt, "sf_corr", False):
+        cl, m = corr_term(pb, sf, getattr(opt, "sf_corr_loss_type", "point-point"))
+        terms["corr_loss"] = opt.sf_corr_weight * cl
+        terms["_corr_matched"] = m
     if getattr(opt, "sf_bn_morph", False):
         bm = bn_morph(pb, sf)
         if bm is not None:

@@ -13,7 +13,9 @@ struct GfSlot {
   double* m1;            // momentum buffer / Adam exp_avg
   double* m2;            // Adam exp_avg_sq
   double* terms;         // [0..3] face, arap, rot, point-plane; [4] residuals kept;
-                         // [5] morphing loss sum (weighted mean after k_gf_finish), [6] kept, [7] candidates
+                         // [5] morphing loss sum (weighted mean after k_gf_finish), [6] kept, [7] candidates;
+                         // [8] flow-correspondence loss, [9] its residuals kept   (SLM_GF_NTERMS)
+  const float* flow;     // (2,H,W) optical flow of the frame (slm_gf_bind_flow) or null
   // ---- Semantic-SuPer (slm_gf_bind_semantic) ----
   slm_gf_semantic sem;
   int32_t sem_bound;

@@ -21,7 +21,82 @@ __global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
   if (!s.bound) return;
   const int n = (s.f.base.J + 1) * 7;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) s.grad[e] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x < 8) s.terms[threadIdx.x] = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x < SLM_GF_NTERMS) s.terms[threadIdx.x] = 0.0;
+}
+
+// 4-tap gather of the target maps at the float pixel (u_, v_) (bilinear_sample, loss.py:9-80, zero fill):
+// false when a tap is unmapped.  o / n = interpolated point / normal, d*u / d*v their derivatives along u / v
+// (autograd through clamp(1 - |tap - x|): d|x|/dx = sign(x) with sign(0) = 0).
+struct GfSample {
+  d3 o, n, dou, dov, dnu, dnv;
+  int rows[4];
+  double wv[4];
+};
+
+__device__ __forceinline__ bool gf_sample(const slm_frame& f, double u_, double v_, GfSample& q) {
+  const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
+  const double nn[4] = {fv, fv, cv, cv}, mm[4] = {fu, cu, fu, cu};
+  bool all_ok = true;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    q.rows[t] = f.index_map[(int)nn[t] * f.W + (int)mm[t]];
+    all_ok = all_ok && q.rows[t] >= 0;
+  }
+  if (!all_ok) return false;
+  d3 o = {0, 0, 0}, n = {0, 0, 0}, dou = {0, 0, 0}, dov = {0, 0, 0}, dnu = {0, 0, 0}, dnv = {0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const double dn = nn[t] - v_, dm = mm[t] - u_;
+    const double an = fmax(1.0 - fabs(dn), 0.0), am = fmax(1.0 - fabs(dm), 0.0);
+    const float* tp = f.tgt_points + 3 * (size_t)q.rows[t];
+    const float* tn = f.tgt_norms + 3 * (size_t)q.rows[t];
+    const d3 Pt = {(double)tp[0], (double)tp[1], (double)tp[2]};
+    const d3 Nt = {(double)tn[0], (double)tn[1], (double)tn[2]};
+    const double wv = an * am;
+    const double sn = dn > 0.0 ? 1.0 : (dn < 0.0 ? -1.0 : 0.0);
+    const double smm = dm > 0.0 ? 1.0 : (dm < 0.0 ? -1.0 : 0.0);
+    const double gu = an * smm, gvv = am * sn;
+    q.wv[t] = wv;
+    o = {o.x + Pt.x * wv, o.y + Pt.y * wv, o.z + Pt.z * wv};
+    n = {n.x + Nt.x * wv, n.y + Nt.y * wv, n.z + Nt.z * wv};
+    dou = {dou.x + Pt.x * gu, dou.y + Pt.y * gu, dou.z + Pt.z * gu};
+    dov = {dov.x + Pt.x * gvv, dov.y + Pt.y * gvv, dov.z + Pt.z * gvv};
+    dnu = {dnu.x + Nt.x * gu, dnu.y + Nt.y * gu, dnu.z + Nt.z * gu};
+    dnv = {dnv.x + Nt.x * gvv, dnv.y + Nt.y * gvv, dnv.z + Nt.z * gvv};
+  }
+  q.o = o; q.n = n; q.dou = dou; q.dov = dov; q.dnu = dnu; q.dnv = dnv;
+  return true;
+}
+
+// The optical flow (2,H,W float32: x then y displacement) at the float pixel (u, v), sampled the way
+// F.grid_sample(flow, grid) does at deform_mesh.py / loss.py:318-323: the grid is float32, bilinear, zero padding,
+// align_corners=False, i.e. position ((g + 1) * size - 1) / 2 in float32; fl = (flow_x, flow_y) and
+// D = [[dfx/du, dfx/dv], [dfy/du, dfy/dv]] (the grid gradient of the same cell, what autograd returns).
+__device__ __forceinline__ void gf_flow_sample(const float* __restrict__ flow, int H, int W, double u, double v,
+                                               double fl[2], double D[4]) {
+  const float gx = (float)(u * 2.0 / (double)W - 1.0), gy = (float)(v * 2.0 / (double)H - 1.0);
+  const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f * (float)W), 0.5f);
+  const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f * (float)H), 0.5f);
+  const float xw = floorf(ix), yn = floorf(iy);
+  const float w = __fsub_rn(ix, xw), e = __fsub_rn(1.f, w), n = __fsub_rn(iy, yn), sth = __fsub_rn(1.f, n);
+  const int x0 = (int)xw, y0 = (int)yn;
+  const bool okx0 = x0 >= 0 && x0 < W, okx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool oky0 = y0 >= 0 && y0 < H, oky1 = y0 + 1 >= 0 && y0 + 1 < H;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float* fc = flow + (size_t)c * H * W;
+    const float nw = (okx0 && oky0) ? fc[(size_t)y0 * W + x0] : 0.f;
+    const float ne = (okx1 && oky0) ? fc[(size_t)y0 * W + x0 + 1] : 0.f;
+    const float sw = (okx0 && oky1) ? fc[(size_t)(y0 + 1) * W + x0] : 0.f;
+    const float se = (okx1 && oky1) ? fc[(size_t)(y0 + 1) * W + x0 + 1] : 0.f;
+    float acc = __fmul_rn(nw, __fmul_rn(e, sth));
+    acc = __fadd_rn(acc, __fmul_rn(ne, __fmul_rn(w, sth)));
+    acc = __fadd_rn(acc, __fmul_rn(sw, __fmul_rn(e, n)));
+    acc = __fadd_rn(acc, __fmul_rn(se, __fmul_rn(w, n)));
+    fl[c] = (double)acc;
+    D[2 * c + 0] = ((double)ne - (double)nw) * (double)sth + ((double)se - (double)sw) * (double)n;
+    D[2 * c + 1] = ((double)sw - (double)nw) * (double)e + ((double)se - (double)ne) * (double)w;
+  }
 }
 
 // grid = (ceil(maxN/256), n_frames)
@@ -30,7 +105,8 @@ __global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
 // use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
 #define GF_TAB 128   // LDS gradient table: slots per workgroup (power of two)
 __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode,
-                                                  double pp_max, int use_morph, double w_morph) {
+                                                  double pp_max, int use_morph, double w_morph, int corr_mode,
+                                                  double lam_c) {
   __shared__ double sm[16];
   // The 256 surfels of a workgroup are neighbours on the image and share a few dozen ED nodes: their
   // gradient rows are summed in an LDS table keyed by node (ds_add_f64) and flushed with one global
@@ -46,7 +122,7 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   const slm_frame& f = s.f.base;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int J = f.J;
-  double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0;
+  double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0, lossc = 0.0, cntc = 0.0;
   if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
     GfSkin k;
     gf_skin(s, i, k);
@@ -63,40 +139,13 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
     const int H = f.H, W = f.W;
     // valid_margin = 1 (loss.py:306-309)
     if (use_pp && vr >= 1.0 && vr < (double)(H - 2) && ur >= 1.0 && ur < (double)(W - 2)) {
-      const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
-      const double nn[4] = {fv, fv, cv, cv}, mm[4] = {fu, cu, fu, cu};
-      int rows[4];
-      bool all_ok = true;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        rows[t] = f.index_map[(int)nn[t] * W + (int)mm[t]];
-        all_ok = all_ok && rows[t] >= 0;
-      }
-      if (all_ok) {
-        d3 o = {0, 0, 0}, n = {0, 0, 0}, dou = {0, 0, 0}, dov = {0, 0, 0}, dnu = {0, 0, 0}, dnv = {0, 0, 0};
+      GfSample q;
+      if (gf_sample(f, u_, v_, q)) {
+        const d3 o = q.o, n = q.n, dou = q.dou, dov = q.dov, dnu = q.dnu, dnv = q.dnv;
         double conf[SLM_MAX_CLASSES] = {0, 0, 0, 0};
         const int C = (seg_mode && s.sem_bound) ? s.sem.num_classes : 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const double dn = nn[t] - v_, dm = mm[t] - u_;
-          const double an = fmax(1.0 - fabs(dn), 0.0), am = fmax(1.0 - fabs(dm), 0.0);
-          const float* tp = f.tgt_points + 3 * (size_t)rows[t];
-          const float* tn = f.tgt_norms + 3 * (size_t)rows[t];
-          const d3 Pt = {(double)tp[0], (double)tp[1], (double)tp[2]};
-          const d3 Nt = {(double)tn[0], (double)tn[1], (double)tn[2]};
-          const double wv = an * am;
-          // autograd through |.|: d|x|/dx = sign(x) with sign(0) = 0
-          const double sn = dn > 0.0 ? 1.0 : (dn < 0.0 ? -1.0 : 0.0);
-          const double smm = dm > 0.0 ? 1.0 : (dm < 0.0 ? -1.0 : 0.0);
-          const double gu = an * smm, gvv = am * sn;
-          o = {o.x + Pt.x * wv, o.y + Pt.y * wv, o.z + Pt.z * wv};
-          n = {n.x + Nt.x * wv, n.y + Nt.y * wv, n.z + Nt.z * wv};
-          dou = {dou.x + Pt.x * gu, dou.y + Pt.y * gu, dou.z + Pt.z * gu};
-          dov = {dov.x + Pt.x * gvv, dov.y + Pt.y * gvv, dov.z + Pt.z * gvv};
-          dnu = {dnu.x + Nt.x * gu, dnu.y + Nt.y * gu, dnu.z + Nt.z * gu};
-          dnv = {dnv.x + Nt.x * gvv, dnv.y + Nt.y * gvv, dnv.z + Nt.z * gvv};
-          for (int c = 0; c < C; ++c) conf[c] += (double)s.sem.tgt_seg_conf[(size_t)rows[t] * C + c] * wv;
-        }
+        for (int t = 0; t < 4; ++t)
+          for (int c = 0; c < C; ++c) conf[c] += (double)s.sem.tgt_seg_conf[(size_t)q.rows[t] * C + c] * q.wv[t];
         const d3 e = P - o;
         const double r = dot(n, e);
         double wgt = 1.0;
@@ -140,6 +189,40 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
           const double G = 2.0 * lam * wgt * r;
           gP = {G * (n.x + s0 * Pi0.x + s1 * Pi1.x), G * (n.y + s0 * Pi0.y + s1 * Pi1.y),
                 G * (n.z + s0 * Pi0.z + s1 * Pi1.z)};
+          any = true;
+        }
+      }
+    }
+    if (corr_mode && s.flow) {
+      // flow-correspondence term (opt.sf_corr, deform_mesh.py:100-109 -> loss.py:293-345 with flow): the UNROUNDED
+      // projection is moved by the flow sampled at it, validity is margin 1 on the moved float coordinates
+      double fl[2], D[4];
+      gf_flow_sample(s.flow, H, W, u_, v_, fl, D);
+      const double uc = u_ + fl[0], vc = v_ + fl[1];
+      if (vc >= 1.0 && vc < (double)(H - 2) && uc >= 1.0 && uc < (double)(W - 2)) {
+        GfSample q;
+        if (gf_sample(f, uc, vc, q)) {
+          // d(u', v')/dP = (I + dflow/d(u,v)) Pi
+          const d3 Au = {(1.0 + D[0]) * Pi0.x + D[1] * Pi1.x, (1.0 + D[0]) * Pi0.y + D[1] * Pi1.y,
+                         (1.0 + D[0]) * Pi0.z + D[1] * Pi1.z};
+          const d3 Av = {D[2] * Pi0.x + (1.0 + D[3]) * Pi1.x, D[2] * Pi0.y + (1.0 + D[3]) * Pi1.y,
+                         D[2] * Pi0.z + (1.0 + D[3]) * Pi1.z};
+          const d3 e = P - q.o;
+          if (corr_mode == 1) {          // 'point-point': |P - o|^2
+            lossc = lam_c * dot(e, e);
+            const double s0 = -dot(e, q.dou), s1 = -dot(e, q.dov);
+            const double G = 2.0 * lam_c;
+            gP = {gP.x + G * (e.x + s0 * Au.x + s1 * Av.x), gP.y + G * (e.y + s0 * Au.y + s1 * Av.y),
+                  gP.z + G * (e.z + s0 * Au.z + s1 * Av.z)};
+          } else {                       // 'point-plane': (n.(P - o))^2
+            const double r = dot(q.n, e);
+            lossc = lam_c * r * r;
+            const double s0 = dot(e, q.dnu) - dot(q.n, q.dou), s1 = dot(e, q.dnv) - dot(q.n, q.dov);
+            const double G = 2.0 * lam_c * r;
+            gP = {gP.x + G * (q.n.x + s0 * Au.x + s1 * Av.x), gP.y + G * (q.n.y + s0 * Au.y + s1 * Av.y),
+                  gP.z + G * (q.n.z + s0 * Au.z + s1 * Av.z)};
+          }
+          cntc = 1.0;
           any = true;
         }
       }
@@ -189,14 +272,16 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
     if (node >= 0 && v != 0.0) atomic_add_f64(s.grad + 7 * node + t % 7, v);
   }
   // global row, loss and count: block reduction, then one atomic each
-  double vals[9] = {gq[0], gq[1], gq[2], gq[3], gb[0], gb[1], gb[2], loss, cnt};
+  double vals[11] = {gq[0], gq[1], gq[2], gq[3], gb[0], gb[1], gb[2], loss, cnt, lossc, cntc};
 #pragma unroll
-  for (int a = 0; a < 9; ++a) {
+  for (int a = 0; a < 11; ++a) {
+    if (a >= 9 && !corr_mode) break;
     const double t = block_sum(vals[a], sm);
     if (threadIdx.x == 0 && t != 0.0) {
       if (a < 7) atomic_add_f64(s.grad + 7 * J + a, t);
       else if (a == 7) atomic_add_f64(s.terms + 3, t);
-      else atomic_add_f64(s.terms + 4, t);
+      else if (a == 8) atomic_add_f64(s.terms + 4, t);
+      else atomic_add_f64(s.terms + (a - 1), t);   // [8] correspondence loss, [9] residuals kept
     }
   }
 }
@@ -457,9 +542,9 @@ static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStrea
 static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
   const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
-  if ((use_pp || c.use_bn_morph) && maxN > 0)
+  if ((use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0)
     hipLaunchKernelGGL(k_gf_data, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
-                       c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph);
+                       c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr);
   if (g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
     hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
                        c.use_rot, c.w_rot, c.use_face, c.w_face);
@@ -491,7 +576,7 @@ extern "C" {
 
 int slm_gf_create(const slm_gf_config* cfg, slm_gf** out) {
   if (!cfg || !out || cfg->max_frames < 1 || cfg->num_iterations < 0 || (cfg->optimizer != 0 && cfg->optimizer != 1) ||
-      cfg->seg_mode < 0 || cfg->seg_mode > 2)
+      cfg->seg_mode < 0 || cfg->seg_mode > 2 || cfg->corr_mode < 0 || cfg->corr_mode > 2)
     return gf_fail(SLM_ERR_INVALID, "slm_gf_create: bad argument");
   if (slm_device_count() < 1) return gf_fail(SLM_ERR_NO_DEVICE, "slm_gf_create: no HIP device visible");
   slm_gf* g = new slm_gf();
@@ -538,7 +623,7 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* fr, void* str
   if (n > g->cap[slot]) {
     if (s.dv) GFCHK(hipFree(s.dv));
     s.dv = nullptr;
-    GFCHK(hipMalloc((void**)&s.dv, sizeof(double) * (4 * n + 8)));
+    GFCHK(hipMalloc((void**)&s.dv, sizeof(double) * (4 * n + SLM_GF_NTERMS)));
     g->cap[slot] = n;
   }
   s.grad = s.dv + n;
@@ -548,7 +633,8 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* fr, void* str
   s.f = *fr;
   s.bound = 1;
   s.step = 0;
-  s.sem_bound = 0;   // semantic inputs belong to the frame: bind them again
+  s.sem_bound = 0;   // semantic inputs and the flow belong to the frame: bind them again
+  s.flow = nullptr;
   s.shard_lo = (int32_t)((int64_t)f.N * g->rank / g->world);
   s.shard_hi = (int32_t)((int64_t)f.N * (g->rank + 1) / g->world);
   GFCHK(hipMemcpyAsync(g->dev + slot, &s, sizeof(GfSlot), hipMemcpyHostToDevice, st));
@@ -589,6 +675,18 @@ int slm_gf_bind_semantic(slm_gf* g, int32_t slot, const slm_gf_semantic* sem, in
   return SLM_OK;
 }
 
+int slm_gf_bind_flow(slm_gf* g, int32_t slot, const float* flow, void* stream) {
+  if (!g || !flow) return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_flow: null argument");
+  if (slot < 0 || slot >= (int)g->host.size()) return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_flow: bad slot");
+  GfSlot& s = g->host[slot];
+  if (!s.bound) return gf_fail(SLM_ERR_UNBOUND, "slm_gf_bind_flow: slm_gf_bind_frame first");
+  hipStream_t st = (hipStream_t)stream;
+  s.flow = flow;
+  GFCHK(hipMemcpyAsync(g->dev + slot, &s, sizeof(GfSlot), hipMemcpyHostToDevice, st));
+  GFCHK(hipStreamSynchronize(st));
+  return SLM_OK;
+}
+
 int slm_gf_get_edge_points(slm_gf* g, int32_t slot, int32_t class_id, float* xy_out, int32_t max_points,
                            void* stream) {
   if (!g || slot < 0 || slot >= (int)g->host.size() || !xy_out)
@@ -614,6 +712,8 @@ static int gf_dims(slm_gf* g, int first, int n, int* maxN, int* maxReg, int* max
     if (!s.bound) return gf_fail(SLM_ERR_UNBOUND, "slm_gf: slot used before slm_gf_bind_frame");
     if ((g->cfg.seg_mode || g->cfg.use_bn_morph) && !s.sem_bound)
       return gf_fail(SLM_ERR_UNBOUND, "slm_gf: semantic terms enabled but slm_gf_bind_semantic was not called");
+    if (g->cfg.corr_mode && !s.flow)
+      return gf_fail(SLM_ERR_UNBOUND, "slm_gf: corr_mode set but slm_gf_bind_flow was not called");
     *maxN = std::max(*maxN, s.f.base.N);
     int reg = std::max(s.f.base.J * s.f.base.K_ED, s.f.base.J + 1);
     if (g->cfg.use_face) reg = std::max(reg, s.f.n_triangles);
@@ -671,7 +771,7 @@ int slm_gf_get_partial(slm_gf* g, int32_t slot, double* out, void* stream) {
   const GfSlot& s = g->host[slot];
   hipStream_t st = (hipStream_t)stream;
   GFCHK(hipMemcpyAsync(out, s.grad, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
-  GFCHK(hipMemcpyAsync(out + maxP, s.terms, sizeof(double) * 8, hipMemcpyDeviceToDevice, st));
+  GFCHK(hipMemcpyAsync(out + maxP, s.terms, sizeof(double) * SLM_GF_NTERMS, hipMemcpyDeviceToDevice, st));
   return SLM_OK;
 }
 
@@ -683,7 +783,7 @@ int slm_gf_set_partial(slm_gf* g, int32_t slot, const double* in, void* stream) 
   const GfSlot& s = g->host[slot];
   hipStream_t st = (hipStream_t)stream;
   GFCHK(hipMemcpyAsync(s.grad, in, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
-  GFCHK(hipMemcpyAsync(s.terms, in + maxP, sizeof(double) * 8, hipMemcpyDeviceToDevice, st));
+  GFCHK(hipMemcpyAsync(s.terms, in + maxP, sizeof(double) * SLM_GF_NTERMS, hipMemcpyDeviceToDevice, st));
   return SLM_OK;
 }
 
@@ -726,7 +826,7 @@ int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv, double* terms, d
   gf_enqueue_eval(g, g->dev + slot, 1, maxN, maxReg, st);
   hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, 1), dim3(256), 0, st, g->dev + slot, g->cfg.optimizer,
                      g->cfg.lr, 0, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
-  if (terms) GFCHK(hipMemcpyAsync(terms, s.terms, sizeof(double) * 8, hipMemcpyDeviceToDevice, st));
+  if (terms) GFCHK(hipMemcpyAsync(terms, s.terms, sizeof(double) * SLM_GF_NTERMS, hipMemcpyDeviceToDevice, st));
   if (grad) GFCHK(hipMemcpyAsync(grad, s.grad, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   GFCHK(hipGetLastError());
   return SLM_OK;

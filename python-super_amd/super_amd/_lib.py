@@ -16,12 +16,14 @@ SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN = 0, 1, 2
 SLM_X_PAIR_BLOCKS, SLM_X_DELTA, SLM_X_DATA_LOSS = 0, 1, 2
 PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 
+GF_NTERMS = 10     # SLM_GF_NTERMS of include/super_lm.h
+
 EXPORTS = [
     "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame",
     "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_plan_info", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
     "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
-    "slm_gf_bind_semantic", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
+    "slm_gf_bind_semantic", "slm_gf_bind_flow", "slm_gf_get_edge_points", "slm_gf_set_shard", "slm_gf_eval_morph",
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
@@ -55,10 +57,10 @@ class SlmGfConfig(C.Structure):
     _fields_ = [("num_iterations", C.c_int32), ("optimizer", C.c_int32), ("use_data", C.c_int32),
                 ("use_arap", C.c_int32), ("use_rot", C.c_int32), ("use_face", C.c_int32),
                 ("max_frames", C.c_int32), ("seg_mode", C.c_int32), ("use_bn_morph", C.c_int32),
-                ("reserved", C.c_int32),
+                ("corr_mode", C.c_int32),
                 ("w_data", C.c_double), ("w_arap", C.c_double), ("w_rot", C.c_double),
                 ("w_face", C.c_double), ("lr", C.c_double), ("w_bn_morph", C.c_double),
-                ("pp_max", C.c_double)]
+                ("pp_max", C.c_double), ("w_corr", C.c_double)]
 
 
 class SlmGfFrame(C.Structure):
@@ -190,6 +192,7 @@ def load():
         "slm_gf_bind_frame": [vp, i32, C.POINTER(SlmGfFrame), vp],
         "slm_gf_run": [vp, i32, vp],
         "slm_gf_bind_semantic": [vp, i32, C.POINTER(SlmGfSemantic), C.POINTER(C.c_int32), vp],
+        "slm_gf_bind_flow": [vp, i32, vp, vp],
         "slm_gf_get_edge_points": [vp, i32, i32, vp, i32, vp],
         "slm_gf_set_shard": [vp, i32, i32],
         "slm_gf_eval_morph": [vp, i32, vp],

@@ -11,10 +11,13 @@ Supported loss flags: ``sf_point_plane``, ``mesh_arap``, ``mesh_rot``, ``mesh_fa
 weights, the Semantic-SuPer terms ``sf_soft_seg_point_plane`` / ``sf_hard_seg_point_plane`` /
 ``sf_bn_morph`` (+ ``sf_bn_morph_weight``, ``num_classes``), the ``max`` clip of the point-plane
 term that ``depth_model == "raft_stereo"`` switches on, ``optimizer`` in {"SGD", "Adam"},
-``learning_rate``, ``num_optimize_iterations``.  ``sf_corr`` (needs the optical-flow network) and
-the (unused) render loss raise ``NotImplementedError``.
-The renderer call the reference makes every iteration (deform_mesh.py:294-298) only feeds the
-render / correspondence losses and is not needed here.
+``learning_rate``, ``num_optimize_iterations``, and the surfel-correspondence term ``sf_corr``
+(+ ``sf_corr_weight``, ``sf_corr_loss_type``): the flow network stays the caller's -- like the reference
+(deform_mesh.py:19-23,302-309) ``forward`` calls ``models.optical_flow(src.rgb, inputs[("color",0)])`` once per
+frame and hands the (1,2,H,W) flow to the library.  ``sf_corr_match_renderimg`` (flow re-inferred from the
+rendered image every iteration) and the (unused) render loss raise ``NotImplementedError``.
+The renderer call the reference makes every iteration (deform_mesh.py:294-298) only feeds those two and is
+not needed here.
 """
 from __future__ import annotations
 
@@ -39,9 +42,9 @@ class GraphFit:
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.SuperLMError("no HIP device visible: super_amd has no CPU fallback")
-        for flag in ("sf_corr", "render_loss"):
-            if getattr(opt, flag, False):
-                raise NotImplementedError(f"super_amd.GraphFit: opt.{flag} is not supported yet")
+        for flag in ("sf_corr_match_renderimg", "render_loss"):
+            if getattr(opt, flag, False) and (flag == "render_loss" or getattr(opt, "sf_corr", False)):
+                raise NotImplementedError(f"super_amd.GraphFit: opt.{flag} is not supported")
         self.valid_margin = 1
         self.optim = opt.optimizer
         self.Niter = opt.num_optimize_iterations
@@ -68,7 +71,14 @@ class GraphFit:
         cfg.use_bn_morph = int(bool(getattr(opt, "sf_bn_morph", False)))
         cfg.w_bn_morph = float(getattr(opt, "sf_bn_morph_weight", 0.1))
         cfg.pp_max = 2e-5 if getattr(opt, "depth_model", None) == "raft_stereo" else 0.0
+        if getattr(opt, "sf_corr", False):                 # deform_mesh.py:100-109
+            lt = getattr(opt, "sf_corr_loss_type", "point-point")
+            if lt not in ("point-point", "point-plane"):
+                raise ValueError(f"sf_corr_loss_type {lt!r}")
+            cfg.corr_mode = 1 if lt == "point-point" else 2
+            cfg.w_corr = float(getattr(opt, "sf_corr_weight", 0.001))
         self.semantic = bool(cfg.seg_mode or cfg.use_bn_morph)
+        self.flow = None
         self.edge_counts = None
         self.cfg = cfg
         self.h = C.c_void_p()
@@ -92,7 +102,14 @@ class GraphFit:
         except Exception:
             pass
 
-    def _bind(self, slot, inputs, src, trg):
+    def infer_flow(self, models, source_img, target_img):
+        """(reference ``deform_mesh.py:19-23``) the caller's flow network; the last element of a list output."""
+        flow = models.optical_flow(source_img, target_img)   # x, y
+        if isinstance(flow, (list, tuple)):
+            flow = flow[-1]
+        return flow.detach()
+
+    def _bind(self, slot, inputs, src, trg, models=None, flow=None):
         new_data = trg
         if not hasattr(trg, "valid"):            # not read on this path
             trg = type("T", (), {})()
@@ -152,6 +169,17 @@ class GraphFit:
             _lib.check(self.lib.slm_gf_bind_semantic(self.h, slot, C.byref(sem), counts, _stream_ptr(dev)),
                        "slm_gf_bind_semantic")
             self.edge_counts = list(counts)[:nc]
+        if self.cfg.corr_mode:
+            if flow is None:
+                if models is None or not hasattr(models, "optical_flow"):
+                    raise ValueError("opt.sf_corr needs models.optical_flow (or flow=...)")   # the reference asserts
+                flow = self.infer_flow(models, src.rgb, inputs[("color", 0)])
+            self.flow = flow
+            fl = _as(flow, torch.float32, dev)
+            if tuple(fl.shape) != (1, 2, bf.c.H, bf.c.W):
+                raise ValueError(f"flow must be (1,2,{bf.c.H},{bf.c.W}), got {tuple(fl.shape)}")
+            keep.append(fl)
+            _lib.check(self.lib.slm_gf_bind_flow(self.h, slot, _dev_ptr(fl), _stream_ptr(dev)), "slm_gf_bind_flow")
         self._keep[slot] = keep
         return bf
 
@@ -159,10 +187,10 @@ class GraphFit:
         """(reference ``deform_mesh.py:232-247``) returns deform_verts (J+1,7) float64."""
         if getattr(self.opt, "deform_udpate_method", "super_edg") != "super_edg":
             raise NotImplementedError("only deform_udpate_method == 'super_edg'")
-        bf = self._bind(0, inputs, src, trg)
+        bf = self._bind(0, inputs, src, trg, models)
         st = _stream_ptr(bf.device)
         if self.world > 1:
-            part = torch.empty((bf.J + 1) * 7 + 8, dtype=torch.float64, device=bf.device)
+            part = torch.empty((bf.J + 1) * 7 + _lib.GF_NTERMS, dtype=torch.float64, device=bf.device)
             for _ in range(int(self.Niter)):
                 self.eval_morph()
                 if self.cfg.use_bn_morph:
@@ -182,8 +210,8 @@ class GraphFit:
     def _st(self):
         return _stream_ptr(self._keep[0][0].device)
 
-    def bind(self, inputs, src, trg):
-        return self._bind(0, inputs, src, trg)
+    def bind(self, inputs, src, trg, models=None, flow=None):
+        return self._bind(0, inputs, src, trg, models, flow)
 
     def eval_morph(self):
         _lib.check(self.lib.slm_gf_eval_morph(self.h, 1, self._st()), "slm_gf_eval_morph")
@@ -202,7 +230,7 @@ class GraphFit:
         _lib.check(self.lib.slm_gf_set_partial(self.h, 0, _dev_ptr(buf), self._st()), "slm_gf_set_partial")
 
     def exchange_partial(self, buf):
-        """partial [(J+1)*7 gradient | 8 terms] -> sum over the ranks -> back into the slot."""
+        """partial [(J+1)*7 gradient | GF_NTERMS terms] -> sum over the ranks -> back into the slot."""
         self.get_partial(buf)
         self._all_reduce(buf)
         self.set_partial(buf)
@@ -213,14 +241,14 @@ class GraphFit:
         _lib.check(self.lib.slm_gf_get_deform(self.h, 0, _dev_ptr(out), self._st()), "slm_gf_get_deform")
         return out
 
-    def loss_and_grad(self, inputs, src, trg, deform_verts):
+    def loss_and_grad(self, inputs, src, trg, deform_verts, models=None, flow=None):
         """One evaluation of ``deform_source`` + ``get_losses`` + backward at ``deform_verts``:
         returns (dict of weighted loss terms, matched count, gradient (J+1,7) with the global
         row divided by J)."""
-        bf = self._bind(0, inputs, src, trg)
+        bf = self._bind(0, inputs, src, trg, models, flow)
         st = _stream_ptr(bf.device)
         dv = _as(deform_verts, torch.float64, bf.device)
-        terms = torch.zeros(8, dtype=torch.float64, device=bf.device)
+        terms = torch.zeros(_lib.GF_NTERMS, dtype=torch.float64, device=bf.device)
         grad = torch.zeros((bf.J + 1, 7), dtype=torch.float64, device=bf.device)
         _lib.check(self.lib.slm_gf_loss_grad(self.h, 0, _dev_ptr(dv), _dev_ptr(terms), _dev_ptr(grad), st),
                    "slm_gf_loss_grad")
@@ -229,6 +257,9 @@ class GraphFit:
         if self.cfg.use_bn_morph and t[7] != 0.0:       # the reference only adds the key when a class contributes
             d["sf_bn_morph_loss"] = t[5]
         self.last_bn_morph_kept = int(t[6])
+        if self.cfg.corr_mode:
+            d["corr_loss"] = t[8]
+            self.last_corr_kept = int(t[9])
         return d, int(t[4]), grad
 
     def edge_points(self, class_id):

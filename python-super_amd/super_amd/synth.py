@@ -151,6 +151,7 @@ class Scene:
     tgt_seg_conf: np.ndarray = None       # (T,C) f32    trg.seg_conf (per-pixel softmax of img_seg_conf)
     sf_seg: np.ndarray = None             # (N,) i64     src.seg
     sf_seg_conf: np.ndarray = None        # (N,C) f32    src.seg_conf
+    flow: np.ndarray = None               # (1,2,H,W) f32 models.optical_flow(src.rgb, color) (deform_mesh.py:286-320)
     meta: dict = field(default_factory=dict)
 
     @property
@@ -286,3 +287,15 @@ WORKLOADS = {
     "C2": dict(N=200_000, J=2_000, H=480, W=640),
     "C4": dict(N=500_000, J=4_000, H=720, W=960),
 }
+
+
+def smooth_flow(H, W, seed, amp=(1.2, 0.9)):
+    """A smooth synthetic optical-flow field (1,2,H,W) float32, channel 0 = x (u) displacement, channel 1 = y,
+    of up to ``amp`` pixels: stands in for the output of the reference's flow network (``models.optical_flow``,
+    ``deform_mesh.py:286-320``), which is outside the hot path."""
+    rng = np.random.default_rng(seed)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    a = rng.uniform(0.5, 1.5, 4)
+    fx = amp[0] * np.sin(2 * np.pi * a[0] * uu / W + 0.3) * np.cos(2 * np.pi * a[1] * vv / H)
+    fy = amp[1] * np.cos(2 * np.pi * a[2] * uu / W) * np.sin(2 * np.pi * a[3] * vv / H + 0.7)
+    return np.stack([fx, fy])[None].astype(np.float32)

@@ -66,3 +66,22 @@ GF_SEMANTIC_VARIANTS = {
     "morph": dict(optimizer="SGD", sf_point_plane=True, sf_bn_morph=True, sf_bn_morph_weight=1e-6),
     "clip": dict(optimizer="SGD", depth_model="raft_stereo"),
 }
+
+
+# option overrides of the flow-correspondence GraphFit variants recorded in s60x80_j48_corr.npz
+# (same table as tests/golden/make_golden_corr.py VARIANTS)
+GF_CORR_VARIANTS = {
+    "corr": dict(optimizer="SGD", sf_corr=True, sf_corr_weight=0.05, sf_corr_loss_type="point-point"),
+    "corradam": dict(optimizer="Adam", sf_corr=True, sf_corr_weight=0.05, sf_corr_loss_type="point-point",
+                     learning_rate=1e-4),
+    "corrpp": dict(optimizer="SGD", sf_corr=True, sf_corr_weight=0.5, sf_corr_loss_type="point-plane"),
+    "corronly": dict(optimizer="SGD", sf_corr=True, sf_corr_weight=0.05, sf_corr_loss_type="point-point",
+                     sf_point_plane=False),
+}
+
+
+def load_corr_golden():
+    g = np.load(os.path.join(GOLDEN_DIR, "s60x80_j48_corr.npz"))
+    sc = synth.Scene(H=int(g["H"]), W=int(g["W"]), K=g["K"],
+                     **{k[3:]: g[k] for k in g.files if k.startswith("in_")})
+    return g, sc

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(SlmConfig) == 8 * 4 + 6 * 8
     assert C.sizeof(SlmIterRecord) == 2 * 8 + 4 * 4
     from super_amd._lib import SlmGfConfig, SlmGfSemantic
-    assert C.sizeof(SlmGfConfig) == 10 * 4 + 7 * 8
+    assert C.sizeof(SlmGfConfig) == 10 * 4 + 8 * 8
     assert C.sizeof(SlmGfSemantic) == 2 * 4 + 5 * 8
     assert C.sizeof(SlmFrame) == 7 * 4 + 4 * 4 + 4 + 9 * 8 + 2 * 4   # 4 bytes padding before pointers; state_f64 + pad
 

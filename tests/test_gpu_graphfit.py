@@ -167,7 +167,7 @@ def test_surfel_sharded_ranks_reproduce_the_single_gpu_solve(tag, world):
     ranks = [GraphFit(opt, rank=r, world=world, all_reduce=lambda t: None) for r in range(world)]
     for gf in ranks:
         gf.bind(inputs, sf, new_data)
-    n = (sc.J + 1) * 7 + 8
+    n = (sc.J + 1) * 7 + 10      # SLM_GF_NTERMS
     bufs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in ranks]
 
     def all_reduce():

@@ -4,15 +4,22 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GF_SEMANTIC_VARIANTS, load_golden
+from helpers import GF_CORR_VARIANTS, GF_SEMANTIC_VARIANTS, load_corr_golden, load_golden
 from oracle import graphfit_oracle as gfo
 
 CASES = [("s60x80_j48", "sgd"), ("s60x80_j48", "adam"), ("s60x80_j48", "sgdface"),
          ("s60x80_j48_reject", "sgd"), ("s60x80_j48_reject", "adam")]
 CASES += [("s60x80_j48_semantic", t) for t in GF_SEMANTIC_VARIANTS]   # Semantic-SuPer terms
+CASES += [("s60x80_j48_corr", t) for t in GF_CORR_VARIANTS]           # flow-correspondence term (opt.sf_corr)
+
+
+def _load(name):
+    return load_corr_golden() if name == "s60x80_j48_corr" else load_golden(name)[:2]
 
 
 def _opt(tag):
+    if tag in GF_CORR_VARIANTS:
+        return gfo.default_opt(**GF_CORR_VARIANTS[tag])
     if tag in GF_SEMANTIC_VARIANTS:
         return gfo.default_opt(**GF_SEMANTIC_VARIANTS[tag])
     return gfo.default_opt(optimizer="Adam" if tag == "adam" else "SGD", mesh_face=(tag == "sgdface"))
@@ -20,7 +27,7 @@ def _opt(tag):
 
 @pytest.mark.parametrize("name,tag", CASES)
 def test_iteration0_losses_and_gradient(name, tag):
-    g, sc, _ = load_golden(name)
+    g, sc = _load(name)
     pb = gfo.Problem(sc)
     dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64)
     dv[:, 0] = 1.0
@@ -39,7 +46,7 @@ def test_iteration0_losses_and_gradient(name, tag):
 
 @pytest.mark.parametrize("name,tag", CASES)
 def test_final_deform_verts(name, tag):
-    g, sc, _ = load_golden(name)
+    g, sc = _load(name)
     dv = gfo.graphfit(gfo.Problem(sc), _opt(tag))
     np.testing.assert_allclose(dv, g[f"gf_{tag}_final"], rtol=0, atol=1e-10)
     assert np.abs(dv - np.eye(1, 7)).max() > 1e-7      # the optimiser moved
@@ -64,3 +71,20 @@ def test_semantic_edge_points_and_weights_are_nontrivial():
     assert 0 < float(hard) < float(plain)
     assert 0 < mc < m
     assert float(gfo.bn_morph(pb, sf)) > 15
+
+
+def test_corr_fixture_is_nontrivial():
+    """the flow moves the sample positions by a fraction of a pixel to > 1 px, some surfels leave the valid
+    window or hit unmapped taps, and the correspondence term carries a visible share of the gradient"""
+    g, sc = load_corr_golden()
+    assert 0.5 < np.abs(sc.flow).max() < 3 and sc.flow.shape == (1, 2, sc.H, sc.W)
+    pb = gfo.Problem(sc)
+    dv = torch.zeros((sc.J + 1, 7), dtype=torch.float64)
+    dv[:, 0] = 1.0
+    _, sf = gfo.deform(pb, dv)
+    _, m_pp = gfo.point_plane(pb, sf)
+    _, m_c = gfo.corr_term(pb, sf)
+    assert 0 < m_c < sc.N and m_c != m_pp
+    d = np.abs(g["gf_corr_grad0"] - g["gf_corronly_grad0"]).max()
+    assert d > 1e-3 * np.abs(g["gf_corr_grad0"]).max()
+    assert np.abs(g["gf_corronly_grad0"]).max() > 1e-6
