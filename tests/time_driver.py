@@ -1,6 +1,15 @@
 """Diagnostic: end-to-end ms/frame of the driver mirror (super_amd.super.SuPer) at the SuPer image size:
 depth_preprocessing -> LM (10 iterations) -> Surfels.update -> fuseInputData -> swap, per stage."""
 import sys, os, time
+# Host thread pools: on the GPU box (256 logical CPUs, cgroup quota of 16 CPUs per 100 ms) the default OpenMP /
+# BLAS pools of torch and numpy (256 spinning threads after every small CPU op) exhaust the quota and the whole
+# process is CFS-throttled for ~25 ms every 100 ms -- every third frame took 45 instead of 19 ms.  The library
+# itself starts no threads; cap the pools like any latency-sensitive host program would.  DRIVER_THREADS=0 keeps
+# the defaults (to reproduce the stalls; nr_throttled of /sys/fs/cgroup/cpu.stat is printed at the end).
+_thr = os.environ.get("DRIVER_THREADS", "4")
+if _thr != "0":
+    for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(_k, _thr)
 from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "python-super_amd")); sys.path.insert(0, ROOT)
@@ -26,8 +35,20 @@ opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, 
                       th_cosine_ang=0.4, th_time_steps=30, disable_merging_new_surfels=False,
                       disable_merging_exist_surfels=False, disable_adding_new_surfels=False,
                       disable_removing_unstable_surfels=False)
+if os.environ.get("DRIVER_SOLVER_PATH"):
+    opt.slm_solver_path = int(os.environ["DRIVER_SOLVER_PATH"])
 model = drv.SuPer(opt)
 stages = {}
+
+
+def cpu_stat():
+    try:
+        return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat"))}
+    except OSError:
+        return {}
+
+
+stat0 = cpu_stat()
 
 
 def timed(name, fn):
@@ -91,10 +112,18 @@ for k in range(frames):
 print("surfels", int(model.sf.points.shape[0]), "nodes", model.sf.ED_nodes.num, "path", "LM" if derived else "GraphFit",
       "| torch reserved MB", torch.cuda.memory_reserved() >> 20, "| device used MB",
       (torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) >> 20)
-print("ms/frame (frames 4..):", round(float(np.mean(tot[4:])), 2), "all:", [round(t, 1) for t in tot])
+print("ms/frame (frames 4..):", round(float(np.mean(tot[4:])), 2), "all:", [round(t, 1) for t in tot[:40]])
+tt = np.array(tot[4:])
+print(f"frame time over {len(tt)} frames: median {np.median(tt):.2f} ms, p90 {np.percentile(tt, 90):.2f}, p99 {np.percentile(tt, 99):.2f}, "
+      f"max {tt.max():.2f}; p99 / median = {np.percentile(tt, 99) / np.median(tt):.3f}")
 ev = np.array(events)
 d = np.diff(ev, axis=0)
 slow = [i + 1 for i in range(len(d)) if tot[i + 1] > 1.3 * np.median(tot)]
+stat1 = cpu_stat()
+if stat1:
+    print("host: torch threads", torch.get_num_threads(), "| cgroup cpu.max", open("/sys/fs/cgroup/cpu.max").read().strip(),
+          "| CFS periods throttled during the run:", stat1.get("nr_throttled", 0) - stat0.get("nr_throttled", 0),
+          "| throttled ms:", (stat1.get("throttled_usec", 0) - stat0.get("throttled_usec", 0)) // 1000)
 print("slow frames:", [(i, round(tot[i], 1), "reallocs", int(d[i - 1][0]), "MB", int(d[i - 1][1]) >> 20, "plan builds", int(d[i - 1][2])) for i in slow[:25]])
 print("totals: reallocs", ev[-1][0], "plan builds", ev[-1][2], "plan reuses", ev[-1][3])
 for k, v in stages.items():
