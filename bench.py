@@ -338,7 +338,7 @@ def fusion_timing(device):
     ms = sum(t_fuse) / len(t_fuse)
     return {"fuse_ms_per_frame": ms, "swap_ms_per_frame": sum(t_swap) / len(t_swap), "surfels_in": n,
             "surfels_after_fuse": rows[0], "surfels_after_swap": rows[1], "algorithmic_bytes": nbytes,
-            "achieved_GBps": nbytes / ms / 1e6, "note": "C calls with resident buffers; 3 count read-backs inside"}
+            "achieved_GBps": nbytes / ms / 1e6, "note": "C calls with resident buffers; one count read-back per call (2 per frame)"}
 
 
 def main():
@@ -348,6 +348,8 @@ def main():
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:   # one rank per GPU: do not let every rank start a host pool as wide as the machine (CFS quota)
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // world)))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:

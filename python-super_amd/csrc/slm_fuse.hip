@@ -37,7 +37,10 @@ struct slm_fuse {
   int32_t* cand_idx = nullptr;  // (H*W,4) nearest nodes of the candidate pixels
   double* cand_w = nullptr;     // (H*W,4)
   uint8_t* dead = nullptr;      // (cap) surfels to drop after the pairwise merges
-  int32_t* counters = nullptr;  // [0] layers in use, [1] candidates without 4 nodes of their class
+  int32_t* counters = nullptr;  // [0] layers in use, [1] candidates without 4 nodes of their class, [2] set flags (k_fu_total)
+  int32_t* h_counters = nullptr;   // pinned host copy of counters: one small D2H read-back per call
+  double* boxes = nullptr;         // (ceil(J / FU_RUN), 6) bounding boxes of the node runs (candidate search)
+  size_t cap_boxes = 0;
   slm_fuse_semantic sem{};      // segmentation fields (num_classes == 0: none)
   int32_t* s_seg = nullptr;     // compaction scratch of the segmentation fields
   double *s_sc = nullptr, *s_d2e = nullptr;
@@ -96,18 +99,24 @@ __global__ void __launch_bounds__(256) k_fu_layers(int n, int HW, const unsigned
                                                     const int32_t* __restrict__ sids, int32_t* __restrict__ layers,
                                                     uint8_t* __restrict__ dead, int32_t* __restrict__ counters) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  const unsigned long long k = skeys[e];
-  if (k == ~0ull) return;
-  const unsigned pix = (unsigned)(k >> 32);
-  int rank = 0;
-  while (rank < FU_LAYERS && e - rank - 1 >= 0 && (unsigned)(skeys[e - rank - 1] >> 32) == pix) ++rank;
-  if (rank < FU_LAYERS) {
-    layers[(size_t)rank * HW + pix] = sids[e];
-    atomicMax(&counters[0], rank + 1);
-  } else {
-    dead[sids[e]] = 1;    // beyond the 16 maps: dropped when surfels are merged (nodes.py:390-391)
+  int used = 0;   // layer maps this element needs
+  if (e < n) {
+    const unsigned long long k = skeys[e];
+    if (k != ~0ull) {
+      const unsigned pix = (unsigned)(k >> 32);
+      int rank = 0;
+      while (rank < FU_LAYERS && e - rank - 1 >= 0 && (unsigned)(skeys[e - rank - 1] >> 32) == pix) ++rank;
+      if (rank < FU_LAYERS) {
+        layers[(size_t)rank * HW + pix] = sids[e];
+        used = rank + 1;
+      } else {
+        dead[sids[e]] = 1;    // beyond the 16 maps: dropped when surfels are merged (nodes.py:390-391)
+      }
+    }
   }
+  // one atomic per wavefront instead of one per surfel
+  for (int off = 32; off >= 1; off >>= 1) used = max(used, __shfl_xor(used, off));
+  if ((threadIdx.x & 63) == 0 && used > 0) atomicMax(&counters[0], used);
 }
 
 struct FuRow {
@@ -186,10 +195,11 @@ __device__ __forceinline__ bool fu_merge(const slm_fuse_config& c, const slm_sur
 // one thread per pixel: new point -> first matching layer, else candidate (flag = 1)
 __global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm,
                                                        slm_new_frame fr, const int32_t* __restrict__ layers,
-                                                       int n_layers, int32_t* __restrict__ flag) {
+                                                       const int32_t* __restrict__ n_layers_dev, int32_t* __restrict__ flag) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   const int HW = c.H * c.W;
   if (pix >= HW) return;
+  const int n_layers = *n_layers_dev;   // number of layer maps in use (k_fu_layers, earlier in the stream)
   int out = 0;
   if (fr.valid[pix]) {
     out = 1;
@@ -226,11 +236,13 @@ __global__ void __launch_bounds__(256) k_fu_merge_new(slm_fuse_config c, slm_sur
 
 // one thread per pixel: pairwise fusion of the surfels that share the pixel (nodes.py:424-447)
 __global__ void __launch_bounds__(256) k_fu_merge_exist(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm, int time,
-                                                         const int32_t* __restrict__ layers, int n_layers,
-                                                         uint8_t* __restrict__ dead) {
+                                                         const int32_t* __restrict__ layers,
+                                                         const int32_t* __restrict__ n_layers_dev, uint8_t* __restrict__ dead) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   const int HW = c.H * c.W;
   if (pix >= HW) return;
+  const int n_layers = min(*n_layers_dev, FU_LAYERS);
+  if (n_layers < 2) return;
   int id[FU_LAYERS];
   unsigned present = 0;
   for (int l = 0; l < n_layers; ++l) {
@@ -323,21 +335,96 @@ __global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m, slm_fuse
   for (int k = 0; k < 4; ++k) m.knn_w[4 * (size_t)i + k] = w[k];
 }
 
+// Bounding boxes of the ED nodes in runs of FU_RUN consecutive indices (the node graph is a mesh grid in
+// row-major order, so a run is a compact row segment; any other order only prunes less).  One wave per run.
+#define FU_RUN 32
+__global__ void __launch_bounds__(64) k_fu_node_boxes(int J, const double* __restrict__ ed_points, double* __restrict__ boxes) {
+  const int b = blockIdx.x, j = b * FU_RUN + (threadIdx.x & (FU_RUN - 1));
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  if (threadIdx.x < FU_RUN && j < J)
+    for (int k = 0; k < 3; ++k) lo[k] = hi[k] = ed_points[3 * (size_t)j + k];
+  for (int off = 32; off >= 1; off >>= 1)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fmin(lo[k], __shfl_xor(lo[k], off));
+      hi[k] = fmax(hi[k], __shfl_xor(hi[k], off));
+    }
+  if (threadIdx.x < 3) boxes[6 * (size_t)b + threadIdx.x] = lo[threadIdx.x];
+  else if (threadIdx.x < 6) boxes[6 * (size_t)b + threadIdx.x] = hi[threadIdx.x - 3];
+}
+
+// squared distance from p to the box (0 inside)
+__device__ __forceinline__ double fu_box_d2(const double* __restrict__ bx, double px, double py, double pz) {
+  const double dx = fmax(fmax(bx[0] - px, px - bx[3]), 0.0);
+  const double dy = fmax(fmax(bx[1] - py, py - bx[4]), 0.0);
+  const double dz = fmax(fmax(bx[2] - pz, pz - bx[5]), 0.0);
+  return dx * dx + dy * dy + dz * dz;
+}
+
 // candidate pixels: 4 nearest nodes (squared L2 ascending, lowest index first), stability test.
-// Node positions are staged through LDS in tiles of FU_TILE (broadcast reads), four distances per
-// step, and the sorted insertion only runs when one of them beats the current 4th best.
-#define FU_TILE 1024
+// Exact search with pruning instead of a J-wide scan per pixel: every lane finds the run of nodes whose box is
+// nearest to its point; those runs are scanned first (a tight 4th-best bound), then only the runs whose box is not
+// farther than some lane's bound.  The top-4 is kept in lexicographic (distance, index) order, so the result is
+// the one of the ascending brute-force scan whatever the visiting order.  The control flow is WAVE-UNIFORM -- a run
+// is scanned by the whole wavefront when any of its lanes needs it (neighbouring pixels need the same runs; a
+// lane that did not is not harmed by the extra insert tests) -- so node and box coordinates come through the
+// scalar cache (s_load) instead of 64 identical vector loads per step.
+__device__ __forceinline__ void fu_insert(double d2, int j, double bd[4], int bi[4]) {
+  if (d2 < bd[3] || (d2 == bd[3] && j < bi[3])) {
+    int k = 3;
+    while (k > 0 && (d2 < bd[k - 1] || (d2 == bd[k - 1] && j < bi[k - 1]))) {
+      bd[k] = bd[k - 1];
+      bi[k] = bi[k - 1];
+      --k;
+    }
+    bd[k] = d2;
+    bi[k] = j;
+  }
+}
+
+__device__ __forceinline__ void fu_scan_run(const slm_surfel_model& m, const slm_fuse_semantic& sm, bool by_class, int cls,
+                                            int b, double px, double py, double pz, double bd[4], int bi[4]) {
+  const int j0 = b * FU_RUN, j1 = min(j0 + FU_RUN, m.J);
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {          // four nodes per step: their 12 coordinates are requested together
+    const double* g = m.ed_points + 3 * (size_t)j;
+    double q[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) q[e] = g[e];
+    int cl[4] = {cls, cls, cls, cls};
+    if (by_class) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cl[e] = sm.ed_seg[j + e];
+    }
+    double d2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double dx = px - q[3 * e], dy = py - q[3 * e + 1], dz = pz - q[3 * e + 2];
+      d2[e] = dx * dx + dy * dy + dz * dz;
+      if (cl[e] != cls) d2[e] = 2e300;     // other class: never a neighbour (2e300 > every list entry)
+    }
+    if (fmin(fmin(d2[0], d2[1]), fmin(d2[2], d2[3])) <= bd[3]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fu_insert(d2[e], j + e, bd, bi);
+    }
+  }
+  for (; j < j1; ++j) {
+    const double* g = m.ed_points + 3 * (size_t)j;
+    const double dx = px - g[0], dy = py - g[1], dz = pz - g[2];
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (!(by_class && sm.ed_seg[j] != cls)) fu_insert(d2, j, bd, bi);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm,
                                                         slm_new_frame fr, int32_t* __restrict__ flag,
                                                         int32_t* __restrict__ cand_idx, double* __restrict__ cand_w,
-                                                        int32_t* __restrict__ counters) {
-  __shared__ double nodes[3 * FU_TILE];
-  __shared__ int ncls[FU_TILE];
+                                                        int32_t* __restrict__ counters, const double* __restrict__ boxes) {
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   const bool act = pix < c.H * c.W && flag[pix] != 0;
+  if (__ballot(act) == 0ull) return;   // no candidate pixel in this wavefront (the common case once the model covers the scene)
   const bool by_class = sm.num_classes > 0 && sm.hard_seg;   // neighbours among the nodes of the point's class
   double px = 0.0, py = 0.0, pz = 0.0;
-  int t = 0, cls = 0;
+  int t = 0, cls = -1;
   if (act) {
     t = fr.index_map[pix];
     px = fr.points[3 * (size_t)t];
@@ -345,44 +432,34 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
     pz = fr.points[3 * (size_t)t + 2];
     if (by_class) cls = sm.new_seg[t];
   }
-  if (!__syncthreads_or(act ? 1 : 0)) return;   // no candidate pixel in this block (the common case once the model covers the scene)
-  double bd[4] = {1e300, 1e300, 1e300, 1e300};
-  int bi[4] = {-1, -1, -1, -1};
-  for (int j0 = 0; j0 < m.J; j0 += FU_TILE) {
-    const int cnt = min(FU_TILE, m.J - j0);
-    __syncthreads();
-    for (int e = threadIdx.x; e < 3 * cnt; e += blockDim.x) nodes[e] = m.ed_points[3 * (size_t)j0 + e];
-    if (by_class)
-      for (int e = threadIdx.x; e < cnt; e += blockDim.x) ncls[e] = sm.ed_seg[j0 + e];
-    __syncthreads();
-    if (!act) continue;
-    for (int jj = 0; jj < cnt; jj += 4) {
-      double d2[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = jj + q < cnt ? jj + q : cnt - 1;     // tail: repeats the last node, rejected below
-        const double dx = px - nodes[3 * k], dy = py - nodes[3 * k + 1], dz = pz - nodes[3 * k + 2];
-        d2[q] = dx * dx + dy * dy + dz * dz;
-        if (by_class && ncls[k] != cls) d2[q] = 1e300;       // other class: never a neighbour
-      }
-      if (fmin(fmin(d2[0], d2[1]), fmin(d2[2], d2[3])) < bd[3]) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (jj + q < cnt && d2[q] < bd[3]) {
-            int k = 3;
-            while (k > 0 && d2[q] < bd[k - 1]) {
-              bd[k] = bd[k - 1];
-              bi[k] = bi[k - 1];
-              --k;
-            }
-            bd[k] = d2[q];
-            bi[k] = j0 + jj + q;
-          }
-        }
-      }
+  // lanes without a candidate follow the wave with a list nothing can enter
+  const double init = act ? 1e300 : -1.0;
+  double bd[4] = {init, init, init, init};
+  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  const int n_runs = (m.J + FU_RUN - 1) / FU_RUN;
+  int seed = -1;
+  double seed_d2 = 1e300;
+  for (int b = 0; b < n_runs; ++b) {
+    const double d2 = fu_box_d2(boxes + 6 * (size_t)b, px, py, pz);
+    if (act && d2 < seed_d2) {
+      seed_d2 = d2;
+      seed = b;
     }
   }
+  unsigned long long pend = __ballot(act && seed >= 0);
+  while (pend) {
+    const int sb = __builtin_amdgcn_readfirstlane(__shfl(seed, __ffsll((long long)pend) - 1));
+    fu_scan_run(m, sm, by_class, cls, sb, px, py, pz, bd, bi);
+    pend &= ~__ballot(seed == sb);
+  }
+  for (int b = 0; b < n_runs; ++b) {
+    const bool need = act && fu_box_d2(boxes + 6 * (size_t)b, px, py, pz) <= bd[3];   // equal: a tie with a lower index may be inside
+    if (__ballot(need) == 0ull) continue;
+    if (__ballot(act && seed == b) != 0ull) continue;     // scanned above as some lane's nearest run
+    fu_scan_run(m, sm, by_class, cls, b, px, py, pz, bd, bi);
+  }
   if (!act) return;
+  if (bd[3] >= 1e300) bi[3] = -1;      // fewer than 4 nodes (of this class)
   if (bi[3] < 0) {       // fewer than 4 nodes of this class: the reference asserts (utils/utils.py:237)
     atomicAdd(&counters[1], 1);
     flag[pix] = 0;
@@ -516,16 +593,18 @@ hipError_t scan_flags(slm_fuse* f, int n, hipStream_t st) {
   return rocprim::exclusive_scan(f->tmp, bytes, f->flag, f->pos, 0, (size_t)n, rocprim::plus<int32_t>(), st);
 }
 
-// number of set flags among the first n entries (after scan_flags); synchronises the stream
-hipError_t count_flags(slm_fuse* f, int n, hipStream_t st, int* out) {
-  int32_t last[2] = {0, 0};
-  if (n > 0) {
-    hipError_t e = hipMemcpyAsync(&last[0], f->pos + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], f->flag + n - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return e;
-  }
-  hipError_t e = hipStreamSynchronize(st);
-  *out = last[0] + last[1];
+__global__ void k_fu_total(const int32_t* __restrict__ pos, const int32_t* __restrict__ flag, int n, int32_t* __restrict__ counters) {
+  counters[2] = n > 0 ? pos[n - 1] + flag[n - 1] : 0;
+}
+
+// number of set flags among the first n entries (after scan_flags) in *out, counters[1] in *aux: one read-back
+// of the counter block into pinned memory; synchronises the stream
+hipError_t count_flags(slm_fuse* f, int n, hipStream_t st, int* out, int* aux = nullptr) {
+  hipLaunchKernelGGL(k_fu_total, dim3(1), dim3(1), 0, st, f->pos, f->flag, n, f->counters);
+  hipError_t e = hipMemcpyAsync(f->h_counters, f->counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  *out = f->h_counters[2];
+  if (aux) *aux = f->h_counters[1];
   return e;
 }
 
@@ -552,6 +631,7 @@ int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out) {
   if (e == hipSuccess) e = falloc(f->cand_w, 4 * HW);
   if (e == hipSuccess) e = falloc(f->dead, cap);
   if (e == hipSuccess) e = falloc(f->counters, 4);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_counters, sizeof(int32_t) * 4, hipHostMallocDefault);
   if (e == hipSuccess) e = falloc(f->s_d3, 6 * cap);
   if (e == hipSuccess) e = falloc(f->s_d1, cap);
   if (e == hipSuccess) e = falloc(f->s_d4, 4 * cap);
@@ -574,10 +654,11 @@ int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out) {
 int slm_fuse_destroy(slm_fuse* f) {
   if (!f) return SLM_OK;
   void* ptrs[] = {f->keys, f->skeys, f->ids, f->sids, f->layers, f->flag, f->pos, f->cand_idx, f->cand_w, f->dead,
-                  f->counters, f->tmp, f->s_d3, f->s_d1, f->s_d4, f->s_f3, f->s_f1, f->s_f2, f->s_i4, f->s_seg, f->s_sc,
+                  f->counters, f->boxes, f->tmp, f->s_d3, f->s_d1, f->s_d4, f->s_f3, f->s_f1, f->s_f2, f->s_i4, f->s_seg, f->s_sc,
                   f->s_d2e};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (f->h_counters) (void)hipHostFree(f->h_counters);
   delete f;
   return SLM_OK;
 }
@@ -628,11 +709,15 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
   FCHK(hipMemsetAsync(f->layers, 0xFF, sizeof(int32_t) * FU_LAYERS * (size_t)HW, st));
   FCHK(hipMemsetAsync(f->dead, 0, (size_t)f->cap, st));
   FCHK(hipMemsetAsync(f->counters, 0, sizeof(int32_t) * 4, st));
-  int n_layers = 0;
+  // (the number of layer maps in use stays on the device, counters[0]: no read-back between the stages)
   if (n > 0) {
     hipLaunchKernelGGL(k_fu_keys, gs, blk, 0, st, c, m, f->keys, f->ids);
     size_t bytes = 0;
-    FCHK(rocprim::radix_sort_pairs(nullptr, bytes, f->keys, f->skeys, f->ids, f->sids, (size_t)n, 0, 64, st));
+    // keys are (pixel << 32) | ~confidence, or ~0 for surfels that do not project: the significant bits are the 32
+    // confidence bits and the bits of H*W (one more so that the all-ones key still sorts last)
+    unsigned end_bit = 33;
+    while (end_bit < 64 && (1ull << (end_bit - 32)) <= (unsigned long long)HW) ++end_bit;
+    FCHK(rocprim::radix_sort_pairs(nullptr, bytes, f->keys, f->skeys, f->ids, f->sids, (size_t)n, 0, end_bit, st));
     if (bytes > f->cap_tmp) {
       if (f->tmp) FCHK(hipFree(f->tmp));
       f->tmp = nullptr;
@@ -640,31 +725,35 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
       FCHK(hipMalloc(&f->tmp, bytes));
       f->cap_tmp = bytes;
     }
-    FCHK(rocprim::radix_sort_pairs(f->tmp, bytes, f->keys, f->skeys, f->ids, f->sids, (size_t)n, 0, 64, st));
+    FCHK(rocprim::radix_sort_pairs(f->tmp, bytes, f->keys, f->skeys, f->ids, f->sids, (size_t)n, 0, end_bit, st));
     hipLaunchKernelGGL(k_fu_layers, gs, blk, 0, st, n, HW, f->skeys, f->sids, f->layers, f->dead, f->counters);
-    FCHK(hipMemcpyAsync(&n_layers, f->counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    FCHK(hipStreamSynchronize(st));
   }
   // 2. the frame's points into the layers; flag = candidate new surfel
-  hipLaunchKernelGGL(k_fu_merge_new, gp, blk, 0, st, c, m, sm, *frame, f->layers, n_layers, f->flag);
+  hipLaunchKernelGGL(k_fu_merge_new, gp, blk, 0, st, c, m, sm, *frame, f->layers, f->counters, f->flag);
   // 3. surfels that share a pixel; drop the absorbed ones and those beyond the 16 maps
-  if (c.merge_exist && n_layers > 0) {
-    if (n_layers > 1)
-      hipLaunchKernelGGL(k_fu_merge_exist, gp, blk, 0, st, c, m, sm, frame->time, f->layers, n_layers, f->dead);
+  if (c.merge_exist && n > 0) {
+    hipLaunchKernelGGL(k_fu_merge_exist, gp, blk, 0, st, c, m, sm, frame->time, f->layers, f->counters, f->dead);
     hipLaunchKernelGGL(k_fu_apply_dead, gs, blk, 0, st, n, f->dead, m.is_stable);
   }
   // 4. skinning weights at the fused positions
   if (n > 0) hipLaunchKernelGGL(k_fu_weights, gs, blk, 0, st, m, sm);
   // 5. unmatched points with a nearby node become new surfels, in row-major pixel (= sfdata) order
   int n_new = 0;
-  if (c.add_new && c.merge_new && n_layers > 0) {
+  if (c.add_new && c.merge_new && n > 0) {   // (no surfel projects anywhere -> every flag is 0, nothing is added)
+    const int n_runs = (m.J + FU_RUN - 1) / FU_RUN;
+    if ((size_t)n_runs > f->cap_boxes) {
+      if (f->boxes) FCHK(hipFree(f->boxes));
+      f->boxes = nullptr;
+      f->cap_boxes = 0;
+      FCHK(hipMalloc((void**)&f->boxes, sizeof(double) * 6 * (size_t)n_runs));
+      f->cap_boxes = (size_t)n_runs;
+    }
+    hipLaunchKernelGGL(k_fu_node_boxes, dim3(n_runs), dim3(64), 0, st, m.J, m.ed_points, f->boxes);
     hipLaunchKernelGGL(k_fu_candidates, gp, blk, 0, st, c, m, sm, *frame, f->flag, f->cand_idx, f->cand_w,
-                       f->counters);
+                       f->counters, f->boxes);
     FCHK(scan_flags(f, HW, st));
     int n_short = 0;
-    if (sm.num_classes > 0 && sm.hard_seg)
-      FCHK(hipMemcpyAsync(&n_short, f->counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    FCHK(count_flags(f, HW, st, &n_new));
+    FCHK(count_flags(f, HW, st, &n_new, &n_short));
     if (n_short > 0)
       return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: hard_seg needs at least 4 ED nodes of every class that has new points");
     if (n + n_new > m.cap) return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: model capacity too small for the new surfels");
@@ -693,10 +782,10 @@ int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mod
     hipLaunchKernelGGL(k_fu_force_keep, dim3((n_keep + 63) / 64), dim3(64), 0, st, n, n_keep, keep_ids, f->flag);
   FCHK(scan_flags(f, n, st));
   if (new_index) hipLaunchKernelGGL(k_fu_new_index, gs, blk, 0, st, n, f->flag, f->pos, new_index);
+  slm_fuse scratch = *f;
+  hipLaunchKernelGGL(k_fu_compact, gs, blk, 0, st, m, scratch, f->flag, f->pos);   // before the read-back: runs under it
   int kept = 0;
   FCHK(count_flags(f, n, st, &kept));
-  slm_fuse scratch = *f;
-  hipLaunchKernelGGL(k_fu_compact, gs, blk, 0, st, m, scratch, f->flag, f->pos);
   const size_t k = (size_t)kept, cap = (size_t)m.cap;
   if (kept > 0) {
     FCHK(hipMemcpyAsync(m.points, f->s_d3, sizeof(double) * 3 * k, hipMemcpyDeviceToDevice, st));
