@@ -406,8 +406,11 @@ def main():
                 st.wait_stream(main)
         for k, (e, st) in enumerate(zip(engs, streams)):
             with torch.cuda.stream(st):
-                for i in range(Bs):
-                    e.bind(i, work[k * Bs + i])          # loss_term.prepare (LM.py:93-94)
+                if os.environ.get("BENCH_SEQ_BIND"):     # A/B knob: one slm_bind_frame per frame
+                    for i in range(Bs):
+                        e.bind(i, work[k * Bs + i])
+                else:
+                    e.bind_batch(work[k * Bs:(k + 1) * Bs])  # loss_term.prepare (LM.py:93-94), the frames concurrently
                 e.run(Bs)                                # LM_Solver.LM         (LM.py:95-117)
                 for i in range(Bs):
                     e.beta(i, betas[k * Bs + i])

@@ -130,6 +130,12 @@ int slm_device_count(void);
  * matrix from the KNN tables (one 4-byte device->host read, stream-synchronising)
  * and (re)sizes the slot's workspace.  Resets beta to identity. */
 int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* frame, void* stream);
+/* The same for the n_frames frames of a batch, slots [first_slot, first_slot + n_frames), `frames` an array in
+ * host memory.  The preparation of a frame is a chain of small launches and size read-backs (latency, not
+ * throughput), so the frames are bound concurrently: one host thread, stream and set of scratch buffers per frame
+ * inside the library (at most 8 at a time), forked from `stream` (they see the work enqueued on it so far) and
+ * joined back into it before the call returns.  Results are those of n_frames slm_bind_frame calls. */
+int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const slm_frame* frames, void* stream);
 
 /* -- the LM loop ------------------------------------------------------------------ */
 /* Enqueues num_iterations damped accept/reject iterations for slots [0,n_frames),

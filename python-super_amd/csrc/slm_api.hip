@@ -1,6 +1,9 @@
 // slm_api.hip -- the C ABI of libsuper_lm.so (include/super_lm.h): slot workspaces,
 // the on-device LM loop, parity entry points.  Host side only orchestrates launches.
+#include <atomic>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <algorithm>
 #include <vector>
 #include <cstdio>
@@ -34,7 +37,7 @@ void launch_iter_begin(const FrameDev*, int, hipStream_t);
 void launch_pack_nodes(const FrameDev*, int, int, hipStream_t);
 void launch_make_trial(const FrameDev*, int, int, hipStream_t);
 void launch_pack_target(int, const float*, const float*, float4*, hipStream_t);
-void launch_accept(const FrameDev*, int, int, int, hipStream_t);
+void launch_accept(const FrameDev*, int, int, int, int, hipStream_t);
 void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
 void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
@@ -112,6 +115,11 @@ struct Slot {
 
 struct slm_solver {
   PrepBuffers* prep = nullptr;
+  // slm_bind_frames: one worker (scratch buffers + stream + events) per frame bound concurrently
+  std::vector<PrepBuffers*> bind_prep;
+  std::vector<hipStream_t> bind_streams;
+  std::vector<hipEvent_t> bind_events;
+  std::mutex band_mutex;        // the bandwidth read-back buffer of ensure_band is shared
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
@@ -124,7 +132,7 @@ struct slm_solver {
 };
 
 // diagnostics (slm_debug_counters): device reallocations and symbolic analyses since the library was loaded
-static long long g_reallocs = 0, g_realloc_bytes = 0, g_plan_builds = 0, g_plan_reuses = 0, g_plan_fill_hits = 0;
+static std::atomic<long long> g_reallocs{0}, g_realloc_bytes{0}, g_plan_builds{0}, g_plan_reuses{0}, g_plan_fill_hits{0};   // (binds may run on worker threads)
 
 template <typename T>
 static hipError_t grow(T*& p, size_t& cap, size_t need) {
@@ -251,6 +259,9 @@ int slm_destroy(slm_solver* s) {
     if (sl.d_dag_trace) (void)hipFree(sl.d_dag_trace);
   }
   prep_destroy(s->prep);
+  for (PrepBuffers* pb : s->bind_prep) prep_destroy(pb);
+  for (hipStream_t q : s->bind_streams) (void)hipStreamDestroy(q);
+  for (hipEvent_t e : s->bind_events) (void)hipEventDestroy(e);
   for (auto& evs : s->ev_runs)
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
@@ -284,8 +295,14 @@ static int ensure_band(slm_solver* s, int slot, hipStream_t st) {
   return SLM_OK;
 }
 
+static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep);
+
 int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream) {
   if (!s || !f) return fail(SLM_ERR_INVALID, "slm_bind_frame: null argument");
+  return bind_frame_impl(s, slot, f, (hipStream_t)stream, s->prep);
+}
+
+static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep) {
   if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad slot");
   if (f->K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_neighbors must be 4");
   if (f->K_ED < 1 || f->K_ED > SLM_MAX_KED)
@@ -295,7 +312,6 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   if ((f->N > 0 && (!f->sf_points || !f->sf_knn_idx || !f->sf_knn_w)) || !f->ed_points || !f->ed_knn_idx ||
       (f->T > 0 && (!f->tgt_points || !f->tgt_norms)) || !f->index_map || !f->tgt_valid)
     return fail(SLM_ERR_INVALID, "slm_bind_frame: null device pointer");
-  hipStream_t st = (hipStream_t)stream;
   Slot& sl = s->slots[slot];
   FrameDev& h = sl.h;
 
@@ -349,7 +365,7 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   h.v1_ready = 0;
   if (s->cfg.use_data && s->cfg.data_path != 1 && f->J < 65536 && f->N > 0) {
     V1Sizes sz;
-    HIPCHK(prep_v1(s->prep, *f, sl.plan, &sz, st));
+    HIPCHK(prep_v1(prep, *f, sl.plan, &sz, st));
     if (sz.n_tuples > 0) {
       h.n_tuples = sz.n_tuples;
       h.n_pos = sz.n_pos;
@@ -551,11 +567,76 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // h is reused by later binds
   if (!h.nd_ready) {
+    std::lock_guard<std::mutex> lock(s->band_mutex);
     int rc = ensure_band(s, slot, st);
     if (rc) return rc;
   }
   launch_init_slot(s->frames_dev, slot, f->J, s->cfg, st);
   HIPCHK(hipGetLastError());
+  return SLM_OK;
+}
+
+int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const slm_frame* frames, void* stream) {
+  if (!s || !frames) return fail(SLM_ERR_INVALID, "slm_bind_frames: null argument");
+  if (first_slot < 0 || n_frames < 1 || first_slot + n_frames > (int)s->slots.size())
+    return fail(SLM_ERR_INVALID, "slm_bind_frames: slot range out of bounds");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_frames == 1) return bind_frame_impl(s, first_slot, frames, st, s->prep);
+  // The preparation of a frame is a chain of ~40 small launches and four size read-backs: latency, not
+  // throughput.  The frames of a batch are therefore bound CONCURRENTLY -- one host thread, stream and set of
+  // scratch buffers per frame (up to kBindWorkers at a time), forked from and joined into the caller's stream.
+  static const int kBindWorkers = [] {
+    const char* e = getenv("SLM_BIND_WORKERS");     // experiments
+    return e && atoi(e) > 0 ? atoi(e) : 8;
+  }();
+  const int W = std::min(n_frames, kBindWorkers);
+  while ((int)s->bind_prep.size() < W) {
+    PrepBuffers* pb = prep_create();
+    if (!pb) return fail(SLM_ERR_HIP, "slm_bind_frames: out of memory");
+    s->bind_prep.push_back(pb);
+  }
+  while ((int)s->bind_streams.size() < W) {
+    hipStream_t q = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    s->bind_streams.push_back(q);
+  }
+  while ((int)s->bind_events.size() < W + 1) {
+    hipEvent_t e = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->bind_events.push_back(e);
+  }
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  // The binds read sizes back, so they wait for the work already on `st` in any case: wait for it HERE, on one
+  // thread, rather than with W workers spinning in their first read-back for as long as the previous LM run takes
+  // (8 busy threads for tens of milliseconds per step cost the process its CPU quota on the GPU box).
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipEventRecord(s->bind_events[W], st));            // fork: the workers see everything enqueued on `st` so far
+  std::vector<int> rcs(W, SLM_OK);
+  std::vector<std::string> errs(W);
+  auto work = [&](int w) {
+    if (hipSetDevice(dev) != hipSuccess || hipStreamWaitEvent(s->bind_streams[w], s->bind_events[W], 0) != hipSuccess) {
+      rcs[w] = SLM_ERR_HIP;
+      errs[w] = "slm_bind_frames: worker setup failed";
+      return;
+    }
+    for (int i = w; i < n_frames; i += W) {
+      const int rc = bind_frame_impl(s, first_slot + i, frames + i, s->bind_streams[w], s->bind_prep[w]);
+      if (rc != SLM_OK) {
+        rcs[w] = rc;
+        errs[w] = g_err;        // thread-local text of this worker
+        return;
+      }
+    }
+    if (hipEventRecord(s->bind_events[w], s->bind_streams[w]) != hipSuccess) rcs[w] = SLM_ERR_HIP;
+  };
+  std::vector<std::thread> threads;
+  for (int w = 1; w < W; ++w) threads.emplace_back(work, w);
+  work(0);
+  for (std::thread& t : threads) t.join();
+  for (int w = 0; w < W; ++w)
+    if (rcs[w] != SLM_OK) return fail(rcs[w], errs[w].c_str());
+  for (int w = 0; w < W; ++w) HIPCHK(hipStreamWaitEvent(st, s->bind_events[w], 0));   // join
   return SLM_OK;
 }
 
@@ -774,7 +855,7 @@ int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream) {
   BatchDims d;
   int rc = shard_dims(s, n_frames, d);
   if (rc) return rc;
-  launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, (hipStream_t)stream);
+  launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, std::max(s->cfg.num_iterations, 1), (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -889,7 +970,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     mark();
     if (d.n_reg_part > 0)
       launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
-    launch_accept(fr, n_frames, c.phase_test, d.n_reg_part, st);
+    launch_accept(fr, n_frames, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st);
     mark();
   }
   HIPCHK(hipGetLastError());

@@ -64,8 +64,10 @@ __global__ void __launch_bounds__(256) k_iter_begin(const FrameDev* __restrict__
 // End of an iteration (reference super/LM.py:99-117): reduce the loss partials in a
 // fixed order, then accept (u /= v, beta += delta) or reject (u *= v, beta kept).
 // A failed factorisation stops the loop with beta unchanged.  grid = (1, n_frames), 1024 thr.
+// Records are kept for the first n_rec iterations after the bind (the capacity of fd.rec): running again
+// without binding continues the loop from the current state and records nothing more.
 __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ frames, int phase_test,
-                                                  int n_reg_part) {
+                                                  int n_reg_part, int n_rec) {
   __shared__ double sm[16];
   __shared__ int s_accept;
   const FrameDev& fd = frames[blockIdx.y];
@@ -75,11 +77,13 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
   const int it = st->iter;
   if (st->chol_fail) {
     if (threadIdx.x == 0) {
-      slm_iter_record r = fd.rec[it];
-      r.status = SLM_ITER_SOLVER_FAILED;
-      r.u = st->u;
-      r.M_grad = st->m_grad;
-      fd.rec[it] = r;
+      if (it < n_rec) {
+        slm_iter_record r = fd.rec[it];
+        r.status = SLM_ITER_SOLVER_FAILED;
+        r.u = st->u;
+        r.M_grad = st->m_grad;
+        fd.rec[it] = r;
+      }
       st->stopped = 1;
     }
     return;
@@ -112,7 +116,7 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
     r.status = SLM_ITER_OK;
     r.M_grad = st->m_grad;
     r.M_loss = (int)m;
-    fd.rec[it] = r;
+    if (it < n_rec) fd.rec[it] = r;
     st->iter = it + 1;
     s_accept = acc;
   }
@@ -487,10 +491,10 @@ void launch_iter_begin(const FrameDev* frames_dev, int n_frames, hipStream_t st)
   hipLaunchKernelGGL(k_iter_begin, dim3(1024, n_frames), dim3(256), 0, st, frames_dev);
 }
 
-void launch_accept(const FrameDev* frames_dev, int n_frames, int phase_test, int n_reg_part,
+void launch_accept(const FrameDev* frames_dev, int n_frames, int phase_test, int n_reg_part, int n_rec,
                    hipStream_t st) {
   hipLaunchKernelGGL(k_accept, dim3(1, n_frames), dim3(1024), 0, st, frames_dev, phase_test,
-                     n_reg_part);
+                     n_reg_part, n_rec);
 }
 
 void launch_loss_out(const FrameDev* frames_dev, int slot, int n_reg_part, double* out,

@@ -19,7 +19,7 @@ PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 GF_NTERMS = 10     # SLM_GF_NTERMS of include/super_lm.h
 
 EXPORTS = [
-    "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame",
+    "slm_create", "slm_destroy", "slm_last_error", "slm_device_count", "slm_bind_frame", "slm_bind_frames",
     "slm_run", "slm_profile_enable", "slm_profile_read", "slm_get_plan_info", "slm_get_beta", "slm_set_beta", "slm_get_records", "slm_assemble", "slm_loss",
     "slm_solve", "slm_solve_dense", "slm_data_residuals", "slm_apply_update", "slm_knn",
     "slm_knn_weights", "slm_gf_create", "slm_gf_destroy", "slm_gf_bind_frame", "slm_gf_run",
@@ -169,6 +169,7 @@ def load():
         "slm_debug_counters": [C.POINTER(C.c_int64)],
         "slm_debug_read": [vp, i32, i32, vp, C.c_int64, C.POINTER(C.c_int64), vp],
         "slm_debug_dag_trace": [vp, i32, i32, vp],
+        "slm_bind_frames": [vp, i32, i32, C.POINTER(SlmFrame), vp],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],

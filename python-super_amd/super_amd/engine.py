@@ -109,6 +109,14 @@ class Engine:
         _lib.check(self.lib.slm_bind_frame(self.h, slot, C.byref(cs), self.stream), "slm_bind_frame")
         self._frames[slot] = frame
 
+    def bind_batch(self, frames, first: int = 0):
+        """Binds ``frames`` to slots ``first ..`` concurrently (``slm_bind_frames``: one host thread / stream per
+        frame inside the library, forked from and joined into the current stream)."""
+        arr = (_lib.SlmFrame * len(frames))(*[f.c_struct() for f in frames])
+        _lib.check(self.lib.slm_bind_frames(self.h, first, len(frames), arr, self.stream), "slm_bind_frames")
+        for i, f in enumerate(frames):
+            self._frames[first + i] = f
+
     def run(self, n_frames: int):
         _lib.check(self.lib.slm_run(self.h, n_frames, self.stream), "slm_run")
 

@@ -1,0 +1,89 @@
+"""slm_bind_frames: the frames of a batch bound concurrently (worker threads / streams inside the library) give
+the same solver state as slm_bind_frame one by one.  Needs an MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+from helpers import GOLDENS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(dev):
+    from super_amd.engine import DeviceFrame
+    out = []
+    for name in GOLDENS + GOLDENS[:2] + GOLDENS:         # 10 frames: different sizes / plans, more than 8 workers
+        g, sc, _ = load_golden(name)
+        out.append((g if name in GOLDENS[:2] else None, DeviceFrame.from_scene(sc, dev)))     # [:2]: default options
+    return out
+
+
+@pytest.mark.parametrize("solver_path", [0, 3])
+def test_batch_bind_matches_sequential_binds_and_the_goldens(solver_path):
+    import torch
+    from super_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    fr = _frames(dev)
+    B = len(fr)
+    kw = dict(max_frames=B, solver_path=solver_path)
+    seq = Engine(dev, **kw)
+    for i, (_, f) in enumerate(fr):
+        seq.bind(i, f)
+    seq.run(B)
+    bat = Engine(dev, **kw)
+    bat.bind_batch([f for _, f in fr])
+    bat.run(B)
+    torch.cuda.synchronize()
+    for i, (g, _) in enumerate(fr):
+        a, b = seq.beta(i).cpu().numpy(), bat.beta(i).cpu().numpy()
+        np.testing.assert_allclose(b, a, rtol=0, atol=1e-11)
+        if g is not None:
+            np.testing.assert_allclose(b, g["lm_beta"], rtol=0, atol=1e-6)
+        ra, rb = seq.records(i), bat.records(i)
+        assert [r["status"] for r in ra] == [r["status"] for r in rb]
+        assert [r["accepted"] for r in ra] == [r["accepted"] for r in rb]
+    # binding again (steady state: plans cached) and a partial batch at an offset
+    bat.bind_batch([f for _, f in fr[:3]], first=4)
+    bat.run(B)
+    torch.cuda.synchronize()
+    for k in range(3):
+        np.testing.assert_allclose(bat.beta(4 + k).cpu().numpy(), seq.beta(k).cpu().numpy(), rtol=0, atol=1e-11)
+    seq.close()
+    bat.close()
+
+
+def test_batch_bind_reports_the_failing_frame():
+    import ctypes as C
+    import torch
+    from super_amd import _lib
+    from super_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    fr = _frames(dev)[:3]
+    eng = Engine(dev, max_frames=3)
+    cs = [f.c_struct() for _, f in fr]
+    cs[1].K = 5                                           # num_neighbors must be 4
+    arr = (_lib.SlmFrame * 3)(*cs)
+    rc = eng.lib.slm_bind_frames(eng.h, 0, 3, arr, eng.stream)
+    assert rc != 0
+    assert b"num_neighbors" in eng.lib.slm_last_error()
+    eng.close()
+
+
+def test_running_again_without_binding_keeps_the_first_records():
+    """slm_run twice on the same binding continues the loop; the record buffer (num_iterations entries) keeps the
+    first run's records and nothing is written past it (this used to fault after a few repetitions)."""
+    import torch
+    from super_amd.engine import Engine
+    dev = torch.device("cuda", 0)
+    (g, f), = _frames(dev)[:1]
+    eng = Engine(dev, max_frames=1)
+    eng.bind(0, f)
+    eng.run(1)
+    first = eng.records(0)
+    beta1 = eng.beta(0).cpu().numpy()
+    for _ in range(40):
+        eng.run(1)
+    torch.cuda.synchronize()
+    assert eng.records(0) == first
+    np.testing.assert_allclose(beta1, g["lm_beta"], rtol=0, atol=1e-6)
+    assert np.isfinite(eng.beta(0).cpu().numpy()).all()
+    eng.close()
