@@ -14,6 +14,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1 < /dev/null
   find $R/gpurun_out/${TAG}_pmc_$c -name '*kernel_trace.csv' -delete
 done
+# SQ counters of the same command (wave lifetime, waiting share, VALU share): two small passes
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
+  n=$(echo $grp | cut -d' ' -f2)
+  timeout 400 rocprofv3 --pmc $grp --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_sq_$n.log 2>&1 < /dev/null
+  find $R/gpurun_out/${TAG}_pmc_sq_$n -name '*kernel_trace.csv' -delete
+done
+python3 $R/profiles/make_sq_summary.py $R/gpurun_out/${TAG}_pmc_sq_*/ --out $R/gpurun_out/${TAG}_pmc_sq_summary.csv > /dev/null 2>&1
 # one frame per launch (the drop-in case): kernel stats of the task-graph solver
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats_b1 -name '*kernel_trace.csv' -delete
