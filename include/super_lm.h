@@ -76,8 +76,11 @@ typedef struct slm_config {
   int32_t solver_path;      /* 0 = nested-dissection multifrontal Cholesky (default, needs data_path 0); its numeric
                                phase runs as ONE persistent launch over a static task graph (per-tile flags instead
                                of launch boundaries: the latency form) for one or two frames per launch, and as one
-                               launch per level / tile column / phase for larger batches (the throughput form);
-                               2 / 3 force the task-graph / the per-level form; 1 = block-banded Cholesky */
+                               launch per level / tile column / phase for larger batches (the throughput form),
+                               with the top of the tree (the root front and its children: a chain of dependent tile
+                               columns) as a task graph over all frames when the frames' trees have the same depth
+                               (the hybrid form); 2 / 3 / 4 force the task-graph / the per-level / the hybrid form
+                               (4 falls back to 3 when the trees differ in depth); 1 = block-banded Cholesky */
   double w_data;            /* opt.sf_point_plane_weight (1.0) */
   double w_arap;            /* opt.mesh_arap_weight (10.0) */
   double w_rot;             /* opt.mesh_rot_weight (1.0) */
@@ -579,6 +582,10 @@ int slm_graph_init_semantic(int32_t H, int32_t W, int32_t step, const uint8_t* v
 
 /* Diagnostics: {device buffer reallocations in the LM solver, bytes asked for, symbolic analyses,
  * plan reuses with a changed pair list} since the library was loaded. */
+/* Form of the numeric phase the last slm_run / slm_lm_solve / slm_solve of this solver enqueued: 0 = per-level
+ * launches, 1 = task graph (one persistent launch), 2 = hybrid (per-level launches below, task graph for the top of
+ * the tree), -1 = none yet (block-banded path or nothing run). */
+int slm_debug_last_solver_form(slm_solver* s);
 int slm_debug_counters(int64_t out[4]);
 /* Diagnostics: copies a solver work buffer of the slot to HOST memory (synchronises `stream`): what = 0 front
  * tiles, 1 front vectors, 2 inverses of the diagonal factor blocks, 3 delta.  *n_doubles receives the buffer's

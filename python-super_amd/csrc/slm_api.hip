@@ -26,7 +26,8 @@ void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hip
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
-void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t);
+void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
+void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
 void launch_reg_loss(const FrameDev*, int, int, int, double, int, double, int, hipStream_t);
 void launch_bandwidth(const slm_frame&, int*, hipStream_t);
 void launch_band_solve(const FrameDev*, int, int, int, double, hipStream_t);
@@ -120,6 +121,8 @@ struct slm_solver {
   std::vector<hipStream_t> bind_streams;
   std::vector<hipEvent_t> bind_events;
   std::mutex band_mutex;        // the bandwidth read-back buffer of ensure_band is shared
+  int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
+  bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
@@ -153,6 +156,8 @@ static hipError_t grow(T*& p, size_t& cap, size_t need) {
 extern "C" {
 
 const char* slm_last_error(void) { return g_err.c_str(); }
+
+int slm_debug_last_solver_form(slm_solver* s) { return s ? s->last_solver_form : -1; }
 
 int slm_debug_counters(int64_t out[4]) {
   if (!out) return fail(SLM_ERR_INVALID, "slm_debug_counters: null output");
@@ -228,6 +233,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
     slm_destroy(s);
     return SLM_ERR_HIP;
   }
+  if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
   *out = s;
   return SLM_OK;
 }
@@ -505,7 +511,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
                             nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size() +
-                            nd.dag_tasks.size() + nd.front_kids.size() + nd.pull_off.size() + nd.pullmap.size() + nd.prng_off.size() +
+                            nd.dag_tasks.size() + nd.dag_top_tasks.size() + nd.front_kids.size() + nd.pull_off.size() + nd.pullmap.size() + nd.prng_off.size() +
                             nd.prng.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
       HIPCHK(grow(sl.d_fronts, sl.cap_fronts, nd.fronts.size()));
@@ -531,6 +537,9 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.schur_items = p; HIPCHK(up(nd.schur_items));
       h.schur_off = p;   HIPCHK(up(nd.schur_off));
       h.dag_tasks = p;   HIPCHK(up(nd.dag_tasks));
+      h.dag_top_tasks = p; HIPCHK(up(nd.dag_top_tasks));
+      h.n_dag_top_tasks = (int32_t)(nd.dag_top_tasks.size() / 2);
+      h.dag_cut_depth = nd.dag_cut_depth;
       h.front_kids = p;  HIPCHK(up(nd.front_kids));
       h.pull_off = p;    HIPCHK(up(nd.pull_off));
       h.pullmap = p;     HIPCHK(up(nd.pullmap));
@@ -659,6 +668,8 @@ struct BatchDims {
   int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
   bool nd = true;   // every slot of the batch has a nested-dissection plan
   int max_tasks = 0;   // tasks of the persistent task-graph solver (maximum over the batch)
+  // hybrid solve: every slot has the same number of levels and the same top-of-tree cut (-1: not available)
+  int hybrid_cut = -2, hybrid_levels = -1, max_top_tasks = 0;
   std::vector<NDLevelSched> sched;   // per-level launch bounds over the batch
 };
 BatchDims dims_of(slm_solver* s, int first, int n) {
@@ -675,6 +686,12 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     if (h.v1_ready) d.gram_variants |= h.v2_ready ? 1 : 2;
     d.nd = d.nd && h.nd_ready;
     d.max_tasks = std::max(d.max_tasks, h.nd_ready ? h.n_dag_tasks : 0);
+    if (h.nd_ready) {
+      const int cut = h.n_dag_top_tasks > 0 ? h.dag_cut_depth : -1;
+      if (d.hybrid_cut == -2) { d.hybrid_cut = cut; d.hybrid_levels = h.n_levels; }
+      else if (d.hybrid_cut != cut || d.hybrid_levels != h.n_levels) d.hybrid_cut = -1;
+      d.max_top_tasks = std::max(d.max_top_tasks, h.n_dag_top_tasks);
+    }
     d.maxP = std::max(d.maxP, h.P);
   }
   if (d.nd) {
@@ -720,8 +737,21 @@ void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDi
   // solver_path 0 picks by batch size: the task graph is a latency scheduler (one or two frames per launch: the
   // drop-in case, one frame at a time); larger batches are throughput-bound and run the per-level launches
   const bool dag = s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && n <= 2);
-  if (dag) launch_front_solve_dag(fr, n, d.max_tasks, u_override, st);
-  else launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
+  // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
+  // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
+  const bool hybrid = !dag && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
+                      d.hybrid_cut >= 0 && d.hybrid_levels == (int)d.sched.size() && d.hybrid_cut + 1 < d.hybrid_levels;
+  s->last_solver_form = dag ? 1 : (hybrid ? 2 : 0);
+  if (dag) {
+    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st);
+  } else if (hybrid) {
+    const int n_levels = (int)d.sched.size(), l_cut = n_levels - 1 - d.hybrid_cut;
+    launch_front_levels(fr, n, d.sched.data(), n_levels, l_cut, 0, u_override, st);
+    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut);
+    launch_front_levels(fr, n, d.sched.data(), n_levels, 0, l_cut, u_override, st);
+  } else {
+    launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
+  }
 }
 
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
@@ -738,7 +768,7 @@ hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims&
     launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
   }
-  launch_reg_grad_nd(fr, n, d.maxJKe, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
+  launch_reg_grad_nd(fr, n, d.maxP / 7, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
   launch_front_load_rhs(fr, n, d.maxP, st);
   return hipSuccess;
 }
@@ -827,7 +857,7 @@ int slm_lm_solve(slm_solver* s, int32_t n_frames, void* stream) {
   const FrameDev* fr = s->frames_dev;
   const slm_config& c = s->cfg;
   if (c.use_data) launch_pair_scatter(fr, n_frames, d.max_blocks, st);
-  launch_reg_grad_nd(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+  launch_reg_grad_nd(fr, n_frames, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
   launch_front_load_rhs(fr, n_frames, d.maxP, st);
   enqueue_front_solve(s, fr, n_frames, d, -1.0, st);
   HIPCHK(hipGetLastError());
@@ -955,7 +985,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     mark();
     if (d.nd) {
       if (c.use_data) launch_front_assemble(fr, n_frames, d.max_blocks, st);
-      launch_reg_grad_nd(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+      launch_reg_grad_nd(fr, n_frames, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
       launch_front_load_rhs(fr, n_frames, d.maxP, st);
     } else {
       if (c.use_data && d.v1) launch_band_assemble(fr, n_frames, d.max_blocks, st);

@@ -108,6 +108,8 @@ struct FrameDev {
   const int32_t* prng;         // per front, tile row, child: child boundary tile rows lo | hi << 8 it gathers from, -1 none
   int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per tile done, per pivot column {b, x, y, 4 x 16 pivots out}
   int32_t n_dag_tasks;
+  const int32_t* dag_top_tasks;   // the tasks of the fronts of depth <= dag_cut_depth, same order (hybrid solve)
+  int32_t n_dag_top_tasks, dag_cut_depth;
   int32_t dag_n_tiles;         // tiles of all fronts
   int32_t dag_n_pcols;         // pivot tile columns of all fronts
   int32_t dag_n_flags;         // ints in dag_flags

@@ -209,7 +209,9 @@ struct TD {
   int n0, n;                             // flags needed to start / all flags
   int pcol_self, pcol_parent, nb, npt, c;
 };
-__device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int type, int r, int s) {
+// nokids: the front's children were factored by the per-level launches, which ADDED their Schur complements into
+// this front's tiles already (hybrid solve, top of the tree only): nothing to gather, nothing to wait for
+__device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int type, int r, int s, bool nokids) {
   TD d;
   d.type = type; d.r = r; d.s = s; d.diag = (r == s); d.npt = f.npt; d.nb = f.nb; d.c = s;
   d.pcol_self = f.pcol0;
@@ -222,7 +224,7 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
     const bool two = type == ND_T_POTRF && s > 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int ch = uni(fd.front_kids[2 * fi + k]);
+      const int ch = nokids ? -1 : uni(fd.front_kids[2 * fi + k]);
       const int rr = ch >= 0 ? uni(pr[2 * r + k]) : -1, cc = ch >= 0 ? uni(pr[2 * s + k]) : -1;
       const int c2 = (ch >= 0 && two) ? uni(pr[2 * (s - 1) + k]) : -1;
       d.pr0[k] = d.pc0[k] = d.pc2[k] = 0; d.pnc[k] = d.pnc2[k] = 1; d.ctile0[k] = d.cnt[k] = d.cnpt[k] = 0;
@@ -545,7 +547,7 @@ __device__ __forceinline__ bool dag_factor_tile(double* g_linv, double* g_ltile,
 // ---- the tasks.  Each kind is a function of its own (a real call): inlined into one loop, every path pays the
 // register demand of all of them, and the tile factorisation -- the critical path -- ends up spilling.
 // A task re-derives its descriptors from (ticket) itself; LDS regions come from the dynamic LDS base.
-__device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+__device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -564,7 +566,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
     const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
-    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
@@ -574,7 +576,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
     const FS f = front_snapshot(fd.fronts[fi]);
     const DagFlags g = dag_flags_of(fdr);
-    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_, cut >= 0 && uni(fd.fronts[fi].depth) == cut);
     double* vecs = fd.fvec + f.vec_off;
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
@@ -770,7 +772,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
   }
 }
 
-__device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+__device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -789,7 +791,7 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
     const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
-    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
@@ -799,7 +801,7 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
     const FS f = front_snapshot(fd.fronts[fi]);
     const DagFlags g = dag_flags_of(fdr);
-    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_, cut >= 0 && uni(fd.fronts[fi].depth) == cut);
     double* vecs = fd.fvec + f.vec_off;
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
@@ -848,7 +850,7 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
   }
 }
 
-__device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+__device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -867,7 +869,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
     const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
-    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
@@ -877,7 +879,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
     const FS f = front_snapshot(fd.fronts[fi]);
     const DagFlags g = dag_flags_of(fdr);
-    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_, cut >= 0 && uni(fd.fronts[fi].depth) == cut);
     double* vecs = fd.fvec + f.vec_off;
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
@@ -931,7 +933,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
   }
 }
 
-__device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override) {
+__device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -950,7 +952,7 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
     const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
-    const int32_t* tasks = unip(fdr.dag_tasks);
+    const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
@@ -960,7 +962,7 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
     const FS f = front_snapshot(fd.fronts[fi]);
     const DagFlags g = dag_flags_of(fdr);
-    const TD d = task_deps(fd, f, fi, type, tr_, ts_);
+    const TD d = task_deps(fd, f, fi, type, tr_, ts_, cut >= 0 && uni(fd.fronts[fi].depth) == cut);
     double* vecs = fd.fvec + f.vec_off;
     LMState* lmst = unip(fdr.st);
     long long* trc_base = unip(fdr.dag_trace);
@@ -1043,8 +1045,10 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     }
 }
 
+// cut < 0: the whole tree (fd.dag_tasks).  cut >= 0: only the fronts of depth <= cut (fd.dag_top_tasks); the deeper
+// levels are factored before and back-substituted after this launch by the per-level kernels (slm_front.hip).
 __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
-                                                 double u_override) {
+                                                 double u_override, int cut) {
   int* s_ok = reinterpret_cast<int*>(dag_lds + 2 * TILE + 7 * 256 + 2 * NB);
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
@@ -1061,12 +1065,12 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
     __syncthreads();
     if (tk >= total || uni(*s_abort)) break;
     const FrameDev& fq = frames[tk % n_frames];
-    if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(fq.n_dag_tasks)) continue;
-    const int type = uni(unip(fq.dag_tasks)[2 * (tk / n_frames)]) >> 24;
-    if (type <= ND_T_COL) dag_task_factor(frames, n_frames, tk, u_override);
-    else if (type == ND_T_SCHUR) dag_task_schur(frames, n_frames, tk, u_override);
-    else if (type == ND_T_BACKB) dag_task_backb(frames, n_frames, tk, u_override);
-    else dag_task_back(frames, n_frames, tk, u_override);
+    if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(cut >= 0 ? fq.n_dag_top_tasks : fq.n_dag_tasks)) continue;
+    const int type = uni(unip(cut >= 0 ? fq.dag_top_tasks : fq.dag_tasks)[2 * (tk / n_frames)]) >> 24;
+    if (type <= ND_T_COL) dag_task_factor(frames, n_frames, tk, u_override, cut);
+    else if (type == ND_T_SCHUR) dag_task_schur(frames, n_frames, tk, u_override, cut);
+    else if (type == ND_T_BACKB) dag_task_backb(frames, n_frames, tk, u_override, cut);
+    else dag_task_back(frames, n_frames, tk, u_override, cut);
   }
 }
 
@@ -1087,7 +1091,7 @@ __global__ void k_dag_check(const FrameDev* __restrict__ frames, int n_frames) {
   }
 }
 
-void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st) {
+void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
   static int n_wg = 0;
@@ -1103,6 +1107,6 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
   hipLaunchKernelGGL(k_dag_reset, dim3(8, n_frames), dim3(256), 0, st, fr);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);
-  hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override);
+  hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut);
   hipLaunchKernelGGL(k_dag_check, dim3(1), dim3(64), 0, st, fr, n_frames);
 }

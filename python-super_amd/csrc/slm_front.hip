@@ -237,20 +237,23 @@ __device__ __forceinline__ void nd_arap_edge(const FrameDev& fd, int j, int k, d
   quat_jac(bk[0], {bk[1], bk[2], bk[3]}, d, Jq);
 }
 
-// No atomics and a fixed summation order: thread (j, slot) owns the cross block of edge j -> k; the
-// thread with slot 0 also owns node j's diagonal block and right-hand side, which it GATHERS from the
-// edges that end in j (reverse KNN graph, ascending edge number), then its own out-edges, then Rot.
-// Entries are read-modify-written by exactly one thread (k_front_assemble stored the data term first).
+// No atomics and a fixed summation order.  Node j is served by a group of RG_LANES = 8 consecutive lanes
+// (K_ED <= 8): lane `slot` < K_ED owns the cross block of edge j -> k; for node j's diagonal block and right-hand
+// side the lanes SHARE the edges -- lane s takes the in-edges start+s, start+s+8, ... (reverse KNN graph) and the
+// out-edge s -- and a butterfly sum over the 8 lanes (same tree in every lane: deterministic) gives the block,
+// whose 35 entries are then read-modify-written 4-5 per lane instead of 35 in a row by one thread.
+// Every entry is touched by exactly one thread (k_front_assemble stored the data term first).
+#define RG_LANES 8
 __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict__ frames, int use_arap,
                                                       double lam_a, int use_rot, double lam_r) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.nd_ready || fd.st->stopped) return;
   const int Ke = fd.f.K_ED, J = fd.f.J;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = t / Ke, slot = t % Ke;
-  if (j >= J) return;
+  const int j = t / RG_LANES, slot = t % RG_LANES;
+  if (j >= J) return;            // (whole groups: RG_LANES divides the wave size)
   const double l2 = lam_a * lam_a;
-  if (use_arap) {
+  if (use_arap && slot < Ke) {
     // ---- cross block between the nodes of edge j -> k ----
     const int k = fd.f.ed_knn_idx[j * Ke + slot];
     if (k >= 0 && k < J && k != j) {
@@ -264,34 +267,36 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
       // the edge with the smaller source node writes them for both
       bool reverse = false;
       for (int s2 = 0; s2 < Ke; ++s2) reverse = reverse || fd.f.ed_knn_idx[k * Ke + s2] == j;
+      double* dst[15];
+      double add[15];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const double cv = -l2 * Jq[c][a];                       // between (k, a) and (j, 4+c)
-          if (k_is_row) *front_entry(fd, fp, prb + a, pcb + 4 + c) += cv;
-          else *front_entry(fd, fp, prb + 4 + c, pcb + a) += cv;
+          add[4 * c + a] = -l2 * Jq[c][a];                       // between (k, a) and (j, 4+c)
+          dst[4 * c + a] = k_is_row ? front_entry(fd, fp, prb + a, pcb + 4 + c) : front_entry(fd, fp, prb + 4 + c, pcb + a);
         }
-        if (!reverse || j < k) {
-          double* e = front_entry(fd, fp, prb + 4 + c, pcb + 4 + c);   // between (k, 4+c) and (j, 4+c)
-          double v = *e - l2;
-          if (reverse) v -= l2;
-          *e = v;
-        }
+        const bool mine = !reverse || j < k;
+        dst[12 + c] = mine ? front_entry(fd, fp, prb + 4 + c, pcb + 4 + c) : nullptr;   // between (k, 4+c) and (j, 4+c)
+        add[12 + c] = reverse ? -2.0 * l2 : -l2;
       }
+      // all loads before the first store: the destinations are distinct but the compiler cannot know
+      double cur[15];
+#pragma unroll
+      for (int e = 0; e < 15; ++e) cur[e] = dst[e] ? *dst[e] : 0.0;
+#pragma unroll
+      for (int e = 0; e < 15; ++e)
+        if (dst[e]) *dst[e] = cur[e] + add[e];
     }
   }
-  if (slot != 0) return;
-  // ---- node j: diagonal block (lower 7x7) and right-hand side ----
-  double acc[7][7], rh[7];
+  // ---- node j: diagonal block (lower 7x7, packed row-major: a(a+1)/2 + b) and right-hand side ----
+  double acc[28], rh[7];
 #pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    rh[a] = 0.0;
+  for (int e = 0; e < 28; ++e) acc[e] = 0.0;
 #pragma unroll
-    for (int b = 0; b < 7; ++b) acc[a][b] = 0.0;
-  }
+  for (int a = 0; a < 7; ++a) rh[a] = 0.0;
   if (use_arap) {
-    for (int ie = fd.in_start[j]; ie < fd.in_start[j + 1]; ++ie) {   // edges src -> j: j plays node k
+    for (int ie = fd.in_start[j] + slot; ie < fd.in_start[j + 1]; ie += RG_LANES) {   // edges src -> j: j plays node k
       const int src = fd.in_edge[ie] / Ke;
       if (src == j) continue;
       double r[3], Jq[3][4];
@@ -307,30 +312,31 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
           double q = 0.0;
 #pragma unroll
           for (int c = 0; c < 3; ++c) q += Jq[c][a] * Jq[c][b];
-          acc[a][b] += l2 * q;
+          acc[a * (a + 1) / 2 + b] += l2 * q;
         }
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         rh[4 + c] += -lam_a * r[c];
-        acc[4 + c][4 + c] += l2;
+        acc[(4 + c) * (5 + c) / 2 + 4 + c] += l2;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[4 + c][a] += l2 * Jq[c][a];
+        for (int a = 0; a < 4; ++a) acc[(4 + c) * (5 + c) / 2 + a] += l2 * Jq[c][a];
       }
     }
-    for (int s2 = 0; s2 < Ke; ++s2) {                                  // edges j -> k: j plays node j
-      const int k = fd.f.ed_knn_idx[j * Ke + s2];
-      if (k < 0 || k >= J || k == j) continue;
-      double r[3], Jq[3][4];
-      nd_arap_edge(fd, j, k, lam_a, r, Jq);
+    if (slot < Ke) {                                                  // edge j -> k: j plays node j
+      const int k = fd.f.ed_knn_idx[j * Ke + slot];
+      if (k >= 0 && k < J && k != j) {
+        double r[3], Jq[3][4];
+        nd_arap_edge(fd, j, k, lam_a, r, Jq);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        rh[4 + c] += lam_a * r[c];
-        acc[4 + c][4 + c] += l2;
+        for (int c = 0; c < 3; ++c) {
+          rh[4 + c] += lam_a * r[c];
+          acc[(4 + c) * (5 + c) / 2 + 4 + c] += l2;
+        }
       }
     }
   }
-  if (use_rot) {
+  if (use_rot && slot == 0) {
     double bb[7];
     nd_load_beta(fd.beta, j, bb);
     float q[4];
@@ -342,18 +348,52 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
     for (int a = 0; a < 4; ++a) {
       rh[a] += (double)jtr[a];
 #pragma unroll
-      for (int b = 0; b <= a; ++b) acc[a][b] += (double)jtj[a][b];
+      for (int b = 0; b <= a; ++b) acc[a * (a + 1) / 2 + b] += (double)jtj[a][b];
     }
+  }
+  // group sum: every lane ends with the same 35 values
+#pragma unroll
+  for (int off = 1; off < RG_LANES; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 28; ++e) acc[e] += __shfl_xor(acc[e], off);
+#pragma unroll
+    for (int a = 0; a < 7; ++a) rh[a] += __shfl_xor(rh[a], off);
   }
   const NDFront fj = fd.fronts[fd.node_front[j]];
   const int bj0 = nd_base(fj, fd.node_pos[j]);
+  // entry e = slot, slot + 8, ...: 0..27 the block, 28..34 the right-hand side
+  double* dst[5];
+  double add[5], cur[5];
 #pragma unroll
-  for (int a = 0; a < 7; ++a) {
-    fd.rhs[7 * j + a] += rh[a];
+  for (int q = 0; q < 5; ++q) {
+    const int e = slot + RG_LANES * q;
+    dst[q] = nullptr;
+    add[q] = 0.0;
+    if (e < 28) {
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= e) ++a;
+      const int b = e - a * (a + 1) / 2;
+      // select acc[e] without dynamic register indexing
+      double v = 0.0;
 #pragma unroll
-    for (int b = 0; b <= a; ++b)
-      if (acc[a][b] != 0.0) *front_entry(fd, fj, bj0 + a, bj0 + b) += acc[a][b];
+      for (int x = 0; x < 28; ++x) v = (x == e) ? acc[x] : v;
+      if (v != 0.0) {
+        dst[q] = front_entry(fd, fj, bj0 + a, bj0 + b);
+        add[q] = v;
+      }
+    } else if (e < 35) {
+      double v = 0.0;
+#pragma unroll
+      for (int x = 0; x < 7; ++x) v = (x == e - 28) ? rh[x] : v;
+      dst[q] = fd.rhs + 7 * j + (e - 28);
+      add[q] = v;
+    }
   }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) cur[q] = dst[q] ? *dst[q] : 0.0;
+#pragma unroll
+  for (int q = 0; q < 5; ++q)
+    if (dst[q]) *dst[q] = cur[q] + add[q];
 }
 
 // global jtl -> the pivot part of each front's vector (boundary parts stay zero)
@@ -1011,10 +1051,10 @@ void launch_front_assemble(const FrameDev* fr, int n_frames, int max_blocks, hip
   hipLaunchKernelGGL(k_front_assemble, dim3((max_blocks + 3) / 4, n_frames), dim3(256), 0, st, fr);
 }
 
-void launch_reg_grad_nd(const FrameDev* fr, int n_frames, int maxJKe, int use_arap, double lam_a,
+void launch_reg_grad_nd(const FrameDev* fr, int n_frames, int maxJ, int use_arap, double lam_a,
                         int use_rot, double lam_r, hipStream_t st) {
-  if (maxJKe <= 0 || (!use_arap && !use_rot)) return;
-  hipLaunchKernelGGL(k_reg_grad_nd, dim3((maxJKe + 255) / 256, n_frames), dim3(256), 0, st, fr, use_arap,
+  if (maxJ <= 0 || (!use_arap && !use_rot)) return;
+  hipLaunchKernelGGL(k_reg_grad_nd, dim3((maxJ * RG_LANES + 255) / 256, n_frames), dim3(256), 0, st, fr, use_arap,
                      lam_a, use_rot, lam_r);
 }
 
@@ -1028,8 +1068,11 @@ void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
 
 // Level schedule shared by all slots of a batch (they may have different plans: the host
 // passes, per level, the maxima over the batch; blocks beyond a front's own size exit).
-void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv, int n_levels,
-                        double u_override, hipStream_t st) {
+// Factorisation launches of levels [0, l_factor_end), back-substitution launches of levels [0, l_back_end), the
+// deepest level being 0.  The whole solve is (n_levels, 0) followed by (0, n_levels); the hybrid solve of a batch
+// runs (l_cut, 0), the task-graph kernel for the levels >= l_cut, then (0, l_cut).
+void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* lv, int n_levels, int l_factor_end,
+                         int l_back_end, double u_override, hipStream_t st) {
   const size_t lds = PANEL_LDS_DOUBLES * sizeof(double);
   const size_t lds11 = L11_LDS_DOUBLES * sizeof(double);
   static bool attr_set = false;
@@ -1039,7 +1082,7 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
     (void)hipFuncSetAttribute((const void*)k_fpotrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  for (int l = 0; l < n_levels; ++l) {
+  for (int l = 0; l < l_factor_end; ++l) {
     const NDLevelSched& s = lv[l];
     if (s.n_fronts <= 0) continue;
     const LevelRef lr{l, s.first, s.n_fronts};
@@ -1094,7 +1137,7 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
       }
     }
   }
-  for (int l = n_levels - 1; l >= 0; --l) {
+  for (int l = l_back_end - 1; l >= 0; --l) {
     const NDLevelSched& s = lv[l];
     if (s.n_fronts <= 0 || s.max_npt <= 0) continue;
     const LevelRef lr{l, s.first, s.n_fronts};
@@ -1105,4 +1148,10 @@ void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv
       hipLaunchKernelGGL(k_fbacksub, dim3(s.max_npt, s.n_fronts, n_frames), dim3(256), 0, st, fr,
                          lr, e);
   }
+}
+
+void launch_front_solve(const FrameDev* fr, int n_frames, const NDLevelSched* lv, int n_levels,
+                        double u_override, hipStream_t st) {
+  launch_front_levels(fr, n_frames, lv, n_levels, n_levels, 0, u_override, st);
+  launch_front_levels(fr, n_frames, lv, n_levels, 0, n_levels, u_override, st);
 }

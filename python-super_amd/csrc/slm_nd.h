@@ -99,6 +99,10 @@ struct NDPlanHost {
   std::vector<int32_t> prng_off;      // per front: offset into prng
   std::vector<int32_t> prng;          // per front, tile row, child k: child boundary tile rows lo | hi << 8 gathered from, -1 none
   std::vector<int32_t> pullmap;       // per child front: parent scalar index -> boundary scalar index of the child, -1
+  // hybrid solve of a batch: the levels with many fronts run as per-level launches (throughput), the top of the tree
+  // -- depth <= dag_cut_depth, the levels with at most SLM_DAG_TOP_FRONTS (2) fronts: the root and its children -- as tasks (latency)
+  std::vector<int32_t> dag_top_tasks; // the tasks of those fronts, in the order of dag_tasks
+  int32_t dag_cut_depth = -1;
   double dag_critical_us = 0.0;       // modelled critical path (diagnostic)
 };
 

@@ -526,6 +526,27 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       out.dag_tasks[2 * k + 1] = tasks[k].w1;
     }
     if (T >= (1 << 24) || out.max_nt > 255) return false;
+    // top of the tree for the hybrid solve
+    {
+      static const int top_fronts = [] {
+        const char* e = getenv("SLM_DAG_TOP_FRONTS");
+        return e && atoi(e) > 0 ? atoi(e) : 2;
+      }();
+      int max_depth = 0;
+      for (int i = 0; i < T; ++i) max_depth = std::max(max_depth, (int)out.fronts[i].depth);
+      std::vector<int> per_depth(max_depth + 1, 0);
+      for (int i = 0; i < T; ++i) ++per_depth[out.fronts[i].depth];
+      int cut = -1;
+      while (cut + 1 <= max_depth && per_depth[cut + 1] <= top_fronts) ++cut;
+      if (cut >= max_depth) cut = max_depth - 1;        // leave at least the deepest level to the launches
+      out.dag_cut_depth = cut;
+      out.dag_top_tasks.clear();
+      for (size_t k = 0; k < tasks.size(); ++k)
+        if (cut >= 0 && out.fronts[tasks[k].w0 & 0xFFFFFF].depth <= cut) {
+          out.dag_top_tasks.push_back(tasks[k].w0);
+          out.dag_top_tasks.push_back(tasks[k].w1);
+        }
+    }
   }
   // ---- destinations of the assembled blocks -------------------------------------------------
   auto dest_of = [&](int a, int bnode, NDDest& d) -> bool {   // block given as (a,b), a >= b by id

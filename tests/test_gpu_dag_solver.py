@@ -103,3 +103,57 @@ def test_c2_full_size_task_graph_solver():
     assert all(r["status"] == 0 for r in res[2][1])
     np.testing.assert_allclose([r["loss"] for r in res[2][1]], [r["loss"] for r in res[3][1]], rtol=1e-9)
     np.testing.assert_allclose(res[2][0], res[3][0], rtol=0, atol=1e-9)
+
+
+def test_hybrid_form_on_a_batch_equals_level_launches():
+    """batches of >= 3 frames whose trees have the same depth: per-level launches for the levels with many fronts,
+    the top of the tree as tasks of one persistent launch over all frames (solver_path 4, and what solver_path 0
+    picks) -- same iterations as the pure per-level form, different plans per frame"""
+    from super_amd import synth
+    scenes = [synth.make_scene(N=20000, J=400, H=240, W=320, seed=70 + k, src_border=8, tgt_border=4, dphi=0.15 + 0.05 * k)
+              for k in range(4)]
+    out = {}
+    for sp in (3, 4, 0):
+        e = _engine(max_frames=4, solver_path=sp)
+        e.bind_batch([_dframe(sc) for sc in scenes])
+        e.run(4)
+        form = e.lib.slm_debug_last_solver_form(e.h)
+        assert form == {3: 0, 4: 2, 0: 2}[sp], (sp, form)
+        out[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(4)]
+    for sp in (4, 0):
+        for i in range(4):
+            b0, r0 = out[3][i]
+            b, r = out[sp][i]
+            assert all(x["status"] == 0 for x in r)
+            np.testing.assert_allclose([x["loss"] for x in r], [x["loss"] for x in r0], rtol=1e-10)
+            assert [x["accepted"] for x in r] == [x["accepted"] for x in r0]
+            np.testing.assert_allclose(b, b0, rtol=0, atol=1e-10)
+    ob = orc.lm(orc.Frame.from_scene(scenes[1]), orc.default_opt())
+    np.testing.assert_allclose(out[0][1][0], ob, rtol=0, atol=1e-6)
+
+
+def test_hybrid_form_falls_back_when_the_trees_differ_in_depth():
+    from super_amd import synth
+    scenes = [synth.make_scene(N=4000, J=96, H=96, W=128, seed=61, src_border=6, tgt_border=3),
+              synth.make_scene(N=2500, J=48, H=60, W=80, seed=62, src_border=5, tgt_border=3),
+              synth.make_scene(N=20000, J=400, H=240, W=320, seed=63, src_border=8, tgt_border=4)]
+    e = _engine(max_frames=3, solver_path=4)
+    for i, sc in enumerate(scenes):
+        e.bind(i, _dframe(sc))
+    e.run(3)
+    assert e.lib.slm_debug_last_solver_form(e.h) == 0
+    for i, sc in enumerate(scenes[:2]):
+        np.testing.assert_allclose(e.beta(i).cpu().numpy(), orc.lm(orc.Frame.from_scene(sc), orc.default_opt()), rtol=0, atol=1e-6)
+
+
+def test_hybrid_form_failure_stops_like_the_reference():
+    """a singular frame inside a hybrid batch: its loop stops with beta unchanged, the other frames finish"""
+    from super_amd import synth
+    good = [synth.make_scene(N=2500, J=96, H=96, W=128, seed=80 + k, src_border=6, tgt_border=3) for k in range(2)]
+    bad = synth.make_scene(N=300, J=96, H=96, W=128, seed=33, src_border=30, tgt_border=3)
+    e = _engine(max_frames=3, solver_path=4, use_arap=False, use_rot=False, u0=0.0)
+    e.bind_batch([_dframe(good[0]), _dframe(bad), _dframe(good[1])])
+    e.run(3)
+    recs = e.records(1)
+    assert recs[0]["status"] == 1 and all(r["status"] == 2 for r in recs[1:])
+    np.testing.assert_allclose(e.beta(1).cpu().numpy(), np.tile([1.0, 0, 0, 0, 0, 0, 0], (bad.J, 1)), rtol=0, atol=0)

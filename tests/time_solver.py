@@ -11,7 +11,7 @@ from super_amd.engine import DeviceFrame, Engine
 dev = torch.device("cuda", 0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 Bs = [int(x) for x in sys.argv[2:] if not x.startswith("-")] or [1, 8]
-PATHS = (3,) if "--launches" in sys.argv else ((2,) if "--dag" in sys.argv else (3, 2))
+PATHS = (3,) if "--launches" in sys.argv else ((2,) if "--dag" in sys.argv else ((4,) if "--hybrid" in sys.argv else (3, 2, 4)))
 for B in Bs:
     frames = [DeviceFrame.from_scene(synth.make_scene(seed=s, **synth.WORKLOADS[wl]), dev) for s in range(B)]
     for sp in PATHS:
