@@ -48,6 +48,9 @@ def parse():
                     help="split the frames of a GPU over this many solver handles / HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event phase timing")
+    ap.add_argument("--no-latency-b1", action="store_true",
+                    help="skip the one-frame-per-launch leg (profiles/collect.sh: keeps the kernel statistics of a "
+                         "profiled run to the launches of the headline configuration)")
     return ap.parse_args()
 
 
@@ -59,12 +62,20 @@ def workload_dims(name):
 
 
 def lib_sha16():
+    """sha256[:16] over the library's SOURCES (csrc/*.hip, csrc/*.h, include/*.h, sorted by name): what a committed
+    profile is tagged with -- the built .so is not in the repository and need not be byte-reproducible."""
+    import glob
     import hashlib
-    from super_amd import _lib
-    try:
-        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
-    except OSError:
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "python-super_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "python-super_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    if not files:
         return None
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel, workload, frames_per_gpu):
@@ -72,7 +83,7 @@ def pmc_traffic(kernel, workload, frames_per_gpu):
     (profiles/*pmc_traffic.json, made by profiles/make_traffic.py from separate FETCH_SIZE /
     WRITE_SIZE passes with the gfx950 corrections).  Returns (bytes or None, provenance): a summary
     is only used when it was collected for THIS workload / batch; the provenance names the file and
-    says whether the library it profiled is byte-identical to the one running now (`stale` otherwise:
+    says whether the library sources it profiled are identical to the ones in the tree now (`stale` otherwise:
     the figure then describes an older build of the kernel and is reported as null)."""
     import glob
     best, src = None, None
@@ -493,7 +504,8 @@ def main():
             # the time-dominant phase: the float64 multifrontal factor + substitutions of all frames of a launch
             out["roofline"] = {"kernel": "solve phase: " + info["solver"] + " Cholesky factor + substitutions ("
                                          + ("k_fdag, one persistent launch" if Bs <= 2 and info["solver_tasks"] > 0
-                                            else "k_fpanel / k_ftrail / k_fschur / k_fbacksub ..., all launches of one LM iteration") + ")",
+                                            else "per-level launches k_fL11 / k_fL21 / k_fschur / k_fpanel / k_ftrail / k_fbacksub + k_fdag (task graph) for the root "
+                                                 "front and its children, all launches of one LM iteration") + ")",
                                "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                                "achieved_unpadded": flops_exact / savg / 1e12 if savg > 0 else 0.0,
@@ -523,7 +535,7 @@ def main():
             # whole step against the HBM peak: algorithmic bytes of one LM iteration x iterations x frames
             step_bytes = world * B * iters * (144.0 * N + 3205.0 * J)
             out["whole_step_hbm_frac"] = step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS
-        if world == 1 and not a.no_profile:
+        if world == 1 and not a.no_profile and not a.no_latency_b1:
             out["latency_b1"] = latency_b1(dims, device, iters)
         out["host"] = host_info()
         if world == 1 and not a.no_cpu_baseline:

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collect the round's judged profiles on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
-# Writes under gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards (see README there).
+# Writes under gpurun_out/<tag>_*; `python profiles/install.py <tag>` then copies the summaries into profiles/.
 # rocprofv3 rules on this pool: the program itself after `--`; --pmc passes separate from --stats.
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err < /dev/null
 timeout 300 python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_b1.json 2> $R/gpurun_out/${TAG}_bench_b1.err < /dev/null
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats -name '*kernel_trace.csv' -delete
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1 < /dev/null
@@ -22,10 +22,10 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_
 done
 python3 $R/profiles/make_sq_summary.py $R/gpurun_out/${TAG}_pmc_sq_*/ --out $R/gpurun_out/${TAG}_pmc_sq_summary.csv > /dev/null 2>&1
 # one frame per launch (the drop-in case): kernel stats of the task-graph solver
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats_b1 -name '*kernel_trace.csv' -delete
 # per-kernel HBM traffic summary, tagged with the library that was profiled
 F=$(find $R/gpurun_out/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
 W=$(find $R/gpurun_out/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python3 $R/profiles/make_traffic.py $F $W --workload C2 --frames-per-gpu 8 --lib $R/python-super_amd/lib/libsuper_lm.so --out $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
+python3 $R/profiles/make_traffic.py $F $W --workload C2 --frames-per-gpu 8 --out $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
 ls $R/gpurun_out/${TAG}_stats/* $R/gpurun_out/${TAG}_pmc_FETCH_SIZE/* < /dev/null

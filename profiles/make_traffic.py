@@ -30,14 +30,15 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--out", required=True)
-    ap.add_argument("--lib", default=None, help="libsuper_lm.so that was profiled (its sha256[:16] is recorded so that "
+    ap.add_argument("--lib", default=None, help="(ignored: the tag is the hash of the library SOURCES, bench.lib_sha16) "
                                                 "bench.py can tell a summary of an older build from a current one)")
     a = ap.parse_args()
     f, w = means(a.fetch_csv), means(a.write_csv)
-    sha = None
-    if a.lib:
-        import hashlib
-        sha = hashlib.sha256(open(a.lib, "rb").read()).hexdigest()[:16]
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    sha = bench.lib_sha16()      # hash of csrc/ + include/: the build that was profiled
     out = {"workload": a.workload, "frames_per_gpu": a.frames_per_gpu, "lib_sha16": sha, "kernels": {}}
     for k in sorted(set(f) & set(w)):
         fetch_kib, n = f[k]
