@@ -15,16 +15,25 @@
 // workgroup, so the earliest unfinished task can always finish: no deadlock whatever the residency.
 // Every spin is bounded; on a time-out the abort flag stops all workgroups and the solve reports failure.
 //
-// Tasks (left-looking: every tile is written by exactly ONE task, then read-only):
-//   POTRF(f,s)   A(s,s) - sum_{c<s} L(s,c) L(s,c)^T (+ u) -> Cholesky + inverse (slm_tile.h) -> flinv;
+// Tasks (left-looking: every tile is written by exactly ONE task, then read-only; the extend-add is a GATHER: a task
+// of a parent front pulls the entries of its children's update tiles that map into its tile, child 0 before child 1):
+//   POTRF(f,s)   owns the diagonal tile (s,s) AND its left neighbour (s,s-1): accumulates the columns c < s-1 as they
+//                become available, then follows the factorisation of column s-1 16 pivots at a time (streamed row
+//                solve L(s,s-1) = A(s,s-1) L_{s-1,s-1}^-T and update of (s,s)), factors (s,s) + inverse -> flinv
+//                (slm_tile.h factor_inverse64p, itself publishing its row blocks per 16 pivots for POTRF(f,s+1)),
 //                y_s = L_ss^-1 (b_s - sum_{c<s} L(s,c) y_c)                                  (forward subst.)
-//   COL(f,r,s)   L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
-//   SCHUR(f,r,s) boundary tile: U = A(r,s) - sum_{c<npt} L(r,c) L(s,c)^T added into the parent front through the
-//                extend-add maps (child 0 before child 1: fixed summation order); diagonal tiles carry the
-//                vector rows  v_r = b_r - sum_c L(r,c) y_c
+//   COL(f,r,s)   r > s+1 (or a boundary row): L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
+//   SCHUR(f,r,s) boundary tile: U = A(r,s) - sum_{c<npt} L(r,c) L(s,c)^T, stored IN PLACE (the parent gathers it);
+//                diagonal tiles carry the vector rows  v_r = b_r - sum_c L(r,c) y_c
 //   BACKB(f,c)   y_c -= sum_{boundary r} L(r,c)^T x_r        (x of the boundary nodes from the global solution)
-//   BACK(f,c)    x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r), scattered into delta
+//   BACK(f)      ONE task per front: the chain x_c = L_cc^-T (y_c - sum_{c<r<npt} L(r,c)^T x_r), c = npt-1 .. 0,
+//                operands streamed three ahead, x scattered into delta
 // All sums run in a fixed order: results are bitwise reproducible from run to run.
+//
+// Top-of-tree mode (cut >= 0, the hybrid solve of a batch, slm_api.hip enqueue_front_solve): only the tasks of the
+// fronts of depth <= cut run here (fd.dag_top_tasks); the deeper levels were factored by the per-level launches of
+// slm_front.hip, whose k_fschur ADDED their Schur complements into the tiles of the fronts at depth == cut -- those
+// fronts gather nothing (task_deps nokids) -- and their back substitution follows this launch as launches again.
 //
 // Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): per-XCD L2s are not coherent and a CU's L1
 // is never refreshed, so EVERY byte that one task hands to another (tiles, vectors, inverses, the solution) is
