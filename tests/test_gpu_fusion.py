@@ -92,7 +92,7 @@ def test_tracked_points_follow_the_surface_through_the_driver():
     synthetic surface deforms in depth; there is no material ground truth to compare with)."""
     import torch
     from super_amd import evaluation as ev, synth
-    from super_amd.super import SuPer
+    from driver_harness import FrameLoop as SuPer
     H, W = 96, 128
     K = synth._scaled_intrinsics(H, W)
     inv_K = np.linalg.pinv(K)
@@ -354,13 +354,13 @@ def test_whole_frame_pipeline_depth_lm_update_fusion():
 
 @pytest.mark.parametrize("derived", [True, False])
 def test_super_driver_tracks_a_deforming_surface(derived):
-    """super_amd.super.SuPer (mirror of super/super.py) over 5 frames of a deforming synthetic surface,
+    """tests/driver_harness.FrameLoop (the stage mirrors in the reference driver's call order, super/super.py) over 5 frames of a deforming synthetic surface,
     LM path and first-order (GraphFit / Adam) path: the surfel model follows the surface (its points
     re-project onto the newest depth map to within a fraction of the inter-frame motion), the ED graph
     comes from the grid mesh, the model stays compact."""
     import torch
     from super_amd import synth
-    from super_amd.super import SuPer
+    from driver_harness import FrameLoop as SuPer
     H, W = 96, 128
     K = synth._scaled_intrinsics(H, W)
     inv_K = np.linalg.pinv(K)
@@ -417,7 +417,7 @@ def test_semantic_super_driver_runs_end_to_end(hard):
     model follows the surface."""
     import torch
     from super_amd import synth
-    from super_amd.super import SuPer
+    from driver_harness import FrameLoop as SuPer
     H, W, C = 96, 128, 3
     K = synth._scaled_intrinsics(H, W)
     inv_K = np.linalg.pinv(K)

@@ -1,4 +1,4 @@
-"""Diagnostic: end-to-end ms/frame of the driver mirror (super_amd.super.SuPer) at the SuPer image size:
+"""Diagnostic: end-to-end ms/frame of the stage mirrors in the reference driver's order (tests/driver_harness.py) at the SuPer image size:
 depth_preprocessing -> LM (10 iterations) -> Surfels.update -> fuseInputData -> swap, per stage."""
 import sys, os, time
 # Host thread pools: on the GPU box (256 logical CPUs, cgroup quota of 16 CPUs per 100 ms) the default OpenMP /
@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "python-super_amd")); sys.path.insert(0, R
 import numpy as np
 import torch
 from super_amd import synth, fusion, nodes
-from super_amd import super as drv
+import driver_harness as drv
 from super_amd import data_loader
 
 H, W = 480, 640
@@ -37,7 +37,7 @@ opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, 
                       disable_removing_unstable_surfels=False)
 if os.environ.get("DRIVER_SOLVER_PATH"):
     opt.slm_solver_path = int(os.environ["DRIVER_SOLVER_PATH"])
-model = drv.SuPer(opt)
+model = drv.FrameLoop(opt)
 stages = {}
 
 
@@ -63,9 +63,9 @@ def timed(name, fn):
 
 
 drv.depth_preprocessing = timed("depth_preprocessing", data_loader.depth_preprocessing)
-drv.Surfels.update = timed("update", nodes.update)
-drv.Surfels.fuseInputData = timed("fuseInputData", fusion.fuseInputData)
-drv.Surfels.prepareStableIndexNSwapAllModel = timed("swap", fusion.prepareStableIndexNSwapAllModel)
+drv.SurfelModel.update = timed("update", nodes.update)
+drv.SurfelModel.fuseInputData = timed("fuseInputData", fusion.fuseInputData)
+drv.SurfelModel.prepareStableIndexNSwapAllModel = timed("swap", fusion.prepareStableIndexNSwapAllModel)
 if derived:
     model.lm.LM = timed("LM", model.lm.LM)
     if "--detail" in sys.argv:
