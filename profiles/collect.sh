@@ -1,19 +1,25 @@
 #!/bin/bash
 # Collect the round's judged profiles on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01'
+#   rm -rf gpurun_out/<tag>_*; gpurun --timeout 1500 -- 'bash profiles/collect.sh <tag>'
 # Writes under gpurun_out/<tag>_*; `python profiles/install.py <tag>` then copies the summaries into profiles/.
 # rocprofv3 rules on this pool: the program itself after `--`; --pmc passes separate from --stats.
-TAG=${1:-r01}
+# Order: the HBM counter passes first, so that the bench line written afterwards can quote `roofline_data.traffic`
+# from a summary of exactly this build (bench.py only uses a summary whose source hash matches the tree).
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout 400 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err < /dev/null
-timeout 300 python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_b1.json 2> $R/gpurun_out/${TAG}_bench_b1.err < /dev/null
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
-find $R/gpurun_out/${TAG}_stats -name '*kernel_trace.csv' -delete
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1 < /dev/null
   find $R/gpurun_out/${TAG}_pmc_$c -name '*kernel_trace.csv' -delete
 done
+F=$(find $R/gpurun_out/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+W=$(find $R/gpurun_out/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+python3 $R/profiles/make_traffic.py $F $W --workload C2 --frames-per-gpu 8 --out $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
+cp $R/gpurun_out/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json      # (on the box; install.py makes the tracked copy)
+timeout 400 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err < /dev/null
+timeout 300 python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_b1.json 2> $R/gpurun_out/${TAG}_bench_b1.err < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
+find $R/gpurun_out/${TAG}_stats -name '*kernel_trace.csv' -delete
 # SQ counters of the same command (wave lifetime, waiting share, VALU share): two small passes
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
   n=$(echo $grp | cut -d' ' -f2)
@@ -24,8 +30,4 @@ python3 $R/profiles/make_sq_summary.py $R/gpurun_out/${TAG}_pmc_sq_*/ --out $R/g
 # one frame per launch (the drop-in case): kernel stats of the task-graph solver
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats_b1 -name '*kernel_trace.csv' -delete
-# per-kernel HBM traffic summary, tagged with the library that was profiled
-F=$(find $R/gpurun_out/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)
-W=$(find $R/gpurun_out/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-python3 $R/profiles/make_traffic.py $F $W --workload C2 --frames-per-gpu 8 --out $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
 ls $R/gpurun_out/${TAG}_stats/* $R/gpurun_out/${TAG}_pmc_FETCH_SIZE/* < /dev/null

@@ -23,7 +23,7 @@ def one(pattern):
     m = glob.glob(os.path.join(G, pattern), recursive=True)
     if not m:
         raise SystemExit("missing " + pattern)
-    return m[0]
+    return max(m, key=os.path.getmtime)      # gpurun merges into gpurun_out/: older collections may still be there
 
 
 shutil.copy(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_C2_b8_bench.json"))
