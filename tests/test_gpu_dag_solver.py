@@ -157,3 +157,53 @@ def test_hybrid_form_failure_stops_like_the_reference():
     recs = e.records(1)
     assert recs[0]["status"] == 1 and all(r["status"] == 2 for r in recs[1:])
     np.testing.assert_allclose(e.beta(1).cpu().numpy(), np.tile([1.0, 0, 0, 0, 0, 0, 0], (bad.J, 1)), rtol=0, atol=0)
+
+
+def test_c2_full_size_hybrid_batch():
+    """BASELINE C2 x 3 frames (different plans): the hybrid form solver_path 0 picks for a batch == per-level launches"""
+    from super_amd import synth
+    scenes = [synth.make_scene(seed=s, **synth.WORKLOADS["C2"]) for s in range(3)]
+    res = {}
+    for sp in (3, 0):
+        e = _engine(max_frames=3, solver_path=sp)
+        e.bind_batch([_dframe(sc) for sc in scenes])
+        e.run(3)
+        assert e.lib.slm_debug_last_solver_form(e.h) == (0 if sp == 3 else 2)
+        res[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(3)]
+        e.close()
+    for i in range(3):
+        assert all(r["status"] == 0 for r in res[0][i][1])
+        np.testing.assert_allclose([r["loss"] for r in res[0][i][1]], [r["loss"] for r in res[3][i][1]], rtol=1e-9)
+        assert [r["accepted"] for r in res[0][i][1]] == [r["accepted"] for r in res[3][i][1]]
+        np.testing.assert_allclose(res[0][i][0], res[3][i][0], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("top_fronts", ["1", "4", "16"])
+def test_hybrid_cut_override_keeps_the_result(top_fronts):
+    """SLM_DAG_TOP_FRONTS moves the cut between the per-level launches and the task graph (root only ... four levels):
+    same solution (read once per process, hence the subprocess)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'python-super_amd')!r}, {os.path.join(root, 'tests')!r}]\n"
+        "import torch\n"
+        "from oracle import lm_oracle as orc\n"
+        "from super_amd import synth\n"
+        "from super_amd.engine import DeviceFrame, Engine\n"
+        "dev = torch.device('cuda', 0)\n"
+        "scs = [synth.make_scene(N=20000, J=400, H=240, W=320, seed=90 + k, src_border=8, tgt_border=4) for k in range(3)]\n"
+        "e = Engine(dev, max_frames=3, solver_path=4, num_iterations=4)\n"
+        "e.bind_batch([DeviceFrame.from_scene(sc, dev) for sc in scs])\n"
+        "e.run(3)\n"
+        "form = e.lib.slm_debug_last_solver_form(e.h)\n"
+        "errs = [float(np.abs(e.beta(i).cpu().numpy() - orc.lm(orc.Frame.from_scene(scs[i]), orc.default_opt(num_optimize_iterations=4))).max()) for i in range(3)]\n"
+        "print('RES', form, max(errs))\n")
+    env = dict(os.environ)
+    env["SLM_DAG_TOP_FRONTS"] = top_fronts
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    form, err = out.stdout.strip().splitlines()[-1].split()[1:]
+    assert int(form) == 2 and float(err) < 1e-6, (top_fronts, form, err)
