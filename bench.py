@@ -490,6 +490,8 @@ def main():
                        "image": [dims["H"], dims["W"]],
                        "storage": "f32/i32 state in HBM (BASELINE's fp32 configs; the drop-in mirror passes the "
                                   "reference's float64 state in place), f64 arithmetic and solve",
+                       "bind": "one slm_bind_frame per frame" if os.environ.get("BENCH_SEQ_BIND") else
+                               "slm_bind_frames: the frames of a step bound concurrently (worker threads / streams inside the library)",
                        "parallelism": f"frames sharded over {world} GPU(s), beta all-gather"},
             "lm_iterations_ok_frame0": n_ok,
             "final_loss_frame0": final_loss[-1] if final_loss else None,
