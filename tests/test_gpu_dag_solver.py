@@ -207,3 +207,22 @@ def test_hybrid_cut_override_keeps_the_result(top_fronts):
     assert out.returncode == 0, out.stderr[-2000:]
     form, err = out.stdout.strip().splitlines()[-1].split()[1:]
     assert int(form) == 2 and float(err) < 1e-6, (top_fronts, form, err)
+
+
+def test_c4_hybrid_batch_matches_level_launches():
+    """500 k surfels / 4 000 nodes (9 levels) x 3 frames: hybrid form == per-level launches, 4 iterations"""
+    from super_amd import synth
+    scenes = [synth.make_scene(seed=s, **synth.WORKLOADS["C4"]) for s in range(3)]
+    frames = [_dframe(sc) for sc in scenes]
+    res = {}
+    for sp in (3, 0):
+        e = _engine(max_frames=3, solver_path=sp, num_iterations=4)
+        e.bind_batch(frames)
+        e.run(3)
+        assert e.lib.slm_debug_last_solver_form(e.h) == (0 if sp == 3 else 2)
+        res[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(3)]
+        e.close()
+    for i in range(3):
+        assert all(r["status"] == 0 for r in res[0][i][1])
+        np.testing.assert_allclose([r["loss"] for r in res[0][i][1]], [r["loss"] for r in res[3][i][1]], rtol=1e-9)
+        np.testing.assert_allclose(res[0][i][0], res[3][i][0], rtol=0, atol=1e-9)
