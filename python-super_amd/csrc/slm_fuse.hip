@@ -337,12 +337,16 @@ __global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m, slm_fuse
 
 // Bounding boxes of the ED nodes in runs of FU_RUN consecutive indices (the node graph is a mesh grid in
 // row-major order, so a run is a compact row segment; any other order only prunes less).  One wave per run.
-#define FU_RUN 32
+#define FU_RUN 64
 __global__ void __launch_bounds__(64) k_fu_node_boxes(int J, const double* __restrict__ ed_points, double* __restrict__ boxes) {
-  const int b = blockIdx.x, j = b * FU_RUN + (threadIdx.x & (FU_RUN - 1));
+  const int b = blockIdx.x;
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-  if (threadIdx.x < FU_RUN && j < J)
-    for (int k = 0; k < 3; ++k) lo[k] = hi[k] = ed_points[3 * (size_t)j + k];
+  for (int j = b * FU_RUN + threadIdx.x; j < min((b + 1) * FU_RUN, J); j += 64)
+    for (int k = 0; k < 3; ++k) {
+      const double v = ed_points[3 * (size_t)j + k];
+      lo[k] = fmin(lo[k], v);
+      hi[k] = fmax(hi[k], v);
+    }
   for (int off = 32; off >= 1; off >>= 1)
     for (int k = 0; k < 3; ++k) {
       lo[k] = fmin(lo[k], __shfl_xor(lo[k], off));
@@ -439,6 +443,7 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
   const int n_runs = (m.J + FU_RUN - 1) / FU_RUN;
   int seed = -1;
   double seed_d2 = 1e300;
+#pragma unroll 4
   for (int b = 0; b < n_runs; ++b) {
     const double d2 = fu_box_d2(boxes + 6 * (size_t)b, px, py, pz);
     if (act && d2 < seed_d2) {
