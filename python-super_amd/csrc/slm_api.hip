@@ -759,7 +759,7 @@ hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims&
   const FrameDev* fr = s->frames_dev + first;
   for (int i = first; i < first + n; ++i) {
     Slot& sl = s->slots[i];
-    hipError_t e = hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_doubles, st);
+    hipError_t e = hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_zero_doubles, st);
     if (e == hipSuccess) e = hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st);
     if (e != hipSuccess) return e;
   }
@@ -837,7 +837,7 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   const FrameDev* fr = s->frames_dev;
   for (int i = 0; i < n_frames; ++i) {
     Slot& sl = s->slots[i];
-    HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_doubles, st));
+    HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_zero_doubles, st));
     HIPCHK(hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st));
   }
   launch_iter_begin_nd(fr, n_frames, st);
@@ -970,7 +970,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     if (d.nd) {
       for (int i = 0; i < n_frames; ++i) {
         Slot& sl = s->slots[i];
-        HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_doubles, st));
+        HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_zero_doubles, st));
         HIPCHK(hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st));
       }
       launch_iter_begin_nd(fr, n_frames, st);

@@ -83,17 +83,18 @@ template <typename T>
 __device__ __forceinline__ T* unip(T* p) { return reinterpret_cast<T*>(uni64(reinterpret_cast<long long>(p))); }
 
 struct FS {   // scalar snapshot of an NDFront
-  int nt, npt, nv, nb, n1, n1p, n2p, parent, which_child, nodes_off, eamap_off;
+  int nt, npt, nv, nb, n1, n1p, n2p, parent, which_child, nodes_off, eamap_off, is_leaf;
   int tile0, pcol0;      // first tile / first pivot tile column of the front in the slot's flag arrays
-  long long tile_off, vec_off, linv_off;
+  long long tile_off, f22_base, vec_off, linv_off;
 };
 __device__ __forceinline__ FS front_snapshot(const NDFront& f) {
   FS o;
   o.nt = uni(f.nt); o.npt = uni(f.npt); o.nv = uni(f.nv); o.nb = uni(f.nb); o.n1 = uni(f.n1); o.n1p = uni(f.n1p);
   o.n2p = uni(f.n2p); o.parent = uni(f.parent); o.which_child = uni(f.which_child);
   o.nodes_off = uni(f.nodes_off); o.eamap_off = uni(f.eamap_off);
-  o.tile_off = uni64(f.tile_off); o.vec_off = uni64(f.vec_off); o.linv_off = uni64(f.linv_off);
-  o.tile0 = (int)(o.tile_off / TILE);
+  o.tile_off = uni64(f.tile_off); o.f22_base = uni64(f.f22_base); o.vec_off = uni64(f.vec_off); o.linv_off = uni64(f.linv_off);
+  o.is_leaf = uni(f.is_leaf);
+  o.tile0 = uni(f.tile_first);
   o.pcol0 = (int)(o.linv_off / TILE);
   return o;
 }
@@ -132,7 +133,12 @@ __device__ __forceinline__ int tile_index(const FS& f, int r, int c) {
 }
 __device__ __forceinline__ double* tile_ptr(const SS& fd, const FS& f, int r, int c) {
   const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
-  return fd.ftiles + f.tile_off + t * TILE;
+  if (c < f.npt) return fd.ftiles + f.tile_off + t * TILE;
+  // boundary block (NDFront::f22_base).  Written with the block's own start and (t - pivot tiles): the direct form
+  // `ftiles + f22_base + t * TILE` makes this compiler merge the two returns into a pointer select and fail in
+  // instruction selection ("Operand has incorrect register class") at the address-space casts of ld1 / st1.
+  const size_t piv = (size_t)f.npt * f.nt - (size_t)f.npt * (f.npt - 1) / 2;
+  return fd.ftiles + (f.f22_base + (long long)(piv * TILE)) + (t - piv) * TILE;
 }
 __device__ __forceinline__ int dag_base(const FS& f, int p) {
   return p < f.nv ? 7 * p : f.n1p + 7 * (p - f.nv);
@@ -239,7 +245,7 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
       d.pr0[k] = d.pc0[k] = d.pc2[k] = 0; d.pnc[k] = d.pnc2[k] = 1; d.ctile0[k] = d.cnt[k] = d.cnpt[k] = 0;
       if (rr >= 0 && (cc >= 0 || c2 >= 0)) {
         const NDFront& cf = fd.fronts[ch];
-        d.ctile0[k] = (int)(uni64(cf.tile_off) / TILE); d.cnt[k] = uni(cf.nt); d.cnpt[k] = uni(cf.npt);
+        d.ctile0[k] = uni(cf.tile_first); d.cnt[k] = uni(cf.nt); d.cnpt[k] = uni(cf.npt);
         d.pr0[k] = rr & 255;
         const int nr = (rr >> 8) - (rr & 255) + 1;
         if (cc >= 0) { d.pc0[k] = cc & 255; d.pnc[k] = (cc >> 8) - (cc & 255) + 1; d.np[k] = nr * d.pnc[k]; }
@@ -369,7 +375,7 @@ __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, dou
     __syncthreads();   // earlier readers of maps are done
     if (threadIdx.x < 128) maps[threadIdx.x] = pm[64 * (w == 0 ? r : s) + l];
     __syncthreads();
-    const double* ct = fd.ftiles + cf.tile_off;
+    const double* ct = fd.ftiles + cf.f22_base;   // the child's update tiles live in its boundary block
     double v[16];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -830,7 +836,12 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
       const int r = tr_, sc = ts_;
       const bool dg = r == sc;
       double4_t acc[4];
-      load_c_frags1(tile_ptr(fd, f, r, sc), acc);
+      if (f.is_leaf) {   // a leaf's boundary block holds nothing yet (its storage is not even zeroed, NDFront::f22_base)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+      } else {
+        load_c_frags1(tile_ptr(fd, f, r, sc), acc);
+      }
       double bvec = 0.0, tsum = 0.0;
       if (dg && threadIdx.x < NB) bvec = ld1(vecs + (size_t)r * NB + threadIdx.x);
       if (dg) dag_pull<true>(fd, fi, r, sc, acc, bvec, d.np, maps);

@@ -18,6 +18,10 @@ __device__ __forceinline__ int nd_base(const NDFront& f, int p) {
   return p < f.nv ? 7 * p : f.n1p + 7 * (p - f.nv);
 }
 
+// Tile (r, c) of a front.  One formula for every tile this file touches: the boundary block of an INTERNAL front
+// follows its pivot columns (NDFront::f22_base == tile_off), and the boundary block of a LEAF -- the only tiles that
+// live elsewhere -- is never read or written by the per-level form (k_fschur starts a leaf's update from zero and
+// adds it straight into the parent, which has children and is therefore internal).
 __device__ __forceinline__ double* ftile(const FrameDev& fd, const NDFront& f, int r, int c) {
   const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
   return fd.ftiles + f.tile_off + t * TILE;
@@ -879,7 +883,12 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
     if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
   }
   double4_t acc[4];
-  load_c_frags(ftile(fd, f, r, sc), acc);
+  if (f.is_leaf) {   // nothing was ever added into a leaf's boundary block (and its storage is not zeroed)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+  } else {
+    load_c_frags(ftile(fd, f, r, sc), acc);
+  }
   // The B operand (L21 tile of block-row sc) passes through LDS in HALF tiles of 32 inner columns,
   // double-buffered (2 x 16 KB): three workgroups per CU instead of two, and the next half is in
   // flight while the current one is on the MFMA.

@@ -31,7 +31,13 @@ struct NDFront {
   int32_t depth;
   int32_t nodes_off;     // into nodes[]: nv pivot node ids then nb boundary node ids
   int32_t eamap_off;     // into eamap[]: boundary index -> local node position in the parent
-  int64_t tile_off;      // into the slot's front tile storage (doubles)
+  int32_t tile_first;    // logical number of the front's first tile (flags of the task-graph form)
+  int32_t is_leaf;       // no children: nothing is ever added into its boundary block before its own Schur update
+  int64_t tile_off;      // into the slot's front tile storage (doubles): the tiles of the PIVOT columns (c < npt)
+  int64_t f22_base;      // ... the tiles of the boundary block (c >= npt): tile t of the front's numbering lives at
+                         // f22_base + t * 4096.  Internal fronts: == tile_off (right behind the pivot columns).
+                         // Leaves: their boundary block sits in a tail region of the storage that is never zeroed
+                         // (it is written once, by the leaf's own Schur update, and read once)
   int64_t vec_off;       // into the slot's front vector storage (doubles), length nt*64
   int64_t linv_off;      // into the slot's diagonal-inverse storage (doubles), npt tiles
 };
@@ -87,6 +93,7 @@ struct NDPlanHost {
   std::vector<int32_t> order, node_tree, front_of_tree, occ_start;
   std::vector<std::pair<int32_t, int32_t>> occ;
   int64_t tile_doubles = 0, vec_doubles = 0, linv_doubles = 0;
+  int64_t tile_zero_doubles = 0;      // leading part of the tile storage that is zeroed before every assembly
   int32_t max_nt = 0, max_npt = 0, max_level_fronts = 0;
   std::vector<NDLevelSched> sched;    // one entry per level
   double flops = 0.0;          // factorisation FLOPs of the 64-padded dense fronts (what the kernels execute)

@@ -294,6 +294,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       if (occ[e].first == tid) return occ[e].second;
     return -1;
   };
+  int64_t n_tiles_logical = 0;
   for (int i = 0; i < T; ++i) {
     const int id = proc[i];
     TreeNode& t = b.tree[id];
@@ -323,8 +324,16 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       out.nodes.push_back(v);
       occ[occ_fill[v]++] = {id, p++};
     }
+    // storage: pivot-column tiles of every front and the boundary blocks of the internal fronts first (zeroed before
+    // every assembly), the boundary blocks of the leaves behind them (see NDFront::f22_base)
+    const int64_t piv_tiles = (int64_t)f.npt * f.nt - (int64_t)f.npt * (f.npt - 1) / 2;
+    const int64_t all_tiles = (int64_t)f.nt * (f.nt + 1) / 2;
+    f.is_leaf = (t.child[0] < 0 && t.child[1] < 0) ? 1 : 0;
+    f.tile_first = (int32_t)n_tiles_logical;
+    n_tiles_logical += all_tiles;
     f.tile_off = out.tile_doubles;
-    out.tile_doubles += (int64_t)f.nt * (f.nt + 1) / 2 * 4096;
+    f.f22_base = f.tile_off;
+    out.tile_doubles += (f.is_leaf ? piv_tiles : all_tiles) * 4096;
     f.vec_off = out.vec_doubles;
     out.vec_doubles += (int64_t)f.nt * 64;
     f.linv_off = out.linv_doubles;
@@ -335,6 +344,14 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     out.flops += n1 * n1 * n1 / 3.0 + n1 * n1 * n2 + n1 * n2 * n2;
     const double e1 = f.n1, e2 = 7.0 * f.nb;
     out.flops_exact += e1 * e1 * e1 / 3.0 + e1 * e1 * e2 + e1 * e2 * e2;
+  }
+  out.tile_zero_doubles = out.tile_doubles;
+  for (int i = 0; i < T; ++i) {
+    NDFront& f = out.fronts[i];
+    if (!f.is_leaf) continue;
+    const int64_t piv = (int64_t)f.npt * f.nt - (int64_t)f.npt * (f.npt - 1) / 2;
+    f.f22_base = out.tile_doubles - piv * 4096;
+    out.tile_doubles += ((int64_t)f.nt * (f.nt + 1) / 2 - piv) * 4096;
   }
   out.sched.clear();
   for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
