@@ -628,13 +628,35 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         double dummy = 0.0;
         dag_pull<false>(fd, fi, s, s - 1, accl, dummy, d.np2, maps);
         {
+          // columns c < s-2: both tiles at once, as the columns come.  The last column, c = s-2, is split: its L(s-1,c)
+          // is the tile POTRF(s-1) itself produces (out only when that task starts factoring), so everything that
+          // does not need it -- the update of (s,s) and the vector sum -- is done before, and only one tile load and
+          // one product remain between its arrival and the streamed rounds.
+          const int clast = s - 2;
           int c = 0, m = 1;
-          while (c < s - 1 && m > 0) {
-            m = dag_wait_prefix(d, f, g, d.n0 + 3 * c, d.n0 + 3 * (s - 1), 3, abort_flag, s_abort, s_cnt);
+          while (c < clast && m > 0) {
+            m = dag_wait_prefix(d, f, g, d.n0 + 3 * c, d.n0 + 3 * clast, 3, abort_flag, s_abort, s_cnt);
             dag_accumulate2(fd, f, s, c, c + m, acc, accl, S, M, yv, tsum);
             c += m;
           }
           if (m == 0) return;
+          if (clast >= 0) {
+            if (!dag_wait_deps(d, f, g, d.n0 + 3 * clast, d.n0 + 3 * clast + 2, abort_flag, s_abort)) return;   // L(s,c), y_c
+            dag_accumulate<true>(fd, f, s, s, clast, clast + 1, acc, S, M, yv, tsum);       // leaves L(s,c) in S
+            if (!dag_wait_deps(d, f, g, d.n0 + 3 * clast + 2, d.n0 + 3 * clast + 3, abort_flag, s_abort)) return;   // L(s-1,c)
+            double areg[16];
+            load_tile_regs1(tile_ptr(fd, f, s - 1, clast), areg);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = areg[e];
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+              const double a = -S[(16 * w + lr) + (4 * ks + lk) * LD];
+#pragma unroll
+              for (int ni = 0; ni < 4; ++ni)
+                accl[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(M[(16 * ni + lr) + (4 * ks + lk) * LD], a, accl[ni], 0, 0, 0);
+            }
+          }
         }
         // ---- streamed row solve against column s-1 and update of (s,s), 16 pivots at a time: the producer
         // (POTRF(s-1), still inside its factorisation) publishes every finished diagonal-block inverse and row
@@ -646,18 +668,35 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
           double* Lst = M;     // row block kb of L(s-1,s-1), at its place in a 64 x 64 tile
           double* Xs = S;      // X(:, 16 kb .. 16 kb + 15) of all 64 rows, column-major ld 64
           const int pkb = d.n - 5;
+          // Software pipeline over the four rounds: the payload of round kb+1 (and a look at the flag of round kb+2)
+          // is requested BEFORE the products of round kb whenever its flag is already up, so that a consumer that has
+          // fallen behind the producer (a round costs it a poll + a load round trip + the products, ~4 us, against
+          // the producer's 2.8 us) catches up instead of ending 4-5 us after the producer's last pivot.
+          double pd[4] = {0.0, 0.0, 0.0, 0.0}, pl[4][3];   // per round: Dinv element, L blocks j = 1..kb
+          const int pe_i = threadIdx.x & 15, pe_k = threadIdx.x >> 4;
+#define STREAM_ISSUE(KB)                                                                                               \
+  do {                                                                                                                 \
+    pd[KB] = ld1(gl + (16 * (KB) + pe_i) + (size_t)(16 * (KB) + pe_k) * NB);                                           \
+    _Pragma("unroll") for (int j = 1; j < 4; ++j)                                                                      \
+      if (j <= (KB)) pl[KB][j - 1] = ld1(gt + (16 * (KB) + pe_i) + (size_t)(16 * (j - 1) + pe_k) * NB);                \
+  } while (0)
+          int issued = 1;
+          if (!dag_wait_deps(d, f, g, pkb, pkb + 1, abort_flag, s_abort)) return;
+          STREAM_ISSUE(0);
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
-            if (!dag_wait_deps(d, f, g, pkb + kb, pkb + kb + 1, abort_flag, s_abort)) return;
+            const bool look = kb < 3 && issued == kb + 1;      // the next round is not requested yet: look at its flag
+            if (look && threadIdx.x == 0) *s_cnt = ldf(dep_flag(d, f, g, pkb + kb + 1));
             if (kb == 3) DAG_READY();
+            dinv[kb * 256 + pe_i + 16 * pe_k] = pd[kb];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (j > kb) break;
-              const int e = threadIdx.x, i = e & 15, k = e >> 4;
-              if (j == 0) dinv[kb * 256 + i + 16 * k] = ld1(gl + (16 * kb + i) + (size_t)(16 * kb + k) * NB);
-              else Lst[(16 * kb + i) + (16 * (j - 1) + k) * LD] = ld1(gt + (16 * kb + i) + (size_t)(16 * (j - 1) + k) * NB);
-            }
+            for (int j = 1; j < 4; ++j)
+              if (j <= kb) Lst[(16 * kb + pe_i) + (16 * (j - 1) + pe_k) * LD] = pl[kb][j - 1];
             __syncthreads();
+            if (look && uni(*s_cnt) >= 1) {      // (uniform: one LDS word written before the barrier)
+              STREAM_ISSUE(kb + 1);
+              issued = kb + 2;
+            }
             double4_t t4 = accl[kb];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -685,7 +724,13 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
               for (int ni = 0; ni < 4; ++ni)
                 acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
             }
+            if (kb < 3 && issued == kb + 1) {
+              if (!dag_wait_deps(d, f, g, pkb + kb + 1, pkb + kb + 2, abort_flag, s_abort)) return;
+              STREAM_ISSUE(kb + 1);
+              issued = kb + 2;
+            }
           }
+#undef STREAM_ISSUE
         }
         store_c_frags1(tile_ptr(fd, f, s, s - 1), accl);         // L(s, s-1) for the other tasks; published below
         xl[0] = accl[0]; xl[1] = accl[1]; xl[2] = accl[2]; xl[3] = accl[3];

@@ -66,3 +66,9 @@ for i in order:
         lvl_front.setdefault(front[i], []).append((s[i], rd[i], en[i]))
 ends = sorted((max(x[2] for x in v), f, len(v)) for f, v in lvl_front.items())
 print("last 12 fronts to finish factoring (end us, front, npt):", [(round(a, 1), int(b), c) for a, b, c in ends[-12:]])
+if "--chain" in sys.argv:
+    # absolute stamps (us) of the root front's POTRF tasks: where does the hand-off between two columns go?
+    print("root chain, absolute us: s | start ready | mark4 mark5 mark6 mark7 end | factor stamps (start, [diag16 done, barrier] x 4, end)")
+    for i in sorted(np.nonzero((typ == 0) & (front == root))[0], key=lambda i: s[i]):
+        a = (tr[i] - t0) / 100.0
+        print(f"  s={s[i]}  {a[0]:8.2f} {a[1]:8.2f} | " + " ".join(f"{x:8.2f}" for x in a[4:8]) + f" {a[2]:8.2f} | " + " ".join(f"{x:7.2f}" for x in a[8:21]))
