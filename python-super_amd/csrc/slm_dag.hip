@@ -367,37 +367,51 @@ template <bool VEC>
 __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const int np[2],
                                          int* maps) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  if (np[0] == 0 && np[1] == 0) return;
+  // both children's maps first, then ALL gathers in flight together (scattered 8-byte sc1 loads: one latency instead
+  // of two), then the sums in the fixed order child 0, child 1
+  __syncthreads();   // earlier readers of maps are done
+#pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (np[k] == 0) continue;
     const int ch = uni(fd.front_kids[2 * fi + k]);
-    const FS cf = front_snapshot(fd.fronts[ch]);
     const int32_t* pm = fd.pullmap + uni(fd.pull_off[ch]);
-    __syncthreads();   // earlier readers of maps are done
-    if (threadIdx.x < 128) maps[threadIdx.x] = pm[64 * (w == 0 ? r : s) + l];
-    __syncthreads();
+    if (threadIdx.x < 128) maps[128 * k + threadIdx.x] = pm[64 * (w == 0 ? r : s) + l];
+  }
+  __syncthreads();
+  double v[2][16], bv[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[k][e] = 0.0;
+    if (np[k] == 0) continue;
+    const int ch = uni(fd.front_kids[2 * fi + k]);
+    const FS cf = front_snapshot(fd.fronts[ch]);
     const double* ct = fd.ftiles + cf.f22_base;   // the child's update tiles live in its boundary block
-    double v[16];
+    const int* mk = maps + 128 * k;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int ci = maps[16 * w + lr], cj = maps[64 + 16 * ni + lk + 4 * rr];
-        double x = 0.0;
+        const int ci = mk[16 * w + lr], cj = mk[64 + 16 * ni + lk + 4 * rr];
         if (ci >= 0 && cj >= 0 && ci >= cj) {
           const int tr = cf.npt + (ci >> 6), tc = cf.npt + (cj >> 6);
           const size_t t = (size_t)tc * cf.nt - (size_t)tc * (tc - 1) / 2 + (size_t)(tr - tc);
-          x = ld1(ct + t * TILE + (ci & 63) + (size_t)(cj & 63) * NB);
+          v[k][4 * ni + rr] = ld1(ct + t * TILE + (ci & 63) + (size_t)(cj & 63) * NB);
         }
-        v[4 * ni + rr] = x;
       }
+    if (VEC && threadIdx.x < NB) {
+      const int ci = mk[threadIdx.x];
+      if (ci >= 0) bv[k] = ld1(fd.fvec + cf.vec_off + (size_t)cf.npt * NB + ci);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[ni][rr] += v[4 * ni + rr];
-    if (VEC && threadIdx.x < NB) {
-      const int ci = maps[threadIdx.x];
-      if (ci >= 0) bvec += ld1(fd.fvec + cf.vec_off + (size_t)cf.npt * NB + ci);
-    }
+      for (int rr = 0; rr < 4; ++rr) acc[ni][rr] += v[k][4 * ni + rr];
+    if (VEC) bvec += bv[k];
   }
 }
 
@@ -759,7 +773,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
           }
         __syncthreads();
         DAG_MARK(5);
-        const bool stream = s + 1 < f.npt;                 // POTRF(s+1) follows the factorisation 16 pivots at a time
+        const bool stream = s + 1 < f.nt;                  // POTRF(s+1) and the column's COL tasks follow the factorisation 16 pivots at a time
         double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
         const bool ok = dag_factor_tile(linv, tile_ptr(fd, f, s, s), stream ? g.pk + 4 * (f.pcol0 + s) : nullptr,
                                        s > 0 ? g.tile + tile_index(f, s, s - 1) : nullptr,    // L(s, s-1) goes out during the first 16 pivots
@@ -805,25 +819,69 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         if (s == 0) DAG_READY();
         DAG_END();
       } else {
-        // stage 2: the factor of the diagonal tile, then X = acc L_ss^-T as one tile product with L_ss^-1
-        if (!dag_wait_deps(d, f, g, d.n - 1, d.n, abort_flag, s_abort)) return;
-        DAG_READY();
-        const double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
-        double breg[16];
-        load_tile_regs1(linv, breg);
-        // (the wait's barrier came after the last MFMA that read M as an operand buffer)
+        // stage 2: X = acc L_ss^-T, 16 pivots at a time behind the factorisation of (s,s) -- the same streamed row solve
+        // as POTRF(s+1) runs on its tile (s+1,s): the row is complete ~3 us after the producer's last pivot instead of
+        // after the whole inverse has been assembled, published and re-read (the boundary rows of a front's LAST pivot
+        // column are what its Schur complement, and with it the parent front, waits for).
+        {
+          const double* gl = fd.flinv + f.linv_off + (size_t)s * TILE;
+          const double* gt = tile_ptr(fd, f, s, s);
+          double* Lst = M;     // row block kb of L(s,s), at its place in a 64 x 64 tile
+          int* pk = g.pk + 4 * (f.pcol0 + s);
+          double pd[4] = {0.0, 0.0, 0.0, 0.0}, pl[4][3];
+          const int pe_i = threadIdx.x & 15, pe_k = threadIdx.x >> 4;
+#define COL_ISSUE(KB)                                                                                                  \
+  do {                                                                                                                 \
+    pd[KB] = ld1(gl + (16 * (KB) + pe_i) + (size_t)(16 * (KB) + pe_k) * NB);                                           \
+    _Pragma("unroll") for (int j = 1; j < 4; ++j)                                                                      \
+      if (j <= (KB)) pl[KB][j - 1] = ld1(gt + (16 * (KB) + pe_i) + (size_t)(16 * (j - 1) + pe_k) * NB);                \
+  } while (0)
+          if (!dag_wait(1, [&](int) { return (const int*)pk; }, 1, abort_flag, s_abort)) return;
+          int issued = 1;
+          COL_ISSUE(0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = breg[e];
-        __syncthreads();
-        double areg[16];
+          for (int kb = 0; kb < 4; ++kb) {
+            const bool look = kb < 3 && issued == kb + 1;
+            if (look && threadIdx.x == 0) *s_cnt = ldf(pk + kb + 1);
+            if (kb == 3) DAG_READY();
+            dinv[kb * 256 + pe_i + 16 * pe_k] = pd[kb];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+            for (int j = 1; j < 4; ++j)
+              if (j <= kb) Lst[(16 * kb + pe_i) + (16 * (j - 1) + pe_k) * LD] = pl[kb][j - 1];
+            __syncthreads();
+            if (look && uni(*s_cnt) >= 1) {
+              COL_ISSUE(kb + 1);
+              issued = kb + 2;
+            }
+            double4_t t4 = acc[kb];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) areg[4 * ni + rr] = acc[ni][rr];
-        double4_t xa[4];
+            for (int t = 0; t < 4; ++t) {
+              if (t >= kb) break;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-        tile_ABt_regs<false>(areg, M, xa);
+              for (int ks = 0; ks < 4; ++ks) {
+                const double y = Lst[(16 * kb + lr) + (16 * t + 4 * ks + lk) * LD];
+                t4 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, -acc[t][ks], t4, 0, 0, 0);
+              }
+            }
+            double4_t x4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double y = dinv[kb * 256 + lr + 16 * (4 * ks + lk)];   // Y[p][n] = Dinv[n][p]
+              x4 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, t4[ks], x4, 0, 0, 0);
+            }
+            acc[kb] = x4;
+            if (kb < 3 && issued == kb + 1) {
+              const int nk = kb + 1;
+              if (!dag_wait(1, [&](int) { return (const int*)(pk + nk); }, 1, abort_flag, s_abort)) return;
+              COL_ISSUE(kb + 1);
+              issued = kb + 2;
+            } else {
+              __syncthreads();   // Lst / dinv / s_cnt are written again by the next round
+            }
+          }
+#undef COL_ISSUE
+        }
+        double4_t* xa = acc;
         store_c_frags1(tile_ptr(fd, f, r, s), xa);
         dag_publish_begin();
         dag_set_flag(g.tile + tile_index(f, r, s));

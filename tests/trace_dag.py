@@ -72,3 +72,22 @@ if "--chain" in sys.argv:
     for i in sorted(np.nonzero((typ == 0) & (front == root))[0], key=lambda i: s[i]):
         a = (tr[i] - t0) / 100.0
         print(f"  s={s[i]}  {a[0]:8.2f} {a[1]:8.2f} | " + " ".join(f"{x:8.2f}" for x in a[4:8]) + f" {a[2]:8.2f} | " + " ".join(f"{x:7.2f}" for x in a[8:21]))
+if "--transition" in sys.argv:
+    # from the last pivot column of the root's children to the root's first factorisation
+    kids = sorted(set(front[(typ == 2)]))[-2:]          # the two fronts with SCHUR tasks that finish last = the root's children
+    print("transition into the root front (us):")
+    for k in kids:
+        mp = (front == k) & (typ == 0)
+        last = np.argmax(np.where(mp, en, -1))
+        print(f"  child {k}: npt {int(s[mp].max()) + 1}; last POTRF s={s[last]} ready {rd[last]:.1f} end {en[last]:.1f};"
+              f" its factor {(tr[last, 8] - t0) / 100:.1f} .. {(tr[last, 20] - t0) / 100:.1f}")
+        mc = (front == k) & (typ == 1) & (s == s[last])
+        print(f"     COL tasks of that column: {mc.sum()}, ready {rd[mc].min():.1f} .. {rd[mc].max():.1f}, end {en[mc].min():.1f} .. {en[mc].max():.1f}")
+        ms = (front == k) & (typ == 2)
+        print(f"     SCHUR tasks: {ms.sum()}, ready {rd[ms].min():.1f} .. {rd[ms].max():.1f}, end {en[ms].min():.1f} .. {en[ms].max():.1f}")
+    m0 = (front == root) & (typ == 0) & (s == 0)
+    i0 = np.nonzero(m0)[0][0]
+    a = (tr[i0] - t0) / 100.0
+    print(f"  root POTRF(0): start {a[0]:.1f}, stage 0 done (mark4) {a[4]:.1f}, factor {a[8]:.1f} .. {a[20]:.1f}")
+    mc0 = (front == root) & (typ == 1) & (s == 0)
+    print(f"  root COL(r,0): ready {rd[mc0].min():.1f} .. {rd[mc0].max():.1f}, end {en[mc0].min():.1f} .. {en[mc0].max():.1f}")
