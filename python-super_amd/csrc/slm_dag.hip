@@ -363,13 +363,11 @@ __device__ __forceinline__ int dag_wait_prefix(const TD& d, const FS& f, const D
 // depend on which workgroup ran when.  (The update tiles are complete: their flags are part of the task's stage 0.)
 // VEC (diagonal tiles): bvec (threads < NB, row threadIdx.x of tile row r) += the children's vector rows.
 // maps: 128 ints of LDS (rows | columns).
-template <bool VEC>
-__device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const int np[2],
-                                         int* maps) {
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+// the pull maps of tile (r,s) -- static plan data -- into LDS: [128 k + 0..63] the child's boundary scalar of every tile
+// row, [128 k + 64..127] of every tile column, child k
+__device__ __forceinline__ void dag_pull_maps(const SS& fd, int fi, int r, int s, const int np[2], int* maps) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (np[0] == 0 && np[1] == 0) return;
-  // both children's maps first, then ALL gathers in flight together (scattered 8-byte sc1 loads: one latency instead
-  // of two), then the sums in the fixed order child 0, child 1
   __syncthreads();   // earlier readers of maps are done
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -379,6 +377,16 @@ __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, dou
     if (threadIdx.x < 128) maps[128 * k + threadIdx.x] = pm[64 * (w == 0 ? r : s) + l];
   }
   __syncthreads();
+}
+
+template <bool VEC>
+__device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const int np[2],
+                                         int* maps, bool maps_loaded = false) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  if (np[0] == 0 && np[1] == 0) return;
+  // both children's maps first (or already in LDS: dag_pull_maps before the task's wait), then ALL gathers in flight
+  // together (scattered 8-byte sc1 loads: one latency instead of two), then the sums in the fixed order child 0, child 1
+  if (!maps_loaded) dag_pull_maps(fd, fi, r, s, np, maps);
   double v[2][16], bv[2] = {0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -617,6 +625,13 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
 #define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
 #define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // The task's own tile and vector rows are final before the launch (assembly; in the hybrid form also the pushes of
+    // the per-level launches): requested BEFORE the wait for what the task needs to start, not after it
+    double4_t acc[4];
+    load_c_frags1(tile_ptr(fd, f, tr_, ts_), acc);
+    double bvec = 0.0, tsum = 0.0;
+    if (type == ND_T_POTRF && threadIdx.x < NB) bvec = ld1(vecs + (size_t)ts_ * NB + threadIdx.x);
+    dag_pull_maps(fd, fi, tr_, ts_, d.np, maps);   // (static plan data: also before the wait)
     // stage 0: what the task needs to start
     if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
 
@@ -626,13 +641,9 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
       const bool diag = type == ND_T_POTRF;
       const double u = (u_override >= 0.0 || !diag) ? u_override : lmst->u;   // requested now, used after the updates
       // (stage 0: the children's update tiles and the operand columns c < s-1)
-      double4_t acc[4];
-      load_c_frags1(tile_ptr(fd, f, r, s), acc);
-      double bvec = 0.0, tsum = 0.0;
-      if (diag && threadIdx.x < NB) bvec = ld1(vecs + (size_t)s * NB + threadIdx.x);
       // the children's contributions to this tile (and to the vector rows of a diagonal tile)
-      if (diag) dag_pull<true>(fd, fi, r, s, acc, bvec, d.np, maps);
-      else dag_pull<false>(fd, fi, r, s, acc, bvec, d.np, maps);
+      if (diag) dag_pull<true>(fd, fi, r, s, acc, bvec, d.np, maps, true);
+      else dag_pull<false>(fd, fi, r, s, acc, bvec, d.np, maps, true);
       double4_t xl[4];   // POTRF(s > 0): L(s, s-1), rows of this wave (for its product with y_{s-1} after the factorisation)
       if (diag && s > 0) {
         // POTRF(s) owns the tile (s, s-1) too: L(s,s-1) = (A(s,s-1) - sum_{c<s-1} L(s,c) L(s-1,c)^T) L_{s-1,s-1}^-T is
@@ -931,6 +942,17 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
 #define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
 #define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // own tile, vector rows and pull maps: final before the launch, requested before the wait (see dag_task_factor)
+    double4_t acc[4];
+    if (f.is_leaf) {   // a leaf's boundary block holds nothing yet (its storage is not even zeroed, NDFront::f22_base)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    } else {
+      load_c_frags1(tile_ptr(fd, f, tr_, ts_), acc);
+    }
+    double bvec = 0.0, tsum = 0.0;
+    if (tr_ == ts_ && threadIdx.x < NB) bvec = ld1(vecs + (size_t)tr_ * NB + threadIdx.x);
+    dag_pull_maps(fd, fi, tr_, ts_, d.np, maps);
     // stage 0: what the task needs to start
     if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
 
@@ -938,17 +960,8 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
       // ================= SCHUR(f,r,s): update tile of the boundary block, stored in place =============
       const int r = tr_, sc = ts_;
       const bool dg = r == sc;
-      double4_t acc[4];
-      if (f.is_leaf) {   // a leaf's boundary block holds nothing yet (its storage is not even zeroed, NDFront::f22_base)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-      } else {
-        load_c_frags1(tile_ptr(fd, f, r, sc), acc);
-      }
-      double bvec = 0.0, tsum = 0.0;
-      if (dg && threadIdx.x < NB) bvec = ld1(vecs + (size_t)r * NB + threadIdx.x);
-      if (dg) dag_pull<true>(fd, fi, r, sc, acc, bvec, d.np, maps);
-      else dag_pull<false>(fd, fi, r, sc, acc, bvec, d.np, maps);
+      if (dg) dag_pull<true>(fd, fi, r, sc, acc, bvec, d.np, maps, true);
+      else dag_pull<false>(fd, fi, r, sc, acc, bvec, d.np, maps, true);
       {
         int c = 0, m = 1;
         while (c < f.npt && m > 0) {
