@@ -1027,6 +1027,13 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
 #define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
 #define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+    // The boundary tiles of this column are final once the front is factored -- long before the parent's solution
+    // arrives: wait for THEM first and request the first two, so that the load latency is gone when x comes
+    const int c_ = ts_;
+    if (!dag_wait(f.nt - f.npt, [&](int i) { return (const int*)(g.tile + tile_index(f, f.npt + i, c_)); }, 1, abort_flag, s_abort)) return;
+    double l0[16], l1[16], l2[16], l3[16];
+    if (f.npt < f.nt) load_tile_regs1(tile_ptr(fd, f, f.npt, c_), l0);
+    if (f.npt + 1 < f.nt) load_tile_regs1(tile_ptr(fd, f, f.npt + 1, c_), l1);
     // stage 0: what the task needs to start
     if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
 
@@ -1039,25 +1046,29 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
       const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
       for (int i = threadIdx.x; i < f.n2p; i += blockDim.x) xb[i] = (i < 7 * f.nb) ? ld1(fd.delta + 7 * nodes[i / 7] + i % 7) : 0.0;
       __syncthreads();
-      // tile-linear (coalesced) loads, two boundary tiles in flight; the partial products of all tiles are summed
-      // per thread first, one butterfly over the lanes at the end
+      // tile-linear (coalesced) loads, two tiles being used while the next two are in flight; the partial products of
+      // all tiles are summed per thread first, one butterfly over the lanes at the end
       double acc16[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc16[e] = 0.0;
-      for (int r = f.npt; r < f.nt; r += 2) {
-        double l0[16], l1[16];
-        const bool h1 = r + 1 < f.nt;
-        load_tile_regs1(tile_ptr(fd, f, r, c), l0);
-        if (h1) load_tile_regs1(tile_ptr(fd, f, r + 1, c), l1);
-        const double x0 = xb[(size_t)(r - f.npt) * NB + l];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc16[e] += l0[e] * x0;
-        if (h1) {
-          const double x1 = xb[(size_t)(r + 1 - f.npt) * NB + l];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc16[e] += l1[e] * x1;
-        }
+#define BACKB_USE(LV, R)                                                          \
+  do {                                                                            \
+    if ((R) < f.nt) {                                                             \
+      const double x_ = xb[(size_t)((R) - f.npt) * NB + l];                       \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] += LV[e] * x_;      \
+    }                                                                             \
+  } while (0)
+      for (int r = f.npt; r < f.nt; r += 4) {
+        if (r + 2 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 2, c), l2);
+        if (r + 3 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 3, c), l3);
+        BACKB_USE(l0, r);
+        BACKB_USE(l1, r + 1);
+        if (r + 4 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 4, c), l0);
+        if (r + 5 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 5, c), l1);
+        BACKB_USE(l2, r + 2);
+        BACKB_USE(l3, r + 3);
       }
+#undef BACKB_USE
       const double a = col_reduce16(acc16);
       if ((l & 3) == 0) {
         double* pv = vecs + (size_t)c * NB + w + 4 * ((l >> 2) & 15);
@@ -1110,26 +1121,20 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
 #define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
 #define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
-    // stage 0: what the task needs to start
-    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
-
-  {
-      // ================= BACK(f): the chain over the front's pivot columns =========================
-      // for r = npt-1 .. 0:  x_r = L_rr^-T y_r,  then  y_c -= L(r,c)^T x_r  for c < r.  y / x stay in LDS, the tiles
-      // (the inverses of the diagonal factors and the L tiles, in the order they are used) stream through
-      // registers three ahead: their addresses do not depend on x, so the chain never waits for memory.
-      // (stage 0: every y_c -- boundary part subtracted --, every tile L(r,c) of the pivot block)
-      DAG_READY();
-      double* ya = S;                  // npt * NB: y, overwritten by x column by column
-      for (int i = threadIdx.x; i < f.npt * NB; i += blockDim.x) ya[i] = ld1(vecs + i);
-      const int nops = f.npt * (f.npt + 1) / 2;      // op k: row r, then the inverse (j = 0) or tile (r, r - j) (j = 1 .. r)
-      auto op_tile = [&](int k, int& r, int& j) -> const double* {
-        r = f.npt - 1;
-        while (k > r) { k -= r + 1; --r; }
-        j = k;
-        return j == 0 ? fd.flinv + f.linv_off + (size_t)r * TILE : tile_ptr(fd, f, r, r - j);
-      };
-      double l0[16], l1[16], l2[16];
+    // stage 0 in two steps: the factorisation's outputs (y of every column, the tiles of the pivot block) are there long
+    // before the boundary part of the right-hand side (BACKB, which waits for the parent's solution): wait for the
+    // former, request the first three tiles of the chain, and only then wait for the latter
+    const int nb_flags = f.nb > 0 ? f.npt : 0;
+    if (!dag_wait_deps(d, f, g, 0, f.npt, abort_flag, s_abort)) return;
+    if (!dag_wait_deps(d, f, g, f.npt + nb_flags, d.n0, abort_flag, s_abort)) return;
+    const int nops = f.npt * (f.npt + 1) / 2;      // op k: row r, then the inverse (j = 0) or tile (r, r - j) (j = 1 .. r)
+    auto op_tile = [&](int k, int& r, int& j) -> const double* {
+      r = f.npt - 1;
+      while (k > r) { k -= r + 1; --r; }
+      j = k;
+      return j == 0 ? fd.flinv + f.linv_off + (size_t)r * TILE : tile_ptr(fd, f, r, r - j);
+    };
+    double l0[16], l1[16], l2[16];
 #define BACK_LOAD(LV, K)                                                                  \
   do {                                                                                    \
     if ((K) < nops) {                                                                     \
@@ -1137,6 +1142,19 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
       load_tile_regs1(op_tile((K), r_, j_), LV);                                          \
     }                                                                                     \
   } while (0)
+    BACK_LOAD(l0, 0);
+    BACK_LOAD(l1, 1);
+    BACK_LOAD(l2, 2);
+    if (!dag_wait_deps(d, f, g, f.npt, f.npt + nb_flags, abort_flag, s_abort)) return;
+
+  {
+      // ================= BACK(f): the chain over the front's pivot columns =========================
+      // for r = npt-1 .. 0:  x_r = L_rr^-T y_r,  then  y_c -= L(r,c)^T x_r  for c < r.  y / x stay in LDS, the tiles
+      // (the inverses of the diagonal factors and the L tiles, in the order they are used) stream through
+      // registers three ahead: their addresses do not depend on x, so the chain never waits for memory.
+      DAG_READY();
+      double* ya = S;                  // npt * NB: y, overwritten by x column by column
+      for (int i = threadIdx.x; i < f.npt * NB; i += blockDim.x) ya[i] = ld1(vecs + i);
       // out[n] = sum_m T[m][n] v[m]: the inverse acts on y_r (giving x_r in place), a tile on x_r (subtracted from y_c)
 #define BACK_OP(LV, K)                                                                    \
   do {                                                                                    \
@@ -1158,9 +1176,6 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
       if (j_ == 0 || j_ == r_) __syncthreads();                                           \
     }                                                                                     \
   } while (0)
-      BACK_LOAD(l0, 0);
-      BACK_LOAD(l1, 1);
-      BACK_LOAD(l2, 2);
       __syncthreads();                 // ya complete
       for (int k0 = 0; k0 < nops; k0 += 3) {
         BACK_OP(l0, k0);
