@@ -44,6 +44,7 @@
 #include <cstdlib>
 
 #include "slm_tile.h"
+#include "slm_lane.h"
 
 namespace {
 
@@ -516,28 +517,10 @@ __device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s
 
 // Transposed matrix-vector product with a tile held tile-linear in registers (lv[e] = T[threadIdx.x + 256 e], i.e.
 // row m = lane, column n = wave + 4 e; loaded with fully coalesced instructions): the caller forms
-// v[e] = lv[e] * x[lane]; this butterfly then sums every column over the 64 lanes with 17 shuffles (halving the
-// number of live values at each of the first four steps).  Returns, in the lanes with (lane & 3) == 0, the sum
+// v[e] = lv[e] * x[lane]; the butterfly then sums every column over the 64 lanes (halving the number of live
+// values at each of the first four steps).  Returns, in the lanes with (lane & 3) == 0, the sum
 // of column n = wave + 4 * ((lane >> 2) & 15).
-__device__ __forceinline__ double col_reduce16(double v[16]) {
-  const int l = threadIdx.x & 63;
-#define CR_STEP(CNT, O)                                                         \
-  _Pragma("unroll") for (int i = 0; i < (CNT); ++i) {                           \
-    const bool up = (l & (O)) != 0;                                             \
-    const double send = up ? v[i] : v[i + (CNT)];                               \
-    const double keep = up ? v[i + (CNT)] : v[i];                               \
-    v[i] = keep + __shfl_xor(send, (O), 64);                                    \
-  }
-  CR_STEP(8, 32)
-  CR_STEP(4, 16)
-  CR_STEP(2, 8)
-  CR_STEP(1, 4)
-#undef CR_STEP
-  double r = v[0];
-  r += __shfl_xor(r, 2, 64);
-  r += __shfl_xor(r, 1, 64);
-  return r;
-}
+// (col_reduce16: slm_lane.h -- the VALU-only butterfly; tests/micro/col_reduce_mb.hip compares it with the __shfl_xor one)
 
 // sum of the four quarter partials of dag_accumulate<true>: result for row i in every thread with (threadIdx.x & 63) == i
 __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4 * NB */) {
@@ -619,12 +602,12 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
     long long* trc_base = unip(fdr.dag_trace);
     long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
     if (trc && threadIdx.x == 0) {
-      trc[0] = wall_clock64();
-      trc[3] = blockIdx.x;
+      trace_put(trc, 0, wall_clock64());
+      trace_put(trc, 3, blockIdx.x);
     }
-#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
-#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
-#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trace_put(trc, 1, wall_clock64()); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trace_put(trc, 2, wall_clock64()); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
     // The task's own tile and vector rows are final before the launch (assembly; in the hybrid form also the pushes of
     // the per-level launches): requested BEFORE the wait for what the task needs to start, not after it
     double4_t acc[4];
@@ -936,12 +919,12 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
     long long* trc_base = unip(fdr.dag_trace);
     long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
     if (trc && threadIdx.x == 0) {
-      trc[0] = wall_clock64();
-      trc[3] = blockIdx.x;
+      trace_put(trc, 0, wall_clock64());
+      trace_put(trc, 3, blockIdx.x);
     }
-#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
-#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
-#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trace_put(trc, 1, wall_clock64()); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trace_put(trc, 2, wall_clock64()); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
     // own tile, vector rows and pull maps: final before the launch, requested before the wait (see dag_task_factor)
     double4_t acc[4];
     if (f.is_leaf) {   // a leaf's boundary block holds nothing yet (its storage is not even zeroed, NDFront::f22_base)
@@ -1021,12 +1004,12 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
     long long* trc_base = unip(fdr.dag_trace);
     long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
     if (trc && threadIdx.x == 0) {
-      trc[0] = wall_clock64();
-      trc[3] = blockIdx.x;
+      trace_put(trc, 0, wall_clock64());
+      trace_put(trc, 3, blockIdx.x);
     }
-#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
-#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
-#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trace_put(trc, 1, wall_clock64()); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trace_put(trc, 2, wall_clock64()); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
     // The boundary tiles of this column are final once the front is factored -- long before the parent's solution
     // arrives: wait for THEM first and request the first two, so that the load latency is gone when x comes
     const int c_ = ts_;
@@ -1115,65 +1098,87 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     long long* trc_base = unip(fdr.dag_trace);
     long long* trc = trc_base ? trc_base + 24 * (size_t)ti : nullptr;
     if (trc && threadIdx.x == 0) {
-      trc[0] = wall_clock64();
-      trc[3] = blockIdx.x;
+      trace_put(trc, 0, wall_clock64());
+      trace_put(trc, 3, blockIdx.x);
     }
-#define DAG_READY() do { if (trc && threadIdx.x == 0) trc[1] = wall_clock64(); } while (0)
-#define DAG_END() do { if (trc && threadIdx.x == 0) trc[2] = wall_clock64(); } while (0)
-#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+#define DAG_READY() do { if (trc && threadIdx.x == 0) trace_put(trc, 1, wall_clock64()); } while (0)
+#define DAG_END() do { if (trc && threadIdx.x == 0) trace_put(trc, 2, wall_clock64()); } while (0)
+#define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
     // stage 0 in two steps: the factorisation's outputs (y of every column, the tiles of the pivot block) are there long
     // before the boundary part of the right-hand side (BACKB, which waits for the parent's solution): wait for the
     // former, request the first three tiles of the chain, and only then wait for the latter
     const int nb_flags = f.nb > 0 ? f.npt : 0;
     if (!dag_wait_deps(d, f, g, 0, f.npt, abort_flag, s_abort)) return;
     if (!dag_wait_deps(d, f, g, f.npt + nb_flags, d.n0, abort_flag, s_abort)) return;
-    const int nops = f.npt * (f.npt + 1) / 2;      // op k: row r, then the inverse (j = 0) or tile (r, r - j) (j = 1 .. r)
-    auto op_tile = [&](int k, int& r, int& j) -> const double* {
-      r = f.npt - 1;
-      while (k > r) { k -= r + 1; --r; }
-      j = k;
-      return j == 0 ? fd.flinv + f.linv_off + (size_t)r * TILE : tile_ptr(fd, f, r, r - j);
+    // LEFT-looking order, column by column from the last: op k of column c is the tile L(npt-1-j, c), j = 0 .. npt-2-c
+    // (its product with the known x_r goes into per-thread partial sums -- no lane reduction per tile), then the
+    // inverse of the diagonal factor.  One workgroup runs the whole chain, so the order costs no latency, and a column
+    // needs two butterflies instead of one per tile.
+    const int nops = f.npt * (f.npt + 1) / 2;
+    // (ops past the end repeat the last one's address: every load below is UNCONDITIONAL, so the compiler can count the
+    // loads in flight and wait for exactly the tile it needs -- behind a branch it falls back to "wait for all")
+    // An op is (c, j); `lc, lj` walk three ops ahead of `oc, oj` (both stop at the last op).
+    // (branch-free on purpose: with branches between an op's multiply-adds and the next request, the compiler sinks
+    // the multiply-adds below the request, needs a second register set for the new tile and copies it over at the
+    // loop end -- behind a wait for ALL loads in flight, which serialises the whole chain on the memory latency)
+    auto op_next = [&](int& c, int& j) {
+      const bool last = j == f.npt - 1 - c, adv = last && c > 0;
+      j = last ? (adv ? 0 : j) : j + 1;
+      c = adv ? c - 1 : c;
     };
+    auto op_addr = [&](int c, int j) -> const double* {
+      const int r = f.npt - 1 - j;
+      const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);   // (tile_ptr, pivot columns)
+      const double* tile = fd.ftiles + f.tile_off + t * TILE;
+      const double* inv = fd.flinv + f.linv_off + (size_t)c * TILE;
+      return j == f.npt - 1 - c ? inv : tile;
+    };
+    int oc = f.npt - 1, oj = 0, lc = oc, lj = 0;
     double l0[16], l1[16], l2[16];
-#define BACK_LOAD(LV, K)                                                                  \
+#define BACK_LOAD(LV)                                                                     \
   do {                                                                                    \
-    if ((K) < nops) {                                                                     \
-      int r_, j_;                                                                         \
-      load_tile_regs1(op_tile((K), r_, j_), LV);                                          \
-    }                                                                                     \
+    load_tile_regs1(op_addr(lc, lj), LV);                                                 \
+    op_next(lc, lj);                                                                      \
   } while (0)
-    BACK_LOAD(l0, 0);
-    BACK_LOAD(l1, 1);
-    BACK_LOAD(l2, 2);
+    BACK_LOAD(l0);
+    BACK_LOAD(l1);
+    BACK_LOAD(l2);
     if (!dag_wait_deps(d, f, g, f.npt, f.npt + nb_flags, abort_flag, s_abort)) return;
 
   {
       // ================= BACK(f): the chain over the front's pivot columns =========================
-      // for r = npt-1 .. 0:  x_r = L_rr^-T y_r,  then  y_c -= L(r,c)^T x_r  for c < r.  y / x stay in LDS, the tiles
-      // (the inverses of the diagonal factors and the L tiles, in the order they are used) stream through
-      // registers three ahead: their addresses do not depend on x, so the chain never waits for memory.
+      // for c = npt-1 .. 0:  x_c = L_cc^-T (y_c - sum_{r>c} L(r,c)^T x_r).  y / x stay in LDS, the tiles (in the order
+      // they are used) stream through registers three ahead: their addresses do not depend on x.
       DAG_READY();
       double* ya = S;                  // npt * NB: y, overwritten by x column by column
       for (int i = threadIdx.x; i < f.npt * NB; i += blockDim.x) ya[i] = ld1(vecs + i);
-      // out[n] = sum_m T[m][n] v[m]: the inverse acts on y_r (giving x_r in place), a tile on x_r (subtracted from y_c)
+      double acc16[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc16[e] = 0.0;
+      // out[n] = sum_m T[m][n] v[m]
 #define BACK_OP(LV, K)                                                                    \
   do {                                                                                    \
-    if ((K) < nops) {                                                                     \
-      int r_, j_;                                                                         \
-      (void)op_tile((K), r_, j_);                                                         \
-      const double xm_ = ya[(size_t)r_ * NB + l];                                         \
-      double pv_[16];                                                                     \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) pv_[e] = LV[e] * xm_;                \
-      BACK_LOAD(LV, (K) + 3);      /* refill this slot: three operations ahead */         \
-      const double a_ = col_reduce16(pv_);                                                \
-      if (j_ == 0) __syncthreads(); /* everybody has read y_r */                          \
-      if ((l & 3) == 0) {                                                                 \
-        const int n_ = w + 4 * ((l >> 2) & 15);                                           \
-        if (j_ == 0) ya[(size_t)r_ * NB + n_] = a_;                                       \
-        else ya[(size_t)(r_ - j_) * NB + n_] -= a_;                                       \
-      }                                                                                   \
-      /* the tiles of one row update different y_c: no barrier between them */            \
-      if (j_ == 0 || j_ == r_) __syncthreads();                                           \
+    const int c_ = oc, j_ = oj;                                                           \
+    op_next(oc, oj);                                                                      \
+    const bool inv_ = (K) < nops && j_ == f.npt - 1 - c_;                                 \
+    const int n_ = w + 4 * ((l >> 2) & 15);                                               \
+    if (inv_ && c_ < f.npt - 1) {           /* the column's tiles are done: finish y_c */ \
+      const double a_ = col_reduce16(acc16);                                              \
+      if ((l & 3) == 0) ya[(size_t)c_ * NB + n_] -= a_;                                   \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] = 0.0;                      \
+      __syncthreads();                                                                    \
+    }                                                                                     \
+    /* tile (r, c): x_r; the inverse: y_c; past the end: nothing */                       \
+    const double xm_ = (K) < nops ? ya[(size_t)(inv_ ? c_ : f.npt - 1 - j_) * NB + l] : 0.0; \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] += LV[e] * xm_;               \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(acc16[e]) :: "memory");   /* (done HERE) */ \
+    BACK_LOAD(LV);                                                                        \
+    if (inv_) {                                                                           \
+      const double x_ = col_reduce16(acc16);                                              \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] = 0.0;                      \
+      __syncthreads();                      /* everybody has read y_c */                  \
+      if ((l & 3) == 0) ya[(size_t)c_ * NB + n_] = x_;                                    \
+      __syncthreads();                      /* x_c visible */                             \
     }                                                                                     \
   } while (0)
       __syncthreads();                 // ya complete

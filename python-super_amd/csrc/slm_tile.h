@@ -6,6 +6,16 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// A time stamp of the (optional) task trace.  The store goes through a GLOBAL-address-space pointer on purpose: a store
+// through a generic pointer is a FLAT instruction, and one pending flat access makes the compiler's wait-count pass
+// drop to "wait for every load in flight" (s_waitcnt vmcnt(0)) at each later use of a loaded register -- in a loop, at
+// every iteration, because the loop header inherits the state of the code before it.  A single trace stamp at the top
+// of a task function serialised every software-pipelined tile stream of that function on the memory latency this way.
+__device__ __forceinline__ void trace_put(long long* trc, int k, long long v) {
+  typedef __attribute__((address_space(1))) long long gll;
+  *((gll*)(trc + k)) = v;
+}
+
 #define NB SLM_NB
 #define TILE (NB * NB)
 
@@ -239,13 +249,16 @@ __device__ __forceinline__ void inverse_assemble64(const double* S, double* M, c
 //   M   out: L^-1 (full 64x64, zeros above)
 //   dinv 4 x 256 (inverses of the diagonal blocks), wt 3 x 256 (one scratch block per trailing wave),
 //   xch 128 doubles (wave 0's exchange buffer for diag16)
-__device__ __forceinline__ void lds_signal(volatile int* f) {
+// (the flags are addressed as LDS, address space 3: through a generic pointer the polls are FLAT loads -- a longer round
+// trip, and a pending flat access makes the compiler wait for every global load in flight at the next use of one)
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+__device__ __forceinline__ void lds_signal(int* f) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if ((threadIdx.x & 63) == 0) *f = 1;
+  if ((threadIdx.x & 63) == 0) *((lds_vint*)f) = 1;
 }
-__device__ __forceinline__ void lds_wait_all(volatile int* f, int n) {
+__device__ __forceinline__ void lds_wait_all(int* f, int n) {
   for (int i = 0; i < n; ++i)
-    while (f[i] == 0) __builtin_amdgcn_s_sleep(1);
+    while (((lds_vint*)f)[i] == 0) __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -308,14 +321,14 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
                                                   int* s_ok, int* pf, double* g_linv = nullptr,
                                                   double* g_ltile = nullptr, int* g_flag = nullptr, int* g_early = nullptr,
                                                   long long* trc = nullptr) {
-#define FTRC(k) do { if (trc && threadIdx.x == 0) trc[k] = wall_clock64(); } while (0)
+#define FTRC(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
   const int w = threadIdx.x >> 6;
   const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
   if (threadIdx.x < 16) pf[threadIdx.x] = 0;
   if (threadIdx.x == 0) *s_ok = 1;
   __syncthreads();
   double* Wscr = wt + (w > 0 ? w - 1 : 0) * 256;
-  volatile int* vpf = pf;
+  int* vpf = pf;
 #pragma unroll 1   // one copy of diag16: the unrolled form needs ~250 VGPRs and spills on the critical path
   for (int kb = 0; kb < 4; ++kb) {
     FTRC(3 * kb);

@@ -1,0 +1,106 @@
+// tile_stream_mb.hip -- how fast can ONE workgroup stream 32 KB tiles through registers?  (the back-substitution chain of
+// the task-graph solver, slm_dag.hip dag_task_back, is one workgroup walking up to 45 tiles)
+//   variants: agent-scope atomic loads (sc1, what the task graph must use) or plain loads; 8-byte or 16-byte per lane;
+//   3 or 6 tiles in flight.
+// build: hipcc --offload-arch=gfx950 -O3 -o tests/micro/bin/tile_stream_mb tests/micro/tile_stream_mb.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((address_space(1))) double gdouble;
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) double2_t gdouble2;
+
+template <int MODE>
+__device__ __forceinline__ void load16(const double* T, double r[16]) {
+  if (MODE == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r[e] = __hip_atomic_load((const gdouble*)(T + threadIdx.x + 256 * e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) r[e] = T[threadIdx.x + 256 * e];
+  } else if (MODE == 2) {     // 16 bytes per lane, plain
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const double2_t v = *reinterpret_cast<const double2_t*>(T + 2 * threadIdx.x + 512 * e);
+      r[2 * e] = v.x; r[2 * e + 1] = v.y;
+    }
+  } else {                    // 16 bytes per lane, sc1, as a buffer load (the language has no 16-byte atomic load)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T), 0, 32768, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * threadIdx.x + 4096 * e, 0, 1 << 4 /* sc1 */);
+      r[2 * e] = __hiloint2double(q.y, q.x); r[2 * e + 1] = __hiloint2double(q.w, q.z);
+    }
+  }
+}
+
+template <int MODE, int DEPTH>
+__global__ void __launch_bounds__(256, 1) k(const double* __restrict__ tiles, double* out, long long* t, int nops) {
+  double l[DEPTH][16], acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0;
+  const long long t0 = wall_clock64();
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load16<MODE>(tiles + 4096 * (size_t)d, l[d]);
+  for (int k0 = 0; k0 < nops; k0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] += l[d][e] * 1.0001;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(acc[e]));
+      load16<MODE>(tiles + 4096 * (size_t)(k0 + d + DEPTH), l[d]);
+    }
+  }
+  const long long t1 = wall_clock64();
+  double s = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s += acc[e];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) s += l[d][0];
+  out[threadIdx.x + 256 * blockIdx.x] = s;
+  if (threadIdx.x == 0) t[blockIdx.x] = t1 - t0;
+}
+
+__global__ void fill(double* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 1.0 + 1e-9 * (double)(i & 1023);
+}
+
+template <int MODE, int DEPTH>
+void run(const char* name, double* tiles, size_t n_tiles, double* out, long long* t, int nops, int wgs) {
+  double best = 1e30;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, tiles, n_tiles * 4096);   // written by other CUs: not in this CU's caches
+    hipLaunchKernelGGL((k<MODE, DEPTH>), dim3(wgs), dim3(256), 0, 0, tiles, out, t, nops);
+    std::vector<long long> h(wgs);
+    (void)hipMemcpy(h.data(), t, wgs * sizeof(long long), hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (long long v : h) worst = worst > v ? worst : (double)v;
+    best = best < worst ? best : worst;
+  }
+  const double us = best / 100.0;   // 100 MHz
+  printf("%-34s depth %d, %d wg: %7.2f us for %d tiles = %.3f us per tile (%.1f GB/s per workgroup)\n", name, DEPTH, wgs, us, nops, us / nops,
+         32768.0 * nops / us / 1e3);
+}
+
+int main() {
+  const int nops = 240;
+  const size_t n_tiles = 256;
+  double *tiles, *out;
+  long long* t;
+  (void)hipMalloc(&tiles, n_tiles * 4096 * sizeof(double));
+  (void)hipMalloc(&out, 256 * 256 * sizeof(double));
+  (void)hipMalloc(&t, 256 * sizeof(long long));
+  for (int wgs : {1, 16}) {
+    run<0, 3>("agent-scope loads (sc1), 8 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<0, 6>("agent-scope loads (sc1), 8 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<1, 3>("plain loads, 8 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<1, 6>("plain loads, 8 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<2, 3>("plain loads, 16 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<2, 6>("plain loads, 16 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<3, 3>("sc1 buffer loads, 16 B/lane", tiles, n_tiles, out, t, nops, wgs);
+    run<3, 6>("sc1 buffer loads, 16 B/lane", tiles, n_tiles, out, t, nops, wgs);
+  }
+  return 0;
+}
