@@ -152,6 +152,13 @@ static hipError_t grow(T*& p, size_t& cap, size_t need) {
   if (e == hipSuccess) cap = want;
   return e;
 }
+template <typename T>
+static hipError_t grow(GP<T>& p, size_t& cap, size_t need) {   // (a descriptor field, slm_common.h GP)
+  T* q = p;
+  const hipError_t e = grow(q, cap, need);
+  p = q;
+  return e;
+}
 
 extern "C" {
 
@@ -195,8 +202,8 @@ int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, 
     case 1: src = sl.fvec; n = sl.h.nd_ready ? sl.nd.vec_doubles : 0; break;
     case 2: src = sl.flinv; n = sl.h.nd_ready ? sl.nd.linv_doubles : 0; break;
     case 3: src = sl.h.delta; n = sl.h.P; break;
-    case 4: src = reinterpret_cast<const double*>(sl.h.dag_trace); n = sl.h.dag_trace ? 24 * (int64_t)sl.h.n_dag_tasks : 0; break;
-    case 5: src = reinterpret_cast<const double*>(sl.h.dag_tasks); n = sl.h.nd_ready ? sl.h.n_dag_tasks : 0; break;
+    case 4: src = reinterpret_cast<const double*>(sl.h.dag_trace.get()); n = sl.h.dag_trace ? 24 * (int64_t)sl.h.n_dag_tasks : 0; break;
+    case 5: src = reinterpret_cast<const double*>(sl.h.dag_tasks.get()); n = sl.h.nd_ready ? sl.h.n_dag_tasks : 0; break;
     default: return fail(SLM_ERR_INVALID, "slm_debug_read: unknown buffer");
   }
   *n_doubles = n;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 #include "super_lm.h"
 #include "slm_nd.h"
@@ -9,6 +10,31 @@
 #define SLM_NB 64            // scalar tile edge of the banded normal matrix
 #define SLM_MAX_KED 8
 #define SLM_K 4              // surfel->node neighbours (28-wide Jacobian rows)
+
+// ---------------------------------------------------------------------------------
+// A device pointer stored in a descriptor that lives in HBM (FrameDev).  Device code sees the field as a GLOBAL-address-
+// space pointer: a plain `T*` loaded from memory is a generic pointer, every access through it becomes a FLAT instruction,
+// and a pending flat access makes the compiler's wait-count pass wait for ALL loads in flight (s_waitcnt vmcnt(0)
+// lgkmcnt(0)) at each use of a loaded value -- no prefetch, no software pipeline survives that.  With the address space in
+// the field's type the accesses are global_load / global_store and the waits count.  (A cast at the use does not do it:
+// generic -> global -> generic folds away before the address spaces are inferred.)  Same size and layout as T*; the host
+// sees a plain pointer.
+template <class T>
+struct GP {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __attribute__((address_space(1))) T* p;
+  GP() = default;
+  __host__ __device__ GP(T* q) : p((__attribute__((address_space(1))) T*)q) {}
+  __host__ __device__ operator T*() const { return (T*)p; }
+#else
+  T* p;
+  GP() = default;
+  GP(T* q) : p(q) {}
+  operator T*() const { return p; }
+#endif
+  __host__ __device__ T* operator->() const { return (T*)*this; }
+  __host__ __device__ T* get() const { return (T*)*this; }
+};
 
 // ---------------------------------------------------------------------------------
 // Per-slot LM state, resident in HBM; every kernel reads it, k_accept advances it.
@@ -31,21 +57,21 @@ struct FrameDev {
   int32_t nt;            // tile columns = ceil(P / NB)
   int32_t wb;            // sub-diagonal tiles per tile column (tile half-bandwidth)
   int32_t bound;         // 1 once slm_bind_frame ran
-  double* beta;          // (J,7) current (== best in test phase)
-  double* delta;         // (nt*NB) solution of the damped system
-  double* rhs;           // (nt*NB) jtl, overwritten by the forward substitution
-  double* band;          // nt*(wb+1) tiles of NB*NB doubles, column-major inside a tile
-  double* linv;          // nt tiles: inverse of each diagonal Cholesky block
-  double* loss_part;     // per-block partial sums of the loss passes
+  GP<double> beta;          // (J,7) current (== best in test phase)
+  GP<double> delta;         // (nt*NB) solution of the damped system
+  GP<double> rhs;           // (nt*NB) jtl, overwritten by the forward substitution
+  GP<double> band;          // nt*(wb+1) tiles of NB*NB doubles, column-major inside a tile
+  GP<double> linv;          // nt tiles: inverse of each diagonal Cholesky block
+  GP<double> loss_part;     // per-block partial sums of the loss passes
   int32_t n_loss_part;
   int32_t pad2;
-  LMState* st;
-  slm_iter_record* rec;  // (num_iterations)
+  GP<LMState> st;
+  GP<slm_iter_record> rec;  // (num_iterations)
   // packed gather tables of the per-surfel evaluation (16-byte loads instead of scalar ones)
-  double* node_pk;       // (J,10): beta[0..6], g.x, g.y, g.z (float64: exact for either state dtype)
-  double* node_pk_try;   // same at the trial point beta + delta (loss pass of the LM loop)
-  float4* tgt_pn;        // (T,2): target point xyz0, target normal xyz0
-  unsigned long long* dbg;  // diagnostic builds only (-DSLM_STAMPS): in-kernel s_memtime stamps
+  GP<double> node_pk;       // (J,10): beta[0..6], g.x, g.y, g.z (float64: exact for either state dtype)
+  GP<double> node_pk_try;   // same at the trial point beta + delta (loss pass of the LM loop)
+  GP<float4> tgt_pn;        // (T,2): target point xyz0, target normal xyz0
+  GP<unsigned long long> dbg;  // diagnostic builds only (-DSLM_STAMPS): in-kernel s_memtime stamps
   // ---- tuple-sorted data-term assembly (slm_prep.hip / slm_data_v1.hip) ----
   int32_t v1_ready;      // 1 when the structures below are valid for this frame
   int32_t n_tuples;      // distinct canonical KNN 4-tuples
@@ -53,68 +79,91 @@ struct FrameDev {
   int32_t n_runs;        // (tuple, 64-chunk) runs = slab entries
   int32_t n_blocks;      // distinct coupled node pairs (a >= b) of the data term
   int32_t pad3;
-  void* s_pts;           // (n_pos,3) surfel xyz in tuple-sorted, 4-padded order (dtype of the state: f.state_f64)
-  int32_t* s_idx;        // (n_pos,4) KNN ids (original order), -1 for padding positions
-  void* s_w;             // (n_pos,4) KNN weights (dtype of the state)
-  int32_t* grp_run;      // (n_pos/4) run id of each group of 4 positions, -1 for padding
-  int32_t* run_nodes;    // (n_runs,4) ascending node ids of each run's tuple
-  double* slab;          // (n_runs, 768) per-run Gram tiles 00,10,11 (16x16 row-major each)
-  int32_t* blk_key;      // (n_blocks) a*J + b
-  int32_t* blk_start;    // (n_blocks+1) CSR offsets into blk_entry
-  int32_t* blk_entry;    // run*16 + pa*4 + pb
+  GP<void> s_pts;           // (n_pos,3) surfel xyz in tuple-sorted, 4-padded order (dtype of the state: f.state_f64)
+  GP<int32_t> s_idx;        // (n_pos,4) KNN ids (original order), -1 for padding positions
+  GP<void> s_w;             // (n_pos,4) KNN weights (dtype of the state)
+  GP<int32_t> grp_run;      // (n_pos/4) run id of each group of 4 positions, -1 for padding
+  GP<int32_t> run_nodes;    // (n_runs,4) ascending node ids of each run's tuple
+  GP<double> slab;          // (n_runs, 768) per-run Gram tiles 00,10,11 (16x16 row-major each)
+  GP<int32_t> blk_key;      // (n_blocks) a*J + b
+  GP<int32_t> blk_start;    // (n_blocks+1) CSR offsets into blk_entry
+  GP<int32_t> blk_entry;    // run*16 + pa*4 + pb
   // ---- workgroup-merged Gram blocks (v2): the 4 waves of a workgroup add their runs' 7x7
   //      blocks into LDS accumulators keyed by node pair; one 56-double record per
   //      (workgroup, node pair) goes to HBM instead of one 768-double Gram per run ----
   int32_t v2_ready;
   int32_t n_wblk;          // (workgroup, pair) records
-  const int32_t* wg_first; // (n_wg) first record of each workgroup
-  const int32_t* wg_last;  // (n_wg) last record (first-1 if none)
-  const uint8_t* run_lidx; // (n_runs,10) local record index of the run's 10 node pairs
-  double* wgslab;          // (n_wblk, 56): 49 block entries (row-major ca,cb) + 7 entries of -J^T r
-  const int32_t* blk2_start;  // (n_blocks+1) CSR over blk2_entry, same pair order as blk_key
-  const int32_t* blk2_entry;  // record ids
+  GP<const int32_t> wg_first; // (n_wg) first record of each workgroup
+  GP<const int32_t> wg_last;  // (n_wg) last record (first-1 if none)
+  GP<const uint8_t> run_lidx; // (n_runs,10) local record index of the run's 10 node pairs
+  GP<double> wgslab;          // (n_wblk, 56): 49 block entries (row-major ca,cb) + 7 entries of -J^T r
+  GP<const int32_t> blk2_start;  // (n_blocks+1) CSR over blk2_entry, same pair order as blk_key
+  GP<const int32_t> blk2_entry;  // record ids
   // ---- one frame sharded over several GPUs (slm_set_shard): this rank evaluates the workgroups
   //      [wg_lo, wg_hi) of the Jacobian pass and the surfels [sf_lo, sf_hi) of the loss pass; the
   //      per-pair sums travel through pairbuf (n_blocks x 56 doubles + matched count) ----
   int32_t wg_lo, wg_hi;
   int32_t sf_lo, sf_hi;
-  double* pairbuf;
+  GP<double> pairbuf;
   // ---- nested-dissection multifrontal solver (slm_nd_host.hip / slm_front.hip) ----
   int32_t nd_ready;      // 1 when the plan below is valid for this frame
   int32_t n_fronts;
   int32_t n_levels;
   int32_t pad4;
-  const int32_t* level_start;  // (n_levels+1) fronts of level l: [level_start[l], level_start[l+1])
-  const NDFront* fronts;       // processing order (deepest level first)
-  const int32_t* nd_nodes;     // per front: pivot node ids then boundary node ids
-  const int32_t* nd_eamap;     // per front: boundary index -> local node position in the parent
-  const int32_t* node_front;   // (J) front eliminating the node
-  const int32_t* node_pos;     // (J) local pivot position
-  const NDDest* block_dest;    // (n_blocks) destination of every data-term block
-  const NDDest* pair_dest;     // (J*K_ED) destination of every ARAP pair block
-  const int32_t* schur_items;  // Schur work lists (slm_nd.h)
-  const int32_t* schur_off;    // (2*n_levels + 1)
-  const int32_t* in_start;     // (J+1) ARAP edges grouped by target node (reverse KNN graph)
-  const int32_t* in_edge;
-  double* ftiles;              // front tile storage
-  double* fvec;                // front vectors (rhs -> y -> x)
-  double* flinv;               // inverses of the diagonal Cholesky blocks of the fronts
+  GP<const int32_t> level_start;  // (n_levels+1) fronts of level l: [level_start[l], level_start[l+1])
+  GP<const NDFront> fronts;       // processing order (deepest level first)
+  GP<const int32_t> nd_nodes;     // per front: pivot node ids then boundary node ids
+  GP<const int32_t> nd_eamap;     // per front: boundary index -> local node position in the parent
+  GP<const int32_t> node_front;   // (J) front eliminating the node
+  GP<const int32_t> node_pos;     // (J) local pivot position
+  GP<const NDDest> block_dest;    // (n_blocks) destination of every data-term block
+  GP<const NDDest> pair_dest;     // (J*K_ED) destination of every ARAP pair block
+  GP<const int32_t> schur_items;  // Schur work lists (slm_nd.h)
+  GP<const int32_t> schur_off;    // (2*n_levels + 1)
+  GP<const int32_t> in_start;     // (J+1) ARAP edges grouped by target node (reverse KNN graph)
+  GP<const int32_t> in_edge;
+  GP<double> ftiles;              // front tile storage
+  GP<double> fvec;                // front vectors (rhs -> y -> x)
+  GP<double> flinv;               // inverses of the diagonal Cholesky blocks of the fronts
   // ---- persistent task-graph solver (slm_dag.hip): task list of the plan + per-iteration flags ----
-  const int32_t* dag_tasks;    // (n_dag_tasks, 2) task words (slm_nd.h), in a topological order
-  const int32_t* front_kids;   // (n_fronts, 2) children with a boundary (front index or -1)
-  const int32_t* pull_off;     // (n_fronts) offset of the front's pull map in pullmap (-1: none)
-  const int32_t* pullmap;      // per child: parent scalar index -> boundary scalar index of the child, -1
-  const int32_t* prng_off;     // (n_fronts) offset into prng
-  const int32_t* prng;         // per front, tile row, child: child boundary tile rows lo | hi << 8 it gathers from, -1 none
-  int32_t* dag_flags;          // [0] ticket, [1] abort, [8..] per tile done, per pivot column {b, x, y, 4 x 16 pivots out}
+  GP<const int32_t> dag_tasks;    // (n_dag_tasks, 2) task words (slm_nd.h), in a topological order
+  GP<const int32_t> front_kids;   // (n_fronts, 2) children with a boundary (front index or -1)
+  GP<const int32_t> pull_off;     // (n_fronts) offset of the front's pull map in pullmap (-1: none)
+  GP<const int32_t> pullmap;      // per child: parent scalar index -> boundary scalar index of the child, -1
+  GP<const int32_t> prng_off;     // (n_fronts) offset into prng
+  GP<const int32_t> prng;         // per front, tile row, child: child boundary tile rows lo | hi << 8 it gathers from, -1 none
+  GP<int32_t> dag_flags;          // [0] ticket, [1] abort, [8..] per tile done, per pivot column {b, x, y, 4 x 16 pivots out}
   int32_t n_dag_tasks;
-  const int32_t* dag_top_tasks;   // the tasks of the fronts of depth <= dag_cut_depth, same order (hybrid solve)
+  GP<const int32_t> dag_top_tasks;   // the tasks of the fronts of depth <= dag_cut_depth, same order (hybrid solve)
   int32_t n_dag_top_tasks, dag_cut_depth;
   int32_t dag_n_tiles;         // tiles of all fronts
   int32_t dag_n_pcols;         // pivot tile columns of all fronts
   int32_t dag_n_flags;         // ints in dag_flags
-  long long* dag_trace;        // diagnostics (slm_debug_dag_trace): per task {start, ready, end} in 10 ns ticks + workgroup; else null
+  GP<long long> dag_trace;        // diagnostics (slm_debug_dag_trace): per task {start, ready, end} in 10 ns ticks + workgroup; else null
 };
+// slm_frame (include/super_lm.h) as DEVICE code reads it: the same bytes, the caller's pointers typed GP<> so that the
+// accesses through them are global, not flat (see GP above).  Host code keeps using FrameDev::f.
+struct FrameIn {
+  int32_t N, J, T, H, W, K, K_ED;
+  float fx, fy, cx, cy;
+  GP<const void> sf_points;
+  GP<const int32_t> sf_knn_idx;
+  GP<const void> sf_knn_w;
+  GP<const void> ed_points;
+  GP<const int32_t> ed_knn_idx;
+  GP<const float> tgt_points;
+  GP<const float> tgt_norms;
+  GP<const int32_t> index_map;
+  GP<const uint8_t> tgt_valid;
+  int32_t state_f64;
+  int32_t pad;
+};
+static_assert(sizeof(FrameIn) == sizeof(slm_frame), "FrameIn mirrors slm_frame");
+static_assert(offsetof(FrameIn, fx) == offsetof(slm_frame, fx) && offsetof(FrameIn, sf_points) == offsetof(slm_frame, sf_points) &&
+              offsetof(FrameIn, ed_knn_idx) == offsetof(slm_frame, ed_knn_idx) && offsetof(FrameIn, tgt_valid) == offsetof(slm_frame, tgt_valid) &&
+              offsetof(FrameIn, state_f64) == offsetof(slm_frame, state_f64), "FrameIn mirrors slm_frame");
+__device__ __forceinline__ const FrameIn& frame_in(const FrameDev& fd) { return reinterpret_cast<const FrameIn&>(fd.f); }
+
 #define SLM_SLAB_STRIDE 768
 #define SLM_WREC 56          // doubles per (workgroup, pair) record
 #define SLM_LB_MAX 96        // records a workgroup can hold in LDS

@@ -82,6 +82,8 @@ __device__ __forceinline__ long long uni64(long long x) {
 }
 template <typename T>
 __device__ __forceinline__ T* unip(T* p) { return reinterpret_cast<T*>(uni64(reinterpret_cast<long long>(p))); }
+template <typename T>
+__device__ __forceinline__ T* unip(const GP<T>& p) { return unip(p.get()); }
 
 struct FS {   // scalar snapshot of an NDFront
   int nt, npt, nv, nb, n1, n1p, n2p, parent, which_child, nodes_off, eamap_off, is_leaf;

@@ -23,7 +23,7 @@ struct SurfelEval {
 template <bool GRAD>
 __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p, int4 ids, const double w[4],
                                                  double lam, const double* __restrict__ npk, SurfelEval& out) {
-  const slm_frame& f = fd.f;
+  const FrameIn& f = frame_in(fd);
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
 
   double qw[4];
@@ -146,5 +146,5 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const void* _
 template <bool GRAD>
 __device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* npk, int i,
                                             SurfelEval& out) {
-  eval_surfel_at<GRAD>(fd, fd.f.sf_points, fd.f.sf_knn_idx, fd.f.sf_knn_w, lam, npk, i, out);
+  eval_surfel_at<GRAD>(fd, frame_in(fd).sf_points, frame_in(fd).sf_knn_idx, frame_in(fd).sf_knn_w, lam, npk, i, out);
 }

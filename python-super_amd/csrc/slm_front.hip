@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
   const double l2 = lam_a * lam_a;
   if (use_arap && slot < Ke) {
     // ---- cross block between the nodes of edge j -> k ----
-    const int k = fd.f.ed_knn_idx[j * Ke + slot];
+    const int k = frame_in(fd).ed_knn_idx[j * Ke + slot];
     if (k >= 0 && k < J && k != j) {
       const NDDest pd = fd.pair_dest[j * Ke + slot];   // block (max(j,k), min(j,k))
       const NDFront fp = fd.fronts[pd.front];
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
       // the reverse edge k -> j (if it exists) shares the three (translation, translation) entries:
       // the edge with the smaller source node writes them for both
       bool reverse = false;
-      for (int s2 = 0; s2 < Ke; ++s2) reverse = reverse || fd.f.ed_knn_idx[k * Ke + s2] == j;
+      for (int s2 = 0; s2 < Ke; ++s2) reverse = reverse || frame_in(fd).ed_knn_idx[k * Ke + s2] == j;
       double* dst[15];
       double add[15];
 #pragma unroll
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
       }
     }
     if (slot < Ke) {                                                  // edge j -> k: j plays node j
-      const int k = fd.f.ed_knn_idx[j * Ke + slot];
+      const int k = frame_in(fd).ed_knn_idx[j * Ke + slot];
       if (k >= 0 && k < J && k != j) {
         double r[3], Jq[3][4];
         nd_arap_edge(fd, j, k, lam_a, r, Jq);

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) k_init_slot(const FrameDev* __restrict__ 
 #pragma unroll
     for (int c = 1; c < 7; ++c) b[c] = 0.0;
     const double ident[7] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    pack_node(fd.node_pk + (size_t)SLM_NPK * t, ident, ld_state3(fd.f.ed_points, (size_t)t, fd.f.state_f64));
+    pack_node(fd.node_pk + (size_t)SLM_NPK * t, ident, ld_state3(frame_in(fd).ed_points, (size_t)t, fd.f.state_f64));
   }
   if (t < num_iterations) {
     slm_iter_record r;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_iter_begin(const FrameDev* __restrict__
   if (!fd.bound || fd.st->stopped) return;
   const size_t nband = (size_t)fd.nt * (fd.wb + 1) * SLM_NB * SLM_NB;
   const size_t nrhs = (size_t)fd.nt * SLM_NB;
-  double2* b2 = reinterpret_cast<double2*>(fd.band);
+  double2* b2 = reinterpret_cast<double2*>(fd.band.get());
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nband / 2;
        e += (size_t)gridDim.x * blockDim.x)
     b2[e] = make_double2(0.0, 0.0);
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_pack_nodes(const FrameDev* __restrict__
   double bb[7];
 #pragma unroll
   for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c];
-  pack_node(fd.node_pk + (size_t)SLM_NPK * j, bb, ld_state3(fd.f.ed_points, (size_t)j, fd.f.state_f64));
+  pack_node(fd.node_pk + (size_t)SLM_NPK * j, bb, ld_state3(frame_in(fd).ed_points, (size_t)j, fd.f.state_f64));
 }
 
 // node_pk_try <- beta + delta: the trial point of the loss pass; grid = (ceil(maxJ/256), n_frames)
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_make_trial(const FrameDev* __restrict__
   double bb[7];
 #pragma unroll
   for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c] + fd.delta[7 * j + c];
-  pack_node(fd.node_pk_try + (size_t)SLM_NPK * j, bb, ld_state3(fd.f.ed_points, (size_t)j, fd.f.state_f64));
+  pack_node(fd.node_pk_try + (size_t)SLM_NPK * j, bb, ld_state3(frame_in(fd).ed_points, (size_t)j, fd.f.state_f64));
 }
 
 // target points + normals -> interleaved float4 pairs; grid = (ceil(T/256))

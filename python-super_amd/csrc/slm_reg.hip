@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) k_reg_grad(const FrameDev* __restrict__ f
   if (j >= fd.f.J) return;
 
   if (use_arap) {
-    const int k = fd.f.ed_knn_idx[j * Ke + slot];
+    const int k = frame_in(fd).ed_knn_idx[j * Ke + slot];
     double r[3], bk[7];
     d3 d;
     arap_residual(fd, fd.beta, nullptr, j, k, lam_a, r, bk, d);
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_reg_loss(const FrameDev* __restrict__ f
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < fd.f.J * Ke; t += gridDim.x * blockDim.x) {
     const int j = t / Ke, slot = t % Ke;
     if (use_arap) {
-      const int k = fd.f.ed_knn_idx[j * Ke + slot];
+      const int k = frame_in(fd).ed_knn_idx[j * Ke + slot];
       double r[3], bk[7];
       d3 d;
       arap_residual(fd, fd.beta, delta, j, k, lam_a, r, bk, d);
