@@ -570,6 +570,8 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.ftiles = sl.ftiles;
       h.fvec = sl.fvec;
       h.flinv = sl.flinv;
+      h.zero_tile_doubles = nd.tile_zero_doubles;
+      h.zero_vec_doubles = nd.vec_doubles;
       h.nd_ready = 1;
       sl.nd_hash = hash;
       sl.nd_knn_hash = knn_hash;
@@ -754,8 +756,9 @@ void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDi
   } else if (hybrid) {
     const int n_levels = (int)d.sched.size(), l_cut = n_levels - 1 - d.hybrid_cut;
     launch_front_levels(fr, n, d.sched.data(), n_levels, l_cut, 0, u_override, st);
+    // the task graph: the fronts above the cut, then the back substitution of the WHOLE tree (the list dag_top_tasks
+    // ends with the BACKB / BACK tasks of the deeper fronts -- 24 small per-level launches, 0.25 ms at C2, otherwise)
     launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut);
-    launch_front_levels(fr, n, d.sched.data(), n_levels, 0, l_cut, u_override, st);
   } else {
     launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
   }
@@ -764,13 +767,8 @@ void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDi
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
 hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st) {
   const FrameDev* fr = s->frames_dev + first;
-  for (int i = first; i < first + n; ++i) {
-    Slot& sl = s->slots[i];
-    hipError_t e = hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_zero_doubles, st);
-    if (e == hipSuccess) e = hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st);
-    if (e != hipSuccess) return e;
-  }
-  launch_iter_begin_nd(fr, n, st);
+  (void)s;
+  launch_iter_begin_nd(fr, n, st);   // zeroes the fronts of all n slots in one launch
   if (s->cfg.use_data) {
     launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
@@ -842,11 +840,6 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FrameDev* fr = s->frames_dev;
-  for (int i = 0; i < n_frames; ++i) {
-    Slot& sl = s->slots[i];
-    HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_zero_doubles, st));
-    HIPCHK(hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st));
-  }
   launch_iter_begin_nd(fr, n_frames, st);
   if (s->cfg.use_data) {
     launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st);
@@ -975,11 +968,6 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     };
     mark();
     if (d.nd) {
-      for (int i = 0; i < n_frames; ++i) {
-        Slot& sl = s->slots[i];
-        HIPCHK(hipMemsetAsync(sl.ftiles, 0, sizeof(double) * (size_t)sl.nd.tile_zero_doubles, st));
-        HIPCHK(hipMemsetAsync(sl.fvec, 0, sizeof(double) * (size_t)sl.nd.vec_doubles, st));
-      }
       launch_iter_begin_nd(fr, n_frames, st);
     } else {
       launch_iter_begin(fr, n_frames, st);

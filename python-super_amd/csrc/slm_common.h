@@ -125,6 +125,8 @@ struct FrameDev {
   GP<double> ftiles;              // front tile storage
   GP<double> fvec;                // front vectors (rhs -> y -> x)
   GP<double> flinv;               // inverses of the diagonal Cholesky blocks of the fronts
+  long long zero_tile_doubles;    // leading part of ftiles / all of fvec that k_iter_begin_nd zeroes before an assembly
+  long long zero_vec_doubles;
   // ---- persistent task-graph solver (slm_dag.hip): task list of the plan + per-iteration flags ----
   GP<const int32_t> dag_tasks;    // (n_dag_tasks, 2) task words (slm_nd.h), in a topological order
   GP<const int32_t> front_kids;   // (n_fronts, 2) children with a boundary (front index or -1)

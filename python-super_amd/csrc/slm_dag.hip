@@ -33,7 +33,9 @@
 // Top-of-tree mode (cut >= 0, the hybrid solve of a batch, slm_api.hip enqueue_front_solve): only the tasks of the
 // fronts of depth <= cut run here (fd.dag_top_tasks); the deeper levels were factored by the per-level launches of
 // slm_front.hip, whose k_fschur ADDED their Schur complements into the tiles of the fronts at depth == cut -- those
-// fronts gather nothing (task_deps nokids) -- and their back substitution follows this launch as launches again.
+// fronts gather nothing (task_deps nokids).  The list ends with the BACKB / BACK tasks of ALL deeper fronts: the back
+// substitution of the whole tree runs here, a deeper front's tasks waiting for their parent's solution only (their own
+// tiles and y are final before the launch: `prefactored`).
 //
 // Memory model (MI355X_MICROARCH.md, inter-workgroup visibility): per-XCD L2s are not coherent and a CU's L1
 // is never refreshed, so EVERY byte that one task hands to another (tiles, vectors, inverses, the solution) is
@@ -1015,7 +1017,10 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
     // The boundary tiles of this column are final once the front is factored -- long before the parent's solution
     // arrives: wait for THEM first and request the first two, so that the load latency is gone when x comes
     const int c_ = ts_;
-    if (!dag_wait(f.nt - f.npt, [&](int i) { return (const int*)(g.tile + tile_index(f, f.npt + i, c_)); }, 1, abort_flag, s_abort)) return;
+    // (hybrid solve: a front below the cut was factored by the per-level launches before this kernel -- no flags to wait for)
+    const bool prefactored = cut >= 0 && uni(fd.fronts[fi].depth) > cut;
+    if (!prefactored &&
+        !dag_wait(f.nt - f.npt, [&](int i) { return (const int*)(g.tile + tile_index(f, f.npt + i, c_)); }, 1, abort_flag, s_abort)) return;
     double l0[16], l1[16], l2[16], l3[16];
     if (f.npt < f.nt) load_tile_regs1(tile_ptr(fd, f, f.npt, c_), l0);
     if (f.npt + 1 < f.nt) load_tile_regs1(tile_ptr(fd, f, f.npt + 1, c_), l1);
@@ -1110,8 +1115,11 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     // before the boundary part of the right-hand side (BACKB, which waits for the parent's solution): wait for the
     // former, request the first three tiles of the chain, and only then wait for the latter
     const int nb_flags = f.nb > 0 ? f.npt : 0;
-    if (!dag_wait_deps(d, f, g, 0, f.npt, abort_flag, s_abort)) return;
-    if (!dag_wait_deps(d, f, g, f.npt + nb_flags, d.n0, abort_flag, s_abort)) return;
+    const bool prefactored = cut >= 0 && uni(fd.fronts[fi].depth) > cut;   // (hybrid solve: factored by the per-level launches)
+    if (!prefactored) {
+      if (!dag_wait_deps(d, f, g, 0, f.npt, abort_flag, s_abort)) return;
+      if (!dag_wait_deps(d, f, g, f.npt + nb_flags, d.n0, abort_flag, s_abort)) return;
+    }
     // LEFT-looking order, column by column from the last: op k of column c is the tile L(npt-1-j, c), j = 0 .. npt-2-c
     // (its product with the known x_r goes into per-thread partial sums -- no lane reduction per tile), then the
     // inverse of the diagonal factor.  One workgroup runs the whole chain, so the order costs no latency, and a column

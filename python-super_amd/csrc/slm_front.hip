@@ -411,14 +411,33 @@ __global__ void __launch_bounds__(256) k_front_load_rhs(const FrameDev* __restri
   fd.fvec[f.vec_off + 7 * fd.node_pos[v] + c] = fd.rhs[e];
 }
 
-// zero rhs + counters (the band is not used on this path)
+// Start of an iteration on the multifrontal path: zero the fronts (the leading part of the tile storage -- the leaves'
+// boundary blocks behind it are written, not added to -- and the front vectors), rhs and the counters, for ALL slots of
+// the batch in one launch (one hipMemsetAsync pair per slot cost ~25 us each, back to back: 0.2 ms per iteration at
+// 8 frames).  grid = (blocks, n_frames); 16-byte stores.
 __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || fd.st->stopped) return;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+  const double2 z = make_double2(0.0, 0.0);
+  if (fd.nd_ready) {
+    // (tile storage and vectors are whole 64-double rows; a workgroup clears contiguous 16 KB pieces, non-temporal)
+    typedef double dvec2 __attribute__((ext_vector_type(2)));
+    dvec2* t2 = reinterpret_cast<dvec2*>(fd.ftiles.get());
+    const size_t npiece = (size_t)fd.zero_tile_doubles / 2048;
+    const dvec2 zz = {0.0, 0.0};
+    for (size_t pc = blockIdx.x; pc < npiece; pc += gridDim.x) {
+      dvec2* q = t2 + pc * 1024 + threadIdx.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(zz, q + 256 * k);
+    }
+    for (size_t e = npiece * 1024 + tid; e < (size_t)fd.zero_tile_doubles / 2; e += nthr) t2[e] = zz;
+    double2* v2 = reinterpret_cast<double2*>(fd.fvec.get());
+    const size_t nv2 = (size_t)fd.zero_vec_doubles / 2;
+    for (size_t e = tid; e < nv2; e += nthr) v2[e] = z;
+  }
   const size_t nrhs = (size_t)fd.nt * SLM_NB;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nrhs;
-       e += (size_t)gridDim.x * blockDim.x)
-    fd.rhs[e] = 0.0;
+  for (size_t e = tid; e < nrhs; e += nthr) fd.rhs[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     fd.st->m_grad = 0;
     fd.st->chol_fail = 0;
@@ -1072,7 +1091,7 @@ void launch_front_load_rhs(const FrameDev* fr, int n_frames, int maxP, hipStream
 }
 
 void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
-  hipLaunchKernelGGL(k_iter_begin_nd, dim3(64, n_frames), dim3(256), 0, st, fr);
+  hipLaunchKernelGGL(k_iter_begin_nd, dim3(2048, n_frames), dim3(256), 0, st, fr);
 }
 
 // Level schedule shared by all slots of a batch (they may have different plans: the host

@@ -558,11 +558,16 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       if (cut >= max_depth) cut = max_depth - 1;        // leave at least the deepest level to the launches
       out.dag_cut_depth = cut;
       out.dag_top_tasks.clear();
-      for (size_t k = 0; k < tasks.size(); ++k)
-        if (cut >= 0 && out.fronts[tasks[k].w0 & 0xFFFFFF].depth <= cut) {
+      // ... plus the back substitution of the WHOLE tree: the deeper fronts are factored (and forward-substituted) by the
+      // per-level launches before this list runs, so their BACKB / BACK tasks need nothing but their parent's solution
+      for (size_t k = 0; k < tasks.size(); ++k) {
+        const bool top = out.fronts[tasks[k].w0 & 0xFFFFFF].depth <= cut;
+        const int type = tasks[k].w0 >> 24;
+        if (cut >= 0 && (top || type == ND_T_BACKB || type == ND_T_BACK)) {
           out.dag_top_tasks.push_back(tasks[k].w0);
           out.dag_top_tasks.push_back(tasks[k].w1);
         }
+      }
     }
   }
   // ---- destinations of the assembled blocks -------------------------------------------------
