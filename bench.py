@@ -405,12 +405,30 @@ def main():
     gathered = [None]
     local = torch.empty((B, J, 7), dtype=torch.float64, device=device)
 
+    # "same problem every step": the four state arrays Surfels.update moves are reset from the pristine copies.  That reset
+    # is the harness's, not the path's: the frames' arrays are views of one allocation per field, so it is 4 copies per
+    # step whatever the number of frames (32 small launches at 8 frames otherwise).
+    reset_fields = ("sf_points", "sf_norms", "ed_points", "ed_norms")
+
+    def stacked(frames, name):
+        big = torch.stack([getattr(fr, name) for fr in frames])
+        for i, fr in enumerate(frames):
+            setattr(fr, name, big[i])
+        return big
+
+    same_shape = all(getattr(fr, nm).shape == getattr(pristine[0], nm).shape for fr in pristine for nm in reset_fields)
+    if same_shape:
+        pristine_big = {nm: stacked(pristine, nm) for nm in reset_fields}
+        work_big = {nm: stacked(work, nm) for nm in reset_fields}
+
     def step():
-        for p, w in zip(pristine, work):                 # same problem every step
-            w.sf_points.copy_(p.sf_points)
-            w.sf_norms.copy_(p.sf_norms)
-            w.ed_points.copy_(p.ed_points)
-            w.ed_norms.copy_(p.ed_norms)
+        if same_shape:
+            for nm in reset_fields:                      # same problem every step
+                work_big[nm].copy_(pristine_big[nm])
+        else:
+            for p, w in zip(pristine, work):
+                for nm in reset_fields:
+                    getattr(w, nm).copy_(getattr(p, nm))
         if S > 1:
             main = torch.cuda.current_stream(device)
             for st in streams:

@@ -429,8 +429,12 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   hipLaunchKernelGGL(k_pairs, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
                      plan.run_nodes, p->pkeys, p->pvals);
   size_t b3 = p->cap_tmp, b4 = p->cap_tmp, b5 = p->cap_tmp;
+  // (only the bits a key can have are sorted: every 8 bits less is one launch less in a chain of ~90 small launches.
+  //  A live pair key is < J*J <= 2^pbits - 1, the padding key 0xFFFFFFFF has all of those bits set and still sorts last.)
+  unsigned pbits = 1;
+  while (pbits < 32 && (1ull << pbits) <= (unsigned long long)f.J * (unsigned long long)f.J) ++pbits;
   PCHK(rocprim::radix_sort_pairs(p->tmp, b3, p->pkeys, p->spkeys, p->pvals, plan.blk_entry, n_entries, 0,
-                                 32, st));
+                                 pbits, st));
   PCHK(rocprim::run_length_encode(p->tmp, b4, p->spkeys, n_entries, p->ukeys, p->bcount, p->scal + 4, st));
   // scan / copy over the full bound: entries past the unique count are never read
   PCHK(rocprim::exclusive_scan(p->tmp, b5, p->bcount, plan.blk_start, 0, n_entries, rocprim::plus<int>(), st));
@@ -470,7 +474,9 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   hipLaunchKernelGGL(k_pairs2, dim3((runs_bound + 255) / 256), blk, 0, st, (int)runs_bound, p->scal, f.J,
                      plan.run_nodes, plan.run_chunk, p->wkeys, p->wvals);
   size_t c1 = p->cap_tmp, c2 = p->cap_tmp, c3 = p->cap_tmp, c4 = p->cap_tmp, c5 = p->cap_tmp;
-  PCHK(rocprim::radix_sort_pairs(p->tmp, c1, p->wkeys, p->swkeys, p->wvals, p->swvals, n_entries, 0, 64, st));
+  unsigned wbits = 1;   // a live key's workgroup is < n_wg <= 2^wbits - 1; the padding key ~0 sorts last
+  while (wbits < 32 && (1ull << wbits) <= (unsigned long long)n_wg) ++wbits;
+  PCHK(rocprim::radix_sort_pairs(p->tmp, c1, p->wkeys, p->swkeys, p->wvals, p->swvals, n_entries, 0, 32 + wbits, st));
   PCHK(rocprim::run_length_encode(p->tmp, c2, p->swkeys, n_entries, p->uwkeys, p->wcount, p->scal + 5, st));
   PCHK(rocprim::exclusive_scan(p->tmp, c3, p->wcount, p->wstart, 0, n_entries, rocprim::plus<int>(), st));
   const dim3 ge((n_entries + 255) / 256);
@@ -481,7 +487,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   hipLaunchKernelGGL(k_run_lidx, ge, blk, 0, st, (int)n_entries, p->scal, p->uwkeys, p->wstart, p->wcount,
                      p->swvals, plan.wg_first, plan.run_lidx);
   // pair -> records: same pair order as blk_key (both are the ascending unique pair keys)
-  PCHK(rocprim::radix_sort_pairs(p->tmp, c4, p->pk2, p->spk2, p->pv2, plan.blk2_entry, n_entries, 0, 32, st));
+  PCHK(rocprim::radix_sort_pairs(p->tmp, c4, p->pk2, p->spk2, p->pv2, plan.blk2_entry, n_entries, 0, pbits, st));
   PCHK(rocprim::run_length_encode(p->tmp, c5, p->spk2, n_entries, p->upk2, p->b2count, p->scal + 4, st));
   PCHK(rocprim::exclusive_scan(p->tmp, c3, p->b2count, plan.blk2_start, 0, n_entries, rocprim::plus<int>(), st));
   hipLaunchKernelGGL(k_totals3, dim3(1), dim3(1), 0, st, p->scal, plan.blk2_start);
