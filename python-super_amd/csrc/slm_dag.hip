@@ -212,6 +212,30 @@ __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, do
 #pragma unroll
   for (int e = 0; e < 16; ++e) breg[e] = ld1(T + threadIdx.x + 256 * e);
 }
+// The same tile with 16 bytes per lane: thread t gets T[2t + 512 e] and T[2t + 512 e + 1] in r[2e], r[2e+1], e = 0..7.
+// One workgroup streams a 32 KB tile in 0.29 us this way, in 0.43 us with 8-byte loads (tests/micro/tile_stream_mb.hip:
+// the address path, not the memory, is the limit).  The language has no 16-byte atomic load, so these are buffer loads
+// with the same cache policy as ld1 (sc1: L1 and the non-coherent L2 bypassed); they follow the task's flag wait in
+// program order (a workgroup barrier with its fence stands between), which is all a hand-off needs.  T is uniform.
+__device__ __forceinline__ void load_tile_regs2(const double* T, double r[16]) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T), 0, TILE * 8, 0x00020000);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * threadIdx.x + 4096 * e, 0, 1 << 4 /* sc1 */);
+    r[2 * e] = __hiloint2double(q.y, q.x);
+    r[2 * e + 1] = __hiloint2double(q.w, q.z);
+  }
+}
+// ... and its tile-linear copy into LDS (16-byte stores)
+__device__ __forceinline__ void store_tile_lds2(double* L, const double r[16]) {
+  typedef double dvec2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const dvec2 v = {r[2 * e], r[2 * e + 1]};
+    *reinterpret_cast<dvec2*>(L + 2 * threadIdx.x + 512 * e) = v;
+  }
+}
 
 // ---- the dependency list of a task ---------------------------------------------------------------------
 // POTRF / COL / SCHUR of tile (r,s):  [update tiles of child 0 it gathers from][... of child 1]
@@ -439,23 +463,19 @@ __device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra
   const bool two = ra != rb;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   double breg[16], areg[16];
-  load_tile_regs1(tile_ptr(fd, f, rb, c0), breg);
-  if (two) load_tile_regs1(tile_ptr(fd, f, ra, c0), areg);
+  load_tile_regs2(tile_ptr(fd, f, rb, c0), breg);
+  if (two) load_tile_regs2(tile_ptr(fd, f, ra, c0), areg);
   double ynext = 0.0;
   if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)c0 * NB + threadIdx.x);
   const double* Ar = two ? Al : Bl;
   for (int c = c0; c < c1; ++c) {
     __syncthreads();   // earlier readers of Bl / Al / yv are done
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
-    if (two) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Al[threadIdx.x + 256 * e] = areg[e];
-    }
+    store_tile_lds2(Bl, breg);
+    if (two) store_tile_lds2(Al, areg);
     if (VEC && threadIdx.x < NB) yv[threadIdx.x] = ynext;
     if (c + 1 < c1) {
-      load_tile_regs1(tile_ptr(fd, f, rb, c + 1), breg);
-      if (two) load_tile_regs1(tile_ptr(fd, f, ra, c + 1), areg);
+      load_tile_regs2(tile_ptr(fd, f, rb, c + 1), breg);
+      if (two) load_tile_regs2(tile_ptr(fd, f, ra, c + 1), areg);
       if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
     }
     __syncthreads();
@@ -483,20 +503,18 @@ __device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s
   if (c0 >= c1) return;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   double breg[16], areg[16];
-  load_tile_regs1(tile_ptr(fd, f, s, c0), breg);
-  load_tile_regs1(tile_ptr(fd, f, s - 1, c0), areg);
+  load_tile_regs2(tile_ptr(fd, f, s, c0), breg);
+  load_tile_regs2(tile_ptr(fd, f, s - 1, c0), areg);
   double ynext = 0.0;
   if (threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)c0 * NB + threadIdx.x);
   for (int c = c0; c < c1; ++c) {
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Al[threadIdx.x + 256 * e] = areg[e];
+    store_tile_lds2(Bl, breg);
+    store_tile_lds2(Al, areg);
     if (threadIdx.x < NB) yv[threadIdx.x] = ynext;
     if (c + 1 < c1) {
-      load_tile_regs1(tile_ptr(fd, f, s, c + 1), breg);
-      load_tile_regs1(tile_ptr(fd, f, s - 1, c + 1), areg);
+      load_tile_regs2(tile_ptr(fd, f, s, c + 1), breg);
+      load_tile_regs2(tile_ptr(fd, f, s - 1, c + 1), areg);
       if (threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
     }
     __syncthreads();
@@ -657,9 +675,8 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
             dag_accumulate<true>(fd, f, s, s, clast, clast + 1, acc, S, M, yv, tsum);       // leaves L(s,c) in S
             if (!dag_wait_deps(d, f, g, d.n0 + 3 * clast + 2, d.n0 + 3 * clast + 3, abort_flag, s_abort)) return;   // L(s-1,c)
             double areg[16];
-            load_tile_regs1(tile_ptr(fd, f, s - 1, clast), areg);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) M[threadIdx.x + 256 * e] = areg[e];
+            load_tile_regs2(tile_ptr(fd, f, s - 1, clast), areg);
+            store_tile_lds2(M, areg);
             __syncthreads();
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
@@ -1021,9 +1038,14 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
     const bool prefactored = cut >= 0 && uni(fd.fronts[fi].depth) > cut;
     if (!prefactored &&
         !dag_wait(f.nt - f.npt, [&](int i) { return (const int*)(g.tile + tile_index(f, f.npt + i, c_)); }, 1, abort_flag, s_abort)) return;
+    // Tiles in the 16-byte-per-lane layout (load_tile_regs2): thread t holds T[n][m], n = (t >> 5) + 8 e, m = 2 (t & 31) + {0, 1}
+    // -- out[n] = sum_m T[n][m] x[m] needs a reduction over the 32 lanes t & 31 only.  Requests are UNCONDITIONAL (rows past
+    // the end repeat the last one, multiplied by 0) so that the compiler's wait counts stay exact.
+    const int rlast = f.nt - 1;
+    auto brow = [&](int r) { return min(r, rlast); };
     double l0[16], l1[16], l2[16], l3[16];
-    if (f.npt < f.nt) load_tile_regs1(tile_ptr(fd, f, f.npt, c_), l0);
-    if (f.npt + 1 < f.nt) load_tile_regs1(tile_ptr(fd, f, f.npt + 1, c_), l1);
+    load_tile_regs2(tile_ptr(fd, f, brow(f.npt), c_), l0);
+    load_tile_regs2(tile_ptr(fd, f, brow(f.npt + 1), c_), l1);
     // stage 0: what the task needs to start
     if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
 
@@ -1036,32 +1058,34 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
       const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
       for (int i = threadIdx.x; i < f.n2p; i += blockDim.x) xb[i] = (i < 7 * f.nb) ? ld1(fd.delta + 7 * nodes[i / 7] + i % 7) : 0.0;
       __syncthreads();
-      // tile-linear (coalesced) loads, two tiles being used while the next two are in flight; the partial products of
-      // all tiles are summed per thread first, one butterfly over the lanes at the end
-      double acc16[16];
+      // two tiles being used while the next two are in flight; the partial products of all tiles are summed per thread
+      // first, one reduction over the lanes at the end
+      double acc8[8];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc16[e] = 0.0;
+      for (int e = 0; e < 8; ++e) acc8[e] = 0.0;
+      const int m2 = 2 * (l & 31);
 #define BACKB_USE(LV, R)                                                          \
   do {                                                                            \
-    if ((R) < f.nt) {                                                             \
-      const double x_ = xb[(size_t)((R) - f.npt) * NB + l];                       \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] += LV[e] * x_;      \
-    }                                                                             \
+    const bool on_ = (R) < f.nt;                                                  \
+    const double x0_ = on_ ? xb[(size_t)(brow(R) - f.npt) * NB + m2] : 0.0;       \
+    const double x1_ = on_ ? xb[(size_t)(brow(R) - f.npt) * NB + m2 + 1] : 0.0;   \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) acc8[e] = fma(LV[2 * e + 1], x1_, fma(LV[2 * e], x0_, acc8[e])); \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(acc8[e]) :: "memory");   \
   } while (0)
       for (int r = f.npt; r < f.nt; r += 4) {
-        if (r + 2 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 2, c), l2);
-        if (r + 3 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 3, c), l3);
+        load_tile_regs2(tile_ptr(fd, f, brow(r + 2), c), l2);
+        load_tile_regs2(tile_ptr(fd, f, brow(r + 3), c), l3);
         BACKB_USE(l0, r);
         BACKB_USE(l1, r + 1);
-        if (r + 4 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 4, c), l0);
-        if (r + 5 < f.nt) load_tile_regs1(tile_ptr(fd, f, r + 5, c), l1);
+        load_tile_regs2(tile_ptr(fd, f, brow(r + 4), c), l0);
+        load_tile_regs2(tile_ptr(fd, f, brow(r + 5), c), l1);
         BACKB_USE(l2, r + 2);
         BACKB_USE(l3, r + 3);
       }
 #undef BACKB_USE
-      const double a = col_reduce16(acc16);
+      const double a = col_reduce8(acc8);
       if ((l & 3) == 0) {
-        double* pv = vecs + (size_t)c * NB + w + 4 * ((l >> 2) & 15);
+        double* pv = vecs + (size_t)c * NB + 2 * w + (l >> 5) + 8 * ((l >> 2) & 7);
         st1(pv, ld1(pv) - a);
       }
       dag_publish_begin();
@@ -1147,7 +1171,7 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     double l0[16], l1[16], l2[16];
 #define BACK_LOAD(LV)                                                                     \
   do {                                                                                    \
-    load_tile_regs1(op_addr(lc, lj), LV);                                                 \
+    load_tile_regs2(op_addr(lc, lj), LV);                                                 \
     op_next(lc, lj);                                                                      \
   } while (0)
     BACK_LOAD(l0);
@@ -1162,30 +1186,32 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
       DAG_READY();
       double* ya = S;                  // npt * NB: y, overwritten by x column by column
       for (int i = threadIdx.x; i < f.npt * NB; i += blockDim.x) ya[i] = ld1(vecs + i);
-      double acc16[16];
+      // tiles in the 16-byte-per-lane layout (load_tile_regs2): thread t holds T[n][m], n = (t >> 5) + 8 e, m = 2 (t & 31) + {0, 1};
+      // out[n] = sum_m T[n][m] v[m]: 8 partial sums per thread, reduced over the 32 lanes t & 31 once per column
+      double acc8[8];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc16[e] = 0.0;
-      // out[n] = sum_m T[m][n] v[m]
+      for (int e = 0; e < 8; ++e) acc8[e] = 0.0;
+      const int m2 = 2 * (l & 31), n_ = 2 * w + (l >> 5) + 8 * ((l >> 2) & 7);
 #define BACK_OP(LV, K)                                                                    \
   do {                                                                                    \
     const int c_ = oc, j_ = oj;                                                           \
     op_next(oc, oj);                                                                      \
     const bool inv_ = (K) < nops && j_ == f.npt - 1 - c_;                                 \
-    const int n_ = w + 4 * ((l >> 2) & 15);                                               \
     if (inv_ && c_ < f.npt - 1) {           /* the column's tiles are done: finish y_c */ \
-      const double a_ = col_reduce16(acc16);                                              \
+      const double a_ = col_reduce8(acc8);                                                \
       if ((l & 3) == 0) ya[(size_t)c_ * NB + n_] -= a_;                                   \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] = 0.0;                      \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) acc8[e] = 0.0;                        \
       __syncthreads();                                                                    \
     }                                                                                     \
     /* tile (r, c): x_r; the inverse: y_c; past the end: nothing */                       \
-    const double xm_ = (K) < nops ? ya[(size_t)(inv_ ? c_ : f.npt - 1 - j_) * NB + l] : 0.0; \
-    _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] += LV[e] * xm_;               \
-    _Pragma("unroll") for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(acc16[e]) :: "memory");   /* (done HERE) */ \
+    const size_t xo_ = (size_t)(inv_ ? c_ : f.npt - 1 - j_) * NB + m2;                    \
+    const double x0_ = (K) < nops ? ya[xo_] : 0.0, x1_ = (K) < nops ? ya[xo_ + 1] : 0.0;  \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) acc8[e] = fma(LV[2 * e + 1], x1_, fma(LV[2 * e], x0_, acc8[e])); \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(acc8[e]) :: "memory");   /* (done HERE) */ \
     BACK_LOAD(LV);                                                                        \
     if (inv_) {                                                                           \
-      const double x_ = col_reduce16(acc16);                                              \
-      _Pragma("unroll") for (int e = 0; e < 16; ++e) acc16[e] = 0.0;                      \
+      const double x_ = col_reduce8(acc8);                                                \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) acc8[e] = 0.0;                        \
       __syncthreads();                      /* everybody has read y_c */                  \
       if ((l & 3) == 0) ya[(size_t)c_ * NB + n_] = x_;                                    \
       __syncthreads();                      /* x_c visible */                             \

@@ -71,3 +71,18 @@ __device__ __forceinline__ double col_reduce16(double v[16]) {
   r += lane_dpp<0xB1>(r);                                                       // quad_perm [1,0,3,2]: lane ^ 1
   return r;
 }
+
+// The same for the 16-byte-per-lane tile layout (load_tile_regs2 in slm_dag.hip): a thread holds 8 partial sums (its two
+// inner indices already added), the inner index runs over the 32 lanes l & 31, lane bit 5 belongs to the OUTPUT index.
+// Steps over the lane bits 16, 8, 4, then the sum over the last two.  Result, in the lanes with (l & 3) == 0: the sum
+// of v[(l >> 2) & 7] over the 32 lanes of the thread's half wave.
+__device__ __forceinline__ double col_reduce8(double v[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = lane_fold16(v[i], v[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) v[i] = lane_fold_dpp<0x128, 8>(v[i], v[i + 2]);   // row_ror:8
+  double r = lane_fold_dpp<0x141, 4>(v[0], v[1]);                                // row_half_mirror
+  r += lane_dpp<0x4E>(r);
+  r += lane_dpp<0xB1>(r);
+  return r;
+}

@@ -14,6 +14,21 @@ __global__ void k_check(double* out) {
   out[threadIdx.x] = col_reduce16_shfl(a);
   out[256 + threadIdx.x] = col_reduce16(b);
 }
+// col_reduce8 (what the solver uses since the 16-byte tile layout): lanes with (l & 3) == 0 hold the sum of
+// v[(l >> 2) & 7] over the 32 lanes of their half wave
+__global__ void k_check8(double* out) {
+  const int l = threadIdx.x & 63;
+  double a[8], ref = 0.0;
+  for (int e = 0; e < 8; ++e) a[e] = 1.0 + 0.001 * l + 0.37 * e + 1e-5 * l * e;
+  const int mine = (l >> 2) & 7;
+  for (int e = 0; e < 8; ++e) {
+    double s = a[e];
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);     // sum over the half wave
+    if (e == mine) ref = s;
+  }
+  out[threadIdx.x] = ref;
+  out[256 + threadIdx.x] = col_reduce8(a);
+}
 template <int MODE>
 __global__ void k_time(double* out, long long* t, int reps) {
   double v[16];
@@ -38,6 +53,11 @@ int main() {
   int bad = 0; double worst = 0;
   for (int i = 0; i < 256; ++i) if ((i & 3) == 0) { const double e = fabs(h[i] - h[256 + i]); worst = e > worst ? e : worst; bad += e > 1e-9 * fabs(h[i]); }
   printf("result lanes ((lane & 3) == 0): %s, largest difference %.3g (sum %.6f)\n", bad ? "MISMATCH" : "ok", worst, h[0]);
+  hipLaunchKernelGGL(k_check8, dim3(1), dim3(256), 0, 0, d);
+  (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  bad = 0; worst = 0;
+  for (int i = 0; i < 256; ++i) if ((i & 3) == 0) { const double e = fabs(h[i] - h[256 + i]); worst = e > worst ? e : worst; bad += e > 1e-9 * fabs(h[i]); }
+  printf("col_reduce8 result lanes: %s, largest difference %.3g (sum %.6f)\n", bad ? "MISMATCH" : "ok", worst, h[0]);
   for (int mode = 0; mode < 2; ++mode) {
     const int reps = 2000;
     if (mode) hipLaunchKernelGGL(k_time<1>, dim3(1), dim3(256), 0, 0, d, t, reps); else hipLaunchKernelGGL(k_time<0>, dim3(1), dim3(256), 0, 0, d, t, reps);
