@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 // grid = (max boundary tile pairs, fronts in level, n_frames)
 __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, LevelRef lvl, int which,
                                                  int n_items, int items_at, int n_frames) {
-  __shared__ double Bl[TILE];
+  __shared__ __attribute__((aligned(16))) double Bl[TILE];
   __shared__ int rmap[NB], cmap[NB];
   // Work items come from the plan's exact list for (level, child index): no empty workgroups, no
   // index arithmetic.  XCD-aware order: blocks b and b+8 share an XCD, so XCD x takes the contiguous
@@ -911,23 +911,28 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   // The B operand (L21 tile of block-row sc) passes through LDS in HALF tiles of 32 inner columns,
   // double-buffered (2 x 16 KB): three workgroups per CU instead of two, and the next half is in
   // flight while the current one is on the MFMA.
-  double breg[8], areg[16], acur[16];
+  // (B half tiles move with 16 bytes per lane: half the load / LDS-store instructions, and a workgroup streams a tile
+  //  1.5x faster that way -- tests/micro/tile_stream_mb.hip)
+  typedef double dvec2 __attribute__((ext_vector_type(2)));
+  dvec2 breg[4];
+  double areg[16], acur[16];
   const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   if (f.npt > 0) {
-    const double* Ls = ftile(fd, f, sc, 0);
+    const dvec2* Ls = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, 0));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
+    for (int e = 0; e < 4; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
     load_a_frags(ftile(fd, f, r, 0), areg);
   }
   for (int c = 0; c < f.npt; ++c) {
-    const double* Ls = ftile(fd, f, sc, c);
+    const dvec2* Ls = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, c));
+    dvec2* Bl2 = reinterpret_cast<dvec2*>(Bl);
     // ---- inner columns 0..31 ----
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+    for (int e = 0; e < 4; ++e) Bl2[threadIdx.x + 256 * e] = breg[e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acur[e] = areg[e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) breg[e] = Ls[TILE / 2 + threadIdx.x + 256 * e];
+    for (int e = 0; e < 4; ++e) breg[e] = Ls[TILE / 4 + threadIdx.x + 256 * e];
     if (c + 1 < f.npt) load_a_frags(ftile(fd, f, r, c + 1), areg);
     __syncthreads();
 #pragma unroll
@@ -939,11 +944,11 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
     }
     // ---- inner columns 32..63 ----
 #pragma unroll
-    for (int e = 0; e < 8; ++e) Bl[TILE / 2 + threadIdx.x + 256 * e] = breg[e];
+    for (int e = 0; e < 4; ++e) Bl2[TILE / 4 + threadIdx.x + 256 * e] = breg[e];
     if (c + 1 < f.npt) {
-      const double* Ln = ftile(fd, f, sc, c + 1);
+      const dvec2* Ln = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, c + 1));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) breg[e] = Ln[threadIdx.x + 256 * e];
+      for (int e = 0; e < 4; ++e) breg[e] = Ln[threadIdx.x + 256 * e];
     }
     __syncthreads();
 #pragma unroll
