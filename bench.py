@@ -524,8 +524,8 @@ def main():
             # the time-dominant phase: the float64 multifrontal factor + substitutions of all frames of a launch
             out["roofline"] = {"kernel": "solve phase: " + info["solver"] + " Cholesky factor + substitutions ("
                                          + ("k_fdag, one persistent launch" if Bs <= 2 and info["solver_tasks"] > 0
-                                            else "per-level launches k_fL11 / k_fL21 / k_fschur / k_fpanel / k_ftrail / k_fbacksub + k_fdag (task graph) for the root "
-                                                 "front and its children, all launches of one LM iteration") + ")",
+                                            else "per-level launches k_fL11 / k_fL21 / k_fschur / k_fpanel / k_ftrail for the lower levels + k_fdag (task graph) for "
+                                                 "the root front, its children and the back substitution of the whole tree; all launches of one LM iteration") + ")",
                                "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
                                "achieved_unpadded": flops_exact / savg / 1e12 if savg > 0 else 0.0,
