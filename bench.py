@@ -40,8 +40,8 @@ NB = 64                      # tile edge of the banded solver (csrc/slm_common.h
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C4", "tiny"])
     ap.add_argument("--frames-per-gpu", type=int, default=8)
     ap.add_argument("--streams", type=int, default=1,
