@@ -24,6 +24,51 @@ struct GfSlot {
   double2* morph_g;      // (N) d(loss_i)/d(x,y) of the morphing term, 0 when not kept
 };
 
+// GfSlot as DEVICE code reads it: the same bytes, every pointer typed GP<> (global address space, slm_common.h) so that
+// the kernels issue global_load / global_store instead of FLAT accesses.  Host code keeps using GfSlot.
+struct GfFrameIn {
+  FrameIn base;
+  GP<const uint8_t> sf_stable;
+  GP<const void> ed_knn_w;
+  GP<const int32_t> ed_triangles;
+  GP<const void> ed_triangle_areas;
+  int32_t n_triangles;
+  int32_t pad;
+};
+struct GfSemIn {
+  int32_t num_classes;
+  int32_t pad;
+  GP<const int32_t> sf_seg;
+  GP<const float> sf_seg_conf;
+  GP<const float> tgt_seg_conf;
+  GP<const float> img_seg_conf;
+  GP<const int32_t> img_seg;
+};
+struct GfSlotDev {
+  GfFrameIn f;
+  int32_t bound;
+  int32_t step;
+  int32_t shard_lo, shard_hi;
+  GP<double> dv;
+  GP<double> grad;
+  GP<double> m1;
+  GP<double> m2;
+  GP<double> terms;
+  GP<const float> flow;
+  GfSemIn sem;
+  int32_t sem_bound;
+  int32_t edge_off[SLM_MAX_CLASSES + 1];
+  GP<float2> edge_xy;
+  GP<double2> morph_g;
+};
+static_assert(sizeof(GfFrameIn) == sizeof(slm_gf_frame) && sizeof(GfSemIn) == sizeof(slm_gf_semantic) &&
+              sizeof(GfSlotDev) == sizeof(GfSlot), "GfSlotDev mirrors GfSlot");
+static_assert(offsetof(GfSlotDev, dv) == offsetof(GfSlot, dv) && offsetof(GfSlotDev, flow) == offsetof(GfSlot, flow) &&
+              offsetof(GfSlotDev, sem) == offsetof(GfSlot, sem) && offsetof(GfSlotDev, edge_xy) == offsetof(GfSlot, edge_xy) &&
+              offsetof(GfSlotDev, morph_g) == offsetof(GfSlot, morph_g) && offsetof(GfFrameIn, ed_triangle_areas) == offsetof(slm_gf_frame, ed_triangle_areas) &&
+              offsetof(GfSemIn, img_seg) == offsetof(slm_gf_semantic, img_seg), "GfSlotDev mirrors GfSlot");
+__device__ __forceinline__ GfSlotDev* gf_dev(GfSlot* slots) { return reinterpret_cast<GfSlotDev*>(slots); }
+
 // R(q)^T c for an un-normalised quaternion = R(conj q) c
 __device__ __forceinline__ d3 quat_apply_t(double w, d3 v, d3 c) {
   return quat_apply(w, {-v.x, -v.y, -v.z}, c);
@@ -39,8 +84,8 @@ struct GfSkin {
   d3 gv;
 };
 
-__device__ __forceinline__ void gf_skin(const GfSlot& s, int i, GfSkin& k) {
-  const slm_frame& f = s.f.base;
+__device__ __forceinline__ void gf_skin(const GfSlotDev& s, int i, GfSkin& k) {
+  const FrameIn& f = s.f.base;
   const d3 p = ld_state3(f.sf_points, (size_t)i, f.state_f64);
   const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * (size_t)i);
   k.id[0] = ids.x; k.id[1] = ids.y; k.id[2] = ids.z; k.id[3] = ids.w;

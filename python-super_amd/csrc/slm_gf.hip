@@ -17,7 +17,7 @@
 #include "slm_sem.h"
 
 __global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
-  GfSlot& s = slots[blockIdx.y];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
   const int n = (s.f.base.J + 1) * 7;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) s.grad[e] = 0.0;
@@ -33,7 +33,7 @@ struct GfSample {
   double wv[4];
 };
 
-__device__ __forceinline__ bool gf_sample(const slm_frame& f, double u_, double v_, GfSample& q) {
+__device__ __forceinline__ bool gf_sample(const FrameIn& f, double u_, double v_, GfSample& q) {
   const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
   const double nn[4] = {fv, fv, cv, cv}, mm[4] = {fu, cu, fu, cu};
   bool all_ok = true;
@@ -114,12 +114,12 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   // and entry.  A slot taken by another node (direct-mapped, node & 127) falls back to global atomics.
   __shared__ int tkey[GF_TAB];
   __shared__ double tval[GF_TAB * 7];
-  GfSlot& s = slots[blockIdx.y];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
   for (int t = threadIdx.x; t < GF_TAB; t += blockDim.x) tkey[t] = -1;
   for (int t = threadIdx.x; t < GF_TAB * 7; t += blockDim.x) tval[t] = 0.0;
   __syncthreads();
-  const slm_frame& f = s.f.base;
+  const FrameIn& f = s.f.base;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int J = f.J;
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0, lossc = 0.0, cntc = 0.0;
@@ -291,9 +291,9 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
 __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int use_arap, double lam_a,
                                                  int use_rot, double lam_r, int use_face, double lam_f) {
   __shared__ double sm[16];
-  GfSlot& s = slots[blockIdx.y];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
-  const slm_frame& f = s.f.base;
+  const FrameIn& f = s.f.base;
   const int J = f.J, Ke = f.K_ED;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   double la = 0.0, lr = 0.0, lf = 0.0;
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
 // Also turns the morphing term's sum into the reference's weighted mean (NaN over an empty set).
 __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int optimizer, double lr,
                                                   int apply, int use_morph, double w_morph) {
-  GfSlot& s = slots[blockIdx.y];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
   const int J = s.f.base.J, n = (J + 1) * 7;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,12 +425,12 @@ __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int
 }
 
 __global__ void k_gf_advance(GfSlot* __restrict__ slots) {
-  GfSlot& s = slots[blockIdx.x];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.x];
   if (s.bound && threadIdx.x == 0) s.step += 1;
 }
 
 __global__ void __launch_bounds__(256) k_gf_init(GfSlot* __restrict__ slots, int slot) {
-  GfSlot& s = slots[slot];
+  GfSlotDev& s = gf_dev(slots)[slot];
   const int n = (s.f.base.J + 1) * 7;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) {

@@ -110,9 +110,9 @@ void sem_free(SemScratch& sc) {
 // grid = (ceil(maxN/256), n_frames)
 __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
   __shared__ double sm[16];
-  GfSlot& s = slots[blockIdx.y];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound || !s.sem_bound) return;
-  const slm_frame& f = s.f.base;
+  const FrameIn& f = s.f.base;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double li_sum = 0.0, kept = 0.0;
   if (i < f.N) {
