@@ -105,12 +105,12 @@ struct Slot {
   int32_t* d_dag_flags = nullptr;   // persistent task-graph solver: ticket, counters, per-tile / per-column flags
   size_t cap_dag_flags = 0;
   NDDest* d_dests = nullptr;    // block_dest | pair_dest
-  double *ftiles = nullptr, *fvec = nullptr, *flinv = nullptr;
+  double *ftiles = nullptr, *fvec = nullptr, *flinv = nullptr, *fmail = nullptr;
   double* pairbuf = nullptr;   // sharded frames: per-pair sums to exchange
   double *band = nullptr, *linv = nullptr;   // block-banded path (allocated on demand)
   bool band_ready = false;
   size_t cap_pairbuf = 0;
-  size_t cap_fronts = 0, cap_ints = 0, cap_dests = 0, cap_ftiles = 0, cap_fvec = 0, cap_flinv = 0;
+  size_t cap_fronts = 0, cap_ints = 0, cap_dests = 0, cap_ftiles = 0, cap_fvec = 0, cap_flinv = 0, cap_fmail = 0;
 };
 }  // namespace
 
@@ -267,6 +267,7 @@ int slm_destroy(slm_solver* s) {
     if (sl.ftiles) (void)hipFree(sl.ftiles);
     if (sl.fvec) (void)hipFree(sl.fvec);
     if (sl.flinv) (void)hipFree(sl.flinv);
+    if (sl.fmail) (void)hipFree(sl.fmail);
     if (sl.pairbuf) (void)hipFree(sl.pairbuf);
     if (sl.d_dag_flags) (void)hipFree(sl.d_dag_flags);
     if (sl.d_dag_trace) (void)hipFree(sl.d_dag_trace);
@@ -527,6 +528,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       HIPCHK(grow(sl.ftiles, sl.cap_ftiles, (size_t)nd.tile_doubles));
       HIPCHK(grow(sl.fvec, sl.cap_fvec, (size_t)nd.vec_doubles));
       HIPCHK(grow(sl.flinv, sl.cap_flinv, (size_t)nd.linv_doubles + 1));
+      HIPCHK(grow(sl.fmail, sl.cap_fmail, (size_t)(nd.linv_doubles / (SLM_NB * SLM_NB)) * 2560 + 1));   // SLM_MAIL_DOUBLES per pivot tile column
       HIPCHK(hipMemcpyAsync(sl.d_fronts, nd.fronts.data(), sizeof(NDFront) * nd.fronts.size(), hipMemcpyHostToDevice, st));
       int32_t* p = sl.d_ints;
       auto up = [&](const std::vector<int32_t>& v) -> hipError_t {
@@ -570,6 +572,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.ftiles = sl.ftiles;
       h.fvec = sl.fvec;
       h.flinv = sl.flinv;
+      h.fmail = sl.fmail;
       h.zero_tile_doubles = nd.tile_zero_doubles;
       h.zero_vec_doubles = nd.vec_doubles;
       h.nd_ready = 1;

@@ -125,6 +125,7 @@ struct FrameDev {
   GP<double> ftiles;              // front tile storage
   GP<double> fvec;                // front vectors (rhs -> y -> x)
   GP<double> flinv;               // inverses of the diagonal Cholesky blocks of the fronts
+  GP<double> fmail;               // task graph: per pivot tile column a mailbox of SLM_MAIL_DOUBLES (slm_tile.h) for the streamed hand-off
   long long zero_tile_doubles;    // leading part of ftiles / all of fvec that k_iter_begin_nd zeroes before an assembly
   long long zero_vec_doubles;
   // ---- persistent task-graph solver (slm_dag.hip): task list of the plan + per-iteration flags ----

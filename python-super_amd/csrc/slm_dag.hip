@@ -104,7 +104,7 @@ __device__ __forceinline__ FS front_snapshot(const NDFront& f) {
   return o;
 }
 struct SS {   // scalar snapshot of the slot's buffers
-  double *ftiles, *fvec, *flinv, *delta;
+  double *ftiles, *fvec, *flinv, *fmail, *delta;
   const int32_t *nd_nodes, *front_kids, *pull_off, *pullmap, *prng_off, *prng;
   const NDFront* fronts;
   int n_fronts;
@@ -562,7 +562,7 @@ __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4
 // whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
 // base inside the function, so their address space stays known.
 extern __shared__ double dag_lds[];
-__device__ __forceinline__ bool dag_factor_tile(double* g_linv, double* g_ltile, int* g_flag, int* g_early, long long* trc) {
+__device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, long long* trc) {
   double* S = dag_lds;
   double* M = dag_lds + TILE;
   double* dinv = dag_lds + 2 * TILE;
@@ -570,10 +570,58 @@ __device__ __forceinline__ bool dag_factor_tile(double* g_linv, double* g_ltile,
   double* xch = wt + 3 * 256;                   // vec | yv: not live while a tile is being factored
   int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
   int* pf = s_ok + 16;                          // 16 hand-off flags of the trailing waves
-  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_linv, g_ltile, g_flag, g_early, trc);
+  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_mail, g_early, trc);
 }
 
 }  // namespace
+
+// ---- the streamed hand-off, consumer side (producer: publish_blocks16 in slm_tile.h) --------------------------------
+// Round kb of a streamed row solve needs the inverse of diagonal block kb and the L blocks (kb, t < kb) of the tile being
+// factored by another workgroup: 1 + kb values per thread, read from the column's mailbox.  A value that is not the
+// "empty" sentinel HAS arrived -- the data is its own flag.  MAIL_ISSUE requests a round's values (registers only: a
+// round is requested before the products of the one before it, speculatively -- what has not arrived reads as "empty"
+// and is requested again); MAIL_TAKE stores them into LDS (dinv block kb, row block kb of Lst) and leaves when, workgroup-
+// wide, all of them were there.  Its barrier doubles as the barrier behind those LDS stores.
+// NB: `dinv` doubles as the pull maps of dag_pull.  The first MAIL_TAKE of a task must be preceded by a workgroup barrier
+// that every wave passes after its last look at the maps -- without it a fast wave's round-0 block lands in a slow wave's
+// gather indices (seen as results that differed from run to run in the third digit).
+__device__ __forceinline__ bool mail_here(double v) { return __double_as_longlong(v) != SLM_MAIL_EMPTY; }
+#define MAIL_ISSUE(MAIL, PD, PL, KB)                                                                             \
+  do {                                                                                                           \
+    PD[KB] = ld1((MAIL) + (KB) * 256 + threadIdx.x);                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                             \
+      if (j_ < (KB)) PL[KB][j_] = ld1((MAIL) + (4 + (KB) * ((KB) - 1) / 2 + j_) * 256 + threadIdx.x);            \
+  } while (0)
+#define MAIL_TAKE(MAIL, PD, PL, KB, DINV, LST)                                                                   \
+  do {                                                                                                           \
+    const int pe_i_ = threadIdx.x & 15, pe_k_ = threadIdx.x >> 4;                                                \
+    int* votes_ = s_ok + 4;                                                                                      \
+    int spins_ = 0;                                                                                              \
+    for (;;) {                                                                                                   \
+      bool here_ = mail_here(PD[KB]);                                                                            \
+      (DINV)[(KB) * 256 + pe_i_ + 16 * pe_k_] = PD[KB];                                                          \
+      _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                           \
+        if (j_ < (KB)) {                                                                                         \
+          here_ = here_ && mail_here(PL[KB][j_]);                                                                \
+          (LST)[(16 * (KB) + pe_i_) + (16 * j_ + pe_k_) * LD] = PL[KB][j_];                                      \
+        }                                                                                                        \
+      const bool stop_ = (++spins_ & 63) == 0 && (ldf(abort_flag) != 0 || spins_ > DAG_SPIN_LIMIT);              \
+      const int vote_ = (__all(here_) ? 1 : 0) | (__any(stop_) ? 2 : 0);                                         \
+      if ((threadIdx.x & 63) == 0) votes_[threadIdx.x >> 6] = vote_;                                             \
+      __syncthreads();                                                                                           \
+      const int v0_ = votes_[0], v1_ = votes_[1], v2_ = votes_[2], v3_ = votes_[3];                              \
+      if ((v0_ & v1_ & v2_ & v3_ & 1) != 0) break;                                                               \
+      if (((v0_ | v1_ | v2_ | v3_) & 2) != 0) {                                                                  \
+        if (threadIdx.x == 0) { stf(abort_flag, 1); *s_abort = 1; }                                              \
+        __syncthreads();                                                                                         \
+        return;                                                                                                  \
+      }                                                                                                          \
+      __syncthreads();                                                                                           \
+      __builtin_amdgcn_s_sleep(1);                                                                               \
+      MAIL_ISSUE(MAIL, PD, PL, KB);                                                                              \
+    }                                                                                                            \
+  } while (0)
+
 
 // grid = persistent (one workgroup per CU), 256 threads
 //
@@ -612,7 +660,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
-    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
@@ -692,40 +740,19 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         // block of L; this task trails it by one block, so that (s,s) is fully updated shortly after the
         // producer's last pivot -- not a whole inverse assembly + publish + reload + 64x64 products later.
         {
-          const double* gl = fd.flinv + f.linv_off + (size_t)(s - 1) * TILE;
-          const double* gt = tile_ptr(fd, f, s - 1, s - 1);
+          const double* mail = fd.fmail + (size_t)(f.pcol0 + s - 1) * SLM_MAIL_DOUBLES;
           double* Lst = M;     // row block kb of L(s-1,s-1), at its place in a 64 x 64 tile
           double* Xs = S;      // X(:, 16 kb .. 16 kb + 15) of all 64 rows, column-major ld 64
-          const int pkb = d.n - 5;
-          // Software pipeline over the four rounds: the payload of round kb+1 (and a look at the flag of round kb+2)
-          // is requested BEFORE the products of round kb whenever its flag is already up, so that a consumer that has
-          // fallen behind the producer (a round costs it a poll + a load round trip + the products, ~4 us, against
-          // the producer's 2.8 us) catches up instead of ending 4-5 us after the producer's last pivot.
-          double pd[4] = {0.0, 0.0, 0.0, 0.0}, pl[4][3];   // per round: Dinv element, L blocks j = 1..kb
-          const int pe_i = threadIdx.x & 15, pe_k = threadIdx.x >> 4;
-#define STREAM_ISSUE(KB)                                                                                               \
-  do {                                                                                                                 \
-    pd[KB] = ld1(gl + (16 * (KB) + pe_i) + (size_t)(16 * (KB) + pe_k) * NB);                                           \
-    _Pragma("unroll") for (int j = 1; j < 4; ++j)                                                                      \
-      if (j <= (KB)) pl[KB][j - 1] = ld1(gt + (16 * (KB) + pe_i) + (size_t)(16 * (j - 1) + pe_k) * NB);                \
-  } while (0)
-          int issued = 1;
-          if (!dag_wait_deps(d, f, g, pkb, pkb + 1, abort_flag, s_abort)) return;
-          STREAM_ISSUE(0);
+          // Software pipeline over the four rounds (a consumer that has fallen behind the producer catches up instead of
+          // ending 4-5 us after the producer's last pivot): see MAIL_ISSUE / MAIL_TAKE
+          double pd[4] = {0.0, 0.0, 0.0, 0.0}, pl[4][3];   // per round: Dinv element, L blocks t = 0..kb-1
+          MAIL_ISSUE(mail, pd, pl, 0);
+          __syncthreads();   // dinv doubles as the pull maps (dag_pull): every wave is done with them before round 0 lands there
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
-            const bool look = kb < 3 && issued == kb + 1;      // the next round is not requested yet: look at its flag
-            if (look && threadIdx.x == 0) *s_cnt = ldf(dep_flag(d, f, g, pkb + kb + 1));
+            MAIL_TAKE(mail, pd, pl, kb, dinv, Lst);
             if (kb == 3) DAG_READY();
-            dinv[kb * 256 + pe_i + 16 * pe_k] = pd[kb];
-#pragma unroll
-            for (int j = 1; j < 4; ++j)
-              if (j <= kb) Lst[(16 * kb + pe_i) + (16 * (j - 1) + pe_k) * LD] = pl[kb][j - 1];
-            __syncthreads();
-            if (look && uni(*s_cnt) >= 1) {      // (uniform: one LDS word written before the barrier)
-              STREAM_ISSUE(kb + 1);
-              issued = kb + 2;
-            }
+            if (kb < 3) MAIL_ISSUE(mail, pd, pl, kb + 1);
             double4_t t4 = accl[kb];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -753,13 +780,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
               for (int ni = 0; ni < 4; ++ni)
                 acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
             }
-            if (kb < 3 && issued == kb + 1) {
-              if (!dag_wait_deps(d, f, g, pkb + kb + 1, pkb + kb + 2, abort_flag, s_abort)) return;
-              STREAM_ISSUE(kb + 1);
-              issued = kb + 2;
-            }
           }
-#undef STREAM_ISSUE
         }
         store_c_frags1(tile_ptr(fd, f, s, s - 1), accl);         // L(s, s-1) for the other tasks; published below
         xl[0] = accl[0]; xl[1] = accl[1]; xl[2] = accl[2]; xl[3] = accl[3];
@@ -790,7 +811,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         DAG_MARK(5);
         const bool stream = s + 1 < f.nt;                  // POTRF(s+1) and the column's COL tasks follow the factorisation 16 pivots at a time
         double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
-        const bool ok = dag_factor_tile(linv, tile_ptr(fd, f, s, s), stream ? g.pk + 4 * (f.pcol0 + s) : nullptr,
+        const bool ok = dag_factor_tile(stream ? fd.fmail + (size_t)(f.pcol0 + s) * SLM_MAIL_DOUBLES : nullptr,
                                        s > 0 ? g.tile + tile_index(f, s, s - 1) : nullptr,    // L(s, s-1) goes out during the first 16 pivots
                                        trc ? trc + 8 : nullptr);
         DAG_MARK(6);
@@ -839,35 +860,16 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         // after the whole inverse has been assembled, published and re-read (the boundary rows of a front's LAST pivot
         // column are what its Schur complement, and with it the parent front, waits for).
         {
-          const double* gl = fd.flinv + f.linv_off + (size_t)s * TILE;
-          const double* gt = tile_ptr(fd, f, s, s);
+          const double* mail = fd.fmail + (size_t)(f.pcol0 + s) * SLM_MAIL_DOUBLES;
           double* Lst = M;     // row block kb of L(s,s), at its place in a 64 x 64 tile
-          int* pk = g.pk + 4 * (f.pcol0 + s);
           double pd[4] = {0.0, 0.0, 0.0, 0.0}, pl[4][3];
-          const int pe_i = threadIdx.x & 15, pe_k = threadIdx.x >> 4;
-#define COL_ISSUE(KB)                                                                                                  \
-  do {                                                                                                                 \
-    pd[KB] = ld1(gl + (16 * (KB) + pe_i) + (size_t)(16 * (KB) + pe_k) * NB);                                           \
-    _Pragma("unroll") for (int j = 1; j < 4; ++j)                                                                      \
-      if (j <= (KB)) pl[KB][j - 1] = ld1(gt + (16 * (KB) + pe_i) + (size_t)(16 * (j - 1) + pe_k) * NB);                \
-  } while (0)
-          if (!dag_wait(1, [&](int) { return (const int*)pk; }, 1, abort_flag, s_abort)) return;
-          int issued = 1;
-          COL_ISSUE(0);
+          MAIL_ISSUE(mail, pd, pl, 0);
+          __syncthreads();   // dinv doubles as the pull maps (dag_pull): every wave is done with them before round 0 lands there
 #pragma unroll
           for (int kb = 0; kb < 4; ++kb) {
-            const bool look = kb < 3 && issued == kb + 1;
-            if (look && threadIdx.x == 0) *s_cnt = ldf(pk + kb + 1);
+            MAIL_TAKE(mail, pd, pl, kb, dinv, Lst);
             if (kb == 3) DAG_READY();
-            dinv[kb * 256 + pe_i + 16 * pe_k] = pd[kb];
-#pragma unroll
-            for (int j = 1; j < 4; ++j)
-              if (j <= kb) Lst[(16 * kb + pe_i) + (16 * (j - 1) + pe_k) * LD] = pl[kb][j - 1];
-            __syncthreads();
-            if (look && uni(*s_cnt) >= 1) {
-              COL_ISSUE(kb + 1);
-              issued = kb + 2;
-            }
+            if (kb < 3) MAIL_ISSUE(mail, pd, pl, kb + 1);
             double4_t t4 = acc[kb];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -885,16 +887,8 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
               x4 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, t4[ks], x4, 0, 0, 0);
             }
             acc[kb] = x4;
-            if (kb < 3 && issued == kb + 1) {
-              const int nk = kb + 1;
-              if (!dag_wait(1, [&](int) { return (const int*)(pk + nk); }, 1, abort_flag, s_abort)) return;
-              COL_ISSUE(kb + 1);
-              issued = kb + 2;
-            } else {
-              __syncthreads();   // Lst / dinv / s_cnt are written again by the next round
-            }
+            __syncthreads();   // the next round rewrites what this one read
           }
-#undef COL_ISSUE
         }
         double4_t* xa = acc;
         store_c_frags1(tile_ptr(fd, f, r, s), xa);
@@ -928,7 +922,7 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
-    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
@@ -1013,7 +1007,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
-    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
@@ -1117,7 +1111,7 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
-    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.delta = unip(fdr.delta);
+    fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
     fd.fronts = unip(fdr.fronts); fd.n_fronts = uni(fdr.n_fronts);
@@ -1266,11 +1260,20 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
   }
 }
 
-// zero the flags of slots [0, n_frames) (ticket, abort, counters, tile / column flags); grid = (blocks, n_frames)
-__global__ void __launch_bounds__(256) k_dag_reset(const FrameDev* __restrict__ frames) {
+// zero the flags of slots [0, n_frames) (ticket, abort, counters, tile / column flags) and empty the mailboxes of the
+// pivot tile columns this launch factors (all fronts, or those of depth <= cut); grid = (blocks, n_frames)
+__global__ void __launch_bounds__(256) k_dag_reset(const FrameDev* __restrict__ frames, int cut) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.nd_ready || !fd.dag_flags) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fd.dag_n_flags; i += gridDim.x * blockDim.x) fd.dag_flags[i] = 0;
+  typedef __attribute__((address_space(1))) long long gll;
+  gll* mail = (gll*)(double*)fd.fmail;
+  for (int fi = blockIdx.x; fi < fd.n_fronts; fi += gridDim.x) {
+    const NDFront& f = fd.fronts[fi];
+    if (cut >= 0 && f.depth > cut) continue;
+    const size_t base = (size_t)(f.linv_off / TILE) * SLM_MAIL_DOUBLES, n = (size_t)f.npt * SLM_MAIL_DOUBLES;
+    for (size_t e = threadIdx.x; e < n; e += blockDim.x) mail[base + e] = SLM_MAIL_EMPTY;
+  }
 }
 
 // a timed-out solve is reported like a failed factorisation (the LM loop stops, beta is kept)
@@ -1296,7 +1299,7 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
     const int per_cu = e ? atoi(e) : 1;
     n_wg = cus * (per_cu > 0 ? per_cu : 1);
   }
-  hipLaunchKernelGGL(k_dag_reset, dim3(8, n_frames), dim3(256), 0, st, fr);
+  hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);
   hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut);

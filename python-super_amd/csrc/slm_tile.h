@@ -283,43 +283,39 @@ __device__ __forceinline__ void blk_trail(double* S, int ib, int jb, int kb) {
   blk_store(Cb, 1, LD, acc);
 }
 
-// Streaming (optional, g_flag != nullptr): as soon as 16 more pivots are done, a trailing wave publishes what a
-// consumer needs to run ITS row solve against this tile block column by block column (slm_dag.hip): the inverse
-// of diagonal block kb -> the diagonal block of the inverse's tile in HBM (g_linv), the finished row block of L
-// (blocks (kb, t < kb)) -> the tile's own place in HBM (g_ltile), then the flag g_flag[kb], all with agent-scope
-// (sc1) accesses.  Only the publishing wave stored, so its own s_waitcnt vmcnt(0) orders data before flag.
+// Streaming (optional, g_mail != nullptr): as soon as 16 more pivots are done, a trailing wave publishes what a
+// consumer needs to run ITS row solve against this tile block column by block column (slm_dag.hip): the inverse of
+// diagonal block kb and the finished row block of L (blocks (kb, t < kb)), with agent-scope (sc1) stores.
 // g_early: a flag for stores that ALL waves of the caller issued just before the call (slm_dag.hip: the tile left of
 // the diagonal one): every wave drains them before the first barrier -- wave 0 after its first 16 pivots, when they
 // have long landed -- and one lane publishes the flag after it.
-__device__ __forceinline__ void publish_blocks16(const double* S, const double* dinv, int kb, double* g_linv,
-                                                 double* g_ltile, int* g_flag) {
+// The streamed hand-off of a tile factorisation (slm_dag.hip): per pivot tile column a MAILBOX of 10 blocks of 16 x 16
+// doubles -- blocks 0..3: the inverses of the diagonal blocks; block 4 + kb (kb - 1) / 2 + t: L block (kb, t), t < kb --
+// element (i, k) of a block at i + 16 k.  The mailbox is filled with SLM_MAIL_EMPTY before the launch (k_dag_reset) and
+// the consumers poll the DATA: a value that is not the sentinel has arrived.  No drain, no flag: one memory round trip
+// per hand-off instead of store - drain - flag, poll, payload load.  The sentinel is a NaN with a payload that no
+// arithmetic produces (operations return the canonical quiet NaN).
+#define SLM_MAIL_DOUBLES 2560
+#define SLM_MAIL_EMPTY 0x7FF8DEADBEEF0001ll
+__device__ __forceinline__ void publish_blocks16(const double* S, const double* dinv, int kb, double* g_mail) {
   typedef __attribute__((address_space(1))) double gdbl;
-  typedef __attribute__((address_space(1))) int gi32;
   const int l = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int e = l + 64 * j, i = e & 15, k = e >> 4;
-    __hip_atomic_store((gdbl*)(g_linv + (16 * kb + i) + (size_t)(16 * kb + k) * NB), dinv[kb * 256 + i + 16 * k],
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int e = l + 64 * j;
+    __hip_atomic_store((gdbl*)(g_mail + kb * 256 + e), dinv[kb * 256 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   for (int t = 0; t < kb; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e = l + 64 * j, i = e & 15, k = e >> 4;
-      __hip_atomic_store((gdbl*)(g_ltile + (16 * kb + i) + (size_t)(16 * t + k) * NB), S[(16 * kb + i) + (16 * t + k) * LD],
+      __hip_atomic_store((gdbl*)(g_mail + (4 + kb * (kb - 1) / 2 + t) * 256 + e), S[(16 * kb + i) + (16 * t + k) * LD],
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// ... and, once the wave has done whatever else it had to do meanwhile, the flag behind the landed stores
-__device__ __forceinline__ void publish_flag16(int kb, int* g_flag) {
-  typedef __attribute__((address_space(1))) int gi32;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store((gi32*)(g_flag + kb), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* dinv, double* wt, double* xch,
-                                                  int* s_ok, int* pf, double* g_linv = nullptr,
-                                                  double* g_ltile = nullptr, int* g_flag = nullptr, int* g_early = nullptr,
+                                                  int* s_ok, int* pf, double* g_mail = nullptr, int* g_early = nullptr,
                                                   long long* trc = nullptr) {
 #define FTRC(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
   const int w = threadIdx.x >> 6;
@@ -378,10 +374,7 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
     FTRC(3 * kb + 2);
     if (kb == 3) break;
     // the wave with the least trailing work in the coming round publishes
-    if (g_flag && w == (kb == 0 ? 3 : 2)) {
-      publish_blocks16(S, dinv, kb, g_linv, g_ltile, g_flag);
-      publish_flag16(kb, g_flag);
-    }
+    if (g_mail && w == (kb == 0 ? 3 : 2)) publish_blocks16(S, dinv, kb, g_mail);
     if (kb == 0 && g_early && threadIdx.x == 128)
       __hip_atomic_store((__attribute__((address_space(1))) int*)g_early, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w < 3 - kb) {
@@ -404,12 +397,11 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
     double4_t m2 = blk_mma<true>(z4, dinv + 768, 1, 16, Wscr, 1, 16);
     blk_store(M + 48 + j * 16 * LD, 1, LD, m2);
   } else {
-    if (g_flag) publish_blocks16(S, dinv, 3, g_linv, g_ltile, g_flag);
+    if (g_mail) publish_blocks16(S, dinv, 3, g_mail);
     for (int e = threadIdx.x; e < 1024; e += 64) {
       const int b = e >> 8, i = e & 15, k = (e >> 4) & 15;
       M[(16 * b + i) + (16 * b + k) * LD] = dinv[b * 256 + i + 16 * k];
     }
-    if (g_flag) publish_flag16(3, g_flag);
   }
   __syncthreads();
   FTRC(12);
