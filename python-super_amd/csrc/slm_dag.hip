@@ -20,7 +20,8 @@
 //   POTRF(f,s)   owns the diagonal tile (s,s) AND its left neighbour (s,s-1): accumulates the columns c < s-1 as they
 //                become available, then follows the factorisation of column s-1 16 pivots at a time (streamed row
 //                solve L(s,s-1) = A(s,s-1) L_{s-1,s-1}^-T and update of (s,s)), factors (s,s) + inverse -> flinv
-//                (slm_tile.h factor_inverse64p, itself publishing its row blocks per 16 pivots for POTRF(f,s+1)),
+//                (slm_tile.h factor_inverse64p, itself publishing its row blocks per 16 pivots into the column's
+//                mailbox for POTRF(f,s+1) and the COL tasks, which poll the DATA: a non-sentinel value has arrived),
 //                y_s = L_ss^-1 (b_s - sum_{c<s} L(s,c) y_c)                                  (forward subst.)
 //   COL(f,r,s)   r > s+1 (or a boundary row): L(r,s) = (A(r,s) - sum_{c<s} L(r,c) L(s,c)^T) L_ss^-T
 //   SCHUR(f,r,s) boundary tile: U = A(r,s) - sum_{c<npt} L(r,c) L(s,c)^T, stored IN PLACE (the parent gathers it);
@@ -117,7 +118,7 @@ struct DagFlags {
   int* pb;
   int* px;
   int* py;
-  int* pk;   // 4 per pivot tile column: 16, 32, 48, 64 pivots of its diagonal tile are out (streamed row solves)
+  int* pk;   // 4 per pivot tile column (unused since the streamed hand-off polls the column's mailbox, slm_tile.h)
 };
 __device__ __forceinline__ DagFlags dag_flags_of(const FrameDev& fd) {
   DagFlags g;
@@ -284,7 +285,8 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
     d.kc = type == ND_T_SCHUR ? f.npt : s;
     const int npull = d.np[0] + d.np[1] + d.np2[0] + d.np2[1];
     d.n0 = npull;                 // to start: the children's update tiles; the operand columns are consumed as they come
-    if (type == ND_T_POTRF)       // per column c < s-1: L(s,c), y_c, L(s-1,c); then 4 x 16 pivots of (s-1,s-1), then y_{s-1}
+    if (type == ND_T_POTRF)       // per column c < s-1: L(s,c), y_c, L(s-1,c); then 4 slots for the 16-pivot rounds of (s-1,s-1)
+                                  // (not waited for: the rounds are taken from the column's mailbox), then y_{s-1}
       d.n = npull + 3 * (s > 0 ? s - 1 : 0) + (s > 0 ? 5 : 0);
     else
       d.n = npull + 2 * d.kc + (type == ND_T_COL ? 1 : 0);
