@@ -455,7 +455,9 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   double* dinv = lds + 2 * TILE;
   double* wt = dinv + 4 * 256;   // 3 scratch blocks (inverse_assemble64 runs on at most 3 waves)
   double* vec = wt + 3 * 256;
-  int* s_ok = reinterpret_cast<int*>(vec + NB);
+  double* xch = vec + NB;        // 2 NB: exchange buffer of the pipelined tile factorisation
+  int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
+  int* pf = s_ok + 8;            // its 16 hand-off flags
   WgId wg;
   if (!wg_decode(map, wg)) return;
   const FrameDev& fd = frames[wg.frame];
@@ -499,12 +501,13 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   }
   __syncthreads();
   SLM_STAMP(fd, stamp, 1);
-  const bool ok = potrf64(S, dinv, wt, s_ok, fd, stamp);
+  // (factor + inverse in the pipelined form of the task graph; the row blocks d > 0 only need L and the diagonal-block
+  //  inverses, which are complete at the same time as with potrf64)
+  const bool ok = factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf);
   SLM_STAMP(fd, stamp, 14);
 
   if (d == 0) {
     if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
-    inverse_assemble64(S, M, dinv, wt);
     double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
     for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];
     if (threadIdx.x < NB) {
@@ -537,7 +540,9 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
   double* dinv = lds + 2 * TILE;
   double* wt = dinv + 4 * 256;   // 3 scratch blocks (inverse_assemble64 runs on at most 3 waves)
   double* vec = wt + 3 * 256;
-  int* s_ok = reinterpret_cast<int*>(vec + NB);
+  double* xch = vec + NB;        // 2 NB: exchange buffer of the pipelined tile factorisation
+  int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
+  int* pf = s_ok + 8;            // its 16 hand-off flags
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   int fi;
@@ -562,9 +567,8 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
     }
   }
   __syncthreads();
-  const bool ok = potrf64(S, dinv, wt, s_ok, fd, false);
+  const bool ok = factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf);
   if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
-  inverse_assemble64(S, M, dinv, wt);
   double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
   for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];
   if (threadIdx.x < NB) {
@@ -618,7 +622,7 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
 // grid k_fL11 = (1, fronts in level, n_frames); k_fL21 = (max boundary tiles, fronts, frames)
 // S (tile being factored; later the B operand of the trailing update), M (its inverse), the four
 // diagonal-block inverses, three 16x16 scratch blocks, two vectors: 80 960 B, two workgroups per CU
-#define L11_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 8)
+#define L11_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 16)   // S, M, dinv, wt, vec | part (= the factorisation's exchange buffer), 32 ints
 
 __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                double u_override) {
@@ -631,6 +635,7 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
   double* vec = wt + 3 * 256;      // NB: rhs tile in / y tile out
   double* part = vec + NB;         // NB scratch
   int* s_ok = reinterpret_cast<int*>(part + NB);
+  int* pf = s_ok + 8;              // 16 hand-off flags of the pipelined tile factorisation
   const FrameDev& fd = frames[blockIdx.z];
   if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
   int fi;
@@ -643,12 +648,13 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
 
   for (int c = 0; c < f.npt; ++c) {
     // ---- diagonal tile: factor + inverse + forward substitution of rhs tile c ----
+    double rhs_c = 0.0;
     {
       const double* src = ftile(fd, f, c, c);
       double v[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = src[threadIdx.x + 256 * t];
-      if (threadIdx.x < NB) vec[threadIdx.x] = vecs[(size_t)c * NB + threadIdx.x];
+      if (threadIdx.x < NB) rhs_c = vecs[(size_t)c * NB + threadIdx.x];   // (kept in a register: vec | part is the factorisation's exchange buffer)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int e = threadIdx.x + 256 * t;
@@ -659,9 +665,12 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
       }
     }
     __syncthreads();
-    const bool ok = potrf64(S, dinv, wt, s_ok, fd, false);
+    // factor + inverse in the pipelined form of the task graph (wave 0 runs the pivot chain, waves 1-3 trail with the
+    // panel / trailing / inverse blocks): 11.7 us per tile against ~14 for potrf64 + inverse_assemble64
+    const bool ok = factor_inverse64p(S, M, dinv, wt, vec, s_ok, pf);
     if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
-    inverse_assemble64(S, M, dinv, wt);
+    if (threadIdx.x < NB) vec[threadIdx.x] = rhs_c;
+    __syncthreads();
     {
       double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
       for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];

@@ -451,7 +451,7 @@ __device__ __forceinline__ void store_c_frags(double* __restrict__ Cg, const dou
 }
 
 // S, M, 4 diagonal-block inverses, 3 scratch blocks, one vector: 80 448 B -> two workgroups per CU
-#define PANEL_LDS_DOUBLES (2 * TILE + 7 * 256 + NB + 8)
+#define PANEL_LDS_DOUBLES (2 * TILE + 7 * 256 + 3 * NB + 16)   // ... + vec, the factorisation's exchange buffer (2 NB), 32 ints: 81 536 B
 
 // Rows [16w,16w+16) of X = A L^-T for one 64x64 tile, blockwise forward substitution on
 // the MFMA with everything in registers: x[kb] / a[kb] are 16x16 blocks in accumulator
