@@ -24,7 +24,8 @@ void launch_pair_reduce(const FrameDev*, int, int, hipStream_t);
 void launch_pair_scatter(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
-void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
+void launch_iter_begin_nd(const FrameDev*, int, bool, hipStream_t);
+void launch_zero_f22(const FrameDev*, int, hipStream_t);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
 void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
@@ -122,6 +123,7 @@ struct slm_solver {
   std::vector<hipEvent_t> bind_events;
   std::mutex band_mutex;        // the bandwidth read-back buffer of ensure_band is shared
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
+  bool f22_skipped = false;     // the last assembly left the F22 blocks of the fronts unzeroed (it planned for the task-graph solve)
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
@@ -745,10 +747,17 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
 
 // factor + substitutions of the assembled fronts: one persistent task-graph launch (solver_path 2) or the
 // per-level launches (solver_path 0)
+// solver_path 0 picks by batch size: the task graph is a latency scheduler (one or two frames per launch: the
+// drop-in case, one frame at a time); larger batches are throughput-bound and run the per-level launches
+static bool solve_is_task_graph(const slm_solver* s, int n) {
+  return s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && n <= 2);
+}
 void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
-  // solver_path 0 picks by batch size: the task graph is a latency scheduler (one or two frames per launch: the
-  // drop-in case, one frame at a time); larger batches are throughput-bound and run the per-level launches
-  const bool dag = s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && n <= 2);
+  const bool dag = solve_is_task_graph(s, n);
+  // the task graph never reads a boundary block before writing it, the per-level form adds into it: if the assembly
+  // planned for the former (and skipped the zeroing) and this solve is the latter, zero them now
+  if (s->f22_skipped && !dag) launch_zero_f22(fr, n, st);
+  s->f22_skipped = false;
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
   const bool hybrid = !dag && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
@@ -770,8 +779,8 @@ void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDi
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
 hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st) {
   const FrameDev* fr = s->frames_dev + first;
-  (void)s;
-  launch_iter_begin_nd(fr, n, st);   // zeroes the fronts of all n slots in one launch
+  s->f22_skipped = solve_is_task_graph(s, n) && d.max_tasks > 0;
+  launch_iter_begin_nd(fr, n, s->f22_skipped, st);   // zeroes the fronts of all n slots in one launch
   if (s->cfg.use_data) {
     launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
@@ -843,7 +852,8 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FrameDev* fr = s->frames_dev;
-  launch_iter_begin_nd(fr, n_frames, st);
+  s->f22_skipped = solve_is_task_graph(s, n_frames) && d.max_tasks > 0;
+  launch_iter_begin_nd(fr, n_frames, s->f22_skipped, st);
   if (s->cfg.use_data) {
     launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_pair_reduce(fr, n_frames, d.max_blocks, st);
@@ -971,7 +981,8 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     };
     mark();
     if (d.nd) {
-      launch_iter_begin_nd(fr, n_frames, st);
+      s->f22_skipped = solve_is_task_graph(s, n_frames) && d.max_tasks > 0;
+      launch_iter_begin_nd(fr, n_frames, s->f22_skipped, st);
     } else {
       launch_iter_begin(fr, n_frames, st);
     }

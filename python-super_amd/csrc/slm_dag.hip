@@ -944,7 +944,10 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
     // own tile, vector rows and pull maps: final before the launch, requested before the wait (see dag_task_factor)
     double4_t acc[4];
-    if (f.is_leaf) {   // a leaf's boundary block holds nothing yet (its storage is not even zeroed, NDFront::f22_base)
+    // A boundary block holds nothing before its Schur tasks write it, unless the per-level launches of the hybrid solve
+    // ADDED the children's contributions into it (the fronts at depth == cut).  It is not read then -- and it is not
+    // zeroed for this form either (slm_front.hip k_iter_begin_nd, skip_f22; a leaf's is never zeroed, NDFront::f22_base).
+    if (f.is_leaf || !(cut >= 0 && uni(fd.fronts[fi].depth) == cut)) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
     } else {

@@ -411,27 +411,52 @@ __global__ void __launch_bounds__(256) k_front_load_rhs(const FrameDev* __restri
   fd.fvec[f.vec_off + 7 * fd.node_pos[v] + c] = fd.rhs[e];
 }
 
-// Start of an iteration on the multifrontal path: zero the fronts (the leading part of the tile storage -- the leaves'
-// boundary blocks behind it are written, not added to -- and the front vectors), rhs and the counters, for ALL slots of
-// the batch in one launch (one hipMemsetAsync pair per slot cost ~25 us each, back to back: 0.2 ms per iteration at
-// 8 frames).  grid = (blocks, n_frames); 16-byte stores.
-__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames) {
+// ---- zeroing of the fronts ------------------------------------------------------------------------------------
+// A front's tiles: the pivot columns (assembly adds into them), then -- internal fronts only -- the boundary block F22,
+// which receives nothing but its children's Schur complements: ADDED into it by k_fschur of the level below in the
+// per-level form (so it must start from zero), GATHERED by the front's own SCHUR tasks in the task-graph form (which
+// never read it first: no zeroing needed, slm_dag.hip).  F22 is two thirds of the tile storage (C2: 134 MB per frame).
+typedef double dvec2_t __attribute__((ext_vector_type(2)));
+// 16 KB pieces of a contiguous region, piece-strided: pc = first, first + step, ...; non-temporal 16-byte stores
+__device__ __forceinline__ void zero_pieces(double* base, size_t n_pieces, size_t first, size_t step) {
+  const dvec2_t zz = {0.0, 0.0};
+  dvec2_t* b2 = reinterpret_cast<dvec2_t*>(base);
+  for (size_t pc = first; pc < n_pieces; pc += step) {
+    dvec2_t* q = b2 + pc * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(zz, q + 256 * k);
+  }
+}
+__device__ __forceinline__ size_t front_piv_tiles(const NDFront& f) {
+  return (size_t)f.npt * f.nt - (size_t)f.npt * (f.npt - 1) / 2;
+}
+// what: 1 = pivot columns, 2 = F22 blocks, 3 = both, of every front of the slot; workgroup b of nb
+__device__ __forceinline__ void zero_fronts(const FrameDev& fd, int what, int b, int nb) {
+  const int nf = fd.n_fronts, slices = 16;
+  for (int u = b; u < nf * slices; u += nb) {
+    const NDFront& f = fd.fronts[u % nf];
+    const size_t piv = front_piv_tiles(f), all = f.is_leaf ? piv : (size_t)f.nt * (f.nt + 1) / 2;
+    const size_t t0 = (what & 1) ? 0 : piv, t1 = (what & 2) ? all : piv;
+    if (t1 > t0) zero_pieces(fd.ftiles.get() + f.tile_off + t0 * TILE, (t1 - t0) * 2, (size_t)(u / nf), (size_t)slices);
+  }
+}
+// the F22 blocks alone (a solve in the per-level form after an assembly that had planned for the task graph)
+__global__ void __launch_bounds__(256) k_zero_f22(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.nd_ready) return;
+  zero_fronts(fd, 2, blockIdx.x, gridDim.x);
+}
+
+// Start of an iteration on the multifrontal path: zero the fronts (pivot columns; the F22 blocks unless `skip_f22`),
+// the front vectors, rhs and the counters, for ALL slots of the batch in one launch (one hipMemsetAsync pair per slot cost
+// ~25 us each, back to back).  grid = (blocks, n_frames); contiguous 16 KB pieces per workgroup.
+__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames, int skip_f22) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || fd.st->stopped) return;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
   const double2 z = make_double2(0.0, 0.0);
   if (fd.nd_ready) {
-    // (tile storage and vectors are whole 64-double rows; a workgroup clears contiguous 16 KB pieces, non-temporal)
-    typedef double dvec2 __attribute__((ext_vector_type(2)));
-    dvec2* t2 = reinterpret_cast<dvec2*>(fd.ftiles.get());
-    const size_t npiece = (size_t)fd.zero_tile_doubles / 2048;
-    const dvec2 zz = {0.0, 0.0};
-    for (size_t pc = blockIdx.x; pc < npiece; pc += gridDim.x) {
-      dvec2* q = t2 + pc * 1024 + threadIdx.x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(zz, q + 256 * k);
-    }
-    for (size_t e = npiece * 1024 + tid; e < (size_t)fd.zero_tile_doubles / 2; e += nthr) t2[e] = zz;
+    zero_fronts(fd, skip_f22 ? 1 : 3, blockIdx.x, gridDim.x);
     double2* v2 = reinterpret_cast<double2*>(fd.fvec.get());
     const size_t nv2 = (size_t)fd.zero_vec_doubles / 2;
     for (size_t e = tid; e < nv2; e += nthr) v2[e] = z;
@@ -1104,8 +1129,11 @@ void launch_front_load_rhs(const FrameDev* fr, int n_frames, int maxP, hipStream
   hipLaunchKernelGGL(k_front_load_rhs, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, fr);
 }
 
-void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
-  hipLaunchKernelGGL(k_iter_begin_nd, dim3(2048, n_frames), dim3(256), 0, st, fr);
+void launch_iter_begin_nd(const FrameDev* fr, int n_frames, bool skip_f22, hipStream_t st) {
+  hipLaunchKernelGGL(k_iter_begin_nd, dim3(2048, n_frames), dim3(256), 0, st, fr, skip_f22 ? 1 : 0);
+}
+void launch_zero_f22(const FrameDev* fr, int n_frames, hipStream_t st) {
+  hipLaunchKernelGGL(k_zero_f22, dim3(1024, n_frames), dim3(256), 0, st, fr);
 }
 
 // Level schedule shared by all slots of a batch (they may have different plans: the host
