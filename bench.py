@@ -102,6 +102,41 @@ def pmc_traffic(kernel, workload, frames_per_gpu):
     return best, src
 
 
+def pmc_phase_traffic(phase, workload, frames_per_gpu):
+    """HBM bytes per LM iteration of one phase (all its launches) from the newest committed PMC summary of THIS
+    workload / batch (profiles/make_traffic.py `phases`); (None, provenance) when the summary is of other sources."""
+    import glob
+    best, src = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("frames_per_gpu") == frames_per_gpu and phase in d.get("phases", {}):
+            best = d["phases"][phase]["traffic_bytes_per_iteration"]
+            src = {"file": os.path.relpath(path, ROOT), "lib_sha16": d.get("lib_sha16"),
+                   "stale": d.get("lib_sha16") != lib_sha16(), "kernels": d["phases"][phase].get("kernels")}
+    if src is not None and src["stale"]:
+        best = None
+    return best, src
+
+
+def cpu_quota():
+    """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None = unlimited:
+    os.cpu_count() reports the machine, not the quota, and a host pool sized by it gets throttled."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def host_info():
     model = None
     try:
@@ -111,7 +146,11 @@ def host_info():
                 break
     except OSError:
         pass
-    return {"cpu_model": model, "logical_cpus": os.cpu_count()}
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = None
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "cpu_affinity": affinity, "cpu_quota": cpu_quota()}
 
 
 def latency_b1(dims, device, iters, steps=6):
@@ -152,10 +191,52 @@ def latency_b1(dims, device, iters, steps=6):
     out = {"value": iters / dt, "unit": "LM it/s", "ms_per_frame": 1e3 * dt, "frames_per_launch": 1,
            "phase_ms_per_iteration": phases,
            "solver_form": "task graph (one persistent launch)" if info["solver_tasks"] > 0 else "per-level launches",
+           "solver_tflops": info["factor_flops_unpadded"] / solve_s / 1e12 if solve_s > 0 else 0.0,
+           "solver_frac_of_f64_mfma_peak": info["factor_flops_unpadded"] / solve_s / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_s > 0 else 0.0,
            "solver_tflops_padded": info["factor_flops"] / solve_s / 1e12 if solve_s > 0 else 0.0,
-           "solver_frac_of_f64_mfma_peak": info["factor_flops"] / solve_s / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_s > 0 else 0.0,
+           "solver_frac_of_f64_mfma_peak_padded": info["factor_flops"] / solve_s / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_s > 0 else 0.0,
            "sample": f"{steps} steps of one {sc.N}-surfel / {sc.J}-node frame"}
     eng.close()
+    return out
+
+
+def bind_timing(dims, device, B, reps=6):
+    """The per-frame prepare (slm_bind_frame / slm_bind_frames = loss_term.prepare, reference super/loss.py:212-220,
+    408-426) on its own, host-timed around a stream sync: `warm` = the frame's coupled-pair list is the one the slot's
+    symbolic plan was built for (what the bench's own steps see: same frames every step); `cold` = every bind needs a new
+    symbolic analysis on the host (the node-KNN table alternates between two orderings of the same neighbour sets: another
+    hash, the same graph, so the work is that of a genuinely new plan with the buffers already allocated)."""
+    import ctypes as C
+    import torch
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+    out = {}
+    cnt = (C.c_int64 * 4)()
+    for label, nb in (("b1", 1), ("batch", B)):
+        scs = [synth.make_scene(seed=i, **dims) for i in range(nb)]
+        fa = [DeviceFrame.from_scene(sc, device) for sc in scs]
+        fb = [DeviceFrame.from_scene(sc, device) for sc in scs]
+        for f in fb:
+            f.ed_knn_idx = torch.roll(f.ed_knn_idx, 1, dims=1).contiguous()
+        eng = Engine(device, max_frames=nb, num_iterations=1)
+        eng.bind_batch(fa)
+        eng.bind_batch(fb)                                  # (both variants have been seen: allocations done)
+        for mode in ("warm", "cold"):
+            eng.bind_batch(fa)
+            torch.cuda.synchronize(device)
+            eng.lib.slm_debug_counters(cnt)
+            builds0 = cnt[2]
+            t0 = time.perf_counter()
+            for r in range(reps):
+                eng.bind_batch(fb if (mode == "cold" and r % 2 == 0) else fa)
+            torch.cuda.synchronize(device)
+            dt = (time.perf_counter() - t0) / reps
+            eng.lib.slm_debug_counters(cnt)
+            out[f"{mode}_ms_per_frame_{label}"] = 1e3 * dt / nb
+            out[f"{mode}_symbolic_analyses_per_bind_{label}"] = (cnt[2] - builds0) / (reps * nb)
+        eng.close()
+    out["note"] = ("host-timed incl. the stream sync; `batch` = slm_bind_frames over the bench's frames per GPU (workers inside "
+                   "the library), `b1` = one slm_bind_frame; the bench's timed steps contain the warm batch bind")
     return out
 
 
@@ -163,26 +244,79 @@ def cpu_baseline(dims, seed):
     """Oracle (NumPy/SciPy float64 port of the reference LM path) on the host cores:
     THREE LM iterations (Jacobian pass + dense Cholesky solve + loss pass each) of one frame,
     about 10 s of CPU work on the GPU box."""
-    import numpy as np  # noqa: F401
+    import numpy as np
     from oracle import lm_oracle as orc
     from super_amd import synth
-    try:                       # threads of the BLAS / LAPACK pool NumPy and SciPy run the oracle on
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
     sc = synth.make_scene(seed=seed, **dims)
     fr = orc.Frame.from_scene(sc)
     n_it = 3
     opt = orc.default_opt(num_optimize_iterations=n_it)
-    t0 = time.perf_counter()
-    orc.lm(fr, opt)
-    dt = time.perf_counter() - t0
-    return {"value": n_it / dt, "unit": "LM it/s", "cores": int(cores), "kind": "port",
+    # The BLAS pool defaults to one thread per LOGICAL CPU of the machine (256 on the GPU box) whatever the cgroup
+    # quota (16 CPUs there): the baseline is timed at the best thread count of a short probe -- a dense Cholesky of the
+    # workload's own size, the part that dominates and the only multi-threaded one -- and `cores` is what was used.
+    used, probe = None, {}
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        n_max = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        import scipy.linalg as sla
+        P = 7 * sc.J
+        rng = np.random.default_rng(0)
+        A = rng.standard_normal((P, 64))
+        A = A @ A.T + P * np.eye(P)
+        quota = cpu_quota()
+        cands = sorted({c for c in (4, 8, 16, 32, 64, n_max, int(quota) if quota else n_max) if 1 <= c <= n_max})
+        for n in cands:
+            with threadpool_limits(limits=n):
+                sla.cho_factor(A, lower=True, check_finite=False)           # warm-up at this thread count
+                t0 = time.perf_counter()
+                sla.cho_factor(A, lower=True, check_finite=False)
+                probe[n] = time.perf_counter() - t0
+        used = min(probe, key=probe.get)
+        ctx = threadpool_limits(limits=used)
+    except Exception:
+        import contextlib
+        ctx = contextlib.nullcontext()
+        used = os.cpu_count() or 1
+    trace = []
+    with ctx:
+        t0 = time.perf_counter()
+        beta = orc.lm(fr, opt, trace=trace)
+        dt = time.perf_counter() - t0
+    return {"value": n_it / dt, "unit": "LM it/s", "cores": int(used), "kind": "port",
             "sample": f"{n_it} LM iterations (of 10) of one {sc.N}-surfel / {sc.J}-node frame, "
-                      f"NumPy/SciPy float64 oracle incl. dense Cholesky, {dt:.1f} s; `cores` = BLAS pool threads "
-                      "(the dense Cholesky dominates and is the only multi-threaded part)",
-            "seconds": dt}
+                      f"NumPy/SciPy float64 oracle incl. dense Cholesky, {dt:.1f} s; `cores` = BLAS pool threads used, the "
+                      "best of `thread_probe_s` (seconds per dense Cholesky of this size at each thread count)",
+            "thread_probe_s": {str(k): v for k, v in probe.items()},
+            "seconds": dt}, beta, trace
+
+
+def parity_check(dims, device, oracle_beta, trace):
+    """`parity_c2`: the oracle's beta after the 3 LM iterations `cpu_baseline` has just computed against the HIP path on
+    the same frame (seed 0), same 3 iterations, in the batch's solver form and at one frame per launch.  The oracle is
+    the checker here, never the thing timed; a mismatch fails the bench."""
+    import numpy as np
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+    sc = synth.make_scene(seed=0, **dims)
+    n_it = len(trace)
+    out = {"iterations": n_it, "tolerance": 1e-4, "reference": "oracle/lm_oracle.py (NumPy float64, dense Cholesky)"}
+    worst = 0.0
+    for label, nb in (("one_frame_per_launch", 1), ("batch_of_3", 3)):
+        eng = Engine(device, max_frames=nb, num_iterations=n_it)
+        eng.bind_batch([DeviceFrame.from_scene(sc, device) for _ in range(nb)])
+        eng.run(nb)
+        recs = eng.records(nb - 1)
+        err = float(np.abs(eng.beta(nb - 1).cpu().numpy() - oracle_beta).max())
+        loss_rel = max(abs(r["loss"] - t["loss"]) / max(abs(t["loss"]), 1e-300) for r, t in zip(recs, trace))
+        out[label] = {"max_abs_beta_diff": err, "max_rel_loss_diff": loss_rel,
+                      "match_counts_equal": [r["M_grad"] for r in recs] == [t["M_grad"] for t in trace],
+                      "solver_form": {0: "per-level", 1: "task graph", 2: "hybrid"}.get(eng.lib.slm_debug_last_solver_form(eng.h))}
+        worst = max(worst, err)
+        eng.close()
+    out["max_abs_beta_diff"] = worst
+    out["ok"] = bool(worst < 1e-4 and all(out[k]["match_counts_equal"] and out[k]["max_rel_loss_diff"] < 1e-6
+                                          for k in ("one_frame_per_launch", "batch_of_3")))
+    return out
 
 
 def cpu_baseline_autograd(dims, seed):
@@ -376,7 +510,12 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    # A process group exists whenever a launcher started this rank (torchrun sets RANK / MASTER_PORT), a world of ONE rank
+    # included: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` then runs the same RCCL barrier /
+    # all-gather / MAX-reduce as the N-GPU job.  A plain `python bench.py` has no group and no collective.
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    use_dist = world > 1 or launched
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -421,7 +560,10 @@ def main():
         pristine_big = {nm: stacked(pristine, nm) for nm in reset_fields}
         work_big = {nm: stacked(work, nm) for nm in reset_fields}
 
+    stamps = []
+
     def step():
+        stamps.append(time.perf_counter())               # (the bind below drains the stream first: no extra sync)
         if same_shape:
             for nm in reset_fields:                      # same problem every step
                 work_big[nm].copy_(pristine_big[nm])
@@ -447,7 +589,7 @@ def main():
         if S > 1:
             for st in streams:
                 torch.cuda.current_stream(device).wait_stream(st)
-        if world > 1:                                    # end-of-frame exchange
+        if use_dist:                                     # end-of-frame exchange
             torch.stack(betas, out=local)
             if backend == "nccl":
                 gathered[0] = all_gather_betas(local, world * B)
@@ -455,7 +597,7 @@ def main():
                 gathered[0] = all_gather_betas(local.cpu(), world * B)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -465,11 +607,15 @@ def main():
     if not a.no_profile:
         for e in engs:
             e.profile(True)
+    del stamps[:]
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    elapsed = t_end - t0
+    # per-step durations: a step's stamp is taken when its bind has drained the previous step's work
+    step_ms = sorted(1e3 * (b_ - a_) for a_, b_ in zip(stamps, stamps[1:] + [t_end]))
     prof = None
     if not a.no_profile:
         for e in engs:
@@ -481,7 +627,7 @@ def main():
                     prof[k2]["ms"] += v2["ms"]
                     prof[k2]["count"] += v2["count"]
             e.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -513,6 +659,10 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), beta all-gather"},
             "lm_iterations_ok_frame0": n_ok,
             "final_loss_frame0": final_loss[-1] if final_loss else None,
+            "step_ms": {"median": step_ms[len(step_ms) // 2], "p99": step_ms[min(len(step_ms) - 1, int(0.99 * len(step_ms)))],
+                        "max": step_ms[-1], "min": step_ms[0], "steps": len(step_ms)},
+            "distributed": {"backend": backend if use_dist else None, "world": world,
+                            "launched_by": "torchrun" if launched else None},
         }
         if prof is not None:
             info = eng.plan_info(0)
@@ -520,16 +670,21 @@ def main():
             flops_exact = Bs * info["factor_flops_unpadded"]
             sp = prof["solve"]
             savg = sp["ms"] / max(sp["count"], 1) * 1e-3
-            tf = flops / savg / 1e12 if savg > 0 else 0.0
-            # the time-dominant phase: the float64 multifrontal factor + substitutions of all frames of a launch
+            tf_pad = flops / savg / 1e12 if savg > 0 else 0.0
+            tf = flops_exact / savg / 1e12 if savg > 0 else 0.0
+            solve_traffic, solve_tsrc = pmc_phase_traffic("solve", a.workload, Bs)
+            # the time-dominant phase: the float64 multifrontal factor + substitutions of all frames of a launch.
+            # `achieved` / `frac` are on the ALGORITHMIC FLOPs (true pivot / boundary sizes); the 64-padded count -- what
+            # the MFMAs execute -- rides along as *_padded.
             out["roofline"] = {"kernel": "solve phase: " + info["solver"] + " Cholesky factor + substitutions ("
                                          + ("k_fdag, one persistent launch" if Bs <= 2 and info["solver_tasks"] > 0
                                             else "per-level launches k_fL11 / k_fL21 / k_fschur / k_fpanel / k_ftrail for the lower levels + k_fdag (task graph) for "
                                                  "the root front, its children and the back substitution of the whole tree; all launches of one LM iteration") + ")",
                                "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "achieved_unpadded": flops_exact / savg / 1e12 if savg > 0 else 0.0,
-                               "frac_unpadded": flops_exact / savg / 1e12 / F64_MFMA_PEAK_TFLOPS if savg > 0 else 0.0,
+                               "frac": tf / F64_MFMA_PEAK_TFLOPS,
+                               "traffic": solve_traffic, "traffic_source": solve_tsrc,
+                               "traffic_note": "HBM bytes of all solver launches of ONE LM iteration (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes)",
+                               "achieved_padded": tf_pad, "frac_padded": tf_pad / F64_MFMA_PEAK_TFLOPS,
                                "avg_phase_ms": savg * 1e3, "share_of_iteration": None,
                                "factor_gflop_per_frame": info["factor_flops"] / 1e9,
                                "factor_gflop_per_frame_unpadded": info["factor_flops_unpadded"] / 1e9,
@@ -558,13 +713,17 @@ def main():
         if world == 1 and not a.no_profile and not a.no_latency_b1:
             out["latency_b1"] = latency_b1(dims, device, iters)
         out["host"] = host_info()
+        if world == 1 and not a.no_profile:
+            out["bind"] = bind_timing(dims, device, B)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, seed=0)
+            out["cpu_baseline"], oracle_beta, oracle_trace = cpu_baseline(dims, seed=0)
+            out["parity_" + a.workload.lower()] = parity_check(dims, device, oracle_beta, oracle_trace)
+            assert out["parity_" + a.workload.lower()]["ok"], out["parity_" + a.workload.lower()]
             out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)
             out["graphfit_gpu"] = graphfit_timing(dims, device)
             out["next_rows"] = next_row_timings(device)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

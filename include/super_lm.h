@@ -57,8 +57,21 @@ enum {
 enum {
   SLM_ITER_OK = 0,
   SLM_ITER_SOLVER_FAILED = 1, /* Cholesky pivot <= 0: "Solver failed: Ill-posed system!" (super/LM.py:99-103) */
-  SLM_ITER_NOT_RUN = 2        /* iteration skipped because an earlier one stopped the loop */
+  SLM_ITER_NOT_RUN = 2,       /* iteration skipped because an earlier one stopped the loop */
+  SLM_ITER_SOLVER_TIMEOUT = 3 /* the task-graph solve gave up waiting (a scheduling time-out of the persistent launch, not
+                                 a property of the matrix); the loop stops like after a failed factorisation */
 };
+
+/* ABI handshake.  The structs of this header are passed by pointer and have grown between rounds; a caller built
+ * against another revision of the header must get an error, not out-of-bounds reads.  slm_abi_version() returns
+ * SLM_ABI_VERSION of the header the library was built from; slm_abi_check() also compares the caller's sizeof of
+ * the five structs that carry pointers or were extended (returns SLM_OK or SLM_ERR_INVALID with the mismatch in
+ * slm_last_error()).  Bindings call it once after loading the library (super_amd/_lib.py does). */
+#define SLM_ABI_VERSION 3
+#define SLM_PLAN_INFO_DOUBLES 12
+int slm_abi_version(void);
+int slm_abi_check(int32_t abi_version, int32_t sizeof_slm_config, int32_t sizeof_slm_frame, int32_t sizeof_slm_gf_config,
+                  int32_t sizeof_slm_gf_frame, int32_t sizeof_slm_iter_record);
 
 typedef struct slm_solver slm_solver; /* opaque */
 
@@ -73,7 +86,7 @@ typedef struct slm_config {
   int32_t data_path;        /* 0 = tuple-sorted MFMA assembly, node-pair blocks merged per workgroup in
                                LDS (default); 1 = per-entry f64 atomics (simple cross-check path, also
                                used when J >= 65536); 2 = MFMA assembly with one Gram per run in HBM */
-  int32_t solver_path;      /* 0 = nested-dissection multifrontal Cholesky (default, needs data_path 0); its numeric
+  int32_t solver_path;      /* 0..4, anything else is rejected by slm_create.  0 = nested-dissection multifrontal Cholesky (default, needs data_path 0); its numeric
                                phase runs as ONE persistent launch over a static task graph (per-tile flags instead
                                of launch boundaries: the latency form) for one or two frames per launch, and as one
                                launch per level / tile column / phase for larger batches (the throughput form),
@@ -152,17 +165,19 @@ int slm_set_beta(slm_solver* s, int32_t slot, const double* beta_in_device, void
 int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int32_t max_records,
                     void* stream);
 
-/* Host-side facts about the slot's per-frame plan (after slm_bind_frame), info_out[12]:
+/* Host-side facts about the slot's per-frame plan (after slm_bind_frame).  info_out has room for `capacity` doubles;
+ * the first min(capacity, SLM_PLAN_INFO_DOUBLES) entries are written (a caller built for fewer entries is never
+ * overrun, one that asks for more gets zeros):
  * [0] solver in use (0 nested dissection, 1 band), [1] fronts, [2] tree levels,
  * [3] FLOPs of one factorisation (padded dense fronts, or P*w^2 for the band),
  * [4] factor storage bytes, [5] distinct KNN tuples, [6] Gram runs, [7] coupled node pairs,
  * [8] workgroup-merged (workgroup, pair) records (0: one Gram per run in HBM), [9] padded positions,
  * [10] FLOPs of one factorisation without the padding of the fronts to 64, [11] tasks of the task-graph solver. */
-int slm_get_plan_info(slm_solver* s, int32_t slot, double* info_out);
+int slm_get_plan_info(slm_solver* s, int32_t slot, double* info_out, int32_t capacity);
 
 /* -- one LARGE frame sharded over the GPUs of a node ----------------
  * After slm_set_shard(rank, world) (before slm_bind_frame; every rank binds the WHOLE frame so that
- * all ranks build the same plan) a context evaluates only its share of the surfels: workgroups
+ * all ranks build the same plan; world == 1 is allowed and runs the same exchange protocol on one rank) a context evaluates only its share of the surfels: workgroups
  * [n_wg*rank/world, ...) of the Jacobian pass and surfels [N*rank/world, ...) of the loss pass.
  * The library holds no communicator; per LM iteration the caller runs on every rank
  *     slm_lm_grad_local   zero, data-term Gram records of the share, per-pair partial sums

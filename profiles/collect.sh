@@ -21,8 +21,10 @@ timeout 300 python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats -name '*kernel_trace.csv' -delete
 # SQ counters of the same command (wave lifetime, waiting share, VALU share): two small passes
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
-  n=$(echo $grp | cut -d' ' -f2)
+# (+ the MFMA pass: MFMA-busy cycles against the kernel's own cycles, and the f64 MFMA op count where the counter exists)
+rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $R/gpurun_out/${TAG}_mfma_counters_available.txt
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA"; do
+  n=$(echo $grp | cut -d' ' -f1)
   timeout 400 rocprofv3 --pmc $grp --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_sq_$n.log 2>&1 < /dev/null
   find $R/gpurun_out/${TAG}_pmc_sq_$n -name '*kernel_trace.csv' -delete
 done

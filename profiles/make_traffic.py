@@ -15,6 +15,18 @@ import csv
 import json
 
 
+# kernels of each phase of an LM iteration on the nested-dissection path (csrc/slm_api.hip slm_run)
+PHASE_KERNELS = {
+    "zero": ["k_iter_begin_nd", "k_zero_f22"],
+    "data_grad": ["k_data_gram"],
+    "reg_grad": ["k_front_assemble", "k_reg_grad_nd", "k_front_load_rhs"],
+    "solve": ["k_fL11", "k_fL21", "k_fpanel", "k_fpotrf", "k_ftrsm", "k_ftrail", "k_fschur", "k_fpull", "k_fdag", "k_dag_reset",
+              "k_dag_check", "k_fback_prep", "k_fbacksub", "k_make_trial"],
+    "data_loss": ["k_data_loss"],
+    "accept": ["k_reg_loss", "k_accept"],
+}
+
+
 def means(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -48,6 +60,16 @@ def main():
             "traffic_bytes_all_launches": (2.0 * fetch_kib + write_kib) * 1024.0 * n,
             "traffic_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
             "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), WRITE_SIZE x1"}
+    # per LM iteration and phase (the phases of include/super_lm.h SLM_PH_*): every launch of the phase's kernels in the
+    # sampled run / the LM iterations of that run (k_accept runs once per iteration)
+    n_iter = out["kernels"].get("k_accept", {}).get("launches_sampled", 0)
+    if n_iter:
+        out["iterations_sampled"] = n_iter
+        out["phases"] = {}
+        for ph, names in PHASE_KERNELS.items():
+            ks = {k: out["kernels"][k]["traffic_bytes_all_launches"] / n_iter for k in names if k in out["kernels"]}
+            out["phases"][ph] = {"traffic_bytes_per_iteration": sum(ks.values()), "kernels": ks}
+        out["traffic_bytes_per_iteration_all_phases"] = sum(p["traffic_bytes_per_iteration"] for p in out["phases"].values())
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

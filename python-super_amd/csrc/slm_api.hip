@@ -1,7 +1,10 @@
 // slm_api.hip -- the C ABI of libsuper_lm.so (include/super_lm.h): slot workspaces,
 // the on-device LM loop, parity entry points.  Host side only orchestrates launches.
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -115,8 +118,78 @@ struct Slot {
 };
 }  // namespace
 
+// Persistent host workers of slm_bind_frames: created on first use, parked on a condition variable between calls, joined
+// in slm_destroy.  (One std::thread per frame and call cost a spawn + join per tracking step inside the timed region
+// and could throw through the extern "C" boundary.)
+namespace {
+class BindPool {
+ public:
+  ~BindPool() { shutdown(); }
+  // runs job(1) .. job(n - 1) on the workers and job(0) on the caller; returns when all are done.  Throws only from
+  // ensure() (thread creation), before any job has started.
+  void run(int n, const std::function<void(int)>& job) {
+    ensure(n - 1);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job;
+      n_active_ = n - 1;
+      pending_ = n - 1;
+      ++generation_;
+    }
+    cv_work_.notify_all();
+    job(0);
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    for (std::thread& t : threads_)
+      if (t.joinable()) t.join();
+    threads_.clear();
+  }
+
+ private:
+  void ensure(int n_workers) {
+    while ((int)threads_.size() < n_workers) {
+      const int id = (int)threads_.size();      // worker id runs job(id + 1)
+      threads_.emplace_back([this, id] { loop(id); });
+    }
+  }
+  void loop(int id) {
+    int seen = 0;
+    for (;;) {
+      const std::function<void(int)>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+        if (id < n_active_) job = job_;
+      }
+      if (job) {
+        (*job)(id + 1);
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) cv_done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int generation_ = 0, n_active_ = 0, pending_ = 0;
+  bool stop_ = false;
+};
+}  // namespace
+
 struct slm_solver {
   PrepBuffers* prep = nullptr;
+  BindPool bind_pool;
   // slm_bind_frames: one worker (scratch buffers + stream + events) per frame bound concurrently
   std::vector<PrepBuffers*> bind_prep;
   std::vector<hipStream_t> bind_streams;
@@ -134,6 +207,7 @@ struct slm_solver {
   int* bw_dev = nullptr;
   int* bw_host = nullptr;       // pinned
   int rank = 0, world = 1;      // surfel sharding of every frame (slm_set_shard)
+  bool shard_mode = false;      // slm_set_shard was called (world == 1 included): slots carry the exchange buffers
 };
 
 // diagnostics (slm_debug_counters): device reallocations and symbolic analyses since the library was loaded
@@ -215,6 +289,24 @@ int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, 
   return SLM_OK;
 }
 
+int slm_abi_version(void) { return SLM_ABI_VERSION; }
+
+int slm_abi_check(int32_t abi_version, int32_t sz_config, int32_t sz_frame, int32_t sz_gf_config, int32_t sz_gf_frame,
+                  int32_t sz_iter_record) {
+  if (abi_version != SLM_ABI_VERSION || sz_config != (int32_t)sizeof(slm_config) || sz_frame != (int32_t)sizeof(slm_frame) ||
+      sz_gf_config != (int32_t)sizeof(slm_gf_config) || sz_gf_frame != (int32_t)sizeof(slm_gf_frame) ||
+      sz_iter_record != (int32_t)sizeof(slm_iter_record)) {
+    char buf[320];
+    snprintf(buf, sizeof(buf),
+             "slm_abi_check: caller built for ABI %d (slm_config %d, slm_frame %d, slm_gf_config %d, slm_gf_frame %d, "
+             "slm_iter_record %d bytes), library is ABI %d (%zu, %zu, %zu, %zu, %zu)",
+             abi_version, sz_config, sz_frame, sz_gf_config, sz_gf_frame, sz_iter_record, SLM_ABI_VERSION, sizeof(slm_config),
+             sizeof(slm_frame), sizeof(slm_gf_config), sizeof(slm_gf_frame), sizeof(slm_iter_record));
+    return fail(SLM_ERR_INVALID, buf);
+  }
+  return SLM_OK;
+}
+
 int slm_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -225,10 +317,18 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   if (!cfg || !out) return fail(SLM_ERR_INVALID, "slm_create: null argument");
   if (cfg->max_frames < 1 || cfg->num_iterations < 0 || !(cfg->v > 0.0))
     return fail(SLM_ERR_INVALID, "slm_create: bad config");
+  if (cfg->solver_path < 0 || cfg->solver_path > 4) return fail(SLM_ERR_INVALID, "slm_create: solver_path must be 0..4");
+  if (cfg->data_path < 0 || cfg->data_path > 2) return fail(SLM_ERR_INVALID, "slm_create: data_path must be 0..2");
   if (slm_device_count() < 1) return fail(SLM_ERR_NO_DEVICE, "slm_create: no HIP device visible");
-  slm_solver* s = new slm_solver();
+  slm_solver* s = new (std::nothrow) slm_solver();
+  if (!s) return fail(SLM_ERR_HIP, "slm_create: out of host memory");
   s->cfg = *cfg;
-  s->slots.resize(cfg->max_frames);
+  try {
+    s->slots.resize(cfg->max_frames);
+  } catch (...) {
+    delete s;
+    return fail(SLM_ERR_HIP, "slm_create: out of host memory");
+  }
   hipError_t e = hipMalloc((void**)&s->frames_dev, sizeof(FrameDev) * cfg->max_frames);
   if (e == hipSuccess) e = hipMemset(s->frames_dev, 0, sizeof(FrameDev) * cfg->max_frames);
   if (e == hipSuccess) e = hipMalloc((void**)&s->bw_dev, sizeof(int));
@@ -249,6 +349,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
 
 int slm_destroy(slm_solver* s) {
   if (!s) return SLM_OK;
+  s->bind_pool.shutdown();
   for (Slot& sl : s->slots) {
     FrameDev& h = sl.h;
     if (h.beta) (void)hipFree(h.beta);
@@ -419,7 +520,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     h.sf_lo = (int32_t)((int64_t)f->N * s->rank / s->world);
     h.sf_hi = (int32_t)((int64_t)f->N * (s->rank + 1) / s->world);
     h.pairbuf = nullptr;
-    if (s->world > 1) {
+    if (s->shard_mode) {
       if (!h.v1_ready)
         return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: sharded frames need the tuple-sorted data path "
                                          "(data_path 0, num_neighbors 4, J < 65536)");
@@ -612,7 +713,16 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
     const char* e = getenv("SLM_BIND_WORKERS");     // experiments
     return e && atoi(e) > 0 ? atoi(e) : 8;
   }();
-  const int W = std::min(n_frames, kBindWorkers);
+  const int W = std::min(std::min(n_frames, kBindWorkers), 63);
+  // per-worker resources: each one is pushed into its pool as soon as it exists, so a failure half way leaves
+  // nothing behind that slm_destroy does not release (the pools are reserved first: push_back cannot throw after)
+  try {
+    s->bind_prep.reserve(64);
+    s->bind_streams.reserve(64);
+    s->bind_events.reserve(65);
+  } catch (...) {
+    return fail(SLM_ERR_HIP, "slm_bind_frames: out of host memory");
+  }
   while ((int)s->bind_prep.size() < W) {
     PrepBuffers* pb = prep_create();
     if (!pb) return fail(SLM_ERR_HIP, "slm_bind_frames: out of memory");
@@ -635,28 +745,37 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
   // (8 busy threads for tens of milliseconds per step cost the process its CPU quota on the GPU box).
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipEventRecord(s->bind_events[W], st));            // fork: the workers see everything enqueued on `st` so far
-  std::vector<int> rcs(W, SLM_OK);
-  std::vector<std::string> errs(W);
-  auto work = [&](int w) {
-    if (hipSetDevice(dev) != hipSuccess || hipStreamWaitEvent(s->bind_streams[w], s->bind_events[W], 0) != hipSuccess) {
-      rcs[w] = SLM_ERR_HIP;
-      errs[w] = "slm_bind_frames: worker setup failed";
-      return;
-    }
-    for (int i = w; i < n_frames; i += W) {
-      const int rc = bind_frame_impl(s, first_slot + i, frames + i, s->bind_streams[w], s->bind_prep[w]);
-      if (rc != SLM_OK) {
-        rcs[w] = rc;
-        errs[w] = g_err;        // thread-local text of this worker
+  // (no exception may cross the extern "C" boundary: the containers are sized before any worker starts, the pool throws
+  //  only from thread creation, and a worker catches whatever its bind throws -- std::bad_alloc from a plan vector)
+  int rcs[64];
+  std::string errs[64];
+  for (int w = 0; w < W; ++w) rcs[w] = SLM_OK;
+  const std::function<void(int)> work = [&](int w) {
+    try {
+      if (hipSetDevice(dev) != hipSuccess || hipStreamWaitEvent(s->bind_streams[w], s->bind_events[W], 0) != hipSuccess) {
+        rcs[w] = SLM_ERR_HIP;
+        errs[w] = "slm_bind_frames: worker setup failed";
         return;
       }
+      for (int i = w; i < n_frames; i += W) {
+        const int rc = bind_frame_impl(s, first_slot + i, frames + i, s->bind_streams[w], s->bind_prep[w]);
+        if (rc != SLM_OK) {
+          rcs[w] = rc;
+          errs[w] = g_err;        // thread-local text of this worker
+          return;
+        }
+      }
+      if (hipEventRecord(s->bind_events[w], s->bind_streams[w]) != hipSuccess) rcs[w] = SLM_ERR_HIP;
+    } catch (...) {
+      rcs[w] = SLM_ERR_HIP;
+      try { errs[w] = "slm_bind_frames: out of host memory in a bind worker"; } catch (...) {}
     }
-    if (hipEventRecord(s->bind_events[w], s->bind_streams[w]) != hipSuccess) rcs[w] = SLM_ERR_HIP;
   };
-  std::vector<std::thread> threads;
-  for (int w = 1; w < W; ++w) threads.emplace_back(work, w);
-  work(0);
-  for (std::thread& t : threads) t.join();
+  try {
+    s->bind_pool.run(W, work);
+  } catch (...) {
+    return fail(SLM_ERR_HIP, "slm_bind_frames: could not start the bind workers");
+  }
   for (int w = 0; w < W; ++w)
     if (rcs[w] != SLM_OK) return fail(rcs[w], errs[w].c_str());
   for (int w = 0; w < W; ++w) HIPCHK(hipStreamWaitEvent(st, s->bind_events[w], 0));   // join
@@ -828,10 +947,11 @@ static hipEvent_t take_event(slm_solver* s) {
 // ---- one frame sharded over several GPUs ----------------------------------------------------
 int slm_set_shard(slm_solver* s, int32_t rank, int32_t world) {
   if (!s || world < 1 || rank < 0 || rank >= world) return fail(SLM_ERR_INVALID, "slm_set_shard: bad rank/world");
-  if (world > 1 && (s->cfg.data_path != 0 || s->cfg.solver_path == 1))
-    return fail(SLM_ERR_UNSUPPORTED, "slm_set_shard: needs data_path 0 and a nested-dissection solver_path (0 or 2)");
+  if (s->cfg.data_path != 0 || s->cfg.solver_path == 1)
+    return fail(SLM_ERR_UNSUPPORTED, "slm_set_shard: needs data_path 0 and a nested-dissection solver_path (0, 2, 3 or 4)");
   s->rank = rank;
   s->world = world;
+  s->shard_mode = true;
   for (Slot& sl : s->slots) sl.h.bound = 0;   // the shares are fixed at bind time
   HIPCHK(hipMemset(s->frames_dev, 0, sizeof(FrameDev) * s->slots.size()));
   return SLM_OK;
@@ -1016,13 +1136,14 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
   return SLM_OK;
 }
 
-int slm_get_plan_info(slm_solver* s, int32_t slot, double* out) {
+int slm_get_plan_info(slm_solver* s, int32_t slot, double* out_caller, int32_t capacity) {
   int rc = check_slots(s, slot, 1);
   if (rc) return rc;
-  if (!out) return fail(SLM_ERR_INVALID, "slm_get_plan_info: null output");
+  if (!out_caller || capacity < 0) return fail(SLM_ERR_INVALID, "slm_get_plan_info: bad output");
   const Slot& sl = s->slots[slot];
   const FrameDev& h = sl.h;
-  for (int i = 0; i < 12; ++i) out[i] = 0.0;
+  double out[SLM_PLAN_INFO_DOUBLES];
+  for (int i = 0; i < SLM_PLAN_INFO_DOUBLES; ++i) out[i] = 0.0;
   if (h.nd_ready) {
     out[0] = 0.0;
     out[1] = (double)sl.nd.fronts.size();
@@ -1042,6 +1163,7 @@ int slm_get_plan_info(slm_solver* s, int32_t slot, double* out) {
   out[7] = h.n_blocks;
   out[8] = h.v1_ready && h.v2_ready ? h.n_wblk : 0;
   out[9] = h.n_pos;
+  for (int i = 0; i < capacity; ++i) out_caller[i] = i < SLM_PLAN_INFO_DOUBLES ? out[i] : 0.0;
   return SLM_OK;
 }
 

@@ -51,7 +51,17 @@
 
 namespace {
 
-#define DAG_SPIN_LIMIT (1 << 22)   // polls before a wait gives up (a few seconds)
+// Deadlock guard: a wait gives up after DAG_TIMEOUT_TICKS of the constant 100 MHz wall clock (not after a number of
+// polls: a poll's duration depends on clocks and memory latency -- a counter-serialised profiler pass or two ranks
+// sharing a GPU stretch it).  The clock is first read after 256 unsuccessful polls, so a wait that is served quickly
+// never touches it.  A time-out sets the abort flag to 2 and is reported as SLM_ITER_SOLVER_TIMEOUT for the slots
+// whose solve did not finish (k_dag_check), distinct from a non-positive pivot.
+#define DAG_TIMEOUT_TICKS 300000000ll   // 3 s
+__device__ __forceinline__ bool dag_timed_out(long long& t0) {
+  const long long now = (long long)wall_clock64();
+  if (t0 == 0) { t0 = now; return false; }
+  return now - t0 > DAG_TIMEOUT_TICKS;
+}
 
 // Every hand-off access is a GLOBAL-segment instruction with sc1 (global_load / global_store ... sc1): pointers read
 // from the slot descriptor are generic, and a flat_ access is not a valid hand-off form (MI355X_MICROARCH.md), so
@@ -156,6 +166,7 @@ template <typename F>
 __device__ __forceinline__ bool dag_wait(int n, F flag_of, int want, int* abort_flag, int* s_abort) {
   if (n > 0 && threadIdx.x < 64) {
     int spins = 0;
+    long long t0 = 0;
     for (int base = 0; base < n; base += 64) {
       const int i = base + threadIdx.x;
       const int* fl = i < n ? flag_of(i) : nullptr;
@@ -164,9 +175,10 @@ __device__ __forceinline__ bool dag_wait(int n, F flag_of, int want, int* abort_
         if (__all(ok)) break;
         __builtin_amdgcn_s_sleep(2);
         if ((++spins & 255) == 0) {
-          if (ldf(abort_flag) != 0 || spins > DAG_SPIN_LIMIT) {
+          const bool late = dag_timed_out(t0);
+          if (ldf(abort_flag) != 0 || late) {
             if (threadIdx.x == 0) {
-              stf(abort_flag, 1);
+              if (late) stf(abort_flag, 2);
               *s_abort = 1;
             }
             base = n;
@@ -365,6 +377,7 @@ __device__ __forceinline__ int dag_wait_prefix(const TD& d, const FS& f, const D
   const int nfl = min(b - a, 64 / per * per);
   if (threadIdx.x < 64) {
     int spins = 0;
+    long long t0 = 0;
     for (;;) {
       const bool ok = (int)threadIdx.x < nfl ? ldf(dep_flag(d, f, g, a + threadIdx.x)) >= 1 : true;
       const unsigned long long m = __ballot(ok);
@@ -375,9 +388,11 @@ __device__ __forceinline__ int dag_wait_prefix(const TD& d, const FS& f, const D
         break;
       }
       __builtin_amdgcn_s_sleep(2);
-      if ((++spins & 255) == 0 && (ldf(abort_flag) != 0 || spins > DAG_SPIN_LIMIT)) {
+      if ((++spins & 255) == 0) {
+        const bool late = dag_timed_out(t0);
+        if (!(ldf(abort_flag) != 0 || late)) continue;
         if (threadIdx.x == 0) {
-          stf(abort_flag, 1);
+          if (late) stf(abort_flag, 2);
           *s_abort = 1;
           *s_cnt = 0;
         }
@@ -599,6 +614,7 @@ __device__ __forceinline__ bool mail_here(double v) { return __double_as_longlon
     const int pe_i_ = threadIdx.x & 15, pe_k_ = threadIdx.x >> 4;                                                \
     int* votes_ = s_ok + 4;                                                                                      \
     int spins_ = 0;                                                                                              \
+    long long t0_ = 0;                                                                                           \
     for (;;) {                                                                                                   \
       bool here_ = mail_here(PD[KB]);                                                                            \
       (DINV)[(KB) * 256 + pe_i_ + 16 * pe_k_] = PD[KB];                                                          \
@@ -607,14 +623,15 @@ __device__ __forceinline__ bool mail_here(double v) { return __double_as_longlon
           here_ = here_ && mail_here(PL[KB][j_]);                                                                \
           (LST)[(16 * (KB) + pe_i_) + (16 * j_ + pe_k_) * LD] = PL[KB][j_];                                      \
         }                                                                                                        \
-      const bool stop_ = (++spins_ & 63) == 0 && (ldf(abort_flag) != 0 || spins_ > DAG_SPIN_LIMIT);              \
-      const int vote_ = (__all(here_) ? 1 : 0) | (__any(stop_) ? 2 : 0);                                         \
+      bool late_ = false;                                                                                        \
+      const bool stop_ = (++spins_ & 63) == 0 && (ldf(abort_flag) != 0 || (late_ = dag_timed_out(t0_)));         \
+      const int vote_ = (__all(here_) ? 1 : 0) | (__any(stop_) ? 2 : 0) | (__any(late_) ? 4 : 0);                \
       if ((threadIdx.x & 63) == 0) votes_[threadIdx.x >> 6] = vote_;                                             \
       __syncthreads();                                                                                           \
       const int v0_ = votes_[0], v1_ = votes_[1], v2_ = votes_[2], v3_ = votes_[3];                              \
       if ((v0_ & v1_ & v2_ & v3_ & 1) != 0) break;                                                               \
       if (((v0_ | v1_ | v2_ | v3_) & 2) != 0) {                                                                  \
-        if (threadIdx.x == 0) { stf(abort_flag, 1); *s_abort = 1; }                                              \
+        if (threadIdx.x == 0) { if (((v0_ | v1_ | v2_ | v3_) & 4) != 0) stf(abort_flag, 2); *s_abort = 1; }      \
         __syncthreads();                                                                                         \
         return;                                                                                                  \
       }                                                                                                          \
@@ -1281,32 +1298,45 @@ __global__ void __launch_bounds__(256) k_dag_reset(const FrameDev* __restrict__ 
   }
 }
 
-// a timed-out solve is reported like a failed factorisation (the LM loop stops, beta is kept)
-__global__ void k_dag_check(const FrameDev* __restrict__ frames, int n_frames) {
+// An aborted launch (time-out of a wait: the abort flag, kept with the ticket in slot 0's flags) stops the LM loop of every
+// slot whose solve did not finish -- a front whose BACK task never published its solution -- with its own status
+// (chol_fail = 2 -> SLM_ITER_SOLVER_TIMEOUT, not "ill-posed system"); slots that were complete keep their result.
+// One workgroup per slot: grid = (n_frames).
+__global__ void __launch_bounds__(64) k_dag_check(const FrameDev* __restrict__ frames, int n_frames) {
   const FrameDev& fd0 = frames[0];
   if (!fd0.bound || !fd0.nd_ready || !fd0.dag_flags) return;
-  if (fd0.dag_flags[1] != 0 && threadIdx.x < n_frames) {
-    const FrameDev& fd = frames[threadIdx.x];
-    if (fd.bound) fd.st->chol_fail = 1;
+  if (fd0.dag_flags[1] == 0) return;
+  const FrameDev& fd = frames[blockIdx.x];
+  if (!fd.bound || !fd.nd_ready || !fd.dag_flags) return;
+  const int* px = fd.dag_flags.get() + 8 + fd.dag_n_tiles + fd.dag_n_pcols;
+  bool done = true;
+  for (int fi = threadIdx.x; fi < fd.n_fronts; fi += blockDim.x) {
+    const NDFront& f = fd.fronts[fi];
+    if (f.npt > 0 && px[(int)(f.linv_off / TILE)] == 0) done = false;
   }
+  if (!__all(done) && threadIdx.x == 0 && fd.st->chol_fail == 0) fd.st->chol_fail = 2;
 }
 
 void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
-  static int n_wg = 0;
-  if (n_wg == 0) {
-    (void)hipFuncSetAttribute((const void*)k_fdag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
+  // per device: the dynamic-LDS attribute is a property of the kernel ON a device, and so is the CU count
+  static int n_wg_dev[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (n_wg_dev[dev] == 0) {
+    if (hipFuncSetAttribute((const void*)k_fdag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;   // (the launch below would fail: hipGetLastError reports it)
+    int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("SLM_DAG_WG_PER_CU");
     const int per_cu = e ? atoi(e) : 1;
-    n_wg = cus * (per_cu > 0 ? per_cu : 1);
+    n_wg_dev[dev] = cus * (per_cu > 0 ? per_cu : 1);
   }
+  const int n_wg = n_wg_dev[dev];
   hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);
   hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut);
-  hipLaunchKernelGGL(k_dag_check, dim3(1), dim3(64), 0, st, fr, n_frames);
+  hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
 }

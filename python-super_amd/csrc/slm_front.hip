@@ -1145,12 +1145,17 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
                          int l_back_end, double u_override, hipStream_t st) {
   const size_t lds = PANEL_LDS_DOUBLES * sizeof(double);
   const size_t lds11 = L11_LDS_DOUBLES * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_fL11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11);
-    (void)hipFuncSetAttribute((const void*)k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)k_fpotrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // the dynamic-LDS limit is a property of a kernel ON a device: set once per device id
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)k_fL11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_fpotrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return;   // (sticky HIP error: the caller's hipGetLastError reports it)
+    attr_set[dev] = true;
   }
   for (int l = 0; l < l_factor_end; ++l) {
     const NDLevelSched& s = lv[l];

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
     if (threadIdx.x == 0) {
       if (it < n_rec) {
         slm_iter_record r = fd.rec[it];
-        r.status = SLM_ITER_SOLVER_FAILED;
+        r.status = st->chol_fail == 2 ? SLM_ITER_SOLVER_TIMEOUT : SLM_ITER_SOLVER_FAILED;
         r.u = st->u;
         r.M_grad = st->m_grad;
         fd.rec[it] = r;

@@ -111,8 +111,9 @@ class LM_Solver():
         self._bound = [None] * max_frames
         self.last_records = None
         self.rank, self.world = 0, 1
+        self.sharded = bool(shard_surfels or world is not None)   # (a world of one rank runs the same protocol)
         self._all_reduce, self._broadcast = all_reduce, broadcast
-        if shard_surfels or world is not None:
+        if self.sharded:
             import torch.distributed as dist
             if world is None:
                 world, rank = dist.get_world_size(), dist.get_rank()
@@ -148,7 +149,7 @@ class LM_Solver():
             out = C.c_void_p()
             _lib.check(self.lib.slm_create(C.byref(cfg), C.byref(out)), "slm_create")
             h = out
-            if self.world > 1:
+            if self.sharded:
                 _lib.check(self.lib.slm_set_shard(h, self.rank, self.world), "slm_set_shard")
             self._solvers[key] = h
         return h
@@ -223,7 +224,7 @@ class LM_Solver():
         bfs = [self._bind(h, i, *fr) for i, fr in enumerate(frames)]
         dev = bfs[0].device
         st = _stream_ptr(dev)
-        if self.world > 1:
+        if self.sharded:
             self._run_sharded(h, n, dev)
         else:
             _lib.check(self.lib.slm_run(h, n, st), "slm_run")
@@ -285,6 +286,8 @@ class LM_Solver():
         for r in recs:
             if r["status"] == _lib.SLM_ITER_SOLVER_FAILED:
                 print("\t\tSolver failed: Ill-posed system!")        # super/LM.py:102
+            elif r["status"] == _lib.SLM_ITER_SOLVER_TIMEOUT:          # not a property of the matrix: say so
+                print("\t\tSolver failed: the task-graph solve timed out (GPU scheduling), beta kept")
         done = [r for r in recs if r["status"] == _lib.SLM_ITER_OK]
         logger = getattr(sf, "logger", None)                         # defect D1: may be absent
         if self.opt.phase == "test" and logger is not None and done:

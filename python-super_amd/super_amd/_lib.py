@@ -12,7 +12,9 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", os.environ.get("SLM_LIB", "libsuper_lm.so"))
 
 SLM_OK = 0
-SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN = 0, 1, 2
+SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN, SLM_ITER_SOLVER_TIMEOUT = 0, 1, 2, 3
+SLM_ABI_VERSION = 3          # SLM_ABI_VERSION of include/super_lm.h this binding was written against
+PLAN_INFO_DOUBLES = 12
 SLM_X_PAIR_BLOCKS, SLM_X_DELTA, SLM_X_DATA_LOSS = 0, 1, 2
 PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 
@@ -32,6 +34,7 @@ EXPORTS = [
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set", "slm_lm_exchange_ptr",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
     "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read", "slm_debug_dag_trace",
+    "slm_abi_version", "slm_abi_check",
 ]
 
 
@@ -174,7 +177,8 @@ def load():
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],
-        "slm_get_plan_info": [vp, i32, C.POINTER(C.c_double)],
+        "slm_get_plan_info": [vp, i32, C.POINTER(C.c_double), i32],
+        "slm_abi_check": [i32, i32, i32, i32, i32, i32],
         "slm_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
         "slm_get_beta": [vp, i32, vp, vp],
         "slm_set_beta": [vp, i32, vp, vp],
@@ -233,6 +237,13 @@ def load():
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = args
+    lib.slm_abi_version.restype = C.c_int
+    lib.slm_abi_version.argtypes = []
+    # ABI handshake: the struct mirrors above must be the library's own layouts
+    rc = lib.slm_abi_check(SLM_ABI_VERSION, C.sizeof(SlmConfig), C.sizeof(SlmFrame), C.sizeof(SlmGfConfig),
+                           C.sizeof(SlmGfFrame), C.sizeof(SlmIterRecord))
+    if rc != SLM_OK:
+        raise SuperLMError(lib.slm_last_error().decode(errors="replace"))
     _lib = lib
     return lib
 

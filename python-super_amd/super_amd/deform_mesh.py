@@ -85,7 +85,8 @@ class GraphFit:
         _lib.check(self.lib.slm_gf_create(C.byref(cfg), C.byref(self.h)), "slm_gf_create")
         self._keep = [None] * max_frames
         self.rank, self.world, self._all_reduce = 0, 1, all_reduce
-        if shard_surfels or world is not None:
+        self.sharded = bool(shard_surfels or world is not None)   # (a world of one rank runs the same protocol)
+        if self.sharded:
             import torch.distributed as dist
             if world is None:
                 world, rank = dist.get_world_size(), dist.get_rank()
@@ -189,7 +190,7 @@ class GraphFit:
             raise NotImplementedError("only deform_udpate_method == 'super_edg'")
         bf = self._bind(0, inputs, src, trg, models)
         st = _stream_ptr(bf.device)
-        if self.world > 1:
+        if self.sharded:
             part = torch.empty((bf.J + 1) * 7 + _lib.GF_NTERMS, dtype=torch.float64, device=bf.device)
             for _ in range(int(self.Niter)):
                 self.eval_morph()

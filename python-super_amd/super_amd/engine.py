@@ -145,8 +145,8 @@ class Engine:
                      M_grad=int(r.M_grad), M_loss=int(r.M_loss)) for r in arr[:n]]
 
     def plan_info(self, slot: int = 0):
-        out = (C.c_double * 12)()
-        _lib.check(self.lib.slm_get_plan_info(self.h, slot, out), "slm_get_plan_info")
+        out = (C.c_double * _lib.PLAN_INFO_DOUBLES)()
+        _lib.check(self.lib.slm_get_plan_info(self.h, slot, out, _lib.PLAN_INFO_DOUBLES), "slm_get_plan_info")
         keys = ("solver", "fronts", "levels", "factor_flops", "factor_bytes", "tuples", "runs", "pairs",
                 "merged_records", "positions", "factor_flops_unpadded", "solver_tasks")
         d = {k: out[i] for i, k in enumerate(keys)}

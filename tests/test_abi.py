@@ -62,6 +62,24 @@ def test_no_device_fails_loudly(lib):
         DirectDeformGraph(SimpleNamespace(method="super"))
 
 
+def test_abi_handshake(lib):
+    """A caller built against another revision of the header gets an error, not out-of-bounds accesses."""
+    from super_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "super_lm.h")).read()
+    assert int(re.search(r"#define SLM_ABI_VERSION (\d+)", hdr).group(1)) == _lib.SLM_ABI_VERSION == lib.slm_abi_version()
+    assert int(re.search(r"#define SLM_PLAN_INFO_DOUBLES (\d+)", hdr).group(1)) == _lib.PLAN_INFO_DOUBLES
+    sizes = [C.sizeof(t) for t in (_lib.SlmConfig, _lib.SlmFrame, _lib.SlmGfConfig, _lib.SlmGfFrame, _lib.SlmIterRecord)]
+    assert lib.slm_abi_check(_lib.SLM_ABI_VERSION, *sizes) == 0
+    assert lib.slm_abi_check(_lib.SLM_ABI_VERSION - 1, *sizes) != 0 and b"slm_abi_check" in lib.slm_last_error()
+    r01_frame = sizes[1] - 8             # slm_frame before state_f64 / pad were added
+    assert lib.slm_abi_check(_lib.SLM_ABI_VERSION, sizes[0], r01_frame, *sizes[2:]) != 0
+    # out-of-range paths are rejected, not silently mapped to a default (checked before the device test)
+    cfg = _lib.SlmConfig(num_iterations=10, phase_test=1, use_data=1, use_arap=1, use_rot=1, max_frames=1,
+                         solver_path=7, w_data=1.0, w_arap=10.0, w_rot=1.0, u0=10.0, v=7.5, minimal_loss0=1e10)
+    out = C.c_void_p()
+    assert lib.slm_create(C.byref(cfg), C.byref(out)) == 1 and b"solver_path" in lib.slm_last_error()
+
+
 def test_argument_validation(lib):
     assert lib.slm_create(None, None) != 0
     assert lib.slm_destroy(None) == 0
