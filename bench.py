@@ -560,10 +560,9 @@ def main():
         pristine_big = {nm: stacked(pristine, nm) for nm in reset_fields}
         work_big = {nm: stacked(work, nm) for nm in reset_fields}
 
-    stamps = []
+    step_events = []
 
     def step():
-        stamps.append(time.perf_counter())               # (the bind below drains the stream first: no extra sync)
         if same_shape:
             for nm in reset_fields:                      # same problem every step
                 work_big[nm].copy_(pristine_big[nm])
@@ -595,6 +594,9 @@ def main():
                 gathered[0] = all_gather_betas(local, world * B)
             else:
                 gathered[0] = all_gather_betas(local.cpu(), world * B)
+        ev = torch.cuda.Event(enable_timing=True)        # end of this step on the GPU timeline (no host sync)
+        ev.record()
+        step_events.append(ev)
 
     def fence():
         if use_dist:
@@ -607,15 +609,18 @@ def main():
     if not a.no_profile:
         for e in engs:
             e.profile(True)
-    del stamps[:]
+    del step_events[:]
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     t_end = time.perf_counter()
     elapsed = t_end - t0
-    # per-step durations: a step's stamp is taken when its bind has drained the previous step's work
-    step_ms = sorted(1e3 * (b_ - a_) for a_, b_ in zip(stamps, stamps[1:] + [t_end]))
+    # per-step durations on the GPU timeline: event at the end of every step (host stalls show up as GPU idle time)
+    evs = [ev0] + step_events
+    step_ms = sorted(a_.elapsed_time(b_) for a_, b_ in zip(evs, evs[1:]))
     prof = None
     if not a.no_profile:
         for e in engs:

@@ -27,8 +27,7 @@ void launch_pair_reduce(const FrameDev*, int, int, hipStream_t);
 void launch_pair_scatter(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
-void launch_iter_begin_nd(const FrameDev*, int, bool, hipStream_t);
-void launch_zero_f22(const FrameDev*, int, hipStream_t);
+void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
 void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
@@ -196,7 +195,6 @@ struct slm_solver {
   std::vector<hipEvent_t> bind_events;
   std::mutex band_mutex;        // the bandwidth read-back buffer of ensure_band is shared
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
-  bool f22_skipped = false;     // the last assembly left the F22 blocks of the fronts unzeroed (it planned for the task-graph solve)
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
@@ -830,7 +828,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
   if (d.nd) {
     for (int i = first; i < first + n; ++i) {
       const auto& sc = s->slots[i].nd.sched;
-      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2, {0, 0}, {-2, -2}});
+      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2, {0, 0}, {-2, -2}, 0});
       for (size_t l = 0; l < sc.size(); ++l) {
         NDLevelSched& m = d.sched[l];
         // same first front and front count in every slot -> passed to the kernels by value
@@ -841,6 +839,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
         m.max_nt = std::max(m.max_nt, sc[l].max_nt);
         m.max_pairs = std::max(m.max_pairs, sc[l].max_pairs);
         m.max_n2p = std::max(m.max_n2p, sc[l].max_n2p);
+        m.has_kids |= sc[l].has_kids;
         for (int w = 0; w < 2; ++w) {
           if (m.schur_at[w] == -2) m.schur_at[w] = sc[l].schur_at[w];
           else if (m.schur_at[w] != sc[l].schur_at[w] || m.n_schur[w] != sc[l].n_schur[w]) m.schur_at[w] = -1;
@@ -873,10 +872,6 @@ static bool solve_is_task_graph(const slm_solver* s, int n) {
 }
 void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
   const bool dag = solve_is_task_graph(s, n);
-  // the task graph never reads a boundary block before writing it, the per-level form adds into it: if the assembly
-  // planned for the former (and skipped the zeroing) and this solve is the latter, zero them now
-  if (s->f22_skipped && !dag) launch_zero_f22(fr, n, st);
-  s->f22_skipped = false;
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
   const bool hybrid = !dag && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
@@ -898,8 +893,7 @@ void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDi
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
 hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st) {
   const FrameDev* fr = s->frames_dev + first;
-  s->f22_skipped = solve_is_task_graph(s, n) && d.max_tasks > 0;
-  launch_iter_begin_nd(fr, n, s->f22_skipped, st);   // zeroes the fronts of all n slots in one launch
+  launch_iter_begin_nd(fr, n, st);   // zeroes the pivot columns of the fronts of all n slots in one launch
   if (s->cfg.use_data) {
     launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
@@ -972,8 +966,7 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FrameDev* fr = s->frames_dev;
-  s->f22_skipped = solve_is_task_graph(s, n_frames) && d.max_tasks > 0;
-  launch_iter_begin_nd(fr, n_frames, s->f22_skipped, st);
+  launch_iter_begin_nd(fr, n_frames, st);
   if (s->cfg.use_data) {
     launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_pair_reduce(fr, n_frames, d.max_blocks, st);
@@ -1101,8 +1094,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     };
     mark();
     if (d.nd) {
-      s->f22_skipped = solve_is_task_graph(s, n_frames) && d.max_tasks > 0;
-      launch_iter_begin_nd(fr, n_frames, s->f22_skipped, st);
+      launch_iter_begin_nd(fr, n_frames, st);
     } else {
       launch_iter_begin(fr, n_frames, st);
     }

@@ -33,8 +33,8 @@
 //
 // Top-of-tree mode (cut >= 0, the hybrid solve of a batch, slm_api.hip enqueue_front_solve): only the tasks of the
 // fronts of depth <= cut run here (fd.dag_top_tasks); the deeper levels were factored by the per-level launches of
-// slm_front.hip, whose k_fschur ADDED their Schur complements into the tiles of the fronts at depth == cut -- those
-// fronts gather nothing (task_deps nokids).  The list ends with the BACKB / BACK tasks of ALL deeper fronts: the back
+// slm_front.hip, whose k_fschur stored their update matrices in place -- the fronts at depth == cut gather them like any
+// child's, without a flag to wait for (task_deps kids_done).  The list ends with the BACKB / BACK tasks of ALL deeper fronts: the back
 // substitution of the whole tree runs here, a deeper front's tasks waiting for their parent's solution only (their own
 // tiles and y are final before the launch: `prefactored`).
 //
@@ -263,12 +263,12 @@ struct TD {
   int np[2], pr0[2], pc0[2], pnc[2];     // gathered child tiles: count, first tile row / column, columns
   int np2[2], pc2[2], pnc2[2];           // POTRF(s > 0): the same for its second tile (s, s-1) (same tile rows)
   int ctile0[2], cnt[2], cnpt[2];        // the children's tile numbering
-  int n0, n;                             // flags needed to start / all flags
+  int n0, n, nskip;                      // flags needed to start / all flags / leading flags that need no wait
   int pcol_self, pcol_parent, nb, npt, c;
 };
-// nokids: the front's children were factored by the per-level launches, which ADDED their Schur complements into
-// this front's tiles already (hybrid solve, top of the tree only): nothing to gather, nothing to wait for
-__device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int type, int r, int s, bool nokids) {
+// kids_done: the front's children were factored by the per-level launches BEFORE this launch (hybrid solve, the fronts
+// at the cut): their update tiles are final -- gathered like any child's, but there is no flag to wait for (nskip)
+__device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int type, int r, int s, bool kids_done) {
   TD d;
   d.type = type; d.r = r; d.s = s; d.diag = (r == s); d.npt = f.npt; d.nb = f.nb; d.c = s;
   d.pcol_self = f.pcol0;
@@ -276,12 +276,13 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
   d.np[0] = d.np[1] = 0;
   d.kc = 0;
   d.np2[0] = d.np2[1] = 0;
+  d.nskip = 0;
   if (type <= ND_T_SCHUR) {
     const int32_t* pr = fd.prng + uni(fd.prng_off[fi]);
     const bool two = type == ND_T_POTRF && s > 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int ch = nokids ? -1 : uni(fd.front_kids[2 * fi + k]);
+      const int ch = uni(fd.front_kids[2 * fi + k]);
       const int rr = ch >= 0 ? uni(pr[2 * r + k]) : -1, cc = ch >= 0 ? uni(pr[2 * s + k]) : -1;
       const int c2 = (ch >= 0 && two) ? uni(pr[2 * (s - 1) + k]) : -1;
       d.pr0[k] = d.pc0[k] = d.pc2[k] = 0; d.pnc[k] = d.pnc2[k] = 1; d.ctile0[k] = d.cnt[k] = d.cnpt[k] = 0;
@@ -297,6 +298,7 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
     d.kc = type == ND_T_SCHUR ? f.npt : s;
     const int npull = d.np[0] + d.np[1] + d.np2[0] + d.np2[1];
     d.n0 = npull;                 // to start: the children's update tiles; the operand columns are consumed as they come
+    if (kids_done) d.nskip = npull;
     if (type == ND_T_POTRF)       // per column c < s-1: L(s,c), y_c, L(s-1,c); then 4 slots for the 16-pivot rounds of (s-1,s-1)
                                   // (not waited for: the rounds are taken from the column's mailbox), then y_{s-1}
       d.n = npull + 3 * (s > 0 ? s - 1 : 0) + (s > 0 ? 5 : 0);
@@ -705,7 +707,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
     if (type == ND_T_POTRF && threadIdx.x < NB) bvec = ld1(vecs + (size_t)ts_ * NB + threadIdx.x);
     dag_pull_maps(fd, fi, tr_, ts_, d.np, maps);   // (static plan data: also before the wait)
     // stage 0: what the task needs to start
-    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
+    if (!dag_wait_deps(d, f, g, d.nskip, d.n0, abort_flag, s_abort)) return;
 
   {
       // ================= POTRF(f,s) / COL(f,r,s) ==================================================
@@ -961,20 +963,14 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
 #define DAG_MARK(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
     // own tile, vector rows and pull maps: final before the launch, requested before the wait (see dag_task_factor)
     double4_t acc[4];
-    // A boundary block holds nothing before its Schur tasks write it, unless the per-level launches of the hybrid solve
-    // ADDED the children's contributions into it (the fronts at depth == cut).  It is not read then -- and it is not
-    // zeroed for this form either (slm_front.hip k_iter_begin_nd, skip_f22; a leaf's is never zeroed, NDFront::f22_base).
-    if (f.is_leaf || !(cut >= 0 && uni(fd.fronts[fi].depth) == cut)) {
+    // A boundary block holds nothing before its Schur task writes it (never read first, never zeroed: k_iter_begin_nd)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    } else {
-      load_c_frags1(tile_ptr(fd, f, tr_, ts_), acc);
-    }
+    for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
     double bvec = 0.0, tsum = 0.0;
     if (tr_ == ts_ && threadIdx.x < NB) bvec = ld1(vecs + (size_t)tr_ * NB + threadIdx.x);
     dag_pull_maps(fd, fi, tr_, ts_, d.np, maps);
     // stage 0: what the task needs to start
-    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
+    if (!dag_wait_deps(d, f, g, d.nskip, d.n0, abort_flag, s_abort)) return;
 
   {
       // ================= SCHUR(f,r,s): update tile of the boundary block, stored in place =============
@@ -1063,7 +1059,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
     load_tile_regs2(tile_ptr(fd, f, brow(f.npt), c_), l0);
     load_tile_regs2(tile_ptr(fd, f, brow(f.npt + 1), c_), l1);
     // stage 0: what the task needs to start
-    if (!dag_wait_deps(d, f, g, 0, d.n0, abort_flag, s_abort)) return;
+    if (!dag_wait_deps(d, f, g, d.nskip, d.n0, abort_flag, s_abort)) return;
 
   {
       // ================= BACKB(f,c): y_c -= sum over boundary tiles L(r,c)^T x_r ====================

@@ -412,10 +412,9 @@ __global__ void __launch_bounds__(256) k_front_load_rhs(const FrameDev* __restri
 }
 
 // ---- zeroing of the fronts ------------------------------------------------------------------------------------
-// A front's tiles: the pivot columns (assembly adds into them), then -- internal fronts only -- the boundary block F22,
-// which receives nothing but its children's Schur complements: ADDED into it by k_fschur of the level below in the
-// per-level form (so it must start from zero), GATHERED by the front's own SCHUR tasks in the task-graph form (which
-// never read it first: no zeroing needed, slm_dag.hip).  F22 is two thirds of the tile storage (C2: 134 MB per frame).
+// A front's tiles: the pivot columns (the assembly adds into them, then the children's updates: k_fpull / the task
+// graph's pulls), then the boundary block F22 -- two thirds of the tile storage (C2: 134 MB per frame) -- which holds
+// the front's update matrix, written once by k_fschur / the SCHUR tasks (first touch is a store: never zeroed).
 typedef double dvec2_t __attribute__((ext_vector_type(2)));
 // 16 KB pieces of a contiguous region, piece-strided: pc = first, first + step, ...; non-temporal 16-byte stores
 __device__ __forceinline__ void zero_pieces(double* base, size_t n_pieces, size_t first, size_t step) {
@@ -440,23 +439,17 @@ __device__ __forceinline__ void zero_fronts(const FrameDev& fd, int what, int b,
     if (t1 > t0) zero_pieces(fd.ftiles.get() + f.tile_off + t0 * TILE, (t1 - t0) * 2, (size_t)(u / nf), (size_t)slices);
   }
 }
-// the F22 blocks alone (a solve in the per-level form after an assembly that had planned for the task graph)
-__global__ void __launch_bounds__(256) k_zero_f22(const FrameDev* __restrict__ frames) {
-  const FrameDev& fd = frames[blockIdx.y];
-  if (!fd.bound || !fd.nd_ready) return;
-  zero_fronts(fd, 2, blockIdx.x, gridDim.x);
-}
-
-// Start of an iteration on the multifrontal path: zero the fronts (pivot columns; the F22 blocks unless `skip_f22`),
-// the front vectors, rhs and the counters, for ALL slots of the batch in one launch (one hipMemsetAsync pair per slot cost
+// Start of an iteration on the multifrontal path: zero the PIVOT columns of the fronts (the assembly adds into them; the
+// boundary blocks are written once by their own Schur kernels / tasks, never zeroed), the front vectors, rhs and the
+// counters, for ALL slots of the batch in one launch (one hipMemsetAsync pair per slot cost
 // ~25 us each, back to back).  grid = (blocks, n_frames); contiguous 16 KB pieces per workgroup.
-__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames, int skip_f22) {
+__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || fd.st->stopped) return;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
   const double2 z = make_double2(0.0, 0.0);
   if (fd.nd_ready) {
-    zero_fronts(fd, skip_f22 ? 1 : 3, blockIdx.x, gridDim.x);
+    zero_fronts(fd, 1, blockIdx.x, gridDim.x);
     double2* v2 = reinterpret_cast<double2*>(fd.fvec.get());
     const size_t nv2 = (size_t)fd.zero_vec_doubles / 2;
     for (size_t e = tid; e < nv2; e += nthr) v2[e] = z;
@@ -892,17 +885,138 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
   }
 }
 
-// Schur complement of a front in one pass: U(r,s) -= sum_{c < npt} L(r,c) L(s,c)^T for the
-// boundary tiles npt <= s <= r < nt, fused with the extend-add: the updated tile never goes back
-// to the child front, it is added from the accumulators into the parent front through the
-// row / column index maps.  The next pivot column's operands are fetched while the current one
-// is on the MFMA.  `which` selects the children with that index (see launch_front_solve).
-// grid = (max boundary tile pairs, fronts in level, n_frames)
-__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, LevelRef lvl, int which,
+// ---- pull-form extend-add (the data flow of the task graph, slm_dag.hip, in the per-level kernels) ---------------
+// Every tile has ONE writer.  A front's boundary block F22 holds its UPDATE matrix U = [children's updates mapped into
+// it] - L21 L21^T, written once by k_fschur (plain coalesced stores: first touch is a store, nothing is zeroed, nothing
+// is read-modify-written) and read once by the parent, which GATHERS the entries that map into its own tiles through
+// the plan's pull maps (pullmap: parent scalar index -> boundary scalar index of the child, -1 none): k_fpull for the
+// pivot columns (added to the assembled entries before the factorisation), k_fschur for the boundary block.  The sums
+// run in a fixed order (own, child 0, child 1): bitwise reproducible.  The boundary rows of the front VECTOR travel
+// the same way (v_r = [children's v mapped] - sum_c L(r,c) y_c).
+struct PullKids {
+  int ch[2];     // child front index, or -1 when the child has nothing for this tile
+};
+// tile (r, c) of the boundary block / pivot columns of front f, one formula for every front (NDFront::f22_base)
+__device__ __forceinline__ double* ftile_any(const FrameDev& fd, const NDFront& f, int r, int c) {
+  const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
+  return fd.ftiles + (c < f.npt ? f.tile_off : f.f22_base) + t * TILE;
+}
+// maps -> LDS: [128 k + 0..63] child k's boundary scalar of every row of tile row r, [128 k + 64..127] of tile row s.
+// Needs a __syncthreads() before the first use (the callers have one on their way).
+__device__ __forceinline__ PullKids pull_maps(const FrameDev& fd, int fi, int r, int s, int* maps) {
+  PullKids pk;
+  const int32_t* pr = fd.prng + fd.prng_off[fi];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int ch = fd.front_kids[2 * fi + k];
+    if (ch >= 0 && (pr[2 * r + k] < 0 || pr[2 * s + k] < 0)) ch = -1;
+    pk.ch[k] = ch;
+    if (ch >= 0 && threadIdx.x < 128) {
+      const int32_t* pm = fd.pullmap + fd.pull_off[ch];
+      maps[128 * k + threadIdx.x] = pm[64 * (threadIdx.x < 64 ? r : s) + (threadIdx.x & 63)];
+    }
+  }
+  return pk;
+}
+// acc (tile (r,s) in accumulator layout: wave w rows 16w.., see load_c_frags) += the children's entries.  All gathers
+// of both children are in flight together; the sum order is child 0, then child 1.
+__device__ __forceinline__ void pull_tile(const FrameDev& fd, const PullKids& pk, const int* maps, double4_t acc[4]) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  double v[2][16];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[k][e] = 0.0;
+    if (pk.ch[k] < 0) continue;
+    const NDFront& cf = fd.fronts[pk.ch[k]];
+    const double* ct = fd.ftiles + cf.f22_base;
+    const int cnt = cf.nt, cnpt = cf.npt;
+    const int* mk = maps + 128 * k;
+    const int ci = mk[16 * w + lr];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int cj = mk[64 + 16 * ni + lk + 4 * rr];
+        // The maps are monotone (a front lists its nodes in elimination order, and so does its parent): an entry of the
+        // parent's lower triangle comes from the child's lower triangle.  ci < cj only occurs above the diagonal of a
+        // diagonal tile, which nothing reads.
+        if (ci >= 0 && cj >= 0 && ci >= cj) {
+          const int tr = cnpt + (ci >> 6), tc = cnpt + (cj >> 6);
+          const size_t t = (size_t)tc * cnt - (size_t)tc * (tc - 1) / 2 + (size_t)(tr - tc);
+          v[k][4 * ni + rr] = ct[t * TILE + (ci & 63) + (size_t)(cj & 63) * NB];
+        }
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[ni][rr] += v[k][4 * ni + rr];
+}
+// the children's boundary vector rows that map into tile row r of the front (threads < NB: row threadIdx.x)
+__device__ __forceinline__ double pull_vec(const FrameDev& fd, const PullKids& pk, const int* maps) {
+  double s = 0.0;
+  if (threadIdx.x < NB) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (pk.ch[k] < 0) continue;
+      const NDFront& cf = fd.fronts[pk.ch[k]];
+      const int ci = maps[128 * k + threadIdx.x];
+      if (ci >= 0) s += fd.fvec[cf.vec_off + (size_t)cf.npt * NB + ci];
+    }
+  }
+  return s;
+}
+
+// Children's updates into the PIVOT columns of the fronts of a level (before their factorisation): one workgroup per
+// pivot-column tile (r, c), c < npt, c <= r < nt; tiles no child maps into leave at once.
+// grid = (max pivot-column tiles, fronts in level, n_frames)
+__global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ frames, LevelRef lvl, WgMap map) {
+  __shared__ int maps[256];
+  WgId wg;
+  if (!wg_decode(map, wg)) return;
+  const FrameDev& fd = frames[wg.frame];
+  if (!fd.bound || !fd.nd_ready) return;
+  int fi;
+  if (!level_front(fd, lvl, wg.front, fi)) return;
+  const NDFront& f = fd.fronts[fi];
+  if (f.is_leaf) return;
+  // unit -> (r, c): column c holds nt - c tiles
+  int t = wg.unit, c = 0;
+  while (c < f.npt && t >= f.nt - c) {
+    t -= f.nt - c;
+    ++c;
+  }
+  if (c >= f.npt) return;
+  const int r = c + t;
+  const PullKids pk = pull_maps(fd, fi, r, c, maps);
+  if (pk.ch[0] < 0 && pk.ch[1] < 0) return;
+  double* T = ftile(fd, f, r, c);
+  double4_t acc[4];
+  load_c_frags(T, acc);
+  __syncthreads();
+  pull_tile(fd, pk, maps, acc);
+  store_c_frags(T, acc);
+  if (r == c) {
+    const double v = pull_vec(fd, pk, maps);
+    if (threadIdx.x < NB && v != 0.0) fd.fvec[f.vec_off + (size_t)c * NB + threadIdx.x] += v;
+  }
+}
+
+// Update matrix of a front in one pass: U(r,s) = [children's updates] - sum_{c < npt} L(r,c) L(s,c)^T for the boundary
+// tiles npt <= s <= r < nt, stored IN PLACE in the front's boundary block (plain stores; the parent gathers it).
+// The next pivot column's operands are fetched while the current one is on the MFMA.  Known-zero parts are skipped:
+// the inner dimension stops at the front's true pivot count (the padding columns of L21 are zero), and a wave whose
+// 16 rows lie beyond the true boundary size, or a 16-column block beyond it, issues no MFMA (its outputs are padding
+// that nothing reads).
+// grid = (work items of the level x frames, rounded to 8)
+__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                  int n_items, int items_at, int n_frames) {
   __shared__ __attribute__((aligned(16))) double Bl[TILE];
-  __shared__ int rmap[NB], cmap[NB];
-  // Work items come from the plan's exact list for (level, child index): no empty workgroups, no
+  __shared__ int maps[256];
+  // Work items come from the plan's exact list for the level: no empty workgroups, no
   // index arithmetic.  XCD-aware order: blocks b and b+8 share an XCD, so XCD x takes the contiguous
   // range [x*chunk, (x+1)*chunk) of the (frame, item) space -- the tiles of a front (adjacent items)
   // run on one XCD, back to back, and its L21 operands are fetched from HBM once.
@@ -917,8 +1031,8 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   int i0 = items_at, first = lvl.first;
   if (items_at < 0) {   // slots with different plans: read this slot's tables
     if (lvl.level >= fd.n_levels) return;
-    i0 = fd.schur_off[2 * lvl.level + which];
-    if (item_idx >= fd.schur_off[2 * lvl.level + which + 1] - i0) return;
+    i0 = fd.schur_off[2 * lvl.level];
+    if (item_idx >= fd.schur_off[2 * lvl.level + 2] - i0) return;
     first = fd.level_start[lvl.level];
   }
   const int item = fd.schur_items[i0 + item_idx];
@@ -926,22 +1040,14 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   const int fi = first + (item >> 16);
   const NDFront& f = fd.fronts[fi];
   const int r = f.npt + tr, sc = f.npt + tc;
-  // child boundary scalar -> scalar index in the parent front (extend-add maps)
-  const NDFront& pf = fd.fronts[f.parent];
-  if (threadIdx.x < 2 * NB) {
-    const int* em = fd.nd_eamap + f.eamap_off;
-    const bool is_row = threadIdx.x < NB;
-    const int i = (is_row ? tr : tc) * NB + (threadIdx.x & 63);
-    const int m = (i < 7 * f.nb) ? nd_base(pf, em[i / 7]) + i % 7 : -1;
-    if (is_row) rmap[threadIdx.x] = m; else cmap[threadIdx.x & 63] = m;
-  }
-  double4_t acc[4];
-  if (f.is_leaf) {   // nothing was ever added into a leaf's boundary block (and its storage is not zeroed)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-  } else {
-    load_c_frags(ftile(fd, f, r, sc), acc);
-  }
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  // true sizes: rows of this tile row / columns of this tile column that are boundary scalars, inner steps of 4
+  const int n2 = 7 * f.nb;
+  const int vrow = min(NB, n2 - NB * tr), vcol = min(NB, n2 - NB * tc);
+  const bool wave_on = 16 * w < vrow;
+  const int nblk = (vcol + 15) >> 4;             // 16-column blocks with real columns
+  PullKids pk = pull_maps(fd, fi, r, sc, maps);
+  if (f.is_leaf) pk.ch[0] = pk.ch[1] = -1;
   // The B operand (L21 tile of block-row sc) passes through LDS in HALF tiles of 32 inner columns,
   // double-buffered (2 x 16 KB): three workgroups per CU instead of two, and the next half is in
   // flight while the current one is on the MFMA.
@@ -950,75 +1056,83 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   typedef double dvec2 __attribute__((ext_vector_type(2)));
   dvec2 breg[4];
   double areg[16], acur[16];
-  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   if (f.npt > 0) {
     const dvec2* Ls = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, 0));
 #pragma unroll
     for (int e = 0; e < 4; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
-    load_a_frags(ftile(fd, f, r, 0), areg);
+    if (wave_on) load_a_frags(ftile(fd, f, r, 0), areg);
   }
+  double4_t acc[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+  __syncthreads();     // maps visible
+  if (pk.ch[0] >= 0 || pk.ch[1] >= 0) pull_tile(fd, pk, maps, acc);
   for (int c = 0; c < f.npt; ++c) {
     const dvec2* Ls = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, c));
     dvec2* Bl2 = reinterpret_cast<dvec2*>(Bl);
+    const int ksteps = min(16, (f.n1 - NB * c + 3) >> 2);   // inner steps of 4 with real pivots in this tile column
     // ---- inner columns 0..31 ----
 #pragma unroll
     for (int e = 0; e < 4; ++e) Bl2[threadIdx.x + 256 * e] = breg[e];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acur[e] = areg[e];
+    if (ksteps > 8) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) breg[e] = Ls[TILE / 4 + threadIdx.x + 256 * e];
-    if (c + 1 < f.npt) load_a_frags(ftile(fd, f, r, c + 1), areg);
+      for (int e = 0; e < 4; ++e) breg[e] = Ls[TILE / 4 + threadIdx.x + 256 * e];
+    }
+    if (c + 1 < f.npt && wave_on) load_a_frags(ftile(fd, f, r, c + 1), areg);
     __syncthreads();
+    if (wave_on) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const double av = -acur[ks];
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < ksteps) {
+          const double av = -acur[ks];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[(16 * ni + lr) + (4 * ks + lk) * LD], av, acc[ni], 0, 0, 0);
+          for (int ni = 0; ni < 4; ++ni)
+            if (ni < nblk)
+              acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[(16 * ni + lr) + (4 * ks + lk) * LD], av, acc[ni], 0, 0, 0);
+        }
+      }
     }
     // ---- inner columns 32..63 ----
+    if (ksteps > 8) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Bl2[TILE / 4 + threadIdx.x + 256 * e] = breg[e];
+      for (int e = 0; e < 4; ++e) Bl2[TILE / 4 + threadIdx.x + 256 * e] = breg[e];
+    }
     if (c + 1 < f.npt) {
       const dvec2* Ln = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, c + 1));
 #pragma unroll
       for (int e = 0; e < 4; ++e) breg[e] = Ln[threadIdx.x + 256 * e];
     }
     __syncthreads();
+    if (wave_on) {
 #pragma unroll
-    for (int ks = 8; ks < 16; ++ks) {
-      const double av = -acur[ks];
+      for (int ks = 8; ks < 16; ++ks) {
+        if (ks < ksteps) {
+          const double av = -acur[ks];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[(16 * ni + lr) + (4 * ks + lk) * LD], av, acc[ni], 0, 0, 0);
+          for (int ni = 0; ni < 4; ++ni)
+            if (ni < nblk)
+              acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[(16 * ni + lr) + (4 * ks + lk) * LD], av, acc[ni], 0, 0, 0);
+        }
+      }
     }
   }
-  __syncthreads();     // maps visible, all waves done with Bl
-  // extend-add: the tile goes through LDS so that every instruction updates 64 consecutive rows of
-  // one parent column (child rows map to parent rows in runs of 7 that are mostly adjacent)
-  store_c_frags(Bl, acc);
-  __syncthreads();
-  {
-    double* dst[16];
-    double cur[16];
+  // the update tile, in place (the parent gathers it): only the 16 x 16 blocks that hold boundary scalars -- the padding
+  // of the last tile row / column is never read by anything (the pull maps address true scalars only)
+  if (wave_on) {
+    double* Cg = ftile_any(fd, f, r, sc);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = threadIdx.x + 256 * e;
-      const int i = idx & 63, j = idx >> 6;
-      const int pr = rmap[i], pc = cmap[j];
-      dst[e] = (pr >= 0 && pc >= 0 && (tr > tc || i >= j)) ? front_entry(fd, pf, pr, pc) : nullptr;
-    }
-    // all loads before the first store: the destinations are distinct but the compiler cannot know
+    for (int ni = 0; ni < 4; ++ni)
+      if (ni < nblk) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cur[e] = dst[e] ? *dst[e] : 0.0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-      if (dst[e]) *dst[e] = cur[e] + Bl[threadIdx.x + 256 * e];
+        for (int rr = 0; rr < 4; ++rr) Cg[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * rr) * NB] = acc[ni][rr];
+      }
   }
-  // rhs: diagonal tiles carry their rows' vector entries
-  if (tr == tc && threadIdx.x < NB) {
-    const int pr = rmap[threadIdx.x];
-    if (pr >= 0) fd.fvec[pf.vec_off + pr] += fd.fvec[f.vec_off + (size_t)(f.npt + tr) * NB + threadIdx.x];
+  // vector rows: diagonal tiles add the children's rows to v_r (k_fL21 / k_ftrail subtracted sum_c L(r,c) y_c before)
+  if (tr == tc && (pk.ch[0] >= 0 || pk.ch[1] >= 0)) {
+    const double v = pull_vec(fd, pk, maps);
+    if (threadIdx.x < NB && v != 0.0) fd.fvec[f.vec_off + (size_t)r * NB + threadIdx.x] += v;
   }
 }
 
@@ -1129,11 +1243,8 @@ void launch_front_load_rhs(const FrameDev* fr, int n_frames, int maxP, hipStream
   hipLaunchKernelGGL(k_front_load_rhs, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, fr);
 }
 
-void launch_iter_begin_nd(const FrameDev* fr, int n_frames, bool skip_f22, hipStream_t st) {
-  hipLaunchKernelGGL(k_iter_begin_nd, dim3(2048, n_frames), dim3(256), 0, st, fr, skip_f22 ? 1 : 0);
-}
-void launch_zero_f22(const FrameDev* fr, int n_frames, hipStream_t st) {
-  hipLaunchKernelGGL(k_zero_f22, dim3(1024, n_frames), dim3(256), 0, st, fr);
+void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
+  hipLaunchKernelGGL(k_iter_begin_nd, dim3(1024, n_frames), dim3(256), 0, st, fr);
 }
 
 // Level schedule shared by all slots of a batch (they may have different plans: the host
@@ -1170,6 +1281,12 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
       return e ? atol(e) : 128L;
     }();
     const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= compact_min;
+    // children's update matrices into the pivot columns (levels whose fronts all are leaves have nothing to gather)
+    if (s.has_kids) {
+      const int units = s.max_npt * s.max_nt - s.max_npt * (s.max_npt - 1) / 2;
+      const WgMap m = make_map(units, s.n_fronts, n_frames);
+      hipLaunchKernelGGL(k_fpull, map_grid(m), dim3(256), 0, st, fr, lr, m);
+    }
     if (compact) {
       hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, lr, u_override);
       if (s.max_n2p > 0) {
@@ -1200,16 +1317,14 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
         hipLaunchKernelGGL(k_ftrail, map_grid(m), dim3(256), 0, st, fr, lr, c, mcap, bcap, ntile, m);
       }
     }
-    // Schur complements of this level, added straight into the parents (next level): one pass
-    // per child index so that the two children of a parent never update the same entry
-    // concurrently (plain read-modify-write, fixed order: bitwise reproducible)
+    // update matrices of this level, stored in place (the parents gather them: k_fpull / k_fschur of the next level,
+    // or the task graph's own pulls): one launch, every tile written by exactly one workgroup
     if (s.max_n2p > 0 && l + 1 < n_levels) {
-      for (int w = 0; w < 2; ++w) {
-        const int total = s.n_schur[w] * n_frames;
-        if (total > 0)
-          hipLaunchKernelGGL(k_fschur, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, fr, lr, w,
-                             s.n_schur[w], s.schur_at[w], n_frames);
-      }
+      const int n_it = s.n_schur[0] + s.n_schur[1];
+      const int total = n_it * n_frames;
+      if (total > 0)
+        hipLaunchKernelGGL(k_fschur, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, fr, lr, n_it,
+                           s.schur_at[0], n_frames);
     }
   }
   for (int l = l_back_end - 1; l >= 0; --l) {

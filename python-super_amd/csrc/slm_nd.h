@@ -58,8 +58,9 @@ struct NDLevelSched {
   int32_t max_pairs;   // boundary node pairs nb*(nb+1)/2 (extend-add)
   int32_t max_n2p;     // padded boundary scalars
   int32_t first;       // first front of the level when all slots of the batch agree, else -1
-  int32_t n_schur[2];  // Schur work items (front, boundary tile pair) of the level per child index
+  int32_t n_schur[2];  // Schur work items (front, boundary tile pair) of the level per child index (adjacent lists)
   int32_t schur_at[2]; // their offset in schur_items when all slots of the batch agree, else -1
+  int32_t has_kids;    // some front of the level has children (k_fpull has work)
 };
 
 // ---- persistent task-graph form of the numeric phase (slm_dag.hip) ------------------------------

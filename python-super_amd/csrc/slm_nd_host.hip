@@ -355,7 +355,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   }
   out.sched.clear();
   for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
-    NDLevelSched sc{0, 0, 0, 0, 0, 0, {0, 0}, {0, 0}};
+    NDLevelSched sc{0, 0, 0, 0, 0, 0, {0, 0}, {0, 0}, 0};
     sc.first = out.level_start[l];
     sc.n_fronts = out.level_start[l + 1] - out.level_start[l];
     for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
@@ -364,6 +364,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       sc.max_nt = std::max(sc.max_nt, f.nt);
       sc.max_pairs = std::max(sc.max_pairs, f.parent >= 0 ? f.nb * (f.nb + 1) / 2 : 0);
       sc.max_n2p = std::max(sc.max_n2p, f.n2p);
+      if (!f.is_leaf) sc.has_kids = 1;
     }
     out.sched.push_back(sc);
     out.max_level_fronts = std::max(out.max_level_fronts, sc.n_fronts);
