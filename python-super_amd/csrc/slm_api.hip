@@ -102,6 +102,8 @@ struct Slot {
   std::vector<float> h_pts;
   std::vector<double> h_pts64;
   NDFront* d_fronts = nullptr;
+  NDTileItem* d_items = nullptr;   // work lists of the pull-form kernels
+  size_t cap_items = 0;
   int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos | ... | dag_tasks | front_nin
   long long* d_dag_trace = nullptr; // diagnostics
   size_t cap_dag_trace = 0;
@@ -362,6 +364,7 @@ int slm_destroy(slm_solver* s) {
     if (h.tgt_pn) (void)hipFree(h.tgt_pn);
     plan_free(sl.plan);
     if (sl.d_fronts) (void)hipFree(sl.d_fronts);
+    if (sl.d_items) (void)hipFree(sl.d_items);
     if (sl.d_ints) (void)hipFree(sl.d_ints);
     if (sl.d_dests) (void)hipFree(sl.d_dests);
     if (sl.d_cur_dests) (void)hipFree(sl.d_cur_dests);
@@ -619,7 +622,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       sl.plan_pairs.swap(all_pairs);
       NDPlanHost& nd = sl.nd;
       const size_t n_ints = nd.level_start.size() + nd.nodes.size() + nd.eamap.size() + 2 * (size_t)f->J +
-                            nd.in_start.size() + nd.in_edge.size() + nd.schur_items.size() + nd.schur_off.size() +
+                            nd.in_start.size() + nd.in_edge.size() + nd.item_off.size() +
                             nd.dag_tasks.size() + nd.dag_top_tasks.size() + nd.front_kids.size() + nd.pull_off.size() + nd.pullmap.size() + nd.prng_off.size() +
                             nd.prng.size();
       const size_t n_dests = nd.block_dest.size() + nd.pair_dest.size();
@@ -644,8 +647,11 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.node_pos = p;    HIPCHK(up(nd.node_pos));
       h.in_start = p;    HIPCHK(up(nd.in_start));
       h.in_edge = p;     HIPCHK(up(nd.in_edge));
-      h.schur_items = p; HIPCHK(up(nd.schur_items));
-      h.schur_off = p;   HIPCHK(up(nd.schur_off));
+      h.item_off = p;    HIPCHK(up(nd.item_off));
+      HIPCHK(grow(sl.d_items, sl.cap_items, nd.tile_items.size() + 1));
+      if (!nd.tile_items.empty())
+        HIPCHK(hipMemcpyAsync(sl.d_items, nd.tile_items.data(), sizeof(NDTileItem) * nd.tile_items.size(), hipMemcpyHostToDevice, st));
+      h.tile_items = sl.d_items;
       h.dag_tasks = p;   HIPCHK(up(nd.dag_tasks));
       h.dag_top_tasks = p; HIPCHK(up(nd.dag_top_tasks));
       h.n_dag_top_tasks = (int32_t)(nd.dag_top_tasks.size() / 2);
@@ -828,7 +834,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
   if (d.nd) {
     for (int i = first; i < first + n; ++i) {
       const auto& sc = s->slots[i].nd.sched;
-      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2, {0, 0}, {-2, -2}, 0});
+      if (sc.size() > d.sched.size()) d.sched.resize(sc.size(), NDLevelSched{0, 0, 0, 0, 0, -2, 0, -2, 0, -2});
       for (size_t l = 0; l < sc.size(); ++l) {
         NDLevelSched& m = d.sched[l];
         // same first front and front count in every slot -> passed to the kernels by value
@@ -839,12 +845,12 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
         m.max_nt = std::max(m.max_nt, sc[l].max_nt);
         m.max_pairs = std::max(m.max_pairs, sc[l].max_pairs);
         m.max_n2p = std::max(m.max_n2p, sc[l].max_n2p);
-        m.has_kids |= sc[l].has_kids;
-        for (int w = 0; w < 2; ++w) {
-          if (m.schur_at[w] == -2) m.schur_at[w] = sc[l].schur_at[w];
-          else if (m.schur_at[w] != sc[l].schur_at[w] || m.n_schur[w] != sc[l].n_schur[w]) m.schur_at[w] = -1;
-          m.n_schur[w] = std::max(m.n_schur[w], sc[l].n_schur[w]);
-        }
+        if (m.schur_at == -2) m.schur_at = sc[l].schur_at;
+        else if (m.schur_at != sc[l].schur_at || m.n_schur != sc[l].n_schur) m.schur_at = -1;
+        m.n_schur = std::max(m.n_schur, sc[l].n_schur);
+        if (m.pull_at == -2) m.pull_at = sc[l].pull_at;
+        else if (m.pull_at != sc[l].pull_at || m.n_pull != sc[l].n_pull) m.pull_at = -1;
+        m.n_pull = std::max(m.n_pull, sc[l].n_pull);
       }
     }
   }
@@ -852,11 +858,13 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     // slots with fewer levels than the batch maximum: their level tables must be read on the device
     for (int i = first; i < first + n; ++i)
       for (size_t l = s->slots[i].nd.sched.size(); l < d.sched.size(); ++l)
-        d.sched[l].first = d.sched[l].schur_at[0] = d.sched[l].schur_at[1] = -1;
+        d.sched[l].first = d.sched[l].schur_at = d.sched[l].pull_at = -1;
   }
   for (auto& m : d.sched) {
     if (m.first == -2) m.first = -1;
-    if (m.first < 0) m.schur_at[0] = m.schur_at[1] = -1;
+    if (m.first < 0) m.schur_at = m.pull_at = -1;
+    if (m.schur_at == -2) m.schur_at = -1;
+    if (m.pull_at == -2) m.pull_at = -1;
   }
   if (s->cfg.use_arap || s->cfg.use_rot)
     d.n_reg_part = std::min(kRegBlocksMax, (d.maxJKe + 255) / 256);

@@ -118,8 +118,8 @@ struct FrameDev {
   GP<const int32_t> node_pos;     // (J) local pivot position
   GP<const NDDest> block_dest;    // (n_blocks) destination of every data-term block
   GP<const NDDest> pair_dest;     // (J*K_ED) destination of every ARAP pair block
-  GP<const int32_t> schur_items;  // Schur work lists (slm_nd.h)
-  GP<const int32_t> schur_off;    // (2*n_levels + 1)
+  GP<const NDTileItem> tile_items;  // work lists of k_fschur / k_fpull (slm_nd.h)
+  GP<const int32_t> item_off;       // (2*n_levels + 1): per level [Schur items | pull items]
   GP<const int32_t> in_start;     // (J+1) ARAP edges grouped by target node (reverse KNN graph)
   GP<const int32_t> in_edge;
   GP<double> ftiles;              // front tile storage

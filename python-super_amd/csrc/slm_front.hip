@@ -627,6 +627,120 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
   store_c_frags(At, acc);
 }
 
+// ---- pull-form extend-add (the data flow of the task graph, slm_dag.hip, in the per-level kernels) ---------------
+// Every tile has ONE writer.  A front's boundary block F22 holds its UPDATE matrix U = [children's updates mapped into
+// it] - L21 L21^T, written once by k_fschur (plain coalesced stores: first touch is a store, nothing is zeroed, nothing
+// is read-modify-written) and read once by the parent, which GATHERS the entries that map into its own tiles through
+// the plan's pull maps (pullmap: parent scalar index -> boundary scalar index of the child, -1 none): k_fpull for the
+// pivot columns (added to the assembled entries before the factorisation), k_fschur for the boundary block.  The sums
+// run in a fixed order (own, child 0, child 1): bitwise reproducible.  The boundary rows of the front VECTOR travel
+// the same way (v_r = [children's v mapped] - sum_c L(r,c) y_c).
+// Both kernels take their work from the plan's exact lists of 128-byte records (NDTileItem, slm_nd.h): no empty
+// workgroups, and one load in place of the chain level table -> front -> child list -> pull ranges -> child fronts.
+//
+// Work item of workgroup blockIdx.x.  XCD-aware order: blocks b and b+8 share an XCD, so XCD x takes the contiguous
+// range [x*chunk, (x+1)*chunk) of the (frame, item) space -- the tiles of a front (adjacent items) run on one XCD,
+// back to back, and its L21 operands are fetched from HBM once.  `at` < 0: the slots of the batch have different
+// plans, the slot's own table says where the level's items are (which: 0 Schur items, 1 pull items).
+__device__ __forceinline__ const NDTileItem* tile_item(const FrameDev* __restrict__ frames, int level, int which, int n_items,
+                                                       int at, int n_frames, const FrameDev*& fdp) {
+  const int total = n_items * n_frames;
+  const int chunk = (total + 7) >> 3;
+  const int q = blockIdx.x >> 3;
+  const int w_id = (blockIdx.x & 7) * chunk + q;
+  if (q >= chunk || w_id >= total) return nullptr;
+  const int frame = w_id / n_items, item_idx = w_id - frame * n_items;
+  const FrameDev& fd = frames[frame];
+  if (!fd.bound || !fd.nd_ready) return nullptr;   // (a stopped slot only wastes the work: no dependent flag load here)
+  int i0 = at;
+  if (at < 0) {
+    if (level >= fd.n_levels) return nullptr;
+    i0 = fd.item_off[2 * level + which];
+    if (item_idx >= fd.item_off[2 * level + which + 1] - i0) return nullptr;
+  }
+  fdp = &fd;
+  return fd.tile_items.get() + i0 + item_idx;
+}
+// The record as scalars: loaded through a pointer that was itself loaded from memory, the fields are "divergent" for the
+// compiler and would live in vector registers (33 VGPRs: k_fschur fell from four to three waves per SIMD); every lane
+// reads the same record, so a v_readfirstlane per word puts it into SGPRs.
+__device__ __forceinline__ NDTileItem item_snapshot(const NDTileItem* p) {
+  NDTileItem o;
+  const int* src = reinterpret_cast<const int*>(p);
+  int* dst = reinterpret_cast<int*>(&o);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(NDTileItem) / 4); ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+  return o;
+}
+// tile (r, c) of a front from its item record (pivot columns at tile_off, boundary block at f22_base: NDFront)
+__device__ __forceinline__ double* item_tile(const FrameDev& fd, const NDTileItem& it, int r, int c) {
+  const size_t t = (size_t)c * it.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
+  return fd.ftiles + (c < it.npt ? it.tile_off : it.f22_base) + t * TILE;
+}
+// maps -> LDS: [128 k + 0..63] child k's boundary scalar of every row of tile row r, [128 k + 64..127] of tile row c.
+// Needs a __syncthreads() before the first use (the callers have one on their way).
+__device__ __forceinline__ void pull_maps(const FrameDev& fd, const NDTileItem& it, int* maps) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (it.kid[k].front >= 0 && threadIdx.x < 128) {
+      const int32_t* pm = fd.pullmap + it.kid[k].pull_off;
+      maps[128 * k + threadIdx.x] = pm[64 * (threadIdx.x < 64 ? it.r : it.c) + (threadIdx.x & 63)];
+    }
+  }
+}
+// acc (the item's tile in accumulator layout: wave w rows 16w.., see load_c_frags) += the children's entries.  All 16
+// gathers of a child are in flight together; the sum order is child 0, then child 1.  (One child at a time, fenced
+// for the instruction scheduler: both children's 32 values in flight cost 64 more registers.)
+__device__ __forceinline__ void pull_tile(const FrameDev& fd, const NDTileItem& it, const int* maps, double4_t acc[4]) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (it.kid[k].front < 0) continue;
+    __builtin_amdgcn_sched_barrier(0);   // (the 16 gather addresses are formed here, not hoisted above the caller's barrier)
+    double v[16];
+    const double* ct = fd.ftiles + it.kid[k].f22_base;
+    const int cnt = it.kid[k].nt, cnpt = it.kid[k].npt;
+    const int* mk = maps + 128 * k;
+    const int ci = mk[16 * w + lr];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int cj = mk[64 + 16 * ni + lk + 4 * rr];
+        // The maps are monotone (a front lists its nodes in elimination order, and so does its parent): an entry of the
+        // parent's lower triangle comes from the child's lower triangle.  ci < cj only occurs above the diagonal of a
+        // diagonal tile, which nothing reads.
+        // (branch-free: an entry nothing maps into reads the child's first word and drops it -- 16 loads back to back
+        //  instead of 16 predicated branches with one load each)
+        const bool ok = ci >= 0 && cj >= 0 && ci >= cj;
+        const int tr = cnpt + (ci >> 6), tc = cnpt + (cj >> 6);
+        const int t = tc * cnt - tc * (tc - 1) / 2 + (tr - tc);
+        const int off = ok ? t * TILE + (ci & 63) + (cj & 63) * NB : 0;
+        const double x = ct[off];
+        v[4 * ni + rr] = ok ? x : 0.0;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[ni][rr] += v[4 * ni + rr];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// the children's boundary vector rows that map into tile row r of the front (threads < NB: row threadIdx.x)
+__device__ __forceinline__ double pull_vec(const FrameDev& fd, const NDTileItem& it, const int* maps) {
+  double s = 0.0;
+  if (threadIdx.x < NB) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (it.kid[k].front < 0) continue;
+      const int ci = maps[128 * k + threadIdx.x];
+      if (ci >= 0) s += fd.fvec[it.kid[k].vec_boundary + ci];
+    }
+  }
+  return s;
+}
+
 // ---------------------------------------------------------------------------------------
 // Compact form for levels whose fronts have few pivot tile columns (npt <= 4: the leaf side
 // of the tree, where there are many fronts): two launches per level instead of three per
@@ -642,7 +756,7 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
 // diagonal-block inverses, three 16x16 scratch blocks, two vectors: 80 960 B, two workgroups per CU
 #define L11_LDS_DOUBLES (2 * TILE + 7 * 256 + 2 * NB + 16)   // S, M, dinv, wt, vec | part (= the factorisation's exchange buffer), 32 ints
 
-__global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frames, LevelRef lvl,
+__global__ void __launch_bounds__(256, 2) k_fL11(const FrameDev* __restrict__ frames, LevelRef lvl,
                                                double u_override) {
   extern __shared__ double lds[];
   double* S = lds;
@@ -750,7 +864,7 @@ __global__ void __launch_bounds__(256) k_fL11(const FrameDev* __restrict__ frame
   }
 }
 
-__global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frames, LevelRef lvl, WgMap map) {
+__global__ void __launch_bounds__(256, 3) k_fL21(const FrameDev* __restrict__ frames, LevelRef lvl, WgMap map) {
   __shared__ double Bl[TILE];
   __shared__ double yv[NB];
   WgId wg;
@@ -764,28 +878,38 @@ __global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frame
   if (f.npt == 0 || r >= f.nt) return;
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
   double* vecs = fd.fvec + f.vec_off;
-  double x[4][16];     // X_c in A-fragment layout: x[c][4*ni + rr] == acc[ni][rr]
+  // known-zero parts are skipped: a wave whose 16 rows lie beyond the true boundary size issues no MFMA and stores
+  // nothing (those rows of the pivot columns stay zero), and the front's last pivot tile column only counts up to the
+  // true pivot count (blocks of 16)
+  const bool wave_on = 16 * w < min(NB, 7 * f.nb - NB * wg.unit);
+  // (X_c' of the earlier columns is re-read from the tile this thread itself stored it to -- the accumulator layout is
+  //  the A-fragment layout, element for element -- instead of being held in 32 registers per column: two workgroups
+  //  per CU instead of one)
   double rhs_acc = 0.0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c < f.npt) {
+  for (int c = 0; c < f.npt; ++c) {
+    {
+      const int ncol = min(NB, f.n1 - NB * c);            // true pivots of this tile column
+      const int nblk = (ncol + 15) >> 4;                  // 16-column blocks with true pivots (also the inner blocks of X_c L_cc^-T)
       double* At = ftile(fd, f, r, c);
       double4_t acc[4];
-      load_c_frags(At, acc);
+      if (wave_on) {
+        load_c_frags(At, acc);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+      }
       // acc -= X_c' L(c,c')^T for the earlier pivot columns
+      for (int cp = 0; cp < c; ++cp) {
+        const double* Lt = ftile(fd, f, c, cp);
+        double breg[16], xreg[16];
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) {
-        if (cp < c) {
-          const double* Lt = ftile(fd, f, c, cp);
-          double breg[16];
+        for (int e = 0; e < 16; ++e) breg[e] = Lt[threadIdx.x + 256 * e];
+        if (wave_on) load_a_frags(ftile(fd, f, r, cp), xreg);
+        __syncthreads();
 #pragma unroll
-          for (int e = 0; e < 16; ++e) breg[e] = Lt[threadIdx.x + 256 * e];
-          __syncthreads();
-#pragma unroll
-          for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
-          __syncthreads();
-          tile_ABt_regs<true>(x[cp], Bl, acc);
-        }
+        for (int e = 0; e < 16; ++e) Bl[threadIdx.x + 256 * e] = breg[e];
+        __syncthreads();
+        if (wave_on) tile_ABt_regs_trim<true>(xreg, Bl, acc, 4, nblk);
       }
       // X_c = acc L_cc^-T
       {
@@ -806,21 +930,25 @@ __global__ void __launch_bounds__(256) k_fL21(const FrameDev* __restrict__ frame
         double4_t xa[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-        tile_ABt_regs<false>(areg, Bl, xa);
-        store_c_frags(At, xa);
+        if (wave_on) {
+          tile_ABt_regs_trim<false>(areg, Bl, xa, nblk, nblk);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            if (ni < nblk) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) At[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * rr) * NB] = xa[ni][rr];
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            x[c][4 * ni + rr] = xa[ni][rr];
-            rhs_acc += xa[ni][rr] * yv[16 * ni + lk + 4 * rr];
-          }
+          for (int rr = 0; rr < 4; ++rr) rhs_acc += xa[ni][rr] * yv[16 * ni + lk + 4 * rr];
       }
     }
   }
   rhs_acc += __shfl_xor(rhs_acc, 16, 64);
   rhs_acc += __shfl_xor(rhs_acc, 32, 64);
-  if (lk == 0) vecs[(size_t)r * NB + 16 * w + lr] -= rhs_acc;
+  if (lk == 0 && wave_on) vecs[(size_t)r * NB + 16 * w + lr] -= rhs_acc;
 }
 
 // Trailing update of tile column c, restricted to the PIVOT tile columns that are still to be
@@ -885,123 +1013,27 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
   }
 }
 
-// ---- pull-form extend-add (the data flow of the task graph, slm_dag.hip, in the per-level kernels) ---------------
-// Every tile has ONE writer.  A front's boundary block F22 holds its UPDATE matrix U = [children's updates mapped into
-// it] - L21 L21^T, written once by k_fschur (plain coalesced stores: first touch is a store, nothing is zeroed, nothing
-// is read-modify-written) and read once by the parent, which GATHERS the entries that map into its own tiles through
-// the plan's pull maps (pullmap: parent scalar index -> boundary scalar index of the child, -1 none): k_fpull for the
-// pivot columns (added to the assembled entries before the factorisation), k_fschur for the boundary block.  The sums
-// run in a fixed order (own, child 0, child 1): bitwise reproducible.  The boundary rows of the front VECTOR travel
-// the same way (v_r = [children's v mapped] - sum_c L(r,c) y_c).
-struct PullKids {
-  int ch[2];     // child front index, or -1 when the child has nothing for this tile
-};
-// tile (r, c) of the boundary block / pivot columns of front f, one formula for every front (NDFront::f22_base)
-__device__ __forceinline__ double* ftile_any(const FrameDev& fd, const NDFront& f, int r, int c) {
-  const size_t t = (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c);
-  return fd.ftiles + (c < f.npt ? f.tile_off : f.f22_base) + t * TILE;
-}
-// maps -> LDS: [128 k + 0..63] child k's boundary scalar of every row of tile row r, [128 k + 64..127] of tile row s.
-// Needs a __syncthreads() before the first use (the callers have one on their way).
-__device__ __forceinline__ PullKids pull_maps(const FrameDev& fd, int fi, int r, int s, int* maps) {
-  PullKids pk;
-  const int32_t* pr = fd.prng + fd.prng_off[fi];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    int ch = fd.front_kids[2 * fi + k];
-    if (ch >= 0 && (pr[2 * r + k] < 0 || pr[2 * s + k] < 0)) ch = -1;
-    pk.ch[k] = ch;
-    if (ch >= 0 && threadIdx.x < 128) {
-      const int32_t* pm = fd.pullmap + fd.pull_off[ch];
-      maps[128 * k + threadIdx.x] = pm[64 * (threadIdx.x < 64 ? r : s) + (threadIdx.x & 63)];
-    }
-  }
-  return pk;
-}
-// acc (tile (r,s) in accumulator layout: wave w rows 16w.., see load_c_frags) += the children's entries.  All gathers
-// of both children are in flight together; the sum order is child 0, then child 1.
-__device__ __forceinline__ void pull_tile(const FrameDev& fd, const PullKids& pk, const int* maps, double4_t acc[4]) {
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
-  double v[2][16];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[k][e] = 0.0;
-    if (pk.ch[k] < 0) continue;
-    const NDFront& cf = fd.fronts[pk.ch[k]];
-    const double* ct = fd.ftiles + cf.f22_base;
-    const int cnt = cf.nt, cnpt = cf.npt;
-    const int* mk = maps + 128 * k;
-    const int ci = mk[16 * w + lr];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int cj = mk[64 + 16 * ni + lk + 4 * rr];
-        // The maps are monotone (a front lists its nodes in elimination order, and so does its parent): an entry of the
-        // parent's lower triangle comes from the child's lower triangle.  ci < cj only occurs above the diagonal of a
-        // diagonal tile, which nothing reads.
-        if (ci >= 0 && cj >= 0 && ci >= cj) {
-          const int tr = cnpt + (ci >> 6), tc = cnpt + (cj >> 6);
-          const size_t t = (size_t)tc * cnt - (size_t)tc * (tc - 1) / 2 + (size_t)(tr - tc);
-          v[k][4 * ni + rr] = ct[t * TILE + (ci & 63) + (size_t)(cj & 63) * NB];
-        }
-      }
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[ni][rr] += v[k][4 * ni + rr];
-}
-// the children's boundary vector rows that map into tile row r of the front (threads < NB: row threadIdx.x)
-__device__ __forceinline__ double pull_vec(const FrameDev& fd, const PullKids& pk, const int* maps) {
-  double s = 0.0;
-  if (threadIdx.x < NB) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (pk.ch[k] < 0) continue;
-      const NDFront& cf = fd.fronts[pk.ch[k]];
-      const int ci = maps[128 * k + threadIdx.x];
-      if (ci >= 0) s += fd.fvec[cf.vec_off + (size_t)cf.npt * NB + ci];
-    }
-  }
-  return s;
-}
-
 // Children's updates into the PIVOT columns of the fronts of a level (before their factorisation): one workgroup per
-// pivot-column tile (r, c), c < npt, c <= r < nt; tiles no child maps into leave at once.
-// grid = (max pivot-column tiles, fronts in level, n_frames)
-__global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ frames, LevelRef lvl, WgMap map) {
+// pivot-column tile (r, c), c < npt, that some child maps into (the plan's pull items).
+// grid = (pull items of the level x frames, rounded to 8)
+__global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ frames, int level, int n_items, int items_at,
+                                                int n_frames) {
   __shared__ int maps[256];
-  WgId wg;
-  if (!wg_decode(map, wg)) return;
-  const FrameDev& fd = frames[wg.frame];
-  if (!fd.bound || !fd.nd_ready) return;
-  int fi;
-  if (!level_front(fd, lvl, wg.front, fi)) return;
-  const NDFront& f = fd.fronts[fi];
-  if (f.is_leaf) return;
-  // unit -> (r, c): column c holds nt - c tiles
-  int t = wg.unit, c = 0;
-  while (c < f.npt && t >= f.nt - c) {
-    t -= f.nt - c;
-    ++c;
-  }
-  if (c >= f.npt) return;
-  const int r = c + t;
-  const PullKids pk = pull_maps(fd, fi, r, c, maps);
-  if (pk.ch[0] < 0 && pk.ch[1] < 0) return;
-  double* T = ftile(fd, f, r, c);
+  const FrameDev* fdp;
+  const NDTileItem* itp = tile_item(frames, level, 1, n_items, items_at, n_frames, fdp);
+  if (!itp) return;
+  const FrameDev& fd = *fdp;
+  const NDTileItem it = item_snapshot(itp);
+  pull_maps(fd, it, maps);
+  double* T = item_tile(fd, it, it.r, it.c);
   double4_t acc[4];
   load_c_frags(T, acc);
   __syncthreads();
-  pull_tile(fd, pk, maps, acc);
+  pull_tile(fd, it, maps, acc);
   store_c_frags(T, acc);
-  if (r == c) {
-    const double v = pull_vec(fd, pk, maps);
-    if (threadIdx.x < NB && v != 0.0) fd.fvec[f.vec_off + (size_t)c * NB + threadIdx.x] += v;
+  if (it.r == it.c) {
+    const double v = pull_vec(fd, it, maps);
+    if (threadIdx.x < NB && v != 0.0) fd.fvec[it.vec_off + (size_t)it.c * NB + threadIdx.x] += v;
   }
 }
 
@@ -1011,43 +1043,26 @@ __global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ fram
 // the inner dimension stops at the front's true pivot count (the padding columns of L21 are zero), and a wave whose
 // 16 rows lie beyond the true boundary size, or a 16-column block beyond it, issues no MFMA (its outputs are padding
 // that nothing reads).
-// grid = (work items of the level x frames, rounded to 8)
-__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, LevelRef lvl,
-                                                 int n_items, int items_at, int n_frames) {
+// grid = (Schur items of the level x frames, rounded to 8)
+__global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, int level, int n_items,
+                                                 int items_at, int n_frames) {
   __shared__ __attribute__((aligned(16))) double Bl[TILE];
   __shared__ int maps[256];
-  // Work items come from the plan's exact list for the level: no empty workgroups, no
-  // index arithmetic.  XCD-aware order: blocks b and b+8 share an XCD, so XCD x takes the contiguous
-  // range [x*chunk, (x+1)*chunk) of the (frame, item) space -- the tiles of a front (adjacent items)
-  // run on one XCD, back to back, and its L21 operands are fetched from HBM once.
-  const int total = n_items * n_frames;
-  const int chunk = (total + 7) >> 3;
-  const int q = blockIdx.x >> 3;
-  const int w_id = (blockIdx.x & 7) * chunk + q;
-  if (q >= chunk || w_id >= total) return;
-  const int frame = w_id / n_items, item_idx = w_id - frame * n_items;
-  const FrameDev& fd = frames[frame];
-  if (!fd.bound || !fd.nd_ready) return;   // (a stopped slot only wastes the work: no dependent flag load here)
-  int i0 = items_at, first = lvl.first;
-  if (items_at < 0) {   // slots with different plans: read this slot's tables
-    if (lvl.level >= fd.n_levels) return;
-    i0 = fd.schur_off[2 * lvl.level];
-    if (item_idx >= fd.schur_off[2 * lvl.level + 2] - i0) return;
-    first = fd.level_start[lvl.level];
-  }
-  const int item = fd.schur_items[i0 + item_idx];
-  const int tr = (item >> 8) & 255, tc = item & 255;
-  const int fi = first + (item >> 16);
-  const NDFront& f = fd.fronts[fi];
-  const int r = f.npt + tr, sc = f.npt + tc;
+  const FrameDev* fdp;
+  const NDTileItem* itp = tile_item(frames, level, 0, n_items, items_at, n_frames, fdp);
+  if (!itp) return;
+  const FrameDev& fd = *fdp;
+  // (fields read through the pointer where they are used, like a front descriptor: a local copy of the record -- in
+  //  vector or scalar registers -- lengthens live ranges by 40 VGPRs in this kernel and costs the fourth wave per SIMD)
+  const NDTileItem& it = *itp;
+  const int r = it.r, sc = it.c, tr = r - it.npt, tc = sc - it.npt;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
-  // true sizes: rows of this tile row / columns of this tile column that are boundary scalars, inner steps of 4
-  const int n2 = 7 * f.nb;
-  const int vrow = min(NB, n2 - NB * tr), vcol = min(NB, n2 - NB * tc);
+  // true sizes: rows of this tile row / columns of this tile column that are boundary scalars
+  const int vrow = min(NB, it.n2 - NB * tr), vcol = min(NB, it.n2 - NB * tc);
   const bool wave_on = 16 * w < vrow;
   const int nblk = (vcol + 15) >> 4;             // 16-column blocks with real columns
-  PullKids pk = pull_maps(fd, fi, r, sc, maps);
-  if (f.is_leaf) pk.ch[0] = pk.ch[1] = -1;
+  const bool kids = it.kid[0].front >= 0 || it.kid[1].front >= 0;
+  pull_maps(fd, it, maps);
   // The B operand (L21 tile of block-row sc) passes through LDS in HALF tiles of 32 inner columns,
   // double-buffered (2 x 16 KB): three workgroups per CU instead of two, and the next half is in
   // flight while the current one is on the MFMA.
@@ -1056,21 +1071,21 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   typedef double dvec2 __attribute__((ext_vector_type(2)));
   dvec2 breg[4];
   double areg[16], acur[16];
-  if (f.npt > 0) {
-    const dvec2* Ls = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, 0));
+  if (it.npt > 0) {
+    const dvec2* Ls = reinterpret_cast<const dvec2*>(item_tile(fd, it, sc, 0));
 #pragma unroll
     for (int e = 0; e < 4; ++e) breg[e] = Ls[threadIdx.x + 256 * e];
-    if (wave_on) load_a_frags(ftile(fd, f, r, 0), areg);
+    if (wave_on) load_a_frags(item_tile(fd, it, r, 0), areg);
   }
   double4_t acc[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
   __syncthreads();     // maps visible
-  if (pk.ch[0] >= 0 || pk.ch[1] >= 0) pull_tile(fd, pk, maps, acc);
-  for (int c = 0; c < f.npt; ++c) {
-    const dvec2* Ls = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, c));
+  if (kids) pull_tile(fd, it, maps, acc);
+  for (int c = 0; c < it.npt; ++c) {
+    const dvec2* Ls = reinterpret_cast<const dvec2*>(item_tile(fd, it, sc, c));
     dvec2* Bl2 = reinterpret_cast<dvec2*>(Bl);
-    const int ksteps = min(16, (f.n1 - NB * c + 3) >> 2);   // inner steps of 4 with real pivots in this tile column
+    const int ksteps = min(16, (it.n1 - NB * c + 3) >> 2);   // inner steps of 4 with real pivots in this tile column
     // ---- inner columns 0..31 ----
 #pragma unroll
     for (int e = 0; e < 4; ++e) Bl2[threadIdx.x + 256 * e] = breg[e];
@@ -1080,7 +1095,7 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) breg[e] = Ls[TILE / 4 + threadIdx.x + 256 * e];
     }
-    if (c + 1 < f.npt && wave_on) load_a_frags(ftile(fd, f, r, c + 1), areg);
+    if (c + 1 < it.npt && wave_on) load_a_frags(item_tile(fd, it, r, c + 1), areg);
     __syncthreads();
     if (wave_on) {
 #pragma unroll
@@ -1099,8 +1114,8 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) Bl2[TILE / 4 + threadIdx.x + 256 * e] = breg[e];
     }
-    if (c + 1 < f.npt) {
-      const dvec2* Ln = reinterpret_cast<const dvec2*>(ftile(fd, f, sc, c + 1));
+    if (c + 1 < it.npt) {
+      const dvec2* Ln = reinterpret_cast<const dvec2*>(item_tile(fd, it, sc, c + 1));
 #pragma unroll
       for (int e = 0; e < 4; ++e) breg[e] = Ln[threadIdx.x + 256 * e];
     }
@@ -1121,7 +1136,7 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   // the update tile, in place (the parent gathers it): only the 16 x 16 blocks that hold boundary scalars -- the padding
   // of the last tile row / column is never read by anything (the pull maps address true scalars only)
   if (wave_on) {
-    double* Cg = ftile_any(fd, f, r, sc);
+    double* Cg = item_tile(fd, it, r, sc);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       if (ni < nblk) {
@@ -1130,9 +1145,9 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
       }
   }
   // vector rows: diagonal tiles add the children's rows to v_r (k_fL21 / k_ftrail subtracted sum_c L(r,c) y_c before)
-  if (tr == tc && (pk.ch[0] >= 0 || pk.ch[1] >= 0)) {
-    const double v = pull_vec(fd, pk, maps);
-    if (threadIdx.x < NB && v != 0.0) fd.fvec[f.vec_off + (size_t)r * NB + threadIdx.x] += v;
+  if (tr == tc && kids) {
+    const double v = pull_vec(fd, it, maps);
+    if (threadIdx.x < NB && v != 0.0) fd.fvec[it.vec_off + (size_t)r * NB + threadIdx.x] += v;
   }
 }
 
@@ -1281,11 +1296,14 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
       return e ? atol(e) : 128L;
     }();
     const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= compact_min;
-    // children's update matrices into the pivot columns (levels whose fronts all are leaves have nothing to gather)
-    if (s.has_kids) {
-      const int units = s.max_npt * s.max_nt - s.max_npt * (s.max_npt - 1) / 2;
-      const WgMap m = make_map(units, s.n_fronts, n_frames);
-      hipLaunchKernelGGL(k_fpull, map_grid(m), dim3(256), 0, st, fr, lr, m);
+    // children's update matrices into the pivot columns (levels whose fronts all are leaves have nothing to gather).
+    // A launch of its own: gathering inside k_fL11 / k_fL21 (at the first touch of every pivot-column tile) was built
+    // and measured -- one launch fewer per level, but the gathers then sit on the critical path of workgroups that run
+    // two per CU (C2, 8 frames: k_fL11 44 -> 83 us and k_fL21 56 -> 114 us at the level with 256 fronts, against 44 us
+    // for this kernel, which runs thousands of small workgroups at four per SIMD)
+    if (s.n_pull > 0) {
+      const int total = s.n_pull * n_frames;
+      hipLaunchKernelGGL(k_fpull, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, fr, l, s.n_pull, s.pull_at, n_frames);
     }
     if (compact) {
       hipLaunchKernelGGL(k_fL11, dim3(1, s.n_fronts, n_frames), dim3(256), lds11, st, fr, lr, u_override);
@@ -1319,12 +1337,10 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
     }
     // update matrices of this level, stored in place (the parents gather them: k_fpull / k_fschur of the next level,
     // or the task graph's own pulls): one launch, every tile written by exactly one workgroup
-    if (s.max_n2p > 0 && l + 1 < n_levels) {
-      const int n_it = s.n_schur[0] + s.n_schur[1];
-      const int total = n_it * n_frames;
-      if (total > 0)
-        hipLaunchKernelGGL(k_fschur, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, fr, lr, n_it,
-                           s.schur_at[0], n_frames);
+    if (s.n_schur > 0) {
+      const int total = s.n_schur * n_frames;
+      hipLaunchKernelGGL(k_fschur, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, st, fr, l, s.n_schur, s.schur_at,
+                         n_frames);
     }
   }
   for (int l = l_back_end - 1; l >= 0; --l) {

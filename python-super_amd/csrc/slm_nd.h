@@ -50,6 +50,31 @@ struct NDDest {
   int32_t transpose;  // 1: the block given as (a,b) with a >= b by id lands transposed
 };
 
+// Work item of the pull-form kernels (k_fpull, k_fschur): everything a workgroup needs about its tile, the front and the
+// two children it gathers from in ONE 128-byte record -- instead of a chain of dependent loads through the level table,
+// the front descriptor, the child lists, the pull-range table and the children's descriptors (each a memory round trip
+// in front of the first useful load of a workgroup that lives for ~10 us).
+struct NDTileKid {
+  int32_t front;        // child front, or -1: nothing of this child maps into the tile
+  int32_t nt, npt;      // the child's tiles per side / pivot tile columns
+  int32_t pull_off;     // offset of the child's pull map in pullmap (parent scalar -> boundary scalar of the child)
+  int64_t f22_base;     // NDFront::f22_base of the child (its update matrix)
+  int64_t vec_boundary; // offset of the child's boundary vector rows in the front-vector storage
+};
+struct NDTileItem {
+  int32_t front;        // front index
+  int32_t r, c;         // tile row / column in the front's numbering (Schur items: both >= npt)
+  int32_t nt, npt;      // the front's tiles per side / pivot tile columns
+  int32_t n1, n2;       // true pivot / boundary scalars (7 nv, 7 nb)
+  int32_t pad0;
+  int64_t tile_off;     // NDFront::tile_off, f22_base, vec_off of the front
+  int64_t f22_base;
+  int64_t vec_off;
+  int64_t pad1;
+  NDTileKid kid[2];
+};
+static_assert(sizeof(NDTileItem) == 128, "NDTileItem is one 128-byte record");
+
 // per-level launch bounds (maxima over the slots of a batch)
 struct NDLevelSched {
   int32_t n_fronts;    // fronts in the level
@@ -58,9 +83,10 @@ struct NDLevelSched {
   int32_t max_pairs;   // boundary node pairs nb*(nb+1)/2 (extend-add)
   int32_t max_n2p;     // padded boundary scalars
   int32_t first;       // first front of the level when all slots of the batch agree, else -1
-  int32_t n_schur[2];  // Schur work items (front, boundary tile pair) of the level per child index (adjacent lists)
-  int32_t schur_at[2]; // their offset in schur_items when all slots of the batch agree, else -1
-  int32_t has_kids;    // some front of the level has children (k_fpull has work)
+  int32_t n_schur;     // Schur work items (front, boundary tile pair) of the level
+  int32_t schur_at;    // their offset in tile_items when all slots of the batch agree, else -1
+  int32_t n_pull;      // pull work items (front, pivot-column tile that a child maps into) of the level
+  int32_t pull_at;     // their offset in tile_items when all slots of the batch agree, else -1
 };
 
 // ---- persistent task-graph form of the numeric phase (slm_dag.hip) ------------------------------
@@ -81,10 +107,10 @@ struct NDPlanHost {
   std::vector<int32_t> eamap;
   std::vector<int32_t> node_front;    // (J) front that eliminates the node
   std::vector<int32_t> node_pos;      // (J) its local pivot position
-  // Schur-complement work lists: per (level, child index) the (front, tile row, tile column) triples,
-  // packed front << 16 | tr << 8 | tc, front-major; schur_off[2*level + which] .. [+1] delimits a list
-  std::vector<int32_t> schur_items;
-  std::vector<int32_t> schur_off;
+  // exact work lists of the pull-form kernels: per level its Schur items (front-major, boundary tile pairs) then its
+  // pull items (pivot-column tiles some child maps into); item_off[2*level] / [2*level+1] / [2*level+2] delimit them
+  std::vector<NDTileItem> tile_items;
+  std::vector<int32_t> item_off;
   std::vector<int32_t> in_start;      // (J+1) CSR over in_edge
   std::vector<int32_t> in_edge;       // ARAP edges e = j*K_ED + slot grouped by their TARGET node k, ascending e
   std::vector<NDDest> block_dest;     // per data-term block (order of blk_key)

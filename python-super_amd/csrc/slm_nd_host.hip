@@ -355,7 +355,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   }
   out.sched.clear();
   for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
-    NDLevelSched sc{0, 0, 0, 0, 0, 0, {0, 0}, {0, 0}, 0};
+    NDLevelSched sc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     sc.first = out.level_start[l];
     sc.n_fronts = out.level_start[l + 1] - out.level_start[l];
     for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
@@ -364,28 +364,10 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       sc.max_nt = std::max(sc.max_nt, f.nt);
       sc.max_pairs = std::max(sc.max_pairs, f.parent >= 0 ? f.nb * (f.nb + 1) / 2 : 0);
       sc.max_n2p = std::max(sc.max_n2p, f.n2p);
-      if (!f.is_leaf) sc.has_kids = 1;
     }
     out.sched.push_back(sc);
     out.max_level_fronts = std::max(out.max_level_fronts, sc.n_fronts);
   }
-  // exact work lists of the fused Schur / extend-add kernel (no empty workgroups)
-  out.schur_items.clear();
-  out.schur_off.assign(1, 0);
-  for (size_t l = 0; l + 1 < out.level_start.size(); ++l)
-    for (int w = 0; w < 2; ++w) {
-      for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
-        const NDFront& f = out.fronts[i];
-        if (f.parent < 0 || f.which_child != w) continue;
-        const int nbt = f.nt - f.npt;
-        if (nbt > 255 || i - out.level_start[l] > 32767) return false;
-        for (int tr = 0; tr < nbt; ++tr)
-          for (int tc = 0; tc <= tr; ++tc) out.schur_items.push_back(((i - out.level_start[l]) << 16) | (tr << 8) | tc);
-      }
-      out.schur_off.push_back((int32_t)out.schur_items.size());
-      out.sched[l].schur_at[w] = out.schur_off[out.schur_off.size() - 2];
-      out.sched[l].n_schur[w] = out.schur_off.back() - out.sched[l].schur_at[w];
-    }
   // extend-add maps: boundary index of a child -> local node position in the parent
   for (int i = 0; i < T; ++i) {
     const int id = proc[i];
@@ -443,6 +425,54 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
         }
         out.prng.push_back(hi >= 0 ? (lo | (hi << 8)) : -1);
       }
+  }
+  // ---- exact work lists of the pull-form per-level kernels (slm_front.hip k_fschur, k_fpull) --------------------
+  {
+    out.tile_items.clear();
+    out.item_off.assign(1, 0);
+    auto make_item = [&](int i, int r, int c) {
+      const NDFront& f = out.fronts[i];
+      NDTileItem it{};
+      it.front = i; it.r = r; it.c = c; it.nt = f.nt; it.npt = f.npt; it.n1 = f.n1; it.n2 = 7 * f.nb;
+      it.tile_off = f.tile_off; it.f22_base = f.f22_base; it.vec_off = f.vec_off;
+      const int32_t* pr = out.prng.data() + out.prng_off[i];
+      for (int k = 0; k < 2; ++k) {
+        NDTileKid& kd = it.kid[k];
+        kd.front = -1;
+        const int ch = out.front_kids[2 * (size_t)i + k];
+        if (ch < 0 || pr[2 * r + k] < 0 || pr[2 * c + k] < 0) continue;
+        const NDFront& cf = out.fronts[ch];
+        kd.front = ch; kd.nt = cf.nt; kd.npt = cf.npt; kd.pull_off = out.pull_off[ch];
+        kd.f22_base = cf.f22_base; kd.vec_boundary = cf.vec_off + (int64_t)cf.npt * 64;
+      }
+      return it;
+    };
+    for (size_t l = 0; l + 1 < out.level_start.size(); ++l) {
+      // Schur items: every boundary tile pair of every front with a parent
+      for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
+        const NDFront& f = out.fronts[i];
+        if (f.parent < 0) continue;
+        if (f.nt > 255) return false;
+        for (int tr = f.npt; tr < f.nt; ++tr)
+          for (int tc = f.npt; tc <= tr; ++tc) out.tile_items.push_back(make_item(i, tr, tc));
+      }
+      out.item_off.push_back((int32_t)out.tile_items.size());
+      // pull items: the pivot-column tiles some child maps into
+      for (int i = out.level_start[l]; i < out.level_start[l + 1]; ++i) {
+        const NDFront& f = out.fronts[i];
+        if (f.is_leaf) continue;
+        for (int c = 0; c < f.npt; ++c)
+          for (int r = c; r < f.nt; ++r) {
+            const NDTileItem it = make_item(i, r, c);
+            if (it.kid[0].front >= 0 || it.kid[1].front >= 0) out.tile_items.push_back(it);
+          }
+      }
+      out.item_off.push_back((int32_t)out.tile_items.size());
+      out.sched[l].schur_at = out.item_off[2 * l];
+      out.sched[l].n_schur = out.item_off[2 * l + 1] - out.item_off[2 * l];
+      out.sched[l].pull_at = out.item_off[2 * l + 1];
+      out.sched[l].n_pull = out.item_off[2 * l + 2] - out.item_off[2 * l + 1];
+    }
   }
   // Earliest start times from a duration model (microseconds; only the ORDER matters): tasks sorted by
   // them are in a topological order, and workgroups that take tasks in that order find them ready

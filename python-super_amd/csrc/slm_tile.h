@@ -439,6 +439,45 @@ __device__ __forceinline__ void tile_ABt_regs(const double areg[16], const doubl
       const double b = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
       acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[ni], 0, 0, 0);
     }
+    // Keep the scheduler from hoisting all 64 LDS operand reads of the product in front of its first MFMA (128 VGPRs
+    // of operands in flight: k_fL11 needed 366 registers -- one workgroup per CU -- because of it; an f64 MFMA issues
+    // in ~70 cycles, the reads of the next four k-steps are covered many times over)
+    if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same product restricted to the first `kblk` blocks of 16 inner columns and the first `nblk` 16-column blocks of
+// the result (uniform bounds, 1..4): what lies beyond is known to be zero -- the padding of a front's last pivot tile
+// column.  The column-block count is a template parameter behind a switch and the inner blocks are whole branches: with
+// per-instruction predicates the compiler hoists every operand read of the product (250 VGPRs).
+template <bool NEGATE, int NBLK>
+__device__ __forceinline__ void tile_ABt_regs_nblk(const double areg[16], const double* Bl, double4_t acc[4], int kblk) {
+  const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    if (kb < kblk) {
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int ks = 4 * kb + k4;
+        const double a = NEGATE ? -areg[ks] : areg[ks];
+#pragma unroll
+        for (int ni = 0; ni < NBLK; ++ni) {
+          const double b = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
+          acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[ni], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <bool NEGATE>
+__device__ __forceinline__ void tile_ABt_regs_trim(const double areg[16], const double* Bl, double4_t acc[4], int kblk,
+                                                   int nblk) {
+  switch (nblk) {
+    case 1: tile_ABt_regs_nblk<NEGATE, 1>(areg, Bl, acc, kblk); break;
+    case 2: tile_ABt_regs_nblk<NEGATE, 2>(areg, Bl, acc, kblk); break;
+    case 3: tile_ABt_regs_nblk<NEGATE, 3>(areg, Bl, acc, kblk); break;
+    default: tile_ABt_regs_nblk<NEGATE, 4>(areg, Bl, acc, kblk); break;
   }
 }
 

@@ -6,7 +6,7 @@ import csv
 import glob
 import sys
 
-path = glob.glob(sys.argv[1])[0] if "*" in sys.argv[1] else sys.argv[1]
+path = glob.glob(sys.argv[1], recursive=True)[0] if "*" in sys.argv[1] else sys.argv[1]
 nth = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
