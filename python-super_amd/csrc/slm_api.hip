@@ -76,6 +76,41 @@ static int fail(int code, const char* msg) {
 void slm_set_error_text(const char* msg) { g_err = msg; }
 
 namespace {
+// Host buffer for per-frame device -> host read-backs, PINNED (hipHostMalloc, grow-only).  A read-back into pageable
+// memory (a std::vector) goes through the runtime's staging path, and several bind workers doing that at once were
+// seen to block for 5-7 ms together once in ~50 steps (tests/studies/stall_hunt.py: the whole rare stall of a bench
+// step sat in this one hipMemcpyAsync + hipStreamSynchronize); a pinned destination is a plain DMA.
+template <typename T>
+struct PinnedBuf {
+  T* p = nullptr;
+  size_t cap = 0, n = 0;
+  hipError_t resize(size_t need) {
+    if (need > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+      cap = 0;
+      const size_t want = need + need / 8 + 16;
+      const hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      cap = want;
+    }
+    n = need;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = n = 0;
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 constexpr int kLossBlocks = 512;   // data-loss partial sums per slot
 constexpr int kRegBlocksMax = 64;
 
@@ -97,10 +132,11 @@ struct Slot {
   NDDest* d_cur_dests = nullptr;
   size_t cap_cur_dests = 0;
   int cur_n_blocks = -1;
-  std::vector<uint32_t> h_pairs;
-  std::vector<int32_t> h_knn;
-  std::vector<float> h_pts;
-  std::vector<double> h_pts64;
+  PinnedBuf<uint32_t> h_pairs;   // read-backs of the bind (pinned)
+  PinnedBuf<int32_t> h_knn;
+  PinnedBuf<float> h_pts;
+  PinnedBuf<double> h_pts64;
+  FrameDev* h_pin = nullptr;       // pinned mirror of `h` for the asynchronous descriptor upload of a bind
   NDFront* d_fronts = nullptr;
   NDTileItem* d_items = nullptr;   // work lists of the pull-form kernels
   size_t cap_items = 0;
@@ -363,6 +399,11 @@ int slm_destroy(slm_solver* s) {
     if (h.node_pk) (void)hipFree(h.node_pk);
     if (h.tgt_pn) (void)hipFree(h.tgt_pn);
     plan_free(sl.plan);
+    if (sl.h_pin) (void)hipHostFree(sl.h_pin);
+    sl.h_pairs.release();
+    sl.h_knn.release();
+    sl.h_pts.release();
+    sl.h_pts64.release();
     if (sl.d_fronts) (void)hipFree(sl.d_fronts);
     if (sl.d_items) (void)hipFree(sl.d_items);
     if (sl.d_ints) (void)hipFree(sl.d_ints);
@@ -415,6 +456,30 @@ static int ensure_band(slm_solver* s, int slot, hipStream_t st) {
 
 static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep);
 
+// Diagnostics (SLM_BIND_TRACE=<ms>): a bind that takes longer than <ms> on the host prints the time stamps of its
+// stages -- which stage of which worker carried a rare multi-millisecond stall (tests/studies/stall_hunt.py).
+#include <chrono>
+namespace {
+struct BindTrace {
+  double t[8];
+  int n;
+};
+thread_local BindTrace g_bt;
+inline double bt_now() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline double bind_trace_threshold() {
+  static const double th = [] {
+    const char* e = getenv("SLM_BIND_TRACE");
+    return e ? atof(e) : -1.0;
+  }();
+  return th;
+}
+inline void bt_mark() {
+  if (bind_trace_threshold() >= 0.0 && g_bt.n < 8) g_bt.t[g_bt.n++] = bt_now();
+}
+}  // namespace
+
 int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream) {
   if (!s || !f) return fail(SLM_ERR_INVALID, "slm_bind_frame: null argument");
   return bind_frame_impl(s, slot, f, (hipStream_t)stream, s->prep);
@@ -432,6 +497,8 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     return fail(SLM_ERR_INVALID, "slm_bind_frame: null device pointer");
   Slot& sl = s->slots[slot];
   FrameDev& h = sl.h;
+  g_bt.n = 0;
+  bt_mark();                                   // [0] entry
 
   const int P = 7 * f->J;
   const int nt = (P + SLM_NB - 1) / SLM_NB;
@@ -481,9 +548,13 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   }
   // tuple-sorted data-term assembly plan (DataLoss.prepare analogue)
   h.v1_ready = 0;
+  uint64_t dev_knn_hash = 0, dev_graph_hash = 0;   // coupling-graph hashes computed by prep_v1 on the device
   if (s->cfg.use_data && s->cfg.data_path != 1 && f->J < 65536 && f->N > 0) {
     V1Sizes sz;
     HIPCHK(prep_v1(prep, *f, sl.plan, &sz, st));
+    dev_knn_hash = sz.knn_hash;
+    dev_graph_hash = sz.graph_hash;
+    bt_mark();                                 // [1] tuple-sorted plan done (its size read-backs included)
     if (sz.n_tuples > 0) {
       h.n_tuples = sz.n_tuples;
       h.n_pos = sz.n_pos;
@@ -535,32 +606,30 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   // nested-dissection plan (symbolic analysis on the host from the coupled-pair list)
   h.nd_ready = 0;
   if (h.v1_ready && s->cfg.solver_path != 1) {
-    sl.h_pairs.resize(h.n_blocks);
-    sl.h_knn.resize((size_t)f->J * f->K_ED);
-    sl.h_pts.resize((size_t)f->J * 3);
-    HIPCHK(hipMemcpyAsync(sl.h_pairs.data(), h.blk_key, sizeof(uint32_t) * h.n_blocks, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(sl.h_knn.data(), f->ed_knn_idx, sizeof(int32_t) * sl.h_knn.size(), hipMemcpyDeviceToHost, st));
-    if (f->state_f64) {
-      sl.h_pts64.resize(sl.h_pts.size());
-      HIPCHK(hipMemcpyAsync(sl.h_pts64.data(), f->ed_points, sizeof(double) * sl.h_pts64.size(), hipMemcpyDeviceToHost, st));
-    } else {
-      HIPCHK(hipMemcpyAsync(sl.h_pts.data(), f->ed_points, sizeof(float) * sl.h_pts.size(), hipMemcpyDeviceToHost, st));
+    // The symbolic plan depends only on the coupling graph (node KNN table + coupled-pair list): reuse it while the
+    // graph is unchanged.  The graph's hash comes from the device with the sizes (prep_v1's one read-back): a frame
+    // whose graph is the slot's cached one reads nothing else back -- the lists only travel to the host when the
+    // hash says that they changed.
+    const uint64_t knn_hash = dev_knn_hash, hash = dev_graph_hash;
+    const bool same_graph = sl.nd_valid && sl.nd_hash == hash && sl.nd_knn_hash == knn_hash && sl.cur_n_blocks == h.n_blocks;
+    if (!same_graph) {
+      HIPCHK(sl.h_pairs.resize(h.n_blocks));
+      HIPCHK(sl.h_knn.resize((size_t)f->J * f->K_ED));
+      HIPCHK(sl.h_pts.resize((size_t)f->J * 3));
+      HIPCHK(hipMemcpyAsync(sl.h_pairs.data(), h.blk_key, sizeof(uint32_t) * h.n_blocks, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(sl.h_knn.data(), f->ed_knn_idx, sizeof(int32_t) * sl.h_knn.size(), hipMemcpyDeviceToHost, st));
+      if (f->state_f64) {
+        HIPCHK(sl.h_pts64.resize(sl.h_pts.size()));
+        HIPCHK(hipMemcpyAsync(sl.h_pts64.data(), f->ed_points, sizeof(double) * sl.h_pts64.size(), hipMemcpyDeviceToHost, st));
+      } else {
+        HIPCHK(hipMemcpyAsync(sl.h_pts.data(), f->ed_points, sizeof(float) * sl.h_pts.size(), hipMemcpyDeviceToHost, st));
+      }
+      HIPCHK(hipStreamSynchronize(st));
+      // the node positions only steer the geometric bisection of the symbolic plan: float32 is plenty
+      if (f->state_f64)
+        for (size_t i = 0; i < sl.h_pts.size(); ++i) sl.h_pts[i] = (float)sl.h_pts64[i];
     }
-    HIPCHK(hipStreamSynchronize(st));
-    // the node positions only steer the geometric bisection of the symbolic plan: float32 is plenty
-    if (f->state_f64)
-      for (size_t i = 0; i < sl.h_pts.size(); ++i) sl.h_pts[i] = (float)sl.h_pts64[i];
-    // the symbolic plan depends only on the coupling graph: reuse it while the graph is unchanged
-    uint64_t hash = 1469598103934665603ull;
-    auto mix = [&](const void* ptr, size_t bytes) {
-      const uint32_t* w = static_cast<const uint32_t*>(ptr);
-      for (size_t i = 0; i < bytes / 4; ++i) hash = (hash ^ w[i]) * 1099511628211ull;
-    };
-    const int32_t dims[2] = {f->J, f->K_ED};
-    mix(dims, sizeof(dims));
-    mix(sl.h_knn.data(), sizeof(int32_t) * sl.h_knn.size());
-    const uint64_t knn_hash = hash;
-    mix(sl.h_pairs.data(), sizeof(uint32_t) * sl.h_pairs.size());
+    bt_mark();                                 // [2] pair list / node table on the host (only when the graph changed)
     // pair -> destination table of this frame from the plan's (sorted) pair list; false when a pair is new
     // A pair the plan was not built from still has a place in it when the later-eliminated node lies in the
     // front of the earlier one (a fill position of the dense front): no new analysis then either.
@@ -602,7 +671,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       sl.plan_pairs.clear();
     }
     std::vector<uint32_t> all_pairs;
-    if (sl.nd_valid && sl.nd_hash == hash && sl.cur_n_blocks == h.n_blocks) {
+    if (same_graph) {
       h.nd_ready = 1;   // device mirrors of the plan and of this pair list are still in place (pointers kept in h)
     } else if (sl.nd_valid && dests_from_plan()) {
       ++g_plan_reuses;
@@ -692,8 +761,13 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     }
   }
   h.bound = 1;
-  HIPCHK(hipMemcpyAsync(s->frames_dev + slot, &h, sizeof(FrameDev), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));   // h is reused by later binds
+  bt_mark();                                   // [3] symbolic plan settled
+  // descriptor -> device through the slot's pinned mirror: no wait for the copy (the mirror always holds the newest
+  // host state, and every change of it is followed by another copy on the stream)
+  if (!sl.h_pin) HIPCHK(hipHostMalloc((void**)&sl.h_pin, sizeof(FrameDev), hipHostMallocDefault));
+  memcpy(sl.h_pin, &h, sizeof(FrameDev));
+  HIPCHK(hipMemcpyAsync(s->frames_dev + slot, sl.h_pin, sizeof(FrameDev), hipMemcpyHostToDevice, st));
+  bt_mark();                                   // [4] descriptor on its way
   if (!h.nd_ready) {
     std::lock_guard<std::mutex> lock(s->band_mutex);
     int rc = ensure_band(s, slot, st);
@@ -701,6 +775,13 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   }
   launch_init_slot(s->frames_dev, slot, f->J, s->cfg, st);
   HIPCHK(hipGetLastError());
+  bt_mark();                                   // [5] end
+  if (bind_trace_threshold() >= 0.0 && g_bt.n >= 2 && g_bt.t[g_bt.n - 1] - g_bt.t[0] > bind_trace_threshold()) {
+    char buf[256];
+    int o = snprintf(buf, sizeof(buf), "[slm bind trace] slot %d start %.3f stages(ms):", slot, g_bt.t[0]);
+    for (int i = 1; i < g_bt.n && o < 220; ++i) o += snprintf(buf + o, sizeof(buf) - o, " %.3f", g_bt.t[i] - g_bt.t[i - 1]);
+    fprintf(stderr, "%s\n", buf);
+  }
   return SLM_OK;
 }
 
@@ -747,7 +828,9 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
   // The binds read sizes back, so they wait for the work already on `st` in any case: wait for it HERE, on one
   // thread, rather than with W workers spinning in their first read-back for as long as the previous LM run takes
   // (8 busy threads for tens of milliseconds per step cost the process its CPU quota on the GPU box).
+  const double bt0 = bind_trace_threshold() >= 0.0 ? bt_now() : 0.0;
   HIPCHK(hipStreamSynchronize(st));
+  const double bt1 = bind_trace_threshold() >= 0.0 ? bt_now() : 0.0;
   HIPCHK(hipEventRecord(s->bind_events[W], st));            // fork: the workers see everything enqueued on `st` so far
   // (no exception may cross the extern "C" boundary: the containers are sized before any worker starts, the pool throws
   //  only from thread creation, and a worker catches whatever its bind throws -- std::bad_alloc from a plan vector)
@@ -782,6 +865,9 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
   }
   for (int w = 0; w < W; ++w)
     if (rcs[w] != SLM_OK) return fail(rcs[w], errs[w].c_str());
+  if (bind_trace_threshold() >= 0.0 && bt_now() - bt1 > bind_trace_threshold())
+    fprintf(stderr, "[slm bind trace] batch of %d: drained the stream at %.3f (waited %.3f ms), workers done %.3f ms later\n",
+            n_frames, bt1, bt1 - bt0, bt_now() - bt1);
   for (int w = 0; w < W; ++w) HIPCHK(hipStreamWaitEvent(st, s->bind_events[w], 0));   // join
   return SLM_OK;
 }

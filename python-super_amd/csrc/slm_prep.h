@@ -26,6 +26,7 @@ struct V1Plan {
   double* wgslab = nullptr;
   int32_t* blk2_start = nullptr;
   int32_t* blk2_entry = nullptr;
+  int32_t nt_hint = 0;            // distinct KNN tuples of the frame this plan was last built for (0: none yet)
   size_t cap_rchunk = 0, cap_wg = 0, cap_lidx = 0, cap_wgslab = 0, cap_b2start = 0, cap_b2entry = 0;
   size_t cap_pts = 0, cap_idx = 0, cap_w = 0, cap_grp = 0, cap_runs = 0, cap_slab = 0, cap_bkey = 0,
          cap_bstart = 0, cap_bentry = 0;
@@ -34,10 +35,13 @@ struct V1Plan {
 struct V1Sizes {
   int n_tuples, n_pos, n_runs, n_blocks;
   int n_wblk, max_wblk_per_wg;   // v2 records; v2 is usable when max_wblk_per_wg <= SLM_LB_MAX
+  // hashes of the coupling graph, computed on the device: (J, K_ED, node KNN table) and the same continued over the
+  // coupled-pair keys -- what the cached symbolic plan of a slot is compared with
+  uint64_t knn_hash = 0, graph_hash = 0;
 };
 
 PrepBuffers* prep_create();
 void prep_destroy(PrepBuffers*);
-// Builds the plan for frame f (stream-synchronising: two small read-backs).
+// Builds the plan for frame f (stream-synchronising: one small read-back, two for a plan's first frame).
 hipError_t prep_v1(PrepBuffers*, const slm_frame& f, V1Plan& plan, V1Sizes* out, hipStream_t st);
 void plan_free(V1Plan& plan);

@@ -229,6 +229,36 @@ __global__ void __launch_bounds__(256) k_run_lidx(int nwb_bound, const int* __re
   }
 }
 
+// Hash of the coupling graph on the DEVICE, so that a bind whose graph is the one the slot's symbolic plan was built
+// for needs no read-back of the lists at all: out[0] = hash of (J, K_ED, node KNN table), out[1] = the same continued
+// over the coupled-pair keys.  h = sum_i mix(word_i, i) mod 2^64 -- position dependent, and a sum, so the order in
+// which the threads add does not matter (integer atomics: bitwise reproducible).
+__device__ __forceinline__ unsigned long long plan_mix(unsigned long long w, unsigned long long i) {
+  unsigned long long z = (w ^ ((i + 1ull) * 0x9E3779B97F4A7C15ull)) + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_plan_hash(int J, int K_ED, const int32_t* __restrict__ ed_knn,
+                                                    const int32_t* __restrict__ blk_key, const int* __restrict__ scal,
+                                                    unsigned long long* __restrict__ out) {
+  const int n_knn = J * K_ED, n_pairs = scal[3];
+  unsigned long long h0 = 0, h1 = 0;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  if (tid == 0) h0 = plan_mix((unsigned long long)(unsigned)J << 32 | (unsigned)K_ED, ~0ull);
+  for (int i = tid; i < n_knn; i += nthr) h0 += plan_mix((unsigned)ed_knn[i], (unsigned long long)i);
+  for (int i = tid; i < n_pairs; i += nthr) h1 += plan_mix((unsigned)blk_key[i], (1ull << 40) + (unsigned long long)i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    h0 += __shfl_down(h0, o, 64);
+    h1 += __shfl_down(h1, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, h0);
+    atomicAdd(out + 1, h0 + h1);
+  }
+}
+
 // blk2_start[n_blocks] = number of live records (end of the last live pair)
 __global__ void k_totals3(const int* __restrict__ scal, int* __restrict__ blk2_start) {
   blk2_start[scal[3]] = scal[6];
@@ -270,14 +300,14 @@ struct PrepBuffers {
   void* tmp = nullptr;
   size_t cap_tmp = 0;
   size_t q_n = 0, q_t = 0, q_e = 0;   // sizes the rocPRIM temporary-storage requirement was last queried for
-  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique
+  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique, ..., [8..11] the two 64-bit graph hashes
   int* scal_host = nullptr;   // pinned mirror
 };
 
 PrepBuffers* prep_create() {
   PrepBuffers* p = new PrepBuffers();
-  if (hipMalloc((void**)&p->scal, 8 * sizeof(int)) != hipSuccess ||
-      hipHostMalloc((void**)&p->scal_host, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+  if (hipMalloc((void**)&p->scal, 12 * sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&p->scal_host, 12 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
     prep_destroy(p);
     return nullptr;
   }
@@ -374,10 +404,22 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   size_t b1 = p->cap_tmp, b2 = p->cap_tmp;
   PCHK(rocprim::radix_sort_pairs(p->tmp, b1, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
   PCHK(rocprim::run_length_encode(p->tmp, b2, p->skeys, N, p->tkeys, p->tcount, p->scal, st));
-  PCHK(hipMemcpyAsync(p->scal_host, p->scal, sizeof(int), hipMemcpyDeviceToHost, st));
-  PCHK(hipStreamSynchronize(st));
-  const size_t nt = (size_t)p->scal_host[0];
-  if (nt == 0) return hipSuccess;
+  // The tuple count sizes the buffers and grids of everything below.  A plan that has been built before carries the
+  // count of its last frame: with 12 % + 64 head-room on that hint as the BOUND nothing has to be read back here (the
+  // kernels take the true count from the device, the bound only sizes grids and scans) -- the one read-back at the end
+  // says whether the bound held; if not (the scene changed abruptly) the preparation runs again with the exact count.
+  // A host <-> device round trip costs 0.1 ms when all is well and was seen to take 3-7 ms now and then (stall_hunt.py).
+  size_t nt;
+  const bool hinted = plan.nt_hint > 0;
+  if (hinted) {
+    nt = (size_t)plan.nt_hint + (size_t)plan.nt_hint / 8 + 64;
+    if (nt > N) nt = N;
+  } else {
+    PCHK(hipMemcpyAsync(p->scal_host, p->scal, sizeof(int), hipMemcpyDeviceToHost, st));
+    PCHK(hipStreamSynchronize(st));
+    nt = (size_t)p->scal_host[0];
+    if (nt == 0) return hipSuccess;
+  }
 
   // ---- phase B: layout, sorted copies, inverted index ------------------------------
   const size_t pos_bound = (N + 3 * nt + 63) / 64 * 64;
@@ -491,9 +533,20 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   PCHK(rocprim::run_length_encode(p->tmp, c5, p->spk2, n_entries, p->upk2, p->b2count, p->scal + 4, st));
   PCHK(rocprim::exclusive_scan(p->tmp, c3, p->b2count, plan.blk2_start, 0, n_entries, rocprim::plus<int>(), st));
   hipLaunchKernelGGL(k_totals3, dim3(1), dim3(1), 0, st, p->scal, plan.blk2_start);
+  // hash of the coupling graph (node KNN table + pair keys): rides along with the sizes in the one read-back
+  PCHK(hipMemsetAsync(p->scal + 8, 0, 4 * sizeof(int), st));
+  hipLaunchKernelGGL(k_plan_hash, dim3(16), blk, 0, st, f.J, f.K_ED, f.ed_knn_idx, plan.blk_key, p->scal,
+                     reinterpret_cast<unsigned long long*>(p->scal + 8));
 
-  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 12 * sizeof(int), hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
+  if ((size_t)p->scal_host[0] > nt) {   // the hinted bound did not hold: once more with the exact count
+    plan.nt_hint = 0;
+    return prep_v1(p, f, plan, out, st);
+  }
+  plan.nt_hint = p->scal_host[0];
+  memcpy(&out->knn_hash, p->scal_host + 8, 8);
+  memcpy(&out->graph_hash, p->scal_host + 10, 8);
   out->n_tuples = p->scal_host[0];
   out->n_pos = (p->scal_host[1] + 63) / 64 * 64;
   out->n_runs = p->scal_host[2];
