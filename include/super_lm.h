@@ -607,7 +607,8 @@ int slm_debug_counters(int64_t out[4]);
  * length; at most max_doubles are copied. */
 /* Diagnostics of the task-graph solver (solver_path 2): with on != 0 every task of the slot records
  * {start, last dependency ready, end} (10 ns ticks) and its workgroup into a trace that slm_debug_read returns
- * as what = 4 (24 int64 per task, reinterpret the doubles) and what = 5 (the task words, 2 int32 per task). */
+ * as what = 4 (24 int64 per task, reinterpret the doubles) and what = 5 (the task words, 2 int32 per task; what = 6: the
+ * task words of the top-of-tree list the hybrid form runs, which the trace is indexed by after a hybrid solve). */
 int slm_debug_dag_trace(slm_solver* s, int32_t slot, int32_t on, void* stream);
 int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, int64_t max_doubles,
                    int64_t* n_doubles, void* stream);

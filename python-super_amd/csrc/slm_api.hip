@@ -19,7 +19,7 @@
 void launch_data_grad(const FrameDev*, int, int, double, hipStream_t);
 void launch_data_loss(const FrameDev*, int, int, double, int, hipStream_t);
 void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
-void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t);
+void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t, const int* reuse = nullptr);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_assemble(const FrameDev*, int, int, hipStream_t);
@@ -27,7 +27,7 @@ void launch_pair_reduce(const FrameDev*, int, int, hipStream_t);
 void launch_pair_scatter(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
-void launch_iter_begin_nd(const FrameDev*, int, hipStream_t);
+void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse = nullptr);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
 void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
@@ -41,7 +41,7 @@ void launch_iter_begin(const FrameDev*, int, hipStream_t);
 void launch_pack_nodes(const FrameDev*, int, int, hipStream_t);
 void launch_make_trial(const FrameDev*, int, int, hipStream_t);
 void launch_pack_target(int, const float*, const float*, float4*, hipStream_t);
-void launch_accept(const FrameDev*, int, int, int, int, hipStream_t);
+void launch_accept(const FrameDev*, int, int, int, int, hipStream_t, int* reuse = nullptr);
 void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
 void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
@@ -233,6 +233,7 @@ struct slm_solver {
   std::vector<hipEvent_t> bind_events;
   std::mutex band_mutex;        // the bandwidth read-back buffer of ensure_band is shared
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
+  bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
@@ -242,6 +243,8 @@ struct slm_solver {
   FrameDev* frames_dev = nullptr;
   int* bw_dev = nullptr;
   int* bw_host = nullptr;       // pinned
+  int* reuse_dev = nullptr;     // per slot: 1 after a rejected iteration -- the next Jacobian pass of the LM loop reuses the
+                                // records of the last one (k_accept writes, k_data_gram / k_iter_begin_nd read)
   int rank = 0, world = 1;      // surfel sharding of every frame (slm_set_shard)
   bool shard_mode = false;      // slm_set_shard was called (world == 1 included): slots carry the exchange buffers
 };
@@ -316,6 +319,7 @@ int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, 
     case 3: src = sl.h.delta; n = sl.h.P; break;
     case 4: src = reinterpret_cast<const double*>(sl.h.dag_trace.get()); n = sl.h.dag_trace ? 24 * (int64_t)sl.h.n_dag_tasks : 0; break;
     case 5: src = reinterpret_cast<const double*>(sl.h.dag_tasks.get()); n = sl.h.nd_ready ? sl.h.n_dag_tasks : 0; break;
+    case 6: src = reinterpret_cast<const double*>(sl.h.dag_top_tasks.get()); n = sl.h.nd_ready ? sl.h.n_dag_top_tasks : 0; break;
     default: return fail(SLM_ERR_INVALID, "slm_debug_read: unknown buffer");
   }
   *n_doubles = n;
@@ -368,6 +372,8 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   hipError_t e = hipMalloc((void**)&s->frames_dev, sizeof(FrameDev) * cfg->max_frames);
   if (e == hipSuccess) e = hipMemset(s->frames_dev, 0, sizeof(FrameDev) * cfg->max_frames);
   if (e == hipSuccess) e = hipMalloc((void**)&s->bw_dev, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&s->reuse_dev, sizeof(int) * cfg->max_frames);
+  if (e == hipSuccess) e = hipMemset(s->reuse_dev, 0, sizeof(int) * cfg->max_frames);
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->bw_host, sizeof(int), hipHostMallocDefault);
   if (e == hipSuccess) {
     s->prep = prep_create();
@@ -379,6 +385,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
     return SLM_ERR_HIP;
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
+  if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
   *out = s;
   return SLM_OK;
 }
@@ -427,6 +434,7 @@ int slm_destroy(slm_solver* s) {
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->frames_dev) (void)hipFree(s->frames_dev);
   if (s->bw_dev) (void)hipFree(s->bw_dev);
+  if (s->reuse_dev) (void)hipFree(s->reuse_dev);
   if (s->bw_host) (void)hipHostFree(s->bw_host);
   delete s;
   return SLM_OK;
@@ -774,6 +782,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     if (rc) return rc;
   }
   launch_init_slot(s->frames_dev, slot, f->J, s->cfg, st);
+  HIPCHK(hipMemsetAsync(s->reuse_dev + slot, 0, sizeof(int), st));   // a new frame: nothing to reuse
   HIPCHK(hipGetLastError());
   bt_mark();                                   // [5] end
   if (bind_trace_threshold() >= 0.0 && g_bt.n >= 2 && g_bt.t[g_bt.n - 1] - g_bt.t[0] > bind_trace_threshold()) {
@@ -1060,9 +1069,10 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FrameDev* fr = s->frames_dev;
-  launch_iter_begin_nd(fr, n_frames, st);
+  const int* reuse = (s->cfg.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
+  launch_iter_begin_nd(fr, n_frames, st, reuse);
   if (s->cfg.use_data) {
-    launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st);
+    launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st, reuse);
     launch_pair_reduce(fr, n_frames, d.max_blocks, st);
   }
   HIPCHK(hipGetLastError());
@@ -1105,7 +1115,8 @@ int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream) {
   BatchDims d;
   int rc = shard_dims(s, n_frames, d);
   if (rc) return rc;
-  launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, std::max(s->cfg.num_iterations, 1), (hipStream_t)stream);
+  launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, std::max(s->cfg.num_iterations, 1), (hipStream_t)stream,
+                s->cfg.phase_test ? s->reuse_dev : nullptr);
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -1187,14 +1198,17 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
       evs->push_back(e);
     };
     mark();
+    // (records of the Jacobian pass are reused after a rejected step on the multifrontal path, where the assembly
+    //  re-reads them; the banded path adds into the band in place)
+    const int* reuse = (d.nd && d.v1 && c.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
     if (d.nd) {
-      launch_iter_begin_nd(fr, n_frames, st);
+      launch_iter_begin_nd(fr, n_frames, st, reuse);
     } else {
       launch_iter_begin(fr, n_frames, st);
     }
     mark();
     if (c.use_data) {
-      if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, d.gram_variants, st);
+      if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, d.gram_variants, st, reuse);
       else launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
     }
     mark();
@@ -1215,7 +1229,8 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     mark();
     if (d.n_reg_part > 0)
       launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
-    launch_accept(fr, n_frames, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st);
+    launch_accept(fr, n_frames, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st,
+                  (d.nd && d.v1 && c.phase_test) ? s->reuse_dev : nullptr);
     mark();
   }
   HIPCHK(hipGetLastError());
@@ -1301,6 +1316,7 @@ int slm_set_beta(slm_solver* s, int32_t slot, const double* in, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // fresh LM state (u0, minimal_loss0, records), then the caller's beta
   launch_init_slot(s->frames_dev, slot, h.f.J, s->cfg, st);
+  HIPCHK(hipMemsetAsync(s->reuse_dev + slot, 0, sizeof(int), st));   // another beta: the kept records do not apply
   HIPCHK(hipMemcpyAsync(h.beta, in, sizeof(double) * h.P, hipMemcpyDeviceToDevice, st));
   launch_pack_nodes(s->frames_dev, slot, h.f.J, st);
   return SLM_OK;

@@ -34,10 +34,15 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // than one 768-double Gram per run, and the assemble kernels read contiguous records.
 template <bool MERGE>
 __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict__ frames, double lam,
-                                                       int dbg) {
+                                                       int dbg, const int* __restrict__ reuse) {
   __shared__ double rows[4][64 * ROW_STRIDE];
   __shared__ double recs[MERGE ? SLM_LB_MAX * SLM_WREC : 1];
   __shared__ uint8_t lidx[4][MERGE ? 160 : 4];   // per wave: record of each of the 10 node pairs of its 16 groups
+  // After a REJECTED step beta is rolled back, so this pass would reproduce the records of the previous iteration
+  // entry for entry (reference super/LM.py:114-117 then :96 rebuilds an identical JtJ): the slot keeps them and
+  // k_front_assemble re-reads them.  (The flag sits in an array of its own, indexed by the slot: a load that does not
+  // depend on the descriptor, so it costs the accepted iterations nothing.)
+  if (reuse && reuse[blockIdx.y]) return;
   const FrameDev& fd = frames[blockIdx.y];
   // (no test of st->stopped here: a stopped slot only wastes this pass, and the test would put one more
   //  dependent load in front of everything)
@@ -246,15 +251,15 @@ __global__ void __launch_bounds__(256) k_band_assemble(const FrameDev* __restric
 
 // variants: bit0 = some slot uses the workgroup-merged records, bit1 = some slot uses the per-run slab
 void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, int variants,
-                      hipStream_t st) {
+                      hipStream_t st, const int* reuse) {
   if (max_pos <= 0) return;
   int dbg = 0;
 #ifdef SLM_STAMPS
   if (const char* e = getenv("SLM_DBG")) dbg = atoi(e);
 #endif
   const dim3 grid((max_pos + 255) / 256, n_frames);
-  if (variants & 1) hipLaunchKernelGGL(k_data_gram<true>, grid, dim3(256), 0, st, frames_dev, lam, dbg);
-  if (variants & 2) hipLaunchKernelGGL(k_data_gram<false>, grid, dim3(256), 0, st, frames_dev, lam, dbg);
+  if (variants & 1) hipLaunchKernelGGL(k_data_gram<true>, grid, dim3(256), 0, st, frames_dev, lam, dbg, reuse);
+  if (variants & 2) hipLaunchKernelGGL(k_data_gram<false>, grid, dim3(256), 0, st, frames_dev, lam, dbg, reuse);
 }
 
 void launch_band_assemble(const FrameDev* frames_dev, int n_frames, int max_blocks, hipStream_t st) {

@@ -443,7 +443,7 @@ __device__ __forceinline__ void zero_fronts(const FrameDev& fd, int what, int b,
 // boundary blocks are written once by their own Schur kernels / tasks, never zeroed), the front vectors, rhs and the
 // counters, for ALL slots of the batch in one launch (one hipMemsetAsync pair per slot cost
 // ~25 us each, back to back).  grid = (blocks, n_frames); contiguous 16 KB pieces per workgroup.
-__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames) {
+__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames, const int* __restrict__ reuse) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || fd.st->stopped) return;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restric
   const size_t nrhs = (size_t)fd.nt * SLM_NB;
   for (size_t e = tid; e < nrhs; e += nthr) fd.rhs[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    fd.st->m_grad = 0;
+    if (!(reuse && reuse[blockIdx.y])) fd.st->m_grad = 0;   // (a reused Jacobian pass keeps its matched count)
     fd.st->chol_fail = 0;
   }
 }
@@ -1258,8 +1258,8 @@ void launch_front_load_rhs(const FrameDev* fr, int n_frames, int maxP, hipStream
   hipLaunchKernelGGL(k_front_load_rhs, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, fr);
 }
 
-void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st) {
-  hipLaunchKernelGGL(k_iter_begin_nd, dim3(1024, n_frames), dim3(256), 0, st, fr);
+void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st, const int* reuse) {
+  hipLaunchKernelGGL(k_iter_begin_nd, dim3(1024, n_frames), dim3(256), 0, st, fr, reuse);
 }
 
 // Level schedule shared by all slots of a batch (they may have different plans: the host

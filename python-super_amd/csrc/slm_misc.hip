@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_iter_begin(const FrameDev* __restrict__
 // Records are kept for the first n_rec iterations after the bind (the capacity of fd.rec): running again
 // without binding continues the loop from the current state and records nothing more.
 __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ frames, int phase_test,
-                                                  int n_reg_part, int n_rec) {
+                                                  int n_reg_part, int n_rec, int* __restrict__ reuse) {
   __shared__ double sm[16];
   __shared__ int s_accept;
   const FrameDev& fd = frames[blockIdx.y];
@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
     if (it < n_rec) fd.rec[it] = r;
     st->iter = it + 1;
     s_accept = acc;
+    if (reuse) reuse[blockIdx.y] = acc ? 0 : 1;   // rejected: the next Jacobian pass would repeat this one (k_data_gram)
   }
   __syncthreads();
   if (s_accept) {
@@ -492,9 +493,9 @@ void launch_iter_begin(const FrameDev* frames_dev, int n_frames, hipStream_t st)
 }
 
 void launch_accept(const FrameDev* frames_dev, int n_frames, int phase_test, int n_reg_part, int n_rec,
-                   hipStream_t st) {
+                   hipStream_t st, int* reuse) {
   hipLaunchKernelGGL(k_accept, dim3(1, n_frames), dim3(1024), 0, st, frames_dev, phase_test,
-                     n_reg_part, n_rec);
+                     n_reg_part, n_rec, reuse);
 }
 
 void launch_loss_out(const FrameDev* frames_dev, int slot, int n_reg_part, double* out,

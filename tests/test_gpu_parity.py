@@ -355,3 +355,30 @@ def test_lm_is_bitwise_reproducible_with_the_per_run_slab():
         np.testing.assert_array_equal(beta, runs[0][0])
         assert losses == runs[0][1]
     np.testing.assert_allclose(runs[0][0], g["lm_beta"], rtol=0, atol=TOL_BETA)
+
+
+def test_rejected_iterations_reuse_the_jacobian_pass_bit_for_bit(monkeypatch):
+    """After a rejected step beta is rolled back, so the next Jacobian pass would rebuild the same JtJ (reference
+    super/LM.py:114-117, :96): the library keeps the Gram records of the slot instead.  On the run-to-run reproducible
+    data path (data_path 2) the result must be BITWISE the one of recomputing (SLM_NO_REUSE=1), and the fixture must
+    contain rejected iterations for the test to mean anything."""
+    from helpers import load_golden
+    import torch
+    from super_amd.engine import DeviceFrame, Engine
+    g, sc, opt = load_golden("s60x80_j48_reject")
+    assert not g["lm_accepted"].all()
+    n_it = int(opt.num_optimize_iterations) + 8      # the fixture's reject is its last iteration: run on past it
+    out = []
+    for no_reuse in ("0", "1"):
+        monkeypatch.setenv("SLM_NO_REUSE", no_reuse)
+        eng = Engine(torch.device("cuda", 0), data_path=2, num_iterations=n_it)
+        eng.bind(0, DeviceFrame.from_scene(sc, torch.device("cuda", 0), state_f64=True))
+        eng.run(1)
+        recs = eng.records(0)
+        out.append((eng.beta(0).cpu().numpy(), [(r["loss"], r["u"], r["accepted"], r["M_grad"], r["M_loss"]) for r in recs]))
+        eng.close()
+    acc = [r[2] for r in out[0][1]]
+    assert acc[:len(g["lm_accepted"])] == [bool(a) for a in g["lm_accepted"]]
+    assert False in acc[:-1]                         # a rejected iteration that is followed by another one
+    assert out[0][1] == out[1][1]
+    np.testing.assert_array_equal(out[0][0], out[1][0])

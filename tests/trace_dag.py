@@ -12,7 +12,8 @@ from super_amd.engine import DeviceFrame, Engine
 dev = torch.device("cuda", 0)
 wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-e = Engine(dev, solver_path=2, max_frames=B)
+HYBRID = "--hybrid" in sys.argv      # the top-of-tree task list of the hybrid form (solver_path 4) instead of the whole tree
+e = Engine(dev, solver_path=4 if HYBRID else 2, max_frames=B)
 for i in range(B):
     e.bind(i, DeviceFrame.from_scene(synth.make_scene(seed=i, **synth.WORKLOADS[wl]), dev))
 e.run(B)
@@ -31,7 +32,8 @@ def read(what, dtype):
 
 
 tr = read(4, np.int64).reshape(-1, 24)
-tk = read(5, np.int32).reshape(-1, 2)
+tk = read(6 if HYBRID else 5, np.int32).reshape(-1, 2)
+tr = tr[:len(tk)]
 typ, front, r, s = tk[:, 0] >> 24, tk[:, 0] & 0xFFFFFF, tk[:, 1] >> 8, tk[:, 1] & 255
 t0 = tr[:, 0].min()
 st, rd, en = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0, (tr[:, 2] - t0) / 100.0   # microseconds
