@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 KEEP = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count",
@@ -44,4 +44,7 @@ subprocess.check_call([sys.executable, os.path.join(P, "make_traffic.py"), trimm
                        "--workload", "C2", "--frames-per-gpu", "8", "--out", os.path.join(P, f"{tag}_pmc_traffic.json")])
 subprocess.check_call([sys.executable, os.path.join(P, "make_sq_summary.py")] +
                       sorted(glob.glob(os.path.join(G, f"{tag}_pmc_sq_*/"))) + ["--out", os.path.join(P, f"{tag}_pmc_sq_summary.csv")])
+avail = os.path.join(G, f"{tag}_mfma_counters_available.txt")
+if os.path.exists(avail):
+    shutil.copy(avail, os.path.join(P, f"{tag}_mfma_counters_available.txt"))
 print("installed", sorted(os.path.basename(p) for p in glob.glob(os.path.join(P, tag + "_*"))))
