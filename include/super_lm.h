@@ -610,6 +610,14 @@ int slm_debug_counters(int64_t out[4]);
  * as what = 4 (24 int64 per task, reinterpret the doubles) and what = 5 (the task words, 2 int32 per task; what = 6: the
  * task words of the top-of-tree list the hybrid form runs, which the trace is indexed by after a hybrid solve). */
 int slm_debug_dag_trace(slm_solver* s, int32_t slot, int32_t on, void* stream);
+/* Diagnostics / tests: the deadline of a wait inside the task-graph solver, in ticks of the 100 MHz wall clock, for every
+ * solver of the process on the current device (0 restores the default of 3 s).  A wait that exceeds it aborts the launch;
+ * the slots whose solve did not finish record SLM_ITER_SOLVER_TIMEOUT and stop like after a failed factorisation. */
+int slm_debug_dag_timeout(int64_t ticks);
+/* Tests: leaves slots [0, n_frames) in the state an ABORTED task-graph launch leaves behind (flags reset, abort flag up,
+ * no front has published its solution), runs the check every launch ends with and the accept step: every slot must
+ * record SLM_ITER_SOLVER_TIMEOUT for its current iteration and stop (also the slots past the first 64 of a batch). */
+int slm_debug_dag_abort(slm_solver* s, int32_t n_frames, void* stream);
 int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, int64_t max_doubles,
                    int64_t* n_doubles, void* stream);
 

@@ -30,6 +30,8 @@ void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse = nullptr);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
 void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
+hipError_t set_dag_timeout_ticks(long long);
+void launch_dag_abort_check(const FrameDev*, int, hipStream_t);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
 void launch_reg_loss(const FrameDev*, int, int, int, double, int, double, int, hipStream_t);
 void launch_bandwidth(const slm_frame&, int*, hipStream_t);
@@ -275,6 +277,9 @@ static hipError_t grow(GP<T>& p, size_t& cap, size_t need) {   // (a descriptor 
   return e;
 }
 
+static int check_slots(slm_solver* s, int first, int n);
+static int check_slots_fwd(slm_solver* s, int first, int n) { return check_slots(s, first, n); }
+
 extern "C" {
 
 const char* slm_last_error(void) { return g_err.c_str(); }
@@ -287,6 +292,24 @@ int slm_debug_counters(int64_t out[4]) {
   out[1] = g_realloc_bytes;
   out[2] = g_plan_builds;
   out[3] = g_plan_reuses;
+  return SLM_OK;
+}
+
+int slm_debug_dag_timeout(int64_t ticks) {
+  if (ticks < 0) return fail(SLM_ERR_INVALID, "slm_debug_dag_timeout: negative");
+  HIPCHK(set_dag_timeout_ticks(ticks == 0 ? 300000000ll : (long long)ticks));
+  return SLM_OK;
+}
+
+int slm_debug_dag_abort(slm_solver* s, int32_t n_frames, void* stream) {
+  int rc = check_slots_fwd(s, 0, n_frames);
+  if (rc) return rc;
+  for (int i = 0; i < n_frames; ++i)
+    if (!s->slots[i].h.nd_ready) return fail(SLM_ERR_UNSUPPORTED, "slm_debug_dag_abort: every slot needs a nested-dissection plan");
+  hipStream_t st = (hipStream_t)stream;
+  launch_dag_abort_check(s->frames_dev, n_frames, st);
+  launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, 0, std::max(s->cfg.num_iterations, 1), st);
+  HIPCHK(hipGetLastError());
   return SLM_OK;
 }
 

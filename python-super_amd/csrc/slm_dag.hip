@@ -57,10 +57,11 @@ namespace {
 // never touches it.  A time-out sets the abort flag to 2 and is reported as SLM_ITER_SOLVER_TIMEOUT for the slots
 // whose solve did not finish (k_dag_check), distinct from a non-positive pivot.
 #define DAG_TIMEOUT_TICKS 300000000ll   // 3 s
+__device__ long long g_dag_timeout_ticks = DAG_TIMEOUT_TICKS;   // (slm_debug_dag_timeout: tests shorten it to force an abort)
 __device__ __forceinline__ bool dag_timed_out(long long& t0) {
   const long long now = (long long)wall_clock64();
   if (t0 == 0) { t0 = now; return false; }
-  return now - t0 > DAG_TIMEOUT_TICKS;
+  return now - t0 > g_dag_timeout_ticks;
 }
 
 // Every hand-off access is a GLOBAL-segment instruction with sc1 (global_load / global_store ... sc1): pointers read
@@ -1313,6 +1314,20 @@ __global__ void __launch_bounds__(64) k_dag_check(const FrameDev* __restrict__ f
   if (!__all(done) && threadIdx.x == 0 && fd.st->chol_fail == 0) fd.st->chol_fail = 2;
 }
 
+// tests: what an aborted launch leaves behind -- flags reset (no front has published its solution), abort flag up --
+// followed by the check that every launch ends with
+__global__ void k_dag_raise_abort(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd0 = frames[0];
+  if (fd0.bound && fd0.nd_ready && fd0.dag_flags) fd0.dag_flags[1] = 2;
+}
+void launch_dag_abort_check(const FrameDev* fr, int n_frames, hipStream_t st) {
+  hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, -1);
+  hipLaunchKernelGGL(k_dag_raise_abort, dim3(1), dim3(1), 0, st, fr);
+  hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
+}
+hipError_t set_dag_timeout_ticks(long long ticks) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dag_timeout_ticks), &ticks, sizeof(ticks));
+}
 void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);

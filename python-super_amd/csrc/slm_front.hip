@@ -1024,13 +1024,35 @@ __global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ fram
   if (!itp) return;
   const FrameDev& fd = *fdp;
   const NDTileItem it = item_snapshot(itp);
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+  // only the 16 x 16 blocks that hold real scalars move: the padding of the last pivot tile column / of the last tile
+  // row of the pivots or of the boundary stays zero (nothing maps into it)
+  const int vrow = it.r < it.npt ? min(NB, it.n1 - NB * it.r) : min(NB, it.n2 - NB * (it.r - it.npt));
+  const int nblk = (min(NB, it.n1 - NB * it.c) + 15) >> 4;
+  const bool wave_on = 16 * w < vrow;
   pull_maps(fd, it, maps);
   double* T = item_tile(fd, it, it.r, it.c);
   double4_t acc[4];
-  load_c_frags(T, acc);
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+  if (wave_on) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      if (ni < nblk) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[ni][rr] = T[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * rr) * NB];
+      }
+  }
   __syncthreads();
-  pull_tile(fd, it, maps, acc);
-  store_c_frags(T, acc);
+  if (wave_on) {
+    pull_tile(fd, it, maps, acc);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+      if (ni < nblk) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) T[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * rr) * NB] = acc[ni][rr];
+      }
+  }
   if (it.r == it.c) {
     const double v = pull_vec(fd, it, maps);
     if (threadIdx.x < NB && v != 0.0) fd.fvec[it.vec_off + (size_t)it.c * NB + threadIdx.x] += v;

@@ -34,7 +34,7 @@ EXPORTS = [
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set", "slm_lm_exchange_ptr",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
     "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read", "slm_debug_dag_trace",
-    "slm_abi_version", "slm_abi_check",
+    "slm_abi_version", "slm_abi_check", "slm_debug_dag_timeout", "slm_debug_dag_abort",
 ]
 
 
@@ -179,6 +179,8 @@ def load():
         "slm_profile_enable": [vp, i32],
         "slm_get_plan_info": [vp, i32, C.POINTER(C.c_double), i32],
         "slm_abi_check": [i32, i32, i32, i32, i32, i32],
+        "slm_debug_dag_timeout": [C.c_int64],
+        "slm_debug_dag_abort": [vp, i32, vp],
         "slm_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
         "slm_get_beta": [vp, i32, vp, vp],
         "slm_set_beta": [vp, i32, vp, vp],

@@ -226,3 +226,34 @@ def test_c4_hybrid_batch_matches_level_launches():
         assert all(r["status"] == 0 for r in res[0][i][1])
         np.testing.assert_allclose([r["loss"] for r in res[0][i][1]], [r["loss"] for r in res[3][i][1]], rtol=1e-9)
         np.testing.assert_allclose(res[0][i][0], res[3][i][0], rtol=0, atol=1e-9)
+
+
+def test_an_aborted_task_graph_stops_every_unfinished_slot_of_a_large_batch():
+    """after an aborted task-graph launch EVERY slot whose solve did not finish must stop -- also slots
+    beyond the first 64 of a batch -- and with a status of its own (a scheduling time-out, not an ill-posed system).
+    `slm_debug_dag_abort` leaves the slots as an aborted launch does and runs the launch's own check + the accept step."""
+    import torch
+    from super_amd import _lib, synth
+    from super_amd.engine import DeviceFrame, Engine
+    B = 72
+    dev = torch.device("cuda", 0)
+    sc = synth.make_scene(N=1500, J=48, H=60, W=80, seed=5, src_border=5, tgt_border=3)
+    frames = [DeviceFrame.from_scene(sc, dev) for _ in range(B)]
+    eng = Engine(dev, max_frames=B, solver_path=2, num_iterations=3)
+    eng.bind_batch(frames)
+    _lib.check(eng.lib.slm_debug_dag_abort(eng.h, B, eng.stream), "abort")
+    eng.run(B)                                           # stopped slots: the remaining iterations are no-ops
+    recs = [eng.records(i) for i in range(B)]
+    assert [r[0]["status"] for r in recs] == [_lib.SLM_ITER_SOLVER_TIMEOUT] * B
+    assert all(x["status"] == _lib.SLM_ITER_NOT_RUN for r in recs for x in r[1:])
+    beta = eng.beta(B - 1).cpu().numpy()
+    np.testing.assert_array_equal(beta, np.tile([1.0, 0, 0, 0, 0, 0, 0], (sc.J, 1)))      # nothing was accepted
+    # the mirror says what happened
+    assert _lib.SLM_ITER_SOLVER_TIMEOUT != _lib.SLM_ITER_SOLVER_FAILED
+    # a fresh bind of the same batch solves (and a shortened, then restored deadline is accepted by the API)
+    _lib.check(eng.lib.slm_debug_dag_timeout(10 ** 9), "timeout")
+    _lib.check(eng.lib.slm_debug_dag_timeout(0), "timeout")
+    eng.bind_batch(frames)
+    eng.run(B)
+    assert all(r["status"] == _lib.SLM_ITER_OK for i in range(B) for r in eng.records(i))
+    eng.close()
