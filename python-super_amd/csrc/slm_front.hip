@@ -1312,12 +1312,18 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
     // One workgroup per front (k_fL11 + k_fL21) only pays when a level has enough fronts to fill the
     // chip: with few fronts the per-column panel launches, which spread a front over its row tiles, have
     // the shorter critical path (C2: 581 instead of 543 it/s at one frame per launch; the cross-over is
-    // around 128 fronts x frames).  SLM_COMPACT_MIN overrides the threshold for experiments.
+    // around 128 fronts x frames; 64 since round 3, with k_fL11 at two workgroups per CU and the leaner k_fL21: C2 at 8
+    // frames 2.133 instead of 2.147 ms per solve).  SLM_COMPACT_MIN / SLM_COMPACT_NPT override the thresholds for
+    // experiments (wider pivot blocks than 4 tile columns lose: 2.22 ms with the 5-column level in this form).
     static const long compact_min = [] {
       const char* e = getenv("SLM_COMPACT_MIN");
-      return e ? atol(e) : 128L;
+      return e ? atol(e) : 64L;
     }();
-    const bool compact = s.max_npt <= 4 && (long)s.n_fronts * n_frames >= compact_min;
+    static const int compact_npt = [] {
+      const char* e = getenv("SLM_COMPACT_NPT");
+      return e ? atoi(e) : 4;
+    }();
+    const bool compact = s.max_npt <= compact_npt && (long)s.n_fronts * n_frames >= compact_min;
     // children's update matrices into the pivot columns (levels whose fronts all are leaves have nothing to gather).
     // A launch of its own: gathering inside k_fL11 / k_fL21 (at the first touch of every pivot-column tile) was built
     // and measured -- one launch fewer per level, but the gathers then sit on the critical path of workgroups that run
