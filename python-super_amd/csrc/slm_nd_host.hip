@@ -493,20 +493,17 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       // when are the children's update tiles that tile (r,s) of this front gathers from complete?
       auto pulled = [&](int r, int s) {
         double t = 0.0;
+        const int32_t* pr = out.prng.data() + out.prng_off[i];   // (per tile row and child: the child's tile rows that map into it)
         for (int k = 0; k < 2; ++k) {
           const int ch = out.front_kids[2 * (size_t)i + k];
           if (ch < 0) continue;
+          const int rr = pr[2 * r + k], cc = pr[2 * s + k];
+          if (rr < 0 || cc < 0) continue;
           const NDFront& cf = out.fronts[ch];
-          const int32_t* pm = out.pullmap.data() + out.pull_off[ch];
-          int r0 = 1 << 30, r1 = -1, c0 = 1 << 30, c1 = -1;
-          for (int e = 0; e < 64; ++e) {
-            const int a = pm[64 * r + e], bb = pm[64 * s + e];
-            if (a >= 0) { r0 = std::min(r0, a >> 6); r1 = std::max(r1, a >> 6); }
-            if (bb >= 0) { c0 = std::min(c0, bb >> 6); c1 = std::max(c1, bb >> 6); }
-          }
+          const int r0 = rr & 255, r1 = rr >> 8, c0 = cc & 255, c1 = cc >> 8;
           for (int cr = r0; cr <= r1; ++cr)
-            for (int cc = c0; cc <= std::min(c1, cr); ++cc) {
-              const size_t ti = (size_t)(cf.npt + cc) * cf.nt - (size_t)(cf.npt + cc) * (cf.npt + cc - 1) / 2 + (size_t)(cr - cc);
+            for (int cc2 = c0; cc2 <= std::min(c1, cr); ++cc2) {
+              const size_t ti = (size_t)(cf.npt + cc2) * cf.nt - (size_t)(cf.npt + cc2) * (cf.npt + cc2 - 1) / 2 + (size_t)(cr - cc2);
               t = std::max(t, done_all[ch][ti] + HOP);
             }
         }
