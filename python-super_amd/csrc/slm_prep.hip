@@ -60,6 +60,16 @@ __global__ void __launch_bounds__(256) k_run_counts(const int* __restrict__ d_nt
   }
 }
 
+// A hinted preparation sizes its buffers and grids for `bound` tuples before the true count is known on the host: the
+// count every later kernel works with is cut down to the bound (a frame with more tuples is then prepared on a
+// truncated tuple list, inside its buffers, and prepared again by the host with the exact count); scal[12] keeps the
+// true count for that decision.
+__global__ void k_clamp_tuples(int* __restrict__ scal, int bound) {
+  const int nt = scal[0];
+  scal[12] = nt;
+  if (nt > bound) scal[0] = bound;
+}
+
 // scal[0] = n_tuples (already there), scal[1] = total padded positions, scal[2] = total runs
 __global__ void k_totals(int* __restrict__ scal, const int* __restrict__ pstart,
                          const int* __restrict__ pc, const int* __restrict__ rstart,
@@ -300,14 +310,14 @@ struct PrepBuffers {
   void* tmp = nullptr;
   size_t cap_tmp = 0;
   size_t q_n = 0, q_t = 0, q_e = 0;   // sizes the rocPRIM temporary-storage requirement was last queried for
-  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique, ..., [8..11] the two 64-bit graph hashes
+  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique, ..., [8..11] the two 64-bit graph hashes, [12] unclamped nt
   int* scal_host = nullptr;   // pinned mirror
 };
 
 PrepBuffers* prep_create() {
   PrepBuffers* p = new PrepBuffers();
-  if (hipMalloc((void**)&p->scal, 12 * sizeof(int)) != hipSuccess ||
-      hipHostMalloc((void**)&p->scal_host, 12 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+  if (hipMalloc((void**)&p->scal, 16 * sizeof(int)) != hipSuccess ||
+      hipHostMalloc((void**)&p->scal_host, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
     prep_destroy(p);
     return nullptr;
   }
@@ -406,7 +416,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   PCHK(rocprim::run_length_encode(p->tmp, b2, p->skeys, N, p->tkeys, p->tcount, p->scal, st));
   // The tuple count sizes the buffers and grids of everything below.  A plan that has been built before carries the
   // count of its last frame: with 12 % + 64 head-room on that hint as the BOUND nothing has to be read back here (the
-  // kernels take the true count from the device, the bound only sizes grids and scans) -- the one read-back at the end
+  // kernels take the count from the device, cut down to the bound by k_clamp_tuples; the bound sizes buffers, grids and scans) -- the one read-back at the end
   // says whether the bound held; if not (the scene changed abruptly) the preparation runs again with the exact count.
   // A host <-> device round trip costs 0.1 ms when all is well and was seen to take 3-7 ms now and then (stall_hunt.py).
   size_t nt;
@@ -414,6 +424,7 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   if (hinted) {
     nt = (size_t)plan.nt_hint + (size_t)plan.nt_hint / 8 + 64;
     if (nt > N) nt = N;
+    hipLaunchKernelGGL(k_clamp_tuples, dim3(1), dim3(1), 0, st, p->scal, (int)nt);
   } else {
     PCHK(hipMemcpyAsync(p->scal_host, p->scal, sizeof(int), hipMemcpyDeviceToHost, st));
     PCHK(hipStreamSynchronize(st));
@@ -538,9 +549,9 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   hipLaunchKernelGGL(k_plan_hash, dim3(16), blk, 0, st, f.J, f.K_ED, f.ed_knn_idx, plan.blk_key, p->scal,
                      reinterpret_cast<unsigned long long*>(p->scal + 8));
 
-  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 12 * sizeof(int), hipMemcpyDeviceToHost, st));
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 13 * sizeof(int), hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
-  if ((size_t)p->scal_host[0] > nt) {   // the hinted bound did not hold: once more with the exact count
+  if (hinted && (size_t)p->scal_host[12] > nt) {   // the hinted bound did not hold: once more with the exact count
     plan.nt_hint = 0;
     return prep_v1(p, f, plan, out, st);
   }

@@ -87,3 +87,35 @@ def test_running_again_without_binding_keeps_the_first_records():
     np.testing.assert_allclose(beta1, g["lm_beta"], rtol=0, atol=1e-6)
     assert np.isfinite(eng.beta(0).cpu().numpy()).all()
     eng.close()
+
+
+def test_a_slot_rebound_with_a_much_larger_and_then_smaller_scene_matches_a_fresh_solver():
+    """A slot's plan carries the tuple count of its last frame as the bound of the next preparation (no read-back);
+    when the scene grows past the bound's head-room the preparation reruns with the exact count, and a shrinking scene
+    is covered by the bound (a count above the bound used to run the preparation kernels past their buffers: a memory
+    fault).  Either way the state is the one a fresh solver builds (1e-12: the loss sums of a large frame are not
+    bit-reproducible from run to run)."""
+    import torch
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+    dev = torch.device("cuda", 0)
+    small = DeviceFrame.from_scene(synth.make_scene(seed=3, N=1500, J=96, H=120, W=160), dev)
+    large = DeviceFrame.from_scene(synth.make_scene(seed=4, N=24000, J=256, H=240, W=320), dev)
+    eng = Engine(dev, max_frames=1, num_iterations=4)
+    got = []
+    for f in (small, large, small, large):
+        eng.bind(0, f)
+        eng.run(1)
+        got.append((eng.beta(0).cpu().numpy().copy(), eng.records(0)))
+    eng.close()
+    for k, f in enumerate((small, large)):
+        ref = Engine(dev, max_frames=1, num_iterations=4)
+        ref.bind(0, f)
+        ref.run(1)
+        want, recs = ref.beta(0).cpu().numpy(), ref.records(0)
+        ref.close()
+        assert any(r["accepted"] for r in recs)
+        for j in (k, k + 2):
+            np.testing.assert_allclose(got[j][0], want, rtol=0, atol=1e-12)
+            assert [(r["status"], r["accepted"]) for r in got[j][1]] == [(r["status"], r["accepted"]) for r in recs]
+            np.testing.assert_allclose([r["loss"] for r in got[j][1]], [r["loss"] for r in recs], rtol=1e-12)
