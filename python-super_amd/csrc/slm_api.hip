@@ -1205,7 +1205,18 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
                 "slm_run: the frame is sharded; drive slm_lm_grad_local / slm_lm_solve / slm_lm_loss_local / "
                 "slm_lm_accept with the exchanges between them");
   hipStream_t st = (hipStream_t)stream;
-  const BatchDims d = dims_of(s, 0, n_frames);
+  BatchDims d = dims_of(s, 0, n_frames);
+  if (!d.nd) {
+    // A batch runs ONE solver form.  When some slot has no nested-dissection plan (a frame without surfels, a graph
+    // the analysis refuses) all of them take the block-banded path -- whose storage the slots WITH a plan have not
+    // been given at bind time: provide it now (a read-back per such slot; the rare path).
+    std::lock_guard<std::mutex> lock(s->band_mutex);
+    for (int i = 0; i < n_frames; ++i) {
+      rc = ensure_band(s, i, st);
+      if (rc) return rc;
+    }
+    d = dims_of(s, 0, n_frames);
+  }
   const FrameDev* fr = s->frames_dev;
   const slm_config& c = s->cfg;
   for (int it = 0; it < c.num_iterations; ++it) {

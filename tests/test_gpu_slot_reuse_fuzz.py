@@ -1,0 +1,90 @@
+"""Slot reuse under changing problem sizes: a seeded random sequence of frames of very different sizes (surfels, ED
+nodes, image, node-KNN width, incl. a frame without surfels and one without any valid target pixel) bound into the
+slots of ONE solver -- singly and through slm_bind_frames, on every solver form -- gives for every bind the state a
+fresh solver builds for that frame.  Grow-only buffers, the cached symbolic plan, the tuple-count hint and the
+descriptor mirrors of a slot all outlive a bind; this is the test that they do so harmlessly.  Needs an MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [dict(N=300, J=12, H=40, W=56, src_border=4, tgt_border=2),             # fewer nodes than one leaf front
+          dict(N=1500, J=96, H=120, W=160),
+          dict(N=900, J=24, H=40, W=56, src_border=4, tgt_border=2, n_ed_neighbors=6),
+          dict(N=24000, J=256, H=240, W=320),
+          dict(N=5000, J=108, H=120, W=160, src_border=6, tgt_border=3, n_ed_neighbors=8),
+          dict(N=60000, J=700, H=240, W=320),
+          dict(N=2000, J=48, H=60, W=80, src_border=5, tgt_border=3)]
+
+
+def _scenes():
+    from super_amd import synth
+    scs = [synth.make_scene(seed=50 + i, **kw) for i, kw in enumerate(SHAPES)]
+    empty = synth.make_scene(seed=70, **SHAPES[2])
+    for name in ("sf_points", "sf_norms", "sf_knn_idx", "sf_knn_w"):
+        setattr(empty, name, getattr(empty, name)[:0].copy())
+    blind = synth.make_scene(seed=71, **SHAPES[6])
+    blind.valid[:] = False
+    blind.index_map[:] = -1
+    return scs + [empty, blind]
+
+
+@pytest.mark.parametrize("solver_path", [0, 3, 4])
+def test_random_rebinds_match_fresh_solvers(solver_path):
+    import torch
+    from super_amd.engine import DeviceFrame, Engine
+    dev = torch.device("cuda", 0)
+    frames = [DeviceFrame.from_scene(sc, dev) for sc in _scenes()]
+    want = []
+    for f in frames:
+        e = Engine(dev, max_frames=1, num_iterations=4, solver_path=solver_path)
+        e.bind(0, f)
+        e.run(1)
+        want.append((e.beta(0).cpu().numpy().copy(), e.records(0)))
+        e.close()
+    S = 3
+    eng = Engine(dev, max_frames=S, num_iterations=4, solver_path=solver_path)
+    rng = np.random.default_rng(1234 + solver_path)
+    cur = [0, 3, 7]
+    eng.bind_batch([frames[k] for k in cur])
+
+    def check(tag):
+        eng.run(S)
+        torch.cuda.synchronize()
+        for slot, k in enumerate(cur):
+            beta, recs = eng.beta(slot).cpu().numpy(), eng.records(slot)
+            key = lambda rs: [(r["status"], r["accepted"], r["M_grad"]) for r in rs]
+            assert key(recs) == key(want[k][1]), (tag, slot, k)
+            np.testing.assert_allclose(beta, want[k][0], rtol=0, atol=1e-9, err_msg=f"{tag}: slot {slot} frame {k}")
+
+    check("first batch")
+    for step in range(14):
+        # (every slot is bound again in every step: slm_run on a slot that was not would continue its LM loop)
+        cur = [int(k) for k in rng.integers(0, len(frames), size=S)]
+        if step % 3 == 2:
+            eng.bind_batch([frames[k] for k in cur])
+        else:
+            for slot in rng.permutation(S):
+                eng.bind(int(slot), frames[cur[slot]])
+        check(f"step {step}")
+    eng.close()
+
+
+def test_rebinding_does_not_leak_device_memory():
+    """The buffers of a slot only grow: alternating two frames for a while leaves the free device memory where it
+    was once both have been seen."""
+    import torch
+    from super_amd.engine import DeviceFrame, Engine
+    dev = torch.device("cuda", 0)
+    scs = _scenes()
+    a, b = DeviceFrame.from_scene(scs[3], dev), DeviceFrame.from_scene(scs[1], dev)
+    eng = Engine(dev, max_frames=2, num_iterations=2)
+    free = []
+    for it in range(40):
+        eng.bind(0, a if it % 2 else b)
+        eng.bind_batch([b, a] if it % 3 else [a, b])
+        eng.run(2)
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info(dev)[0])
+    eng.close()
+    assert free[8] - free[-1] <= 4 << 20, (free[8], free[-1])
