@@ -29,22 +29,22 @@ def _scenes():
     return scs + [empty, blind]
 
 
-@pytest.mark.parametrize("solver_path", [0, 3, 4])
-def test_random_rebinds_match_fresh_solvers(solver_path):
+@pytest.mark.parametrize("solver_path,data_path", [(0, 0), (3, 0), (4, 0), (2, 0), (1, 0), (0, 1), (0, 2)])
+def test_random_rebinds_match_fresh_solvers(solver_path, data_path):
     import torch
     from super_amd.engine import DeviceFrame, Engine
     dev = torch.device("cuda", 0)
     frames = [DeviceFrame.from_scene(sc, dev) for sc in _scenes()]
     want = []
     for f in frames:
-        e = Engine(dev, max_frames=1, num_iterations=4, solver_path=solver_path)
+        e = Engine(dev, max_frames=1, num_iterations=4, solver_path=solver_path, data_path=data_path)
         e.bind(0, f)
         e.run(1)
         want.append((e.beta(0).cpu().numpy().copy(), e.records(0)))
         e.close()
     S = 3
-    eng = Engine(dev, max_frames=S, num_iterations=4, solver_path=solver_path)
-    rng = np.random.default_rng(1234 + solver_path)
+    eng = Engine(dev, max_frames=S, num_iterations=4, solver_path=solver_path, data_path=data_path)
+    rng = np.random.default_rng(1234 + solver_path + 10 * data_path)
     cur = [0, 3, 7]
     eng.bind_batch([frames[k] for k in cur])
 
@@ -88,3 +88,32 @@ def test_rebinding_does_not_leak_device_memory():
         free.append(torch.cuda.mem_get_info(dev)[0])
     eng.close()
     assert free[8] - free[-1] <= 4 << 20, (free[8], free[-1])
+
+
+@pytest.mark.parametrize("optimizer", ["SGD", "Adam"])
+def test_one_graphfit_object_over_frames_of_changing_size_matches_fresh_objects(optimizer):
+    """The autograd-path mirror keeps ONE solver handle for the whole sequence (as the reference keeps one GraphFit
+    module, super/deform_mesh.py:30-44): frames of very different sizes through the same object give what a fresh
+    object gives for each."""
+    import torch
+    from helpers import torch_frame
+    from oracle import graphfit_oracle as gfo
+    from super_amd.deform_mesh import GraphFit
+    from super_amd import synth
+
+    def opt():
+        o = gfo.default_opt(optimizer=optimizer)
+        o.deform_udpate_method = "super_edg"
+        return o
+
+    shapes = [SHAPES[1], SHAPES[3], SHAPES[0], SHAPES[5], SHAPES[6], SHAPES[3]]
+    scs = [synth.make_scene(seed=80 + i, **kw) for i, kw in enumerate(shapes)]
+    one = GraphFit(opt())
+    for i, sc in enumerate(scs):
+        sf, inputs, new_data = torch_frame(sc)
+        got = one(inputs, sf, new_data, None).cpu().numpy()
+        sf, inputs, new_data = torch_frame(sc)
+        want = GraphFit(opt())(inputs, sf, new_data, None).cpu().numpy()
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10, err_msg=f"frame {i}")
+        assert np.abs(want[:, 1:]).max() > 1e-6            # the fit moved something
