@@ -117,3 +117,57 @@ def test_one_graphfit_object_over_frames_of_changing_size_matches_fresh_objects(
         assert np.isfinite(got).all()
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-10, err_msg=f"frame {i}")
         assert np.abs(want[:, 1:]).max() > 1e-6            # the fit moved something
+
+
+def test_surfel_sharded_ranks_rebound_with_frames_of_changing_size():
+    """The surfel-sharded protocol (super/LM.py:93-133 split over ranks; here two solver contexts on this GPU with the
+    exchanges emulated) over a sequence of frames of very different sizes in the same slot: every frame ends at the
+    single-GPU solve."""
+    import torch
+    from helpers import ref_opt, torch_frame
+    from oracle import lm_oracle as orc
+    from super_amd import _lib, synth
+    from super_amd.LM import LM_Solver, _dev_ptr, _stream_ptr
+    world = 2
+    o = ref_opt(orc.default_opt())
+    o.num_optimize_iterations = 4
+    ranks = [LM_Solver(o, rank=r, world=world, all_reduce=lambda t: None, broadcast=lambda t: None) for r in range(world)]
+    hs = [lm._handle() for lm in ranks]
+    lib = ranks[0].lib
+    shapes = [SHAPES[1], SHAPES[3], SHAPES[0], SHAPES[5], SHAPES[1]]
+    for i, kw in enumerate(shapes):
+        sc = synth.make_scene(seed=90 + i, **kw)
+        sf, inputs, new_data = torch_frame(sc)
+        bfs = [lm._bind(h, 0, sf, inputs, new_data) for lm, h in zip(ranks, hs)]
+        dev = bfs[0].device
+        st = _stream_ptr(dev)
+
+        def exchange(what, combine):
+            bufs = [lm.exchange_buffer(h, 0, what, dev) for lm, h in zip(ranks, hs)]
+            for h, b in zip(hs, bufs):
+                _lib.check(lib.slm_lm_exchange_get(h, 0, what, _dev_ptr(b), st), "get")
+            out = combine(bufs)
+            for h in hs:
+                _lib.check(lib.slm_lm_exchange_set(h, 0, what, _dev_ptr(out), st), "set")
+
+        for _ in range(int(o.num_optimize_iterations)):
+            for h in hs:
+                _lib.check(lib.slm_lm_grad_local(h, 1, st), "grad_local")
+            exchange(_lib.SLM_X_PAIR_BLOCKS, lambda b: torch.stack(b).sum(0))
+            for h in hs:
+                _lib.check(lib.slm_lm_solve(h, 1, st), "solve")
+            exchange(_lib.SLM_X_DELTA, lambda b: b[0].clone())
+            for h in hs:
+                _lib.check(lib.slm_lm_loss_local(h, 1, st), "loss_local")
+            exchange(_lib.SLM_X_DATA_LOSS, lambda b: torch.stack(b).sum(0))
+            for h in hs:
+                _lib.check(lib.slm_lm_accept(h, 1, st), "accept")
+        betas = []
+        for h, bf in zip(hs, bfs):
+            beta = torch.empty((bf.J, 7), dtype=torch.float64, device=dev)
+            _lib.check(lib.slm_get_beta(h, 0, _dev_ptr(beta), st), "get_beta")
+            betas.append(beta.cpu().numpy())
+        np.testing.assert_array_equal(betas[0], betas[1])
+        single = LM_Solver(o)
+        want = single.LM(sf, inputs, new_data).cpu().numpy()
+        np.testing.assert_allclose(betas[0], want, rtol=0, atol=1e-9, err_msg=f"frame {i}")
