@@ -636,6 +636,10 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   for (int j = 0; j < J; ++j)
     for (int s = 0; s < K_ED; ++s) {
       const int k = ed_knn[j * K_ED + s];
+      if (k < 0 || k >= J) {   // not an edge (the kernels skip such entries): no destination
+        out.pair_dest[(size_t)j * K_ED + s] = NDDest{-1, 0, 0, 0};
+        continue;
+      }
       const int a = std::max(j, k), bb = std::min(j, k);
       if (!dest_of(a, bb, out.pair_dest[(size_t)j * K_ED + s])) return false;
     }
