@@ -142,9 +142,12 @@ const char* slm_last_error(void);
 int slm_device_count(void);
 
 /* -- per-frame binding (loss_term.prepare) ------------------------------------- */
-/* Binds device pointers to `slot`, computes the tile half-bandwidth of the normal
- * matrix from the KNN tables (one 4-byte device->host read, stream-synchronising)
- * and (re)sizes the slot's workspace.  Resets beta to identity. */
+/* Binds device pointers to `slot`, builds the frame's assembly plan (tuple-sorted surfel copies, coupled node pairs)
+ * and the symbolic plan of the solver (kept while the coupling graph is unchanged), (re)sizes the slot's workspace and
+ * resets beta to identity.  Stream-synchronising (one small device->host read when the slot's plan still applies).
+ * A surfel KNN index outside [0, J) -- an IndexError in the reference, super/loss.py:189-197 -- is found on the device
+ * and refused: SLM_ERR_INVALID, nothing was read out of bounds.  A bind that fails leaves the slot UNBOUND (slm_run
+ * and friends return SLM_ERR_UNBOUND for it) until a later bind succeeds. */
 int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* frame, void* stream);
 /* The same for the n_frames frames of a batch, slots [first_slot, first_slot + n_frames), `frames` an array in
  * host memory.  The preparation of a frame is a chain of small launches and size read-backs (latency, not

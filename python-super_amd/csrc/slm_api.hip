@@ -538,6 +538,7 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   int wb = 0;
   sl.band_ready = false;
   h.dag_trace = nullptr;   // a trace buffer is sized for the plan it was enabled on
+  h.bound = 0;             // a bind that fails half way leaves the slot unbound (slm_run refuses it)
   h.f = *f;
   h.P = P;
   h.nt = nt;
@@ -583,6 +584,8 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   if (s->cfg.use_data && s->cfg.data_path != 1 && f->J < 65536 && f->N > 0) {
     V1Sizes sz;
     HIPCHK(prep_v1(prep, *f, sl.plan, &sz, st));
+    if (sz.bad_knn)
+      return fail(SLM_ERR_INVALID, "slm_bind_frame: a surfel KNN index (sf_knn_idx) lies outside [0, J)");
     dev_knn_hash = sz.knn_hash;
     dev_graph_hash = sz.graph_hash;
     bt_mark();                                 // [1] tuple-sorted plan done (its size read-backs included)

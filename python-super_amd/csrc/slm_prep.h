@@ -38,6 +38,7 @@ struct V1Sizes {
   // hashes of the coupling graph, computed on the device: (J, K_ED, node KNN table) and the same continued over the
   // coupled-pair keys -- what the cached symbolic plan of a slot is compared with
   uint64_t knn_hash = 0, graph_hash = 0;
+  bool bad_knn = false;          // a surfel KNN index outside [0, J) was seen: the frame must be refused
 };
 
 PrepBuffers* prep_create();

@@ -30,13 +30,19 @@ __device__ __forceinline__ void sort4(int& a, int& b, int& c, int& d) {
 #undef CSWAP
 }
 
-__global__ void __launch_bounds__(256) k_tuple_keys(int N, const int* __restrict__ knn,
+// (a node index outside [0, J) -- the reference would raise an IndexError -- is reported through *bad and clamped, so
+//  that nothing downstream reads out of bounds before the host has seen the flag)
+__global__ void __launch_bounds__(256) k_tuple_keys(int N, int J, const int* __restrict__ knn,
                                                      unsigned long long* __restrict__ keys,
-                                                     int* __restrict__ ids) {
+                                                     int* __restrict__ ids, int* __restrict__ bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   int4 v = *reinterpret_cast<const int4*>(knn + 4 * i);
   int a = v.x, b = v.y, c = v.z, d = v.w;
+  if ((unsigned)a >= (unsigned)J || (unsigned)b >= (unsigned)J || (unsigned)c >= (unsigned)J || (unsigned)d >= (unsigned)J) {
+    *bad = 1;
+    a = min(max(a, 0), J - 1); b = min(max(b, 0), J - 1); c = min(max(c, 0), J - 1); d = min(max(d, 0), J - 1);
+  }
   sort4(a, b, c, d);
   keys[i] = ((unsigned long long)a << 48) | ((unsigned long long)b << 32) |
             ((unsigned long long)c << 16) | (unsigned long long)d;
@@ -310,7 +316,7 @@ struct PrepBuffers {
   void* tmp = nullptr;
   size_t cap_tmp = 0;
   size_t q_n = 0, q_t = 0, q_e = 0;   // sizes the rocPRIM temporary-storage requirement was last queried for
-  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique, ..., [8..11] the two 64-bit graph hashes, [12] unclamped nt
+  int* scal = nullptr;        // device: nt, ptot, nruns, nblocks, nunique, ..., [8..11] the two 64-bit graph hashes, [12] unclamped nt, [13] bad surfel KNN index seen
   int* scal_host = nullptr;   // pinned mirror
 };
 
@@ -408,8 +414,9 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
     c = p->cap_n; PCHK(grow_raw(p->tcount, c, N));
     p->cap_n = c;
   }
-  hipLaunchKernelGGL(k_tuple_keys, dim3((N + 255) / 256), dim3(256), 0, st, (int)N, f.sf_knn_idx,
-                     p->keys, p->ids);
+  PCHK(hipMemsetAsync(p->scal + 13, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_tuple_keys, dim3((N + 255) / 256), dim3(256), 0, st, (int)N, f.J, f.sf_knn_idx,
+                     p->keys, p->ids, p->scal + 13);
   PCHK(ensure_tmp_for(p, N, p->cap_t ? p->cap_t : 1, p->cap_e ? p->cap_e : 1, st));
   size_t b1 = p->cap_tmp, b2 = p->cap_tmp;
   PCHK(rocprim::radix_sort_pairs(p->tmp, b1, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
@@ -549,8 +556,13 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
   hipLaunchKernelGGL(k_plan_hash, dim3(16), blk, 0, st, f.J, f.K_ED, f.ed_knn_idx, plan.blk_key, p->scal,
                      reinterpret_cast<unsigned long long*>(p->scal + 8));
 
-  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 13 * sizeof(int), hipMemcpyDeviceToHost, st));
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 14 * sizeof(int), hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
+  out->bad_knn = p->scal_host[13] != 0;
+  if (out->bad_knn) {   // the caller refuses the frame; the next preparation starts without a hint
+    plan.nt_hint = 0;
+    return hipSuccess;
+  }
   if (hinted && (size_t)p->scal_host[12] > nt) {   // the hinted bound did not hold: once more with the exact count
     plan.nt_hint = 0;
     return prep_v1(p, f, plan, out, st);

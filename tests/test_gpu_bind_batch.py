@@ -119,3 +119,32 @@ def test_a_slot_rebound_with_a_much_larger_and_then_smaller_scene_matches_a_fres
             np.testing.assert_allclose(got[j][0], want, rtol=0, atol=1e-12)
             assert [(r["status"], r["accepted"]) for r in got[j][1]] == [(r["status"], r["accepted"]) for r in recs]
             np.testing.assert_allclose([r["loss"] for r in got[j][1]], [r["loss"] for r in recs], rtol=1e-12)
+
+
+def test_a_surfel_knn_index_out_of_range_is_refused_and_the_slot_stays_usable():
+    """The reference indexes the node arrays with sf.knn_indices (super/loss.py:189-197): an index >= J is an
+    IndexError there.  Here the preparation reports it from the device (clamped meanwhile: no out-of-bounds access),
+    slm_bind_frame fails, the slot counts as unbound, and a good frame binds and solves in it afterwards."""
+    import torch
+    from super_amd import _lib, synth
+    from super_amd.engine import DeviceFrame, Engine
+    dev = torch.device("cuda", 0)
+    sc = synth.make_scene(seed=5, N=3000, J=64, H=120, W=160)
+    good = DeviceFrame.from_scene(sc, dev)
+    eng = Engine(dev, max_frames=1, num_iterations=3)
+    eng.bind(0, good)
+    eng.run(1)
+    want = eng.beta(0).cpu().numpy().copy()
+    for bad_value in (sc.J, -1, 1 << 20):
+        bad = DeviceFrame.from_scene(sc, dev)
+        bad.sf_knn_idx[1234, 2] = bad_value
+        torch.cuda.synchronize()
+        c = bad.c_struct()
+        import ctypes as C
+        rc = eng.lib.slm_bind_frame(eng.h, 0, C.byref(c), eng.stream)
+        assert rc == _lib.SLM_ERR_INVALID and b"sf_knn_idx" in eng.lib.slm_last_error()
+        assert eng.lib.slm_run(eng.h, 1, eng.stream) == _lib.SLM_ERR_UNBOUND
+        eng.bind(0, good)                                  # hinted or not: the slot works again
+        eng.run(1)
+        np.testing.assert_allclose(eng.beta(0).cpu().numpy(), want, rtol=0, atol=1e-11)
+    eng.close()
