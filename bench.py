@@ -137,6 +137,21 @@ def cpu_quota():
         return None
 
 
+def thread_cpu():
+    """{tid: (user + system CPU seconds, name)} of every thread of this process (/proc/self/task)."""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for t in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{t}/stat").read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(t)] = ((int(rest[11]) + int(rest[12])) / tck, name)
+        except (OSError, ValueError):
+            pass
+    return out
+
+
 def host_info():
     model = None
     try:
@@ -612,12 +627,28 @@ def main():
     del step_events[:]
     ev0 = torch.cuda.Event(enable_timing=True)
     ev0.record()
+    cpu0 = os.times()
+    thr0 = thread_cpu() if os.environ.get("BENCH_THREAD_CPU") else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     t_end = time.perf_counter()
+    cpu1 = os.times()
     elapsed = t_end - t0
+    # host CPU time of this rank (all its threads) per second of the timed region: what a rank costs of the node's quota
+    cpu_busy = ((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(elapsed, 1e-9)
+    if thr0 is not None and rank == 0:   # diagnostic: which threads of the process burn host CPU during the timed region
+        thr1 = thread_cpu()
+        use = sorted(((thr1[t][0] - thr0.get(t, (0.0, ""))[0], t, thr1[t][1]) for t in thr1), reverse=True)
+        print("thread CPU seconds over %.2f s: " % elapsed + ", ".join(f"{nm}[{t}] {u:.2f}" for u, t, nm in use[:14] if u > 0.005), file=sys.stderr)
+        for u, t, nm in use[:3]:
+            for fn in ("wchan", "syscall", "stack"):
+                try:
+                    print(f"   [{t}] {fn}: " + open(f"/proc/self/task/{t}/{fn}").read().strip()[:300], file=sys.stderr)
+                except OSError as e:
+                    print(f"   [{t}] {fn}: {e}", file=sys.stderr)
+        print("   all tids: " + " ".join(str(t) for t in sorted(thr1)), file=sys.stderr)
     # per-step durations on the GPU timeline: event at the end of every step (host stalls show up as GPU idle time)
     evs = [ev0] + step_events
     step_ms = sorted(a_.elapsed_time(b_) for a_, b_ in zip(evs, evs[1:]))
@@ -718,6 +749,7 @@ def main():
         if world == 1 and not a.no_profile and not a.no_latency_b1:
             out["latency_b1"] = latency_b1(dims, device, iters)
         out["host"] = host_info()
+        out["host"]["cpu_cores_busy_per_rank"] = round(cpu_busy, 2)   # (rank 0; timed region; user + system time of all threads)
         if world == 1 and not a.no_profile:
             out["bind"] = bind_timing(dims, device, B)
         if world == 1 and not a.no_cpu_baseline:

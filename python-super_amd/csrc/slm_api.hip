@@ -234,6 +234,8 @@ struct slm_solver {
   std::vector<hipStream_t> bind_streams;
   std::vector<hipEvent_t> bind_events;
   std::mutex band_mutex;        // the bandwidth read-back buffer of ensure_band is shared
+  hipEvent_t drain_event = nullptr;   // slm_bind_frames' wait for the caller's stream (polled, see there)
+  double drain_est_ms = 0.0;          // how long that wait took last time
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
@@ -455,6 +457,7 @@ int slm_destroy(slm_solver* s) {
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+  if (s->drain_event) (void)hipEventDestroy(s->drain_event);
   if (s->frames_dev) (void)hipFree(s->frames_dev);
   if (s->bw_dev) (void)hipFree(s->bw_dev);
   if (s->reuse_dev) (void)hipFree(s->reuse_dev);
@@ -863,8 +866,40 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
   // The binds read sizes back, so they wait for the work already on `st` in any case: wait for it HERE, on one
   // thread, rather than with W workers spinning in their first read-back for as long as the previous LM run takes
   // (8 busy threads for tens of milliseconds per step cost the process its CPU quota on the GPU box).
+  // This is the one LONG host wait of a tracking step (the LM run of the previous step, tens of milliseconds).  Every
+  // blocking wait of this HIP runtime spins (hipStreamSynchronize, hipEventSynchronize with or without
+  // hipEventBlockingSync: one CPU at 100 %, tests/studies/wait_cpu.py), which counts where the ranks of a node share a
+  // CPU quota: the wait is therefore a poll of an event with naps while the end is far (estimated from the previous
+  // wait on this solver) and a tight poll only over the last stretch.  SLM_SPIN_WAIT=1: hipStreamSynchronize as before.
   const double bt0 = bind_trace_threshold() >= 0.0 ? bt_now() : 0.0;
-  HIPCHK(hipStreamSynchronize(st));
+  static const bool spin_wait = [] {
+    const char* e = getenv("SLM_SPIN_WAIT");
+    return e && atoi(e) != 0;
+  }();
+  if (spin_wait) {
+    HIPCHK(hipStreamSynchronize(st));
+  } else {
+    if (!s->drain_event) HIPCHK(hipEventCreateWithFlags(&s->drain_event, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(s->drain_event, st));
+    const auto w0 = std::chrono::steady_clock::now();
+    auto waited_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); };
+    const double est = s->drain_est_ms;
+    for (;;) {
+      const hipError_t q = hipEventQuery(s->drain_event);
+      if (q == hipSuccess) break;
+      (void)hipGetLastError();   // hipErrorNotReady is not an error here: keep it out of the sticky last-error slot
+      if (q != hipErrorNotReady) return fail(SLM_ERR_HIP, hipGetErrorString(q));
+      const double w = waited_ms();
+      if (w < 0.85 * est - 0.4) {
+        std::this_thread::sleep_for(std::chrono::microseconds(300));    // far from the expected end
+      } else if (w > est + 1.5) {
+        std::this_thread::sleep_for(std::chrono::microseconds(100));    // overdue (the step got longer): nap again
+      } else {
+        __builtin_ia32_pause();                                          // the last stretch: poll
+      }
+    }
+    s->drain_est_ms = waited_ms();
+  }
   const double bt1 = bind_trace_threshold() >= 0.0 ? bt_now() : 0.0;
   HIPCHK(hipEventRecord(s->bind_events[W], st));            // fork: the workers see everything enqueued on `st` so far
   // (no exception may cross the extern "C" boundary: the containers are sized before any worker starts, the pool throws
