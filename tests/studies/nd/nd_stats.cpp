@@ -5,7 +5,7 @@
 #include "slm_nd.h"
 
 extern "C" int nd_stats(int J, int K_ED, const float* pts, const int32_t* knn, const uint32_t* pairs, int n_pairs,
-                        double* out, int32_t* fronts, int max_fronts) {
+                        double* out, int32_t* fronts, int max_fronts, int32_t* kp_out) {
   NDPlanHost p;
   if (!nd_build_plan(J, K_ED, pts, knn, pairs, n_pairs, p)) return -1;
   out[0] = p.flops;
@@ -23,6 +23,12 @@ extern "C" int nd_stats(int J, int K_ED, const float* pts, const int32_t* knn, c
     fronts[4 * n + 1] = f.nv;
     fronts[4 * n + 2] = f.nb;
     fronts[4 * n + 3] = f.parent;
+    if (kp_out) {   // boundary nodes of the front that are PIVOTS of its parent (they come first: elimination order)
+      int kp = 0;
+      if (f.parent >= 0)
+        for (int b = 0; b < f.nb; ++b) kp += p.eamap[f.eamap_off + b] < p.fronts[f.parent].nv;
+      kp_out[n] = kp;
+    }
     ++n;
   }
   return n;

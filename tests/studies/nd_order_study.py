@@ -43,9 +43,11 @@ def graph_of(sc):
 def stats(lib, J, pts, knn, pairs):
     out = (C.c_double * 8)()
     fr = np.zeros((4096, 4), dtype=np.int32)
+    kp = np.zeros(4096, dtype=np.int32)
     n = lib.nd_stats(J, knn.shape[1], pts.ctypes.data_as(C.c_void_p), knn.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
-                     len(pairs), out, fr.ctypes.data_as(C.c_void_p), 4096)
+                     len(pairs), out, fr.ctypes.data_as(C.c_void_p), 4096, kp.ctypes.data_as(C.c_void_p))
     assert n > 0
+    stats.kp = kp[:n]
     return list(out), fr[:n]
 
 

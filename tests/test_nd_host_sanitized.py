@@ -22,7 +22,7 @@ DRIVER = textwrap.dedent('''
         pts = np.ascontiguousarray(pts, np.float32); knn = np.ascontiguousarray(knn, np.int32)
         pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1)
         n = lib.nd_stats(J, K, pts.ctypes.data_as(C.c_void_p), knn.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p),
-                         len(pairs), out, fr.ctypes.data_as(C.c_void_p), 8192)
+                         len(pairs), out, fr.ctypes.data_as(C.c_void_p), 8192, None)
         assert n >= 1, (J, n)
         assert sum(int(f[1]) for f in fr[:n]) == J, "every node is a pivot of exactly one front"
         return n
