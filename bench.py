@@ -5,7 +5,7 @@
 
 One *step* = one pass of the hot path over one batch of synthetic input: for each of the
 B independent frames resident on a GPU, bind the frame (``loss_term.prepare``), run
-``num_optimize_iterations`` = 10 damped LM iterations on the device (Jacobian pass, banded
+``num_optimize_iterations`` = 10 damped LM iterations on the device (Jacobian pass, multifrontal
 Cholesky solve, loss pass, accept/reject) and apply ``Surfels.update``.  Inputs are in HBM
 before the timed region starts.  N > 1: one process per GPU (torchrun), frames sharded
 across ranks (weak scaling, B frames per GPU), end-of-frame RCCL all-gather of beta
@@ -18,7 +18,9 @@ data-term Jacobian pass (one launch per LM iteration, HBM bound); `whole_step_hb
 algorithmic bytes of the whole step against the HBM peak (the path is latency-bound: an exact
 float64 solve is a chain of dependent tile factorisations); `latency_b1` = the same workload at
 ONE frame per launch -- what a sequential tracker (run_super.py) sees; `cpu_baseline` = the NumPy
-oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample.
+oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample;
+`host.cpu_cores_busy_per_rank` = user + system CPU time of this rank's threads per second of the timed region (what a rank
+costs of a node's CPU quota; `BENCH_THREAD_CPU=1` lists it per thread on stderr).
 """
 from __future__ import annotations
 
