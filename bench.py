@@ -307,32 +307,35 @@ def cpu_baseline(dims, seed):
             "seconds": dt}, beta, trace
 
 
-def parity_check(dims, device, oracle_beta, trace):
-    """`parity_c2`: the oracle's beta after the 3 LM iterations `cpu_baseline` has just computed against the HIP path on
-    the same frame (seed 0), same 3 iterations, in the batch's solver form and at one frame per launch.  The oracle is
-    the checker here, never the thing timed; a mismatch fails the bench."""
+def parity_check(dims, device, oracle_beta, trace, B):
+    """`parity_<workload>`: the oracle's beta after the 3 LM iterations `cpu_baseline` has just computed (frame seed 0)
+    against the HIP path on the same frame, same 3 iterations: at one frame per launch, and as slot 0 of a batch of the
+    bench's own `frames_per_gpu` frames (seeds 0 .. B-1: the solver form and launch shapes of the timed loop).  The
+    oracle is the checker here, never the thing timed; a mismatch fails the bench.  (All ten iterations of the first
+    and the last slot of an 8-frame batch are compared in tests/test_gpu_bench_shape_parity.py.)"""
     import numpy as np
     from super_amd import synth
     from super_amd.engine import DeviceFrame, Engine
-    sc = synth.make_scene(seed=0, **dims)
     n_it = len(trace)
     out = {"iterations": n_it, "tolerance": 1e-4, "reference": "oracle/lm_oracle.py (NumPy float64, dense Cholesky)"}
     worst = 0.0
-    for label, nb in (("one_frame_per_launch", 1), ("batch_of_3", 3)):
+    legs = [("one_frame_per_launch", 1)] + ([(f"batch_of_{B}", B)] if B > 1 else [])
+    for label, nb in legs:
         eng = Engine(device, max_frames=nb, num_iterations=n_it)
-        eng.bind_batch([DeviceFrame.from_scene(sc, device) for _ in range(nb)])
+        eng.bind_batch([DeviceFrame.from_scene(synth.make_scene(seed=i, **dims), device) for i in range(nb)])
         eng.run(nb)
-        recs = eng.records(nb - 1)
-        err = float(np.abs(eng.beta(nb - 1).cpu().numpy() - oracle_beta).max())
+        recs = eng.records(0)
+        err = float(np.abs(eng.beta(0).cpu().numpy() - oracle_beta).max())
         loss_rel = max(abs(r["loss"] - t["loss"]) / max(abs(t["loss"]), 1e-300) for r, t in zip(recs, trace))
-        out[label] = {"max_abs_beta_diff": err, "max_rel_loss_diff": loss_rel,
+        out[label] = {"max_abs_beta_diff": err, "max_rel_loss_diff": loss_rel, "frames_per_launch": nb,
                       "match_counts_equal": [r["M_grad"] for r in recs] == [t["M_grad"] for t in trace],
+                      "accept_flags_equal": [r["accepted"] for r in recs] == [bool(t["accepted"]) for t in trace],
                       "solver_form": {0: "per-level", 1: "task graph", 2: "hybrid"}.get(eng.lib.slm_debug_last_solver_form(eng.h))}
         worst = max(worst, err)
         eng.close()
     out["max_abs_beta_diff"] = worst
     out["ok"] = bool(worst < 1e-4 and all(out[k]["match_counts_equal"] and out[k]["max_rel_loss_diff"] < 1e-6
-                                          for k in ("one_frame_per_launch", "batch_of_3")))
+                                          for k, _ in legs))
     return out
 
 
@@ -665,10 +668,20 @@ def main():
                     prof[k2]["ms"] += v2["ms"]
                     prof[k2]["count"] += v2["count"]
             e.profile(False)
+    # worst per-iteration status over all slots of this rank (0 = every iteration ran; 3 = SLM_ITER_SOLVER_TIMEOUT)
+    worst_status = max(r["status"] for e in engs for i in range(Bs) for r in e.records(i))
+    cpu_busy_all = cpu_busy
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, float(worst_status)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, worst_status = float(t[0].item()), int(t[1].item())
+        t = torch.tensor([cpu_busy], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        cpu_busy_all = float(t.item())
+        # test hook (tests/test_gpu_eight_rank_rehearsal.py): the betas rank 0 holds after the last end-of-frame all-gather
+        dump = os.environ.get("BENCH_DUMP_BETAS")
+        if dump and rank == 0 and gathered[0] is not None:
+            np.save(dump, gathered[0].cpu().numpy())
 
     recs = eng.records(0)
     final_loss = [r["loss"] for r in recs if r["status"] == 0]
@@ -701,6 +714,7 @@ def main():
                         "max": step_ms[-1], "min": step_ms[0], "steps": len(step_ms)},
             "distributed": {"backend": backend if use_dist else None, "world": world,
                             "launched_by": "torchrun" if launched else None},
+            "worst_iter_status_all_ranks": worst_status,
         }
         if prof is not None:
             info = eng.plan_info(0)
@@ -752,11 +766,12 @@ def main():
             out["latency_b1"] = latency_b1(dims, device, iters)
         out["host"] = host_info()
         out["host"]["cpu_cores_busy_per_rank"] = round(cpu_busy, 2)   # (rank 0; timed region; user + system time of all threads)
+        out["host"]["cpu_cores_busy_all_ranks"] = round(cpu_busy_all, 2)   # (sum over the ranks: what the job costs of the node's CPU quota)
         if world == 1 and not a.no_profile:
             out["bind"] = bind_timing(dims, device, B)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], oracle_beta, oracle_trace = cpu_baseline(dims, seed=0)
-            out["parity_" + a.workload.lower()] = parity_check(dims, device, oracle_beta, oracle_trace)
+            out["parity_" + a.workload.lower()] = parity_check(dims, device, oracle_beta, oracle_trace, B)
             assert out["parity_" + a.workload.lower()]["ok"], out["parity_" + a.workload.lower()]
             out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)
             out["graphfit_gpu"] = graphfit_timing(dims, device)

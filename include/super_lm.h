@@ -146,7 +146,7 @@ int slm_device_count(void);
  * and the symbolic plan of the solver (kept while the coupling graph is unchanged), (re)sizes the slot's workspace and
  * resets beta to identity.  Stream-synchronising (one small device->host read when the slot's plan still applies).
  * A surfel KNN index outside [0, J) -- an IndexError in the reference, super/loss.py:189-197 -- is found on the device
- * and refused: SLM_ERR_INVALID, nothing was read out of bounds.  A bind that fails leaves the slot UNBOUND (slm_run
+ * and refused on every data path: SLM_ERR_INVALID, nothing was read out of bounds.  A bind that fails leaves the slot UNBOUND (slm_run
  * and friends return SLM_ERR_UNBOUND for it) until a later bind succeeds. */
 int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* frame, void* stream);
 /* The same for the n_frames frames of a batch, slots [first_slot, first_slot + n_frames), `frames` an array in
@@ -158,7 +158,9 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
 
 /* -- the LM loop ------------------------------------------------------------------ */
 /* Enqueues num_iterations damped accept/reject iterations for slots [0,n_frames),
- * entirely on the device (no host synchronisation). */
+ * entirely on the device (no host synchronisation).  Running again without binding continues the loop from the slot's
+ * current state; the library may then reuse what it derived from the bound input buffers (the Jacobian records of a
+ * rejected step), so a caller that changes those buffers IN PLACE must bind the slot again before the next run. */
 int slm_run(slm_solver* s, int32_t n_frames, void* stream);
 /* Copies the slot's current beta (J*7 doubles) into caller device memory. */
 int slm_get_beta(slm_solver* s, int32_t slot, double* beta_out_device, void* stream);

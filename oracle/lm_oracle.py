@@ -363,17 +363,38 @@ def default_opt(**kw):
     return o
 
 
-def lm(fr: Frame, opt, u=10.0, v=7.5, minimal_loss=1e10, trace=None):
+def solve_damped_sparse(JtJ_csr, jtl, u):
+    """The same system through a sparse direct solve (SciPy's SuperLU, symmetric mode, no pivoting off the diagonal) on
+    the block-sparse JtJ: what makes full-size traces at 4 k nodes affordable for the checker (the dense factor is
+    6 GB / 7 TFLOP at P = 28 000).  Not positive definite -- a non-positive pivot, or a pivot taken off the diagonal --
+    raises ``np.linalg.LinAlgError`` like the dense Cholesky of the reference would (``super/LM.py:47-51,99-103``)."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import splu
+    n = JtJ_csr.shape[0]
+    A = (JtJ_csr + u * sp.identity(n, format="csr")).tocsc()
+    try:
+        lu = splu(A, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    except RuntimeError as e:                                  # exactly singular
+        raise np.linalg.LinAlgError(str(e))
+    # positive definite <=> elimination on the diagonal (row and column permutations coincide) with positive pivots
+    if not np.array_equal(lu.perm_r, lu.perm_c) or not (lu.U.diagonal() > 0.0).all():
+        raise np.linalg.LinAlgError("matrix is not positive definite")
+    return lu.solve(jtl)
+
+
+def lm(fr: Frame, opt, u=10.0, v=7.5, minimal_loss=1e10, trace=None, solve="dense"):
     """The damped accept/reject loop (reference ``super/LM.py:81-122``): beta0 =
     identity; per iteration build, damp, solve (failure -> stop), step, re-evaluate
     the loss with a fresh match set, accept (u /= v) or reject (u *= v, roll back).
-    Returns beta (J,7).  ``trace`` (a list) receives one dict per iteration."""
+    Returns beta (J,7).  ``trace`` (a list) receives one dict per iteration.
+    ``solve``: "dense" (Cholesky of the dense matrix like the reference) or "sparse" (``solve_damped_sparse``: the same
+    system, checked against the dense path on the reference's goldens in tests/test_oracle_golden.py)."""
     beta = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (fr.J, 1))
     best = beta.copy()
     for it in range(opt.num_optimize_iterations):
-        JtJ, jtl, M = normal_equations(fr, beta, opt)
+        JtJ, jtl, M = normal_equations(fr, beta, opt, dense=(solve == "dense"))
         try:
-            delta = solve_damped(JtJ, jtl, u).reshape(-1, 7)
+            delta = (solve_damped(JtJ, jtl, u) if solve == "dense" else solve_damped_sparse(JtJ, jtl, u)).reshape(-1, 7)
         except np.linalg.LinAlgError:
             if trace is not None:
                 trace.append(dict(it=it, status="solver_failed", u=u))

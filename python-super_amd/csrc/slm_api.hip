@@ -29,7 +29,7 @@ void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hip
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse = nullptr);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
-void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
+void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1, int max_wg = 0);
 hipError_t set_dag_timeout_ticks(long long);
 void launch_dag_abort_check(const FrameDev*, int, hipStream_t);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
@@ -80,7 +80,7 @@ void slm_set_error_text(const char* msg) { g_err = msg; }
 namespace {
 // Host buffer for per-frame device -> host read-backs, PINNED (hipHostMalloc, grow-only).  A read-back into pageable
 // memory (a std::vector) goes through the runtime's staging path, and several bind workers doing that at once were
-// seen to block for 5-7 ms together once in ~50 steps (tests/studies/stall_hunt.py: the whole rare stall of a bench
+// seen to block for 5-7 ms together once in ~50 steps (tools/studies/stall_hunt.py: the whole rare stall of a bench
 // step sat in this one hipMemcpyAsync + hipStreamSynchronize); a pinned destination is a plain DMA.
 template <typename T>
 struct PinnedBuf {
@@ -239,9 +239,20 @@ struct slm_solver {
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
+  // Grouped run (slm_run, batches in the hybrid form): the frames of a launch are split into two groups whose LM loops
+  // run on two streams, phase-shifted, so that the latency-bound task-graph launch of one group (top of the tree + back
+  // substitution, capped to dag_cap workgroups) runs UNDER the bandwidth-bound per-level launches of the other.
+  int groups = 1;               // SLM_GROUPS
+  int group_min_frames = 6;     // batches below this stay in one group
+  int dag_cap = 96;             // SLM_DAG_CAP: workgroups of a group's task-graph launch
+  int group_sync = 1;           // SLM_GROUP_SYNC: 1 = the groups' assembly + per-level phases alternate (events), 0 = free-running
+  hipStream_t group_stream = nullptr;
+  std::vector<hipEvent_t> group_events;   // fork, join, and one per (group, iteration)
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
+  std::vector<char> ev_counts;                // ... and whether the entry counts as an iteration (the second group of a
+                                              // grouped run adds its phase times to the first group's iteration)
   slm_config cfg{};
   std::vector<Slot> slots;
   FrameDev* frames_dev = nullptr;
@@ -411,6 +422,10 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
   if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
+  if (const char* e = getenv("SLM_GROUPS")) s->groups = atoi(e) >= 2 ? 2 : 1;
+  if (const char* e = getenv("SLM_GROUP_MIN")) s->group_min_frames = std::max(2, atoi(e));
+  if (const char* e = getenv("SLM_DAG_CAP")) s->dag_cap = std::max(0, atoi(e));
+  if (const char* e = getenv("SLM_GROUP_SYNC")) s->group_sync = atoi(e);
   *out = s;
   return SLM_OK;
 }
@@ -458,6 +473,8 @@ int slm_destroy(slm_solver* s) {
       if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->drain_event) (void)hipEventDestroy(s->drain_event);
+  for (hipEvent_t e : s->group_events) (void)hipEventDestroy(e);
+  if (s->group_stream) (void)hipStreamDestroy(s->group_stream);
   if (s->frames_dev) (void)hipFree(s->frames_dev);
   if (s->bw_dev) (void)hipFree(s->bw_dev);
   if (s->reuse_dev) (void)hipFree(s->reuse_dev);
@@ -491,7 +508,7 @@ static int ensure_band(slm_solver* s, int slot, hipStream_t st) {
 static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep);
 
 // Diagnostics (SLM_BIND_TRACE=<ms>): a bind that takes longer than <ms> on the host prints the time stamps of its
-// stages -- which stage of which worker carried a rare multi-millisecond stall (tests/studies/stall_hunt.py).
+// stages -- which stage of which worker carried a rare multi-millisecond stall (tools/studies/stall_hunt.py).
 #include <chrono>
 namespace {
 struct BindTrace {
@@ -620,6 +637,11 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
         h.v2_ready = 1;
       }
     }
+  } else if (s->cfg.use_data && f->N > 0) {
+    // the per-entry atomics path (data_path 1, J >= 65536) dereferences the table too: same refusal
+    bool bad = false;
+    HIPCHK(prep_check_knn(prep, *f, &bad, st));
+    if (bad) return fail(SLM_ERR_INVALID, "slm_bind_frame: a surfel KNN index (sf_knn_idx) lies outside [0, J)");
   }
   // share of this rank when the frame is sharded over several GPUs (whole frame otherwise)
   {
@@ -700,7 +722,10 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       if (e == hipSuccess && !sl.cur_dest.empty())
         e = hipMemcpyAsync(sl.d_cur_dests, sl.cur_dest.data(), sizeof(NDDest) * sl.cur_dest.size(), hipMemcpyHostToDevice, st);
       h.block_dest = sl.d_cur_dests;
-      sl.cur_n_blocks = h.n_blocks;
+      // (a failed grow / copy leaves d_cur_dests freed or half written: the slot's cached pair list must not be trusted
+      //  by a later bind of the old graph -- same_graph compares the hash AND this count)
+      sl.cur_n_blocks = e == hipSuccess ? h.n_blocks : -1;
+      if (e != hipSuccess) sl.nd_hash = 0;
       return e;
     };
     if (sl.nd_valid && sl.nd_knn_hash != knn_hash) {   // another node graph: nothing of the old plan applies
@@ -868,7 +893,7 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
   // (8 busy threads for tens of milliseconds per step cost the process its CPU quota on the GPU box).
   // This is the one LONG host wait of a tracking step (the LM run of the previous step, tens of milliseconds).  Every
   // blocking wait of this HIP runtime spins (hipStreamSynchronize, hipEventSynchronize with or without
-  // hipEventBlockingSync: one CPU at 100 %, tests/studies/wait_cpu.py), which counts where the ranks of a node share a
+  // hipEventBlockingSync: one CPU at 100 %, tools/studies/wait_cpu.py), which counts where the ranks of a node share a
   // CPU quota: the wait is therefore a poll of an event with naps while the end is far (estimated from the previous
   // wait on this solver) and a tight poll only over the last stretch.  SLM_SPIN_WAIT=1: hipStreamSynchronize as before.
   const double bt0 = bind_trace_threshold() >= 0.0 ? bt_now() : 0.0;
@@ -1034,21 +1059,28 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
 static bool solve_is_task_graph(const slm_solver* s, int n) {
   return s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && n <= 2);
 }
-void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
+static bool solve_is_hybrid(const slm_solver* s, int n, const BatchDims& d) {
+  return !solve_is_task_graph(s, n) && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
+         d.hybrid_cut >= 0 && d.hybrid_levels == (int)d.sched.size() && d.hybrid_cut + 1 < d.hybrid_levels;
+}
+// dag_cap > 0: workgroups of the task-graph launch (grouped run); `between` runs after the per-level launches of the
+// hybrid form have been enqueued, before the task-graph launch
+void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st,
+                         int dag_cap = 0, const std::function<void()>* between = nullptr) {
   const bool dag = solve_is_task_graph(s, n);
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
-  const bool hybrid = !dag && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
-                      d.hybrid_cut >= 0 && d.hybrid_levels == (int)d.sched.size() && d.hybrid_cut + 1 < d.hybrid_levels;
+  const bool hybrid = solve_is_hybrid(s, n, d);
   s->last_solver_form = dag ? 1 : (hybrid ? 2 : 0);
   if (dag) {
-    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st);
+    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1, dag_cap);
   } else if (hybrid) {
     const int n_levels = (int)d.sched.size(), l_cut = n_levels - 1 - d.hybrid_cut;
     launch_front_levels(fr, n, d.sched.data(), n_levels, l_cut, 0, u_override, st);
+    if (between) (*between)();
     // the task graph: the fronts above the cut, then the back substitution of the WHOLE tree (the list dag_top_tasks
     // ends with the BACKB / BACK tasks of the deeper fronts -- 24 small per-level launches, 0.25 ms at C2, otherwise)
-    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut);
+    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut, dag_cap);
   } else {
     launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
   }
@@ -1235,6 +1267,103 @@ int slm_lm_exchange_set(slm_solver* s, int32_t slot, int32_t what, const double*
   return SLM_OK;
 }
 
+// One LM iteration of slots [first, first + n) on `st`.  `between` (grouped run): called once the launches of the
+// assembly and of the per-level part of the solve are enqueued.
+static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st, bool counts,
+                                 int dag_cap, const std::function<void()>* between) {
+  const FrameDev* fr = s->frames_dev + first;
+  const slm_config& c = s->cfg;
+  std::vector<hipEvent_t>* evs = nullptr;
+  if (s->profile) {
+    s->ev_runs.emplace_back();
+    s->ev_counts.push_back(counts ? 1 : 0);
+    evs = &s->ev_runs.back();
+  }
+  auto mark = [&]() {
+    if (!evs) return;
+    hipEvent_t e = take_event(s);
+    if (e) (void)hipEventRecord(e, st);
+    evs->push_back(e);
+  };
+  mark();
+  // (records of the Jacobian pass are reused after a rejected step on the multifrontal path, where the assembly
+  //  re-reads them; the banded path adds into the band in place)
+  const int* reuse = (d.nd && d.v1 && c.phase_test && !s->no_reuse) ? s->reuse_dev + first : nullptr;
+  if (d.nd) {
+    launch_iter_begin_nd(fr, n, st, reuse);
+  } else {
+    launch_iter_begin(fr, n, st);
+  }
+  mark();
+  if (c.use_data) {
+    if (d.v1) launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
+    else launch_data_grad(fr, n, d.maxN, c.w_data, st);
+  }
+  mark();
+  if (d.nd) {
+    if (c.use_data) launch_front_assemble(fr, n, d.max_blocks, st);
+    launch_reg_grad_nd(fr, n, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+    launch_front_load_rhs(fr, n, d.maxP, st);
+  } else {
+    if (c.use_data && d.v1) launch_band_assemble(fr, n, d.max_blocks, st);
+    launch_reg_grad(fr, n, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
+  }
+  mark();
+  if (d.nd) enqueue_front_solve(s, fr, n, d, -1.0, st, dag_cap, between);
+  else launch_band_solve(fr, n, d.nt_max, d.wb_cap, -1.0, st);
+  if (c.use_data) launch_make_trial(fr, n, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
+  mark();
+  if (c.use_data) launch_data_loss(fr, n, kLossBlocks, c.w_data, 1, st);
+  mark();
+  if (d.n_reg_part > 0)
+    launch_reg_loss(fr, n, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
+  launch_accept(fr, n, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st,
+                (d.v1 && c.phase_test) ? s->reuse_dev + first : nullptr);
+  mark();
+}
+
+// Grouped run: slots [0, n0) on the caller's stream, [n0, n) on the solver's second stream.  With group_sync the
+// throughput phases A (zeroing, Jacobian pass, assembly, per-level launches) of the two groups ALTERNATE -- A(0,i),
+// A(1,i), A(0,i+1), ... chained by events -- and each group's latency phase D (task graph for the top of the tree and
+// the back substitution, loss pass, accept) runs under the other group's next A.  Every frame sees exactly the launches
+// it would see in a batch of its group's size: results do not depend on the grouping.
+static int run_grouped(slm_solver* s, int n_frames, const BatchDims d[2], int n0, hipStream_t st) {
+  const int n_it = s->cfg.num_iterations;
+  if (!s->group_stream) HIPCHK(hipStreamCreateWithFlags(&s->group_stream, hipStreamNonBlocking));
+  const size_t need_ev = 2 + 2 * (size_t)std::max(n_it, 1);
+  try {
+    s->group_events.reserve(need_ev);
+  } catch (...) {
+    return fail(SLM_ERR_HIP, "slm_run: out of host memory");
+  }
+  while (s->group_events.size() < need_ev) {
+    hipEvent_t e = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->group_events.push_back(e);
+  }
+  hipStream_t q[2] = {st, s->group_stream};
+  const int first[2] = {0, n0}, cnt[2] = {n0, n_frames - n0};
+  auto evA = [&](int g, int it) { return s->group_events[2 + 2 * (size_t)it + g]; };
+  HIPCHK(hipEventRecord(s->group_events[0], st));                       // fork
+  HIPCHK(hipStreamWaitEvent(s->group_stream, s->group_events[0], 0));
+  for (int it = 0; it < n_it; ++it) {
+    for (int g = 0; g < 2; ++g) {
+      if (s->group_sync) {
+        if (g == 0 && it > 0) HIPCHK(hipStreamWaitEvent(q[0], evA(1, it - 1), 0));
+        if (g == 1) HIPCHK(hipStreamWaitEvent(q[1], evA(0, it), 0));
+      }
+      hipError_t rec_err = hipSuccess;
+      const std::function<void()> between = [&]() { rec_err = hipEventRecord(evA(g, it), q[g]); };
+      enqueue_lm_iteration(s, first[g], cnt[g], d[g], q[g], g == 0, s->dag_cap, &between);
+      HIPCHK(rec_err);
+    }
+  }
+  HIPCHK(hipEventRecord(s->group_events[1], s->group_stream));          // join
+  HIPCHK(hipStreamWaitEvent(st, s->group_events[1], 0));
+  s->last_solver_form = 2;
+  return SLM_OK;
+}
+
 int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
   int rc = check_slots(s, 0, n_frames);
   if (rc) return rc;
@@ -1243,6 +1372,20 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
                 "slm_run: the frame is sharded; drive slm_lm_grad_local / slm_lm_solve / slm_lm_loss_local / "
                 "slm_lm_accept with the exchanges between them");
   hipStream_t st = (hipStream_t)stream;
+  const slm_config& c = s->cfg;
+  if (s->groups == 2 && n_frames >= s->group_min_frames && c.num_iterations > 0) {
+    const int n0 = (n_frames + 1) / 2;
+    BatchDims dg[2] = {dims_of(s, 0, n0), dims_of(s, n0, n_frames - n0)};
+    bool ok = true;
+    for (int g = 0; g < 2; ++g)
+      ok = ok && dg[g].nd && dg[g].v1 && solve_is_hybrid(s, g == 0 ? n0 : n_frames - n0, dg[g]);
+    if (ok) {
+      rc = run_grouped(s, n_frames, dg, n0, st);
+      if (rc) return rc;
+      HIPCHK(hipGetLastError());
+      return SLM_OK;
+    }
+  }
   BatchDims d = dims_of(s, 0, n_frames);
   if (!d.nd) {
     // A batch runs ONE solver form.  When some slot has no nested-dissection plan (a frame without surfels, a graph
@@ -1255,56 +1398,11 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     }
     d = dims_of(s, 0, n_frames);
   }
-  const FrameDev* fr = s->frames_dev;
-  const slm_config& c = s->cfg;
-  for (int it = 0; it < c.num_iterations; ++it) {
-    std::vector<hipEvent_t>* evs = nullptr;
-    if (s->profile) {
-      s->ev_runs.emplace_back();
-      evs = &s->ev_runs.back();
-    }
-    auto mark = [&]() {
-      if (!evs) return;
-      hipEvent_t e = take_event(s);
-      if (e) (void)hipEventRecord(e, st);
-      evs->push_back(e);
-    };
-    mark();
-    // (records of the Jacobian pass are reused after a rejected step on the multifrontal path, where the assembly
-    //  re-reads them; the banded path adds into the band in place)
-    const int* reuse = (d.nd && d.v1 && c.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
-    if (d.nd) {
-      launch_iter_begin_nd(fr, n_frames, st, reuse);
-    } else {
-      launch_iter_begin(fr, n_frames, st);
-    }
-    mark();
-    if (c.use_data) {
-      if (d.v1) launch_data_gram(fr, n_frames, d.max_pos, c.w_data, d.gram_variants, st, reuse);
-      else launch_data_grad(fr, n_frames, d.maxN, c.w_data, st);
-    }
-    mark();
-    if (d.nd) {
-      if (c.use_data) launch_front_assemble(fr, n_frames, d.max_blocks, st);
-      launch_reg_grad_nd(fr, n_frames, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
-      launch_front_load_rhs(fr, n_frames, d.maxP, st);
-    } else {
-      if (c.use_data && d.v1) launch_band_assemble(fr, n_frames, d.max_blocks, st);
-      launch_reg_grad(fr, n_frames, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
-    }
-    mark();
-    if (d.nd) enqueue_front_solve(s, fr, n_frames, d, -1.0, st);
-    else launch_band_solve(fr, n_frames, d.nt_max, d.wb_cap, -1.0, st);
-    if (c.use_data) launch_make_trial(fr, n_frames, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
-    mark();
-    if (c.use_data) launch_data_loss(fr, n_frames, kLossBlocks, c.w_data, 1, st);
-    mark();
-    if (d.n_reg_part > 0)
-      launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
-    launch_accept(fr, n_frames, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st,
-                  (d.nd && d.v1 && c.phase_test) ? s->reuse_dev : nullptr);
-    mark();
-  }
+  for (int it = 0; it < c.num_iterations; ++it) enqueue_lm_iteration(s, 0, n_frames, d, st, true, 0, nullptr);
+  // The reuse flag of a slot says "the Gram records in HBM were computed at the slot's CURRENT beta".  k_accept keeps it
+  // on every path that writes records (banded path included: a later multifrontal run may then reuse them); a run that
+  // wrote none (per-entry atomics) leaves nothing to reuse.
+  if (!(d.v1 && c.phase_test) && n_frames > 0) HIPCHK(hipMemsetAsync(s->reuse_dev, 0, sizeof(int) * n_frames, st));
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -1352,7 +1450,9 @@ int slm_profile_read(slm_solver* s, double* ms_out, int64_t* count_out) {
     ms_out[p] = 0.0;
     count_out[p] = 0;
   }
-  for (auto& evs : s->ev_runs) {
+  for (size_t r = 0; r < s->ev_runs.size(); ++r) {
+    auto& evs = s->ev_runs[r];
+    const bool counts = r >= s->ev_counts.size() || s->ev_counts[r] != 0;
     if ((int)evs.size() == SLM_PH_COUNT + 1 && evs.back()) {
       HIPCHK(hipEventSynchronize(evs.back()));
       for (int p = 0; p < SLM_PH_COUNT; ++p) {
@@ -1360,13 +1460,14 @@ int slm_profile_read(slm_solver* s, double* ms_out, int64_t* count_out) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, evs[p], evs[p + 1]));
         ms_out[p] += ms;
-        count_out[p] += 1;
+        if (counts) count_out[p] += 1;
       }
     }
     for (hipEvent_t e : evs)
       if (e) s->ev_pool.push_back(e);
   }
   s->ev_runs.clear();
+  s->ev_counts.clear();
   return SLM_OK;
 }
 

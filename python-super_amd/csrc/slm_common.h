@@ -47,7 +47,8 @@ struct LMState {
   int32_t m_grad;        // matched-surfel counter of the current Jacobian pass
   int32_t m_loss;        // matched-surfel counter of the current loss pass
   int32_t chol_fail;     // set by the factorisation of the current iteration
-  int32_t pad;
+  int32_t m_grad_local;  // surfel-sharded frames: this rank's own share of m_grad (k_pair_scatter puts the all-reduced count into
+                         // m_grad; a Jacobian pass reused after a rejected step sends the share again, not the global count)
 };
 
 // Per-slot descriptor, resident in HBM as an array indexed by blockIdx.y.

@@ -6,7 +6,7 @@
 // per LM iteration at C2 -- an iteration at one frame per launch is a chain of launch boundaries (each
 // 3-5 us of dispatch + a kernel prologue of dependent descriptor loads) around 33 sequential 64x64 tile
 // factorisations.  Here a dependent step costs one flag hand-off between two resident workgroups
-// (measured 1.8-1.9 us including a 32 KB tile written and re-read, tests/micro/launch_gap_mb.hip), tasks
+// (measured 1.8-1.9 us including a 32 KB tile written and re-read, tools/micro/launch_gap_mb.hip), tasks
 // of different fronts / levels / frames overlap freely, and nothing waits for a whole level.
 //
 // Scheduling.  The plan carries the task list in a topological order (sorted by modelled earliest start,
@@ -44,6 +44,7 @@
 // (s_waitcnt vmcnt(0) in every wave, then the workgroup barrier) before ONE lane publishes the flag / counter,
 // a consumer polls with relaxed agent-scope loads, then the workgroup barrier.  Descriptors (FrameDev, NDFront,
 // task list, maps) are written by the host before the launch and read with plain loads.
+#include <atomic>
 #include <cstdlib>
 
 #include "slm_tile.h"
@@ -227,7 +228,7 @@ __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, do
   for (int e = 0; e < 16; ++e) breg[e] = ld1(T + threadIdx.x + 256 * e);
 }
 // The same tile with 16 bytes per lane: thread t gets T[2t + 512 e] and T[2t + 512 e + 1] in r[2e], r[2e+1], e = 0..7.
-// One workgroup streams a 32 KB tile in 0.29 us this way, in 0.43 us with 8-byte loads (tests/micro/tile_stream_mb.hip:
+// One workgroup streams a 32 KB tile in 0.29 us this way, in 0.43 us with 8-byte loads (tools/micro/tile_stream_mb.hip:
 // the address path, not the memory, is the limit).  The language has no 16-byte atomic load, so these are buffer loads
 // with the same cache policy as ld1 (sc1: L1 and the non-coherent L2 bypassed); they follow the task's flag wait in
 // program order (a workgroup barrier with its fence stands between), which is all a hand-off needs.  T is uniform.
@@ -562,7 +563,7 @@ __device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s
 // v[e] = lv[e] * x[lane]; the butterfly then sums every column over the 64 lanes (halving the number of live
 // values at each of the first four steps).  Returns, in the lanes with (lane & 3) == 0, the sum
 // of column n = wave + 4 * ((lane >> 2) & 15).
-// (col_reduce16: slm_lane.h -- the VALU-only butterfly; tests/micro/col_reduce_mb.hip compares it with the __shfl_xor one)
+// (col_reduce16: slm_lane.h -- the VALU-only butterfly; tools/micro/col_reduce_mb.hip compares it with the __shfl_xor one)
 
 // sum of the four quarter partials of dag_accumulate<true>: result for row i in every thread with (threadIdx.x & 63) == i
 __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4 * NB */) {
@@ -1328,23 +1329,29 @@ void launch_dag_abort_check(const FrameDev* fr, int n_frames, hipStream_t st) {
 hipError_t set_dag_timeout_ticks(long long ticks) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_dag_timeout_ticks), &ticks, sizeof(ticks));
 }
-void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut) {
+// max_wg > 0 caps the persistent launch's grid: a launch that shares the GPU with the per-level launches of ANOTHER group
+// of frames (slm_api.hip, grouped run) must leave CUs to them -- a workgroup of this kernel owns its CU (one wave per SIMD
+// with the whole register file).  Tickets make any grid size deadlock-free.
+void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut, int max_wg) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
-  // per device: the dynamic-LDS attribute is a property of the kernel ON a device, and so is the CU count
-  static int n_wg_dev[64] = {0};
+  // per device: the dynamic-LDS attribute is a property of the kernel ON a device, and so is the CU count (host threads
+  // may drive different solvers on one device: atomics; a device id beyond the table is set up on every call)
+  static std::atomic<int> n_wg_dev[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
-  if (n_wg_dev[dev] == 0) {
+  const bool tracked = dev >= 0 && dev < 64;
+  int n_wg = tracked ? n_wg_dev[dev].load(std::memory_order_acquire) : 0;
+  if (n_wg == 0) {
     if (hipFuncSetAttribute((const void*)k_fdag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;   // (the launch below would fail: hipGetLastError reports it)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("SLM_DAG_WG_PER_CU");
     const int per_cu = e ? atoi(e) : 1;
-    n_wg_dev[dev] = cus * (per_cu > 0 ? per_cu : 1);
+    n_wg = cus * (per_cu > 0 ? per_cu : 1);
+    if (tracked) n_wg_dev[dev].store(n_wg, std::memory_order_release);
   }
-  const int n_wg = n_wg_dev[dev];
+  if (max_wg > 0 && max_wg < n_wg) n_wg = max_wg;
   hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);

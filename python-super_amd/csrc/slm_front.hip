@@ -10,6 +10,7 @@
 //    each front scatters its pivots' solution into delta.
 // Grid convention: blockIdx.y = front within the level, blockIdx.z = frame slot.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "slm_tile.h"
@@ -178,7 +179,12 @@ __global__ void __launch_bounds__(256) k_pair_scatter(const FrameDev* __restrict
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.v1_ready || !fd.nd_ready || fd.st->stopped) return;
   const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bi == 0 && (threadIdx.x & 63) == 0) fd.st->m_grad = (int)fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC];
+  if (bi == 0 && (threadIdx.x & 63) == 0) {
+    // the rank's own count is kept apart: after a rejected step the records -- and this count -- are sent again
+    // (k_iter_begin_nd restores it), and the all-reduced count must not take its place
+    fd.st->m_grad_local = fd.st->m_grad;
+    fd.st->m_grad = (int)fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC];
+  }
   if (bi >= fd.n_blocks) return;
   const int l = threadIdx.x & 63;
   if (l >= SLM_WREC) return;
@@ -457,7 +463,10 @@ __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restric
   const size_t nrhs = (size_t)fd.nt * SLM_NB;
   for (size_t e = tid; e < nrhs; e += nthr) fd.rhs[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (!(reuse && reuse[blockIdx.y])) fd.st->m_grad = 0;   // (a reused Jacobian pass keeps its matched count)
+    // (a reused Jacobian pass keeps its matched count -- on a surfel-sharded frame the rank's OWN share of it, which
+    //  k_pair_scatter set aside before it stored the all-reduced count)
+    if (!(reuse && reuse[blockIdx.y])) fd.st->m_grad = 0;
+    else if (fd.pairbuf) fd.st->m_grad = fd.st->m_grad_local;
     fd.st->chol_fail = 0;
   }
 }
@@ -1089,7 +1098,7 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   // double-buffered (2 x 16 KB): three workgroups per CU instead of two, and the next half is in
   // flight while the current one is on the MFMA.
   // (B half tiles move with 16 bytes per lane: half the load / LDS-store instructions, and a workgroup streams a tile
-  //  1.5x faster that way -- tests/micro/tile_stream_mb.hip)
+  //  1.5x faster that way -- tools/micro/tile_stream_mb.hip)
   typedef double dvec2 __attribute__((ext_vector_type(2)));
   dvec2 breg[4];
   double areg[16], acur[16];
@@ -1294,16 +1303,18 @@ void launch_front_levels(const FrameDev* fr, int n_frames, const NDLevelSched* l
   const size_t lds = PANEL_LDS_DOUBLES * sizeof(double);
   const size_t lds11 = L11_LDS_DOUBLES * sizeof(double);
   // the dynamic-LDS limit is a property of a kernel ON a device: set once per device id
-  static bool attr_set[64] = {false};
+  // (host threads may drive different solvers on one device: the flags are atomics; a device id beyond the table sets
+  //  the attributes on every call instead of aliasing another device's flag)
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
+  const bool tracked = dev >= 0 && dev < 64;
+  if (!tracked || !attr_set[dev].load(std::memory_order_acquire)) {
     if (hipFuncSetAttribute((const void*)k_fL11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_fpanel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_fpotrf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return;   // (sticky HIP error: the caller's hipGetLastError reports it)
-    attr_set[dev] = true;
+    if (tracked) attr_set[dev].store(true, std::memory_order_release);
   }
   for (int l = 0; l < l_factor_end; ++l) {
     const NDLevelSched& s = lv[l];

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_init_slot(const FrameDev* __restrict__ 
     s.m_grad = 0;
     s.m_loss = 0;
     s.chol_fail = 0;
-    s.pad = 0;
+    s.m_grad_local = 0;
     *fd.st = s;
   }
 }

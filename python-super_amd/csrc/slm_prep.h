@@ -45,4 +45,7 @@ PrepBuffers* prep_create();
 void prep_destroy(PrepBuffers*);
 // Builds the plan for frame f (stream-synchronising: one small read-back, two for a plan's first frame).
 hipError_t prep_v1(PrepBuffers*, const slm_frame& f, V1Plan& plan, V1Sizes* out, hipStream_t st);
+// The range test of the surfel KNN table on its own (frames that do not take the tuple-sorted path): *bad = an index
+// outside [0, J) exists.  Stream-synchronising (one 4-byte read-back).
+hipError_t prep_check_knn(PrepBuffers*, const slm_frame& f, bool* bad, hipStream_t st);
 void plan_free(V1Plan& plan);

@@ -95,7 +95,7 @@ __device__ __forceinline__ double rsq1(double p) {
 // 16x16 diagonal block on ONE wave, register resident: blocked right-looking Cholesky with 4x4
 // pivot blocks, so that all four k-slots of v_mfma_f64_16x16x4_f64 carry a rank-1 term (on gfx950
 // an f64 MFMA issues in 70 cycles and does not overlap f64 VALU work: one MFMA per pivot, as in a
-// rank-1 formulation, costs 370 cycles per pivot; this costs 260, tests/micro/diag16_mb.hip).
+// rank-1 formulation, costs 370 cycles per pivot; this costs 260, tools/micro/diag16_mb.hip).
 // The block S (full symmetric) and the running inverse M (starts as I) live in MFMA accumulator
 // layout: reg r of lane l <-> [row (l>>4)+4r][col l&15].  Block step b (rows 4b..4b+3 = register
 // b of the four lane quarters):

@@ -1,6 +1,6 @@
 """TEST HARNESS (not product code): runs the stage mirrors in the order the reference's per-frame driver calls
 them (``SuPer.forward`` -> ``init_surfels`` / ``fusion``, ``super/super.py:23-73``), so that the tests and
-``tests/time_driver.py`` can exercise whole sequences through libsuper_lm.so.  A reference user does NOT need
+``tools/time_driver.py`` can exercise whole sequences through libsuper_lm.so.  A reference user does NOT need
 this file: INTEGRATION.md section 2 binds the stage mirrors onto the reference's own ``SuPer`` / ``Surfels``.
 
     loop = FrameLoop(opt)                       # opt: the reference's option names

@@ -30,12 +30,16 @@ def _worker(rank, world, port, mode, name, tmp):
         sf, inputs, new_data = torch_frame(sc)
         if mode == "lm":
             from super_amd.LM import LM_Solver
-            lm = LM_Solver(ref_opt(opt), shard_surfels=True)
+            o = ref_opt(opt)
+            if name.endswith("_reject"):                       # run on past the fixture's rejected (last) iteration
+                o.num_optimize_iterations = int(o.num_optimize_iterations) + 8
+            lm = LM_Solver(o, shard_surfels=True)
             assert (lm.rank, lm.world) == (rank, world)
             beta = lm.LM(sf, inputs, new_data).cpu().numpy()
             recs = lm.last_records[0]
             np.savez(os.path.join(tmp, f"rank{rank}.npz"), beta=beta, loss=np.array([r["loss"] for r in recs]),
-                     accepted=np.array([r["accepted"] for r in recs]), status=np.array([r["status"] for r in recs]))
+                     accepted=np.array([r["accepted"] for r in recs]), status=np.array([r["status"] for r in recs]),
+                     M_grad=np.array([r["M_grad"] for r in recs]), M_loss=np.array([r["M_loss"] for r in recs]))
         else:
             from oracle import graphfit_oracle as gfo
             from super_amd.deform_mesh import GraphFit
@@ -68,6 +72,29 @@ def test_surfel_sharded_lm_under_a_process_group(tmp_path, name):
     np.testing.assert_allclose(r0["loss"], g["lm_loss"], rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(r0["beta"], g["lm_beta"], rtol=0, atol=1e-4)
     assert np.abs(r0["beta"] - g["lm_beta"]).max() < 1e-7
+
+
+def test_surfel_sharded_lm_matched_counts_survive_a_reject_under_a_process_group(tmp_path):
+    """the record's M_grad after a rejected step (reused Jacobian pass) must be the frame's matched
+    count, not world x the count -- compared with the unsharded solve over the same (extended) iterations."""
+    from helpers import load_golden, ref_opt, torch_frame
+    from super_amd.LM import LM_Solver
+    name = "s60x80_j48_reject"
+    r0, r1 = _spawn("lm", name, tmp_path)
+    _, sc, opt = load_golden(name)
+    o = ref_opt(opt)
+    o.num_optimize_iterations = int(o.num_optimize_iterations) + 8
+    lm = LM_Solver(o)
+    want_beta = lm.LM(*torch_frame(sc)).cpu().numpy()
+    want = lm.last_records[0]
+    acc = [r["accepted"] for r in want]
+    assert False in acc[:-1]
+    for r in (r0, r1):
+        assert list(r["accepted"]) == acc
+        assert list(r["M_grad"]) == [x["M_grad"] for x in want]
+        assert list(r["M_loss"]) == [x["M_loss"] for x in want]
+    np.testing.assert_array_equal(r0["beta"], r1["beta"])
+    np.testing.assert_allclose(r0["beta"], want_beta, rtol=0, atol=1e-9)
 
 
 def test_surfel_sharded_graphfit_under_a_process_group(tmp_path):

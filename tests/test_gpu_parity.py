@@ -279,18 +279,17 @@ def test_nd_multifrontal_solve_matches_band_and_numpy(name):
     np.testing.assert_allclose(sols[0], sols[2], rtol=0, atol=1e-11)   # (the default data path is not bitwise reproducible)
 
 
-@pytest.mark.parametrize("name,world", [("s60x80_j48", 2), ("s120x160_j108", 3), ("s60x80_j48_reject", 4)])
-def test_surfel_sharded_lm_reproduces_the_single_gpu_solve(name, world):
+def _run_emulated_ranks(name, world, extra_iterations=0):
     """One frame split over `world` ranks (one solver context each on this GPU; the all-reduce of
     the J^T J / J^T r pair blocks and of the loss partials and the broadcast of delta are emulated by
-    combining the ranks' exchange buffers): same iterations, same accept flags, same beta."""
-    import ctypes as C
+    combining the ranks' exchange buffers).  Returns (golden, opt, betas per rank, records per rank)."""
     import torch
     from super_amd import _lib
     from super_amd.LM import LM_Solver, _dev_ptr, _stream_ptr
     g, sc, opt = load_golden(name)
     sf, inputs, new_data = torch_frame(sc)
     o = ref_opt(opt)
+    o.num_optimize_iterations = int(o.num_optimize_iterations) + extra_iterations
     ranks = [LM_Solver(o, rank=r, world=world, all_reduce=lambda t: None, broadcast=lambda t: None)
              for r in range(world)]
     hs = [lm._handle() for lm in ranks]
@@ -327,6 +326,13 @@ def test_surfel_sharded_lm_reproduces_the_single_gpu_solve(name, world):
         _lib.check(lib.slm_get_beta(h, 0, _dev_ptr(beta), st), "get_beta")
         betas.append(beta.cpu().numpy())
     recs = [lm.records(h, 0, st) for lm, h in zip(ranks, hs)]
+    return g, o, betas, recs
+
+
+@pytest.mark.parametrize("name,world", [("s60x80_j48", 2), ("s120x160_j108", 3), ("s60x80_j48_reject", 4)])
+def test_surfel_sharded_lm_reproduces_the_single_gpu_solve(name, world):
+    """Same iterations, same accept flags, same beta as the single-GPU solve and the reference's golden."""
+    g, o, betas, recs = _run_emulated_ranks(name, world)
     for b in betas[1:]:
         np.testing.assert_array_equal(b, betas[0])                      # every rank: identical parameters
     for r in recs[1:]:
@@ -336,6 +342,29 @@ def test_surfel_sharded_lm_reproduces_the_single_gpu_solve(name, world):
     np.testing.assert_allclose([x["loss"] for x in recs[0]], g["lm_loss"], rtol=1e-6)
     assert [x["accepted"] for x in recs[0]] == [bool(a) for a in g["lm_accepted"]]
     assert recs[0][0]["M_grad"] == len(g["b0_match"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_surfel_sharded_lm_keeps_the_matched_count_after_a_rejected_step(world):
+    """after a rejected step the ranks send their Gram records AGAIN (the Jacobian pass is
+    reused) -- and with them their OWN share of the matched-surfel count, not the all-reduced one of the iteration
+    before (which would come back multiplied by the world size, compounding over consecutive rejects).  Runs past the
+    fixture's reject and compares every record field with the unsharded solve."""
+    from super_amd.LM import LM_Solver
+    extra = 8
+    g, o, betas, recs = _run_emulated_ranks("s60x80_j48_reject", world, extra_iterations=extra)
+    _, sc, _ = load_golden("s60x80_j48_reject")
+    lm = LM_Solver(o)
+    want_beta = lm.LM(*torch_frame(sc)).cpu().numpy()
+    want = lm.last_records[0]
+    acc = [r["accepted"] for r in want]
+    assert False in acc[:-1]                                   # a rejected iteration that is followed by another one
+    for r in recs:
+        assert [x["accepted"] for x in r] == acc
+        assert [x["M_grad"] for x in r] == [x["M_grad"] for x in want]
+        assert [x["M_loss"] for x in r] == [x["M_loss"] for x in want]
+        assert [x["status"] for x in r] == [x["status"] for x in want]
+    np.testing.assert_allclose(betas[0], want_beta, rtol=0, atol=1e-9)
 
 
 def test_lm_is_bitwise_reproducible_with_the_per_run_slab():

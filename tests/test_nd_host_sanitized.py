@@ -1,7 +1,7 @@
 """The host-side symbolic analysis of the multifrontal solver (python-super_amd/csrc/slm_nd_host.hip: plain C++, runs
 inside slm_bind_frame) under AddressSanitizer + UBSan on degenerate coupling graphs: one node, random graphs with
 self references and duplicates, duplicate points, disconnected islands, invalid (-1) node-KNN entries, a dense graph.
-CPU only (GPU sanitizers are not available on the pool); the harness is tests/studies/nd/nd_stats.cpp."""
+CPU only (GPU sanitizers are not available on the pool); the harness is tools/studies/nd/nd_stats.cpp."""
 import os
 import shutil
 import subprocess
@@ -52,7 +52,7 @@ def test_symbolic_analysis_is_clean_under_asan_and_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "python-super_amd", "csrc")
     subprocess.check_call([gxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
                            "-std=c++17", "-shared", "-fPIC", "-I", csrc, "-x", "c++",
-                           os.path.join(ROOT, "tests", "studies", "nd", "nd_stats.cpp"), os.path.join(csrc, "slm_nd_host.hip"), "-o", so])
+                           os.path.join(ROOT, "tools", "studies", "nd", "nd_stats.cpp"), os.path.join(csrc, "slm_nd_host.hip"), "-o", so])
     asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
     if not os.path.isabs(asan):
         pytest.skip("libasan not found")

@@ -69,6 +69,34 @@ def test_lm_trace_matches_reference(name):
     assert not g["lm_accepted"].all() or name != "s60x80_j48_reject"
 
 
+@pytest.mark.parametrize("name", GOLDENS)
+def test_sparse_solve_option_reproduces_the_reference_trace(name):
+    """``lm(..., solve="sparse")`` (SuperLU on the block-sparse JtJ + uI -- what the full-size checks at 4 k nodes use)
+    against the reference's own trace and against the dense path, delta by delta."""
+    g, sc, opt = load_golden(name)
+    fr = orc.Frame.from_scene(sc)
+    tr_s, tr_d = [], []
+    beta_s = orc.lm(fr, opt, trace=tr_s, solve="sparse")
+    beta_d = orc.lm(fr, opt, trace=tr_d)
+    assert len(tr_s) == len(g["lm_loss"])
+    np.testing.assert_array_equal([t["accepted"] for t in tr_s], g["lm_accepted"])
+    np.testing.assert_allclose([t["loss"] for t in tr_s], g["lm_loss"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(beta_s, g["lm_beta"], rtol=0, atol=1e-6)
+    for a, b in zip(tr_s, tr_d):
+        scale = max(1.0, np.abs(b["delta"]).max())
+        np.testing.assert_allclose(a["delta"], b["delta"], rtol=0, atol=1e-7 * scale)
+    np.testing.assert_allclose(beta_s, beta_d, rtol=0, atol=1e-7)
+
+
+def test_sparse_solve_refuses_an_indefinite_matrix():
+    import scipy.sparse as sp
+    A = sp.csr_matrix(np.diag([4.0, -1.0, 3.0]) + 0.1 * (np.ones((3, 3)) - np.eye(3)))
+    with pytest.raises(np.linalg.LinAlgError):
+        orc.solve_damped_sparse(A, np.ones(3), 0.0)
+    x = orc.solve_damped_sparse(A, np.ones(3), 2.0)            # damped: positive definite
+    np.testing.assert_allclose((A.toarray() + 2.0 * np.eye(3)) @ x, np.ones(3), atol=1e-12)
+
+
 @pytest.mark.parametrize("name", ["s60x80_j48", "s120x160_j108"])
 def test_update_matches_reference(name):
     g, sc, opt = load_golden(name)

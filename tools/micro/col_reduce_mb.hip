@@ -1,7 +1,7 @@
 // col_reduce_mb.hip -- the 16-value lane reduction of the back substitution (slm_dag.hip col_reduce16): ds_bpermute
 // butterfly (__shfl_xor) against a VALU-only one (v_permlane32_swap, v_permlane16_swap, DPP).  Checks that both return
 // the same sums in the same lanes, and times a dependent chain of reductions.
-// build: hipcc --offload-arch=gfx950 -O3 -I python-super_amd/csrc -o tests/micro/bin/col_reduce_mb tests/micro/col_reduce_mb.hip
+// build: hipcc --offload-arch=gfx950 -O3 -I python-super_amd/csrc -o tools/micro/bin/col_reduce_mb tools/micro/col_reduce_mb.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

@@ -1,6 +1,6 @@
 // Diagnostic micro-benchmark (not part of the library): cycles per pivot step of variants of the
 // 16x16 diagonal-block factorisation used by potrf64 (slm_tile.h::diag16).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I python-super_amd/csrc tests/micro/diag16_mb.hip -o python-super_amd/build/mb.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I python-super_amd/csrc tools/micro/diag16_mb.hip -o python-super_amd/build/mb.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

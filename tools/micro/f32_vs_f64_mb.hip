@@ -1,9 +1,9 @@
-// Diagnostic micro-benchmark for the mixed-precision study (tests/studies/f32_factor_study.py):
+// Diagnostic micro-benchmark for the mixed-precision study (tools/studies/f32_factor_study.py):
 // what would a float32 tile factorisation gain on the CRITICAL PATH of the multifrontal solver?  One wave, dependent
 // chains, float32 against float64, of the pieces the 16 x 16 diagonal-block factorisation (slm_tile.h diag16) is made
 // of: the MFMA (16x16x4), the fused multiply-add, the reciprocal square root + Newton step, and one emulated 4-pivot
 // block step of diag16 (4 rsq, a 10-entry Cholesky of the pivot block, two 4-term forward substitutions, 2 MFMAs).
-//   hipcc --offload-arch=gfx950 -O3 tests/micro/f32_vs_f64_mb.hip -o tests/micro/bin/f32_vs_f64_mb && tests/micro/bin/f32_vs_f64_mb
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/f32_vs_f64_mb.hip -o tools/micro/bin/f32_vs_f64_mb && tools/micro/bin/f32_vs_f64_mb
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double double4_t __attribute__((ext_vector_type(4)));

@@ -2,7 +2,7 @@
 // the task-graph solver, slm_dag.hip dag_task_back, is one workgroup walking up to 45 tiles)
 //   variants: agent-scope atomic loads (sc1, what the task graph must use) or plain loads; 8-byte or 16-byte per lane;
 //   3 or 6 tiles in flight.
-// build: hipcc --offload-arch=gfx950 -O3 -o tests/micro/bin/tile_stream_mb tests/micro/tile_stream_mb.hip
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/bin/tile_stream_mb tools/micro/tile_stream_mb.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

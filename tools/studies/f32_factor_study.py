@@ -14,7 +14,7 @@ Gate, per fixture recorded from the reference (incl. the data-term-only problem 
       pose bar is 1e-4),
     * no float32 factorisation breaks down (non-positive pivot).
 
-    python tests/studies/f32_factor_study.py            (CPU, ~1 min)  -> table on stdout (recorded in f32_factor_study.txt)
+    python tools/studies/f32_factor_study.py            (CPU, ~1 min)  -> table on stdout (recorded in f32_factor_study.txt)
 """
 from __future__ import annotations
 

@@ -10,7 +10,7 @@ would do to the result, and reports the node-pose error against the goldens reco
            starts at 6e-5) and un-scaled after the float32 accumulation
   all16    tgt16 + jac16s
 
-    python tests/studies/fp16_study.py            (CPU, ~1 min)   ->  table on stdout (recorded in DESIGN.md)
+    python tools/studies/fp16_study.py            (CPU, ~1 min)   ->  table on stdout (recorded in DESIGN.md)
 """
 from __future__ import annotations
 

@@ -1,6 +1,6 @@
 """Diagnostic: start / end of every kernel of ONE LM iteration (all streams) from a rocprofv3 kernel trace.
-    rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 tests/time_solver.py C2 8 --hybrid
-    python tests/studies/iteration_timeline.py "/tmp/lt/**/*kernel_trace.csv" [iteration=30]"""
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 tools/time_solver.py C2 8 --hybrid
+    python tools/studies/iteration_timeline.py "/tmp/lt/**/*kernel_trace.csv" [iteration=30]"""
 import csv
 import glob
 import sys

@@ -1,6 +1,6 @@
 """Diagnostic: per-kernel time per LM iteration from a rocprofv3 --kernel-trace --stats run.
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 tests/time_solver.py C2 8 --hybrid
-    python tests/studies/kernel_sums.py "/tmp/ks/**/*kernel_stats.csv" [top]
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 tools/time_solver.py C2 8 --hybrid
+    python tools/studies/kernel_sums.py "/tmp/ks/**/*kernel_stats.csv" [top]
 One line per kernel: calls, us per iteration (iterations = launches of k_accept), average us per launch."""
 import csv
 import glob

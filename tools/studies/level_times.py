@@ -1,6 +1,6 @@
 """Diagnostic: per-LAUNCH durations of the solver kernels inside one LM iteration, from a rocprofv3 kernel trace.
-    rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 tests/time_solver.py C2 8 --hybrid
-    python tests/studies/level_times.py "/tmp/lt/**/*kernel_trace.csv"
+    rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -- python3 tools/time_solver.py C2 8 --hybrid
+    python tools/studies/level_times.py "/tmp/lt/**/*kernel_trace.csv"
 Prints, for the median iteration (delimited by k_accept), every launch in order: kernel, grid (workgroups), duration, gap to
 the previous launch's end; then per kernel name the list of per-launch medians over all iterations (one entry per level)."""
 import csv

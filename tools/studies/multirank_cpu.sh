@@ -1,7 +1,7 @@
 #!/bin/bash
 # Study (1-GPU box): N bench ranks sharing cuda:0 (BENCH_SHARE_GPU=1, gloo exchange) -- the host-CPU pattern of an N-GPU job
 # under the container's CPU quota: CFS throttling counters before / after, with the spinning and the polled drain.
-#   bash tests/studies/multirank_cpu.sh [ranks=4] [steps=10]
+#   bash tools/studies/multirank_cpu.sh [ranks=4] [steps=10]
 # Result (round 3): inconclusive for the drain -- under gloo the host-staged all-gather (`local.cpu()`) spins by itself, 3.2-3.5
 # CPUs per rank either way, 3-4 throttled periods per run (the start-up).  Side observation: four processes of 8 frames on
 # ONE GPU reach 3 260-3 400 it/s in total (one process of 8 frames: 2 740): their latency- and throughput-bound phases overlap.

@@ -1,5 +1,5 @@
 // Host-only harness around the symbolic analysis (python-super_amd/csrc/slm_nd_host.hip): builds the plan of a coupling
-// graph handed over by tests/studies/nd_order_study.py and returns its cost figures.  Study tool, not part of the library.
+// graph handed over by tools/studies/nd_order_study.py and returns its cost figures.  Study tool, not part of the library.
 #include <cstdint>
 #include <cstring>
 #include "slm_nd.h"

@@ -1,8 +1,8 @@
 """Study: how good is the elimination ordering of the multifrontal solver, and what would a better one buy?
 
-    python tests/studies/nd_order_study.py [C2] [seeds=4]          (CPU only)
+    python tools/studies/nd_order_study.py [C2] [seeds=4]          (CPU only)
 
-Builds tests/studies/nd/nd_stats.cpp + python-super_amd/csrc/slm_nd_host.hip with g++ (the symbolic analysis is host
+Builds tools/studies/nd/nd_stats.cpp + python-super_amd/csrc/slm_nd_host.hip with g++ (the symbolic analysis is host
 code), hands it the coupling graph of synthetic frames (surfel KNN tuples + node KNN, as slm_bind_frame does) and prints
 the plan's cost figures: factorisation FLOPs (64-padded, as the tile kernels execute them, and exact), fronts, levels,
 pivot-column chain of the top fronts.  Environment switches of the analysis (SLM_ND_*) select ordering variants."""
@@ -19,8 +19,8 @@ from super_amd import synth  # noqa: E402
 
 
 def build():
-    out = os.path.join(ROOT, "tests", "studies", "nd", "_nd_stats.so")
-    src = [os.path.join(ROOT, "tests", "studies", "nd", "nd_stats.cpp"), os.path.join(ROOT, "python-super_amd", "csrc", "slm_nd_host.hip")]
+    out = os.path.join(ROOT, "tools", "studies", "nd", "_nd_stats.so")
+    src = [os.path.join(ROOT, "tools", "studies", "nd", "nd_stats.cpp"), os.path.join(ROOT, "python-super_amd", "csrc", "slm_nd_host.hip")]
     if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in src + [os.path.join(ROOT, "python-super_amd", "csrc", "slm_nd.h")]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "python-super_amd", "csrc"),
                                "-x", "c++", *src, "-o", out])

@@ -2,7 +2,7 @@
 (VERDICT r01 item 4 proposed writing single-workgroup pairs straight into the fronts from the kernel's epilogue.)
 Restates the layout of slm_prep.hip: canonical 4-tuples sorted, each tuple's surfels padded to a multiple of 4
 positions, 256 positions per workgroup; a (workgroup, pair) record exists for every pair of every tuple the workgroup
-touches.      python tests/studies/pair_ownership.py [C1|C2|C4]
+touches.      python tools/studies/pair_ownership.py [C1|C2|C4]
 C2: 11055 tuples, 853 workgroups, 15471 pairs, 42779 records (= the plan's own counts in the bench line);
     pairs with 1 / 2 / 3 / 4 / 5+ records: 3890 / 3370 / 4049 / 2199 / 1963 -- single-workgroup pairs are 25 % of the
     pairs and 9 % of the records."""

@@ -1,8 +1,8 @@
 """Study: the rare ~8 ms stall of a bench step.
 
-    python tests/studies/stall_hunt.py run [steps=200] [frames=8]        # per-step / per-segment timing, outliers
-    rocprofv3 --hip-trace --kernel-trace --output-format csv -d /tmp/sh -o sh -- python3 tests/studies/stall_hunt.py run 200
-    python tests/studies/stall_hunt.py gaps "/tmp/sh/**/" [gap_ms=2]      # GPU idle gaps and the HIP calls spanning them
+    python tools/studies/stall_hunt.py run [steps=200] [frames=8]        # per-step / per-segment timing, outliers
+    rocprofv3 --hip-trace --kernel-trace --output-format csv -d /tmp/sh -o sh -- python3 tools/studies/stall_hunt.py run 200
+    python tools/studies/stall_hunt.py gaps "/tmp/sh/**/" [gap_ms=2]      # GPU idle gaps and the HIP calls spanning them
 
 `run` executes bench.py's step (reset copies, slm_bind_frames, slm_run, beta + Surfels.update per frame) with a device
 event after every segment and host time stamps around every call: for an outlier step it tells whether the GPU was

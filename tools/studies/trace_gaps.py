@@ -1,5 +1,5 @@
 """Diagnostic: idle gaps and long kernels in a rocprofv3 --kernel-trace csv.
-    python tests/studies/trace_gaps.py <kernel_trace.csv> [gap_us=1000] [long_us=3000]"""
+    python tools/studies/trace_gaps.py <kernel_trace.csv> [gap_us=1000] [long_us=3000]"""
 import csv
 import sys
 

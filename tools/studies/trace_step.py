@@ -1,6 +1,6 @@
 """Diagnostic: what runs BETWEEN two LM runs of the bench step (bind, update, copies) from a rocprofv3 --kernel-trace csv
 of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency-b1 --no-profile`.
-    python tests/studies/trace_step.py <kernel_trace.csv>
+    python tools/studies/trace_step.py <kernel_trace.csv>
 Prints the span from the last k_accept of one step to the first k_data_gram of the next: per-kernel busy time, the union
 busy time (streams overlap), idle time."""
 import csv

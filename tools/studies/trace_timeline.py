@@ -1,6 +1,6 @@
 """Diagnostic: timeline of ONE LM iteration from a rocprofv3 --kernel-trace csv.
-    rocprofv3 --kernel-trace -d gpurun_out/tl -o tl --output-format csv -- python3 tests/time_solver.py C2 8
-    python tests/studies/trace_timeline.py gpurun_out/tl/*/tl_kernel_trace.csv [nth-from-last data_gram]
+    rocprofv3 --kernel-trace -d gpurun_out/tl -o tl --output-format csv -- python3 tools/time_solver.py C2 8
+    python tools/studies/trace_timeline.py gpurun_out/tl/*/tl_kernel_trace.csv [nth-from-last data_gram]
 Prints, from one k_data_gram to the next, every dispatch: start offset (us), duration, gap before it, name."""
 import csv
 import glob

@@ -1,5 +1,5 @@
 """Diagnostic: ms per LM iteration (bind excluded) for the per-level launch solver (0) and the persistent
-task-graph solver (2), B frames per launch.   python tests/time_solver.py [workload] [B ...]"""
+task-graph solver (2), B frames per launch.   python tools/time_solver.py [workload] [B ...]"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """Diagnostic: per-task timeline of the task-graph solver (solver_path 2) for one damped solve.
-    python tests/trace_dag.py [workload] [frames]"""
+    python tools/trace_dag.py [workload] [frames]"""
 import ctypes as C
 import os
 import sys

@@ -1,7 +1,7 @@
 """Diagnostic: print the kernel timeline of one LM iteration from a rocprofv3 kernel trace.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile
-    python tests/trace_iteration.py gpurun_out/trace
+    python tools/trace_iteration.py gpurun_out/trace
 """
 import csv
 import glob
