@@ -217,6 +217,96 @@ def latency_b1(dims, device, iters, steps=6):
     return out
 
 
+def latency_b1_sequence(device, frames=48):
+    """`latency_b1_sequence`: the one-frame-per-launch path as a TRACKER sees it -- not the always-warm re-bind of one
+    frame that `latency_b1` times, but a moving surface at the SuPer image size (480 x 640, about 300 k surfels / 2.5 k
+    grid-mesh nodes) through the stage mirrors in the reference driver's order (tests/driver_harness.py: depth
+    preprocessing -> LM -> update -> fusion -> swap; reference super/super.py:23-73): surfels come and go, the coupling
+    graph changes, some frames need a new symbolic analysis.  Host-timed per stage around stream syncs.  Run twice: with the
+    model-side prepare started ahead of the next frame (`slm_prepare_model`, after the swap) and with the whole prepare
+    inside LM() as in rounds 1-3."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import driver_harness as drv
+    from super_amd import _lib, synth
+    H, W = 480, 640
+    K = synth.intrinsics()
+    inv_K = np.linalg.pinv(K)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    color = np.random.default_rng(2).uniform(0, 1, (3, H, W)).astype(np.float32)
+    depths = []
+    for k in range(frames):
+        d = (0.2 * synth._surface(uu, vv, H, W, 0.3 + 0.3 * np.sin(0.05 * k))).astype(np.float32)
+        d[:4] = 0.0
+        d[:, :4] = 0.0
+        depths.append(torch.from_numpy(d)[None, None])
+    lib = _lib.load()
+    cnt = (C.c_int64 * 4)()
+    out = {}
+    for label, ahead in (("prepare_ahead", True), ("prepare_inside_lm", False)):
+        opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, depth_model="monodepth2",
+                              dilate_invalid_kernel=0, normal_model="naive", phase="test", method="super", load_depth=True,
+                              deform_udpate_method="super_edg", mesh_step_size=11, use_derived_gradient=True,
+                              sf_point_plane=True, mesh_arap=True, mesh_rot=True, mesh_face=False, sf_point_plane_weight=1.0,
+                              mesh_arap_weight=10.0, mesh_rot_weight=1.0, mesh_face_weight=1.0, num_optimize_iterations=10,
+                              num_neighbors=4, num_ED_neighbors=4, th_dist=0.02, th_cosine_ang=0.4, th_time_steps=30,
+                              disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
+                              disable_adding_new_surfels=False, disable_removing_unstable_surfels=False,
+                              slm_prepare_ahead=ahead)
+        loop = drv.FrameLoop(opt)
+        lm_ms, tot_ms, builds, rej, its = [], [], [], 0, 0
+        lm_call = loop.lm.LM
+
+        def timed_lm(*a, **k):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            r = lm_call(*a, **k)
+            torch.cuda.synchronize(device)
+            lm_ms.append((time.perf_counter() - t0) * 1e3)
+            return r
+        loop.lm.LM = timed_lm
+        for k in range(frames):
+            inputs = {("depth", 0): depths[k].to(device), ("disp", 0): torch.zeros(1, 1, H, W, device=device),
+                      "inv_K": torch.from_numpy(inv_K)[None].to(device), "K": torch.from_numpy(K)[None].to(device),
+                      ("color", 0): torch.from_numpy(color)[None].to(device), "divterm": torch.tensor(1.0 / (2 * 0.6 * 0.6)),
+                      "filename": ["%06d" % k], "time": k, "ID": torch.tensor([k])}
+            torch.cuda.synchronize(device)
+            lib.slm_debug_counters(cnt)
+            b0 = cnt[2]
+            t0 = time.perf_counter()
+            loop(SimpleNamespace(), inputs)
+            torch.cuda.synchronize(device)
+            tot_ms.append((time.perf_counter() - t0) * 1e3)
+            if k + 1 < frames:                          # the next frame's acquisition: a preparation queued after the swap runs under it
+                time.sleep(0.004)
+            lib.slm_debug_counters(cnt)
+            builds.append(int(cnt[2] - b0))
+            if loop.lm.last_records and k > 0:
+                recs = loop.lm.last_records[0]
+                its += len(recs)
+                rej += sum(1 for r in recs if r["status"] == 0 and not r["accepted"])
+        skip = 4                                         # first frames: allocations, the first plan
+        lm = np.array(lm_ms[skip - 1:])                  # (no LM on frame 0)
+        tt = np.array(tot_ms[skip:])
+        q = lambda a, p: float(np.percentile(a, p))
+        out[label] = {"lm_stage_ms": {"median": q(lm, 50), "p99": q(lm, 99), "mean": float(lm.mean())},
+                      "frame_ms": {"median": q(tt, 50), "p99": q(tt, 99), "mean": float(tt.mean())},
+                      "symbolic_analyses": int(sum(builds[skip:])),
+                      "frames_with_a_symbolic_analysis": float(np.mean([b > 0 for b in builds[skip:]])),
+                      "rejected_iteration_share": rej / max(its, 1)}
+        surf, nodes = int(loop.sf.points.shape[0]), int(loop.sf.ED_nodes.num)
+        del loop
+    out["sample"] = (f"{frames} frames of a moving synthetic surface, {H}x{W}, {surf} surfels / {nodes} nodes at the end, 10 LM "
+                     "iterations per frame, one frame per launch (task-graph solver); the first 4 frames are not counted; 4 ms of host "
+                     "idle time between frames stand for the acquisition of the next frame (a depth network takes far longer)")
+    out["note"] = ("`prepare_ahead`: slm_prepare_model right after the swap -- the sort, the size read-backs and the symbolic analyses "
+                   "run on the library's worker thread between frames, LM() only binds the target; `prepare_inside_lm`: rounds 1-3")
+    return out
+
+
 def bind_timing(dims, device, B, reps=6):
     """The per-frame prepare (slm_bind_frame / slm_bind_frames = loss_term.prepare, reference super/loss.py:212-220,
     408-426) on its own, host-timed around a stream sync: `warm` = the frame's coupled-pair list is the one the slot's
@@ -764,6 +854,7 @@ def main():
             out["whole_step_hbm_frac"] = step_bytes / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not a.no_profile and not a.no_latency_b1:
             out["latency_b1"] = latency_b1(dims, device, iters)
+            out["latency_b1_sequence"] = latency_b1_sequence(device)
         out["host"] = host_info()
         out["host"]["cpu_cores_busy_per_rank"] = round(cpu_busy, 2)   # (rank 0; timed region; user + system time of all threads)
         out["host"]["cpu_cores_busy_all_ranks"] = round(cpu_busy_all, 2)   # (sum over the ranks: what the job costs of the node's CPU quota)

@@ -7,6 +7,7 @@
  *
  *   slm_create / slm_destroy   <- LM_Solver.__init__            super/LM.py:11-34
  *   slm_bind_frame             <- {Data,ARAP,Rot}Loss.prepare   super/loss.py:212-220,408-426,480-485
+ *   slm_prepare_model          <- its model-side half, ahead of the frame (see there)
  *   slm_run                    <- LM_Solver.LM                  super/LM.py:81-122
  *   slm_assemble               <- LM_Solver.prepareCostTerm(grad=True)   super/LM.py:54-68
  *   slm_loss                   <- LM_Solver.prepareCostTerm(grad=False)  super/LM.py:70-78
@@ -155,6 +156,21 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* frame, void* st
  * inside the library (at most 8 at a time), forked from `stream` (they see the work enqueued on it so far) and
  * joined back into it before the call returns.  Results are those of n_frames slm_bind_frame calls. */
 int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const slm_frame* frames, void* stream);
+
+/* The MODEL-side half of slm_bind_frame, ahead of time and asynchronously.  What a bind derives from the surfel model
+ * alone -- the tuple-sorted copies and the pair index of the data term (from sf.points, sf.knn_indices, sf.knn_w), the
+ * hash of the coupling graph and, when it changed, the symbolic plan of the solver (a host analysis) -- is known as soon
+ * as the PREVIOUS frame has finished with the model (after Surfels.update / fuseInputData / the swap: super/super.py:66-73,
+ * super/nodes.py:170-191), long before the next frame's target exists.  `model` carries N, J, K, K_ED, state_f64 and the
+ * five model pointers (sf_points, sf_knn_idx, sf_knn_w, ed_points, ed_knn_idx); the target fields are ignored.  The call
+ * records an event on `stream` (the preparation sees everything enqueued on it so far), queues the work on the solver's
+ * own worker thread and stream, and RETURNS AT ONCE; the slot is unbound until the next slm_bind_frame.  That bind joins
+ * the preparation; if its model fields are the ones prepared it only binds the target side (no sort, no read-back of
+ * sizes, no analysis inside the frame's critical path), otherwise it discards the preparation and binds in full.  The
+ * caller must leave the model arrays unchanged (and alive) between the two calls.  An error of the preparation is
+ * returned by the bind that consumes it.  Replaces the model-side part of loss_term.prepare, super/loss.py:212-220,
+ * 408-426, moved to where its inputs become final. */
+int slm_prepare_model(slm_solver* s, int32_t slot, const slm_frame* model, void* stream);
 
 /* -- the LM loop ------------------------------------------------------------------ */
 /* Enqueues num_iterations damped accept/reject iterations for slots [0,n_frames),

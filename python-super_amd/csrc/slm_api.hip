@@ -154,6 +154,73 @@ struct Slot {
   bool band_ready = false;
   size_t cap_pairbuf = 0;
   size_t cap_fronts = 0, cap_ints = 0, cap_dests = 0, cap_ftiles = 0, cap_fvec = 0, cap_flinv = 0, cap_fmail = 0;
+  // slm_prepare_model: the model-side half of a bind, done ahead of the frame's target (possibly still running on the
+  // solver's worker thread: prep_ticket)
+  bool model_ready = false;        // the model part below is complete and valid for prep_model
+  slm_frame prep_model{};          // the model fields it was prepared for
+  unsigned long long prep_ticket = 0;   // job number on the worker (0: none pending)
+  int prep_rc = SLM_OK;
+  std::string prep_err;
+  hipEvent_t prep_fork = nullptr, prep_done = nullptr;
+};
+}  // namespace
+
+// One persistent host thread running queued jobs in order (slm_prepare_model): created on first use, joined in slm_destroy.
+namespace {
+class AsyncWorker {
+ public:
+  ~AsyncWorker() { shutdown(); }
+  // returns the job's ticket (> 0); throws only from thread creation / allocation, before the job is queued
+  unsigned long long submit(std::function<void()> job) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (!started_) {
+      thread_ = std::thread([this] { loop(); });
+      started_ = true;
+    }
+    jobs_.push_back(std::move(job));
+    cv_work_.notify_one();
+    return ++submitted_;
+  }
+  void wait(unsigned long long ticket) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return completed_ >= ticket; });
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      if (!started_) return;
+      stop_ = true;
+    }
+    cv_work_.notify_all();
+    if (thread_.joinable()) thread_.join();
+    started_ = false;
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+        if (jobs_.empty()) return;     // (stop: queued jobs are still run first)
+        job = std::move(jobs_.front());
+        jobs_.erase(jobs_.begin());
+      }
+      job();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        ++completed_;
+      }
+      cv_done_.notify_all();
+    }
+  }
+  std::thread thread_;
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_done_;
+  std::vector<std::function<void()>> jobs_;
+  unsigned long long submitted_ = 0, completed_ = 0;
+  bool started_ = false, stop_ = false;
 };
 }  // namespace
 
@@ -229,6 +296,10 @@ class BindPool {
 struct slm_solver {
   PrepBuffers* prep = nullptr;
   BindPool bind_pool;
+  // slm_prepare_model: worker thread, its stream and scratch buffers
+  AsyncWorker prep_worker;
+  PrepBuffers* prep_async = nullptr;
+  hipStream_t prep_stream = nullptr;
   // slm_bind_frames: one worker (scratch buffers + stream + events) per frame bound concurrently
   std::vector<PrepBuffers*> bind_prep;
   std::vector<hipStream_t> bind_streams;
@@ -246,8 +317,8 @@ struct slm_solver {
   int group_min_frames = 6;     // batches below this stay in one group
   int dag_cap = 96;             // SLM_DAG_CAP: workgroups of a group's task-graph launch
   int group_sync = 1;           // SLM_GROUP_SYNC: 1 = the groups' assembly + per-level phases alternate (events), 0 = free-running
-  hipStream_t group_stream = nullptr;
-  std::vector<hipEvent_t> group_events;   // fork, join, and one per (group, iteration)
+  std::vector<hipStream_t> group_streams; // groups 1.. (group 0 runs on the caller's stream)
+  std::vector<hipEvent_t> group_events;   // fork, joins, and one per (group, iteration)
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
@@ -422,7 +493,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
   if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
-  if (const char* e = getenv("SLM_GROUPS")) s->groups = atoi(e) >= 2 ? 2 : 1;
+  if (const char* e = getenv("SLM_GROUPS")) s->groups = std::min(std::max(atoi(e), 1), 4);
   if (const char* e = getenv("SLM_GROUP_MIN")) s->group_min_frames = std::max(2, atoi(e));
   if (const char* e = getenv("SLM_DAG_CAP")) s->dag_cap = std::max(0, atoi(e));
   if (const char* e = getenv("SLM_GROUP_SYNC")) s->group_sync = atoi(e);
@@ -432,6 +503,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
 
 int slm_destroy(slm_solver* s) {
   if (!s) return SLM_OK;
+  s->prep_worker.shutdown();      // (runs what is still queued: the jobs reference the slots freed below)
   s->bind_pool.shutdown();
   for (Slot& sl : s->slots) {
     FrameDev& h = sl.h;
@@ -463,8 +535,12 @@ int slm_destroy(slm_solver* s) {
     if (sl.pairbuf) (void)hipFree(sl.pairbuf);
     if (sl.d_dag_flags) (void)hipFree(sl.d_dag_flags);
     if (sl.d_dag_trace) (void)hipFree(sl.d_dag_trace);
+    if (sl.prep_fork) (void)hipEventDestroy(sl.prep_fork);
+    if (sl.prep_done) (void)hipEventDestroy(sl.prep_done);
   }
   prep_destroy(s->prep);
+  prep_destroy(s->prep_async);
+  if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
   for (PrepBuffers* pb : s->bind_prep) prep_destroy(pb);
   for (hipStream_t q : s->bind_streams) (void)hipStreamDestroy(q);
   for (hipEvent_t e : s->bind_events) (void)hipEventDestroy(e);
@@ -474,7 +550,7 @@ int slm_destroy(slm_solver* s) {
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->drain_event) (void)hipEventDestroy(s->drain_event);
   for (hipEvent_t e : s->group_events) (void)hipEventDestroy(e);
-  if (s->group_stream) (void)hipStreamDestroy(s->group_stream);
+  for (hipStream_t q : s->group_streams) (void)hipStreamDestroy(q);
   if (s->frames_dev) (void)hipFree(s->frames_dev);
   if (s->bw_dev) (void)hipFree(s->bw_dev);
   if (s->reuse_dev) (void)hipFree(s->reuse_dev);
@@ -536,15 +612,16 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
   return bind_frame_impl(s, slot, f, (hipStream_t)stream, s->prep);
 }
 
-static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep) {
+// The MODEL-side half of a bind (what depends on sf.points / sf.knn_indices / sf.knn_w / ED_nodes only: the tuple-sorted
+// copies and indices of the data term, the hashes of the coupling graph, the symbolic plan of the solver, the slot's
+// grow-only work buffers).  Leaves the slot UNBOUND; bind_target_part completes it.
+static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep) {
   if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad slot");
   if (f->K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_neighbors must be 4");
   if (f->K_ED < 1 || f->K_ED > SLM_MAX_KED)
     return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_ED_neighbors must be in 1..8");
-  if (f->N < 0 || f->J < 1 || f->H < 2 || f->W < 2 || f->T < 0)
-    return fail(SLM_ERR_INVALID, "slm_bind_frame: bad sizes");
-  if ((f->N > 0 && (!f->sf_points || !f->sf_knn_idx || !f->sf_knn_w)) || !f->ed_points || !f->ed_knn_idx ||
-      (f->T > 0 && (!f->tgt_points || !f->tgt_norms)) || !f->index_map || !f->tgt_valid)
+  if (f->N < 0 || f->J < 1) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad sizes");
+  if ((f->N > 0 && (!f->sf_points || !f->sf_knn_idx || !f->sf_knn_w)) || !f->ed_points || !f->ed_knn_idx)
     return fail(SLM_ERR_INVALID, "slm_bind_frame: null device pointer");
   Slot& sl = s->slots[slot];
   FrameDev& h = sl.h;
@@ -571,8 +648,6 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     HIPCHK(grow(h.node_pk, c, (size_t)2 * SLM_NPK * f->J));
     sl.cap_npk = c;
     h.node_pk_try = h.node_pk + (size_t)SLM_NPK * f->J;
-    HIPCHK(grow(h.tgt_pn, sl.cap_tpn, (size_t)2 * (f->T > 0 ? f->T : 1)));
-    launch_pack_target(f->T, f->tgt_points, f->tgt_norms, h.tgt_pn, st);
   }
   {
     size_t need = (size_t)nt * SLM_NB, c1 = sl.cap_vec, c2 = sl.cap_vec;
@@ -822,8 +897,21 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       sl.plan_pairs.clear();
     }
   }
-  h.bound = 1;
   bt_mark();                                   // [3] symbolic plan settled
+  return SLM_OK;
+}
+
+// The TARGET-side half: the frame's target tables, image size and intrinsics; descriptor upload, LM state reset.
+static int bind_target_part(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st) {
+  if (f->H < 2 || f->W < 2 || f->T < 0) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad sizes");
+  if ((f->T > 0 && (!f->tgt_points || !f->tgt_norms)) || !f->index_map || !f->tgt_valid)
+    return fail(SLM_ERR_INVALID, "slm_bind_frame: null device pointer");
+  Slot& sl = s->slots[slot];
+  FrameDev& h = sl.h;
+  h.f = *f;
+  HIPCHK(grow(h.tgt_pn, sl.cap_tpn, (size_t)2 * (f->T > 0 ? f->T : 1)));
+  launch_pack_target(f->T, f->tgt_points, f->tgt_norms, h.tgt_pn, st);
+  h.bound = 1;
   // descriptor -> device through the slot's pinned mirror: no wait for the copy (the mirror always holds the newest
   // host state, and every change of it is followed by another copy on the stream)
   if (!sl.h_pin) HIPCHK(hipHostMalloc((void**)&sl.h_pin, sizeof(FrameDev), hipHostMallocDefault));
@@ -844,6 +932,91 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     int o = snprintf(buf, sizeof(buf), "[slm bind trace] slot %d start %.3f stages(ms):", slot, g_bt.t[0]);
     for (int i = 1; i < g_bt.n && o < 220; ++i) o += snprintf(buf + o, sizeof(buf) - o, " %.3f", g_bt.t[i] - g_bt.t[i - 1]);
     fprintf(stderr, "%s\n", buf);
+  }
+  return SLM_OK;
+}
+
+static bool same_model(const slm_frame& a, const slm_frame& b) {
+  return a.N == b.N && a.J == b.J && a.K == b.K && a.K_ED == b.K_ED && a.state_f64 == b.state_f64 && a.sf_points == b.sf_points &&
+         a.sf_knn_idx == b.sf_knn_idx && a.sf_knn_w == b.sf_knn_w && a.ed_points == b.ed_points && a.ed_knn_idx == b.ed_knn_idx;
+}
+
+// waits for the slot's queued model-side preparation, if any (host side: the worker has finished the job)
+static void join_prepare(slm_solver* s, int slot) {
+  Slot& sl = s->slots[slot];
+  if (sl.prep_ticket) {
+    s->prep_worker.wait(sl.prep_ticket);
+    sl.prep_ticket = 0;
+  }
+}
+
+static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep) {
+  if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad slot");
+  Slot& sl = s->slots[slot];
+  join_prepare(s, slot);
+  // A model prepared ahead (slm_prepare_model) serves ONE bind, and only the bind of the very arrays it read: the
+  // frame's update / fusion rewrites them in place afterwards.
+  const bool prepared = sl.model_ready && same_model(sl.prep_model, *f);
+  sl.model_ready = false;
+  if (prepared) {
+    if (sl.prep_rc != SLM_OK) return fail(sl.prep_rc, sl.prep_err.c_str());
+    HIPCHK(hipStreamWaitEvent(st, sl.prep_done, 0));     // the preparation ran on the solver's own stream
+    g_bt.n = 0;
+    bt_mark();
+  } else {
+    const int rc = bind_model_part(s, slot, f, st, prep);
+    if (rc != SLM_OK) return rc;
+  }
+  return bind_target_part(s, slot, f, st);
+}
+
+int slm_prepare_model(slm_solver* s, int32_t slot, const slm_frame* model, void* stream) {
+  if (!s || !model) return fail(SLM_ERR_INVALID, "slm_prepare_model: null argument");
+  if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_prepare_model: bad slot");
+  Slot& sl = s->slots[slot];
+  join_prepare(s, slot);
+  sl.model_ready = false;
+  sl.h.bound = 0;                   // the slot's plan is being rebuilt: unbound until the next slm_bind_frame
+  if (!s->prep_stream) HIPCHK(hipStreamCreateWithFlags(&s->prep_stream, hipStreamNonBlocking));
+  if (!s->prep_async) {
+    s->prep_async = prep_create();
+    if (!s->prep_async) return fail(SLM_ERR_HIP, "slm_prepare_model: out of memory");
+  }
+  if (!sl.prep_fork) HIPCHK(hipEventCreateWithFlags(&sl.prep_fork, hipEventDisableTiming));
+  if (!sl.prep_done) HIPCHK(hipEventCreateWithFlags(&sl.prep_done, hipEventDisableTiming));
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  sl.prep_model = *model;
+  sl.prep_model.T = 0;              // (only the model fields are read)
+  sl.prep_model.tgt_points = sl.prep_model.tgt_norms = nullptr;
+  sl.prep_model.index_map = nullptr;
+  sl.prep_model.tgt_valid = nullptr;
+  sl.prep_rc = SLM_OK;
+  HIPCHK(hipEventRecord(sl.prep_fork, (hipStream_t)stream));   // the preparation sees what the caller has enqueued so far
+  try {
+    sl.prep_err.clear();
+    sl.prep_ticket = s->prep_worker.submit([s, slot, dev] {
+      Slot& w = s->slots[slot];
+      int rc = SLM_OK;
+      try {
+        if (hipSetDevice(dev) != hipSuccess || hipStreamWaitEvent(s->prep_stream, w.prep_fork, 0) != hipSuccess) {
+          rc = fail(SLM_ERR_HIP, "slm_prepare_model: worker setup failed");
+        } else {
+          rc = bind_model_part(s, slot, &w.prep_model, s->prep_stream, s->prep_async);
+          if (rc == SLM_OK && hipEventRecord(w.prep_done, s->prep_stream) != hipSuccess)
+            rc = fail(SLM_ERR_HIP, "slm_prepare_model: hipEventRecord failed");
+        }
+        if (rc != SLM_OK) w.prep_err = g_err;          // (thread-local text of the worker)
+      } catch (...) {
+        rc = SLM_ERR_HIP;
+        try { w.prep_err = "slm_prepare_model: out of host memory in the worker"; } catch (...) {}
+      }
+      w.prep_rc = rc;
+      w.model_ready = true;         // (an error is reported by the bind that consumes the preparation)
+    });
+  } catch (...) {
+    sl.prep_ticket = 0;
+    return fail(SLM_ERR_HIP, "slm_prepare_model: could not start the worker");
   }
   return SLM_OK;
 }
@@ -973,8 +1146,10 @@ static int check_slots(slm_solver* s, int first, int n) {
   if (!s) return fail(SLM_ERR_INVALID, "null solver");
   if (first < 0 || n < 1 || first + n > (int)s->slots.size())
     return fail(SLM_ERR_INVALID, "slot range out of bounds");
-  for (int i = first; i < first + n; ++i)
+  for (int i = first; i < first + n; ++i) {
+    join_prepare(s, i);             // (a queued slm_prepare_model owns the slot until it is done; it leaves it unbound)
     if (!s->slots[i].h.bound) return fail(SLM_ERR_UNBOUND, "slot used before slm_bind_frame");
+  }
   return SLM_OK;
 }
 
@@ -1142,7 +1317,11 @@ int slm_set_shard(slm_solver* s, int32_t rank, int32_t world) {
   s->rank = rank;
   s->world = world;
   s->shard_mode = true;
-  for (Slot& sl : s->slots) sl.h.bound = 0;   // the shares are fixed at bind time
+  for (size_t i = 0; i < s->slots.size(); ++i) {   // the shares are fixed at bind time
+    join_prepare(s, (int)i);
+    s->slots[i].model_ready = false;
+    s->slots[i].h.bound = 0;
+  }
   HIPCHK(hipMemset(s->frames_dev, 0, sizeof(FrameDev) * s->slots.size()));
   return SLM_OK;
 }
@@ -1322,45 +1501,58 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   mark();
 }
 
-// Grouped run: slots [0, n0) on the caller's stream, [n0, n) on the solver's second stream.  With group_sync the
-// throughput phases A (zeroing, Jacobian pass, assembly, per-level launches) of the two groups ALTERNATE -- A(0,i),
-// A(1,i), A(0,i+1), ... chained by events -- and each group's latency phase D (task graph for the top of the tree and
-// the back substitution, loss pass, accept) runs under the other group's next A.  Every frame sees exactly the launches
-// it would see in a batch of its group's size: results do not depend on the grouping.
-static int run_grouped(slm_solver* s, int n_frames, const BatchDims d[2], int n0, hipStream_t st) {
+// Grouped run: the slots are split into G contiguous groups; group 0 runs on the caller's stream, the others on the
+// solver's own streams, forked from / joined into the caller's.  group_sync 1 (two groups): the throughput phases A
+// (zeroing, Jacobian pass, assembly, per-level launches) of the two groups ALTERNATE -- A(0,i), A(1,i), A(0,i+1), ...
+// chained by events -- and each group's latency phase D (task graph for the top of the tree and the back substitution,
+// loss pass, accept) runs under the other group's next A.  group_sync 2: only the FIRST iteration is staggered (group g
+// starts its assembly when group g-1 has enqueued its per-level part), then the groups run free.  group_sync 0: free.
+// Every frame sees exactly the launches it would see in a batch of its group's size.
+static int run_grouped(slm_solver* s, int G, const int first[], const int cnt[], const BatchDims d[], hipStream_t st) {
   const int n_it = s->cfg.num_iterations;
-  if (!s->group_stream) HIPCHK(hipStreamCreateWithFlags(&s->group_stream, hipStreamNonBlocking));
-  const size_t need_ev = 2 + 2 * (size_t)std::max(n_it, 1);
   try {
-    s->group_events.reserve(need_ev);
+    s->group_streams.reserve(8);
+    s->group_events.reserve(1 + 8 + 8 * (size_t)std::max(n_it, 1));
   } catch (...) {
     return fail(SLM_ERR_HIP, "slm_run: out of host memory");
   }
+  while ((int)s->group_streams.size() < G - 1) {
+    hipStream_t q = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    s->group_streams.push_back(q);
+  }
+  const size_t need_ev = 1 + 8 + 8 * (size_t)std::max(n_it, 1);
   while (s->group_events.size() < need_ev) {
     hipEvent_t e = nullptr;
     HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s->group_events.push_back(e);
   }
-  hipStream_t q[2] = {st, s->group_stream};
-  const int first[2] = {0, n0}, cnt[2] = {n0, n_frames - n0};
-  auto evA = [&](int g, int it) { return s->group_events[2 + 2 * (size_t)it + g]; };
+  hipStream_t q[8];
+  q[0] = st;
+  for (int g = 1; g < G; ++g) q[g] = s->group_streams[g - 1];
+  auto evA = [&](int g, int it) { return s->group_events[9 + 8 * (size_t)it + g]; };
   HIPCHK(hipEventRecord(s->group_events[0], st));                       // fork
-  HIPCHK(hipStreamWaitEvent(s->group_stream, s->group_events[0], 0));
+  for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(q[g], s->group_events[0], 0));
   for (int it = 0; it < n_it; ++it) {
-    for (int g = 0; g < 2; ++g) {
-      if (s->group_sync) {
+    for (int g = 0; g < G; ++g) {
+      if (s->group_sync == 1 && G == 2) {
         if (g == 0 && it > 0) HIPCHK(hipStreamWaitEvent(q[0], evA(1, it - 1), 0));
         if (g == 1) HIPCHK(hipStreamWaitEvent(q[1], evA(0, it), 0));
+      } else if (s->group_sync == 2 && it == 0 && g > 0) {
+        HIPCHK(hipStreamWaitEvent(q[g], evA(g - 1, 0), 0));
       }
       hipError_t rec_err = hipSuccess;
-      const std::function<void()> between = [&]() { rec_err = hipEventRecord(evA(g, it), q[g]); };
+      const bool need_ev_rec = s->group_sync == 1 || (s->group_sync == 2 && it == 0);
+      const std::function<void()> between = [&]() { if (need_ev_rec) rec_err = hipEventRecord(evA(g, it), q[g]); };
       enqueue_lm_iteration(s, first[g], cnt[g], d[g], q[g], g == 0, s->dag_cap, &between);
+      if (need_ev_rec && s->last_solver_form != 2) rec_err = hipEventRecord(evA(g, it), q[g]);   // (no per-level part: after the iteration)
       HIPCHK(rec_err);
     }
   }
-  HIPCHK(hipEventRecord(s->group_events[1], s->group_stream));          // join
-  HIPCHK(hipStreamWaitEvent(st, s->group_events[1], 0));
-  s->last_solver_form = 2;
+  for (int g = 1; g < G; ++g) {                                          // join
+    HIPCHK(hipEventRecord(s->group_events[g], q[g]));
+    HIPCHK(hipStreamWaitEvent(st, s->group_events[g], 0));
+  }
   return SLM_OK;
 }
 
@@ -1373,14 +1565,20 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
                 "slm_lm_accept with the exchanges between them");
   hipStream_t st = (hipStream_t)stream;
   const slm_config& c = s->cfg;
-  if (s->groups == 2 && n_frames >= s->group_min_frames && c.num_iterations > 0) {
-    const int n0 = (n_frames + 1) / 2;
-    BatchDims dg[2] = {dims_of(s, 0, n0), dims_of(s, n0, n_frames - n0)};
+  if (s->groups >= 2 && n_frames >= s->group_min_frames && n_frames >= 2 * s->groups && c.num_iterations > 0) {
+    const int G = s->groups;
+    int first[8], cnt[8];
+    BatchDims dg[8];
     bool ok = true;
-    for (int g = 0; g < 2; ++g)
-      ok = ok && dg[g].nd && dg[g].v1 && solve_is_hybrid(s, g == 0 ? n0 : n_frames - n0, dg[g]);
+    for (int g = 0, at = 0; g < G; ++g) {
+      first[g] = at;
+      cnt[g] = n_frames / G + (g < n_frames % G ? 1 : 0);
+      at += cnt[g];
+      dg[g] = dims_of(s, first[g], cnt[g]);
+      ok = ok && dg[g].nd && dg[g].v1;
+    }
     if (ok) {
-      rc = run_grouped(s, n_frames, dg, n0, st);
+      rc = run_grouped(s, G, first, cnt, dg, st);
       if (rc) return rc;
       HIPCHK(hipGetLastError());
       return SLM_OK;

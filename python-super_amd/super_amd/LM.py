@@ -50,24 +50,64 @@ def state_dtype(sf, override=None):
     return torch.float64 if sf.points.dtype == torch.float64 else torch.float32
 
 
-class BoundFrame:
-    """Device-resident, ABI-layout view of what LM reads from ``sf`` / ``inputs`` /
-    ``new_data``.  Holds the tensors alive while the library uses them."""
+class ModelView:
+    """The MODEL side of a frame in ABI layout (what ``slm_prepare_model`` reads): ``sf.points``, ``sf.knn_indices``,
+    ``sf.knn_w``, ``ED_nodes.points``, ``ED_nodes.knn_indices``.  Remembers which tensors (and which in-place versions
+    of them) it was made from, so that the bind of the next frame can tell whether it is still the same model."""
 
-    def __init__(self, sf, inputs, new_data, device=None, state=None):
+    FIELDS = ("sf_points", "sf_knn_idx", "sf_knn_w", "ed_points", "ed_knn_idx")
+
+    def __init__(self, sf, device=None, state=None):
         dev = device if device is not None else sf.points.device
         if dev.type != "cuda":
             raise _lib.SuperLMError("super_amd needs tensors on a HIP device (no CPU fallback)")
         ed = sf.ED_nodes
-        f32, i32 = torch.float32, torch.int32
+        i32 = torch.int32
         sdt = state_dtype(sf, state)
         self.device = dev
         self.state_dtype = sdt
+        self.sources = (sf.points, sf.knn_indices, sf.knn_w, ed.points, ed.knn_indices)
+        self.stamp = self._stamp(self.sources)
         self.sf_points = _as(sf.points, sdt, dev)          # no copy when already float64 / contiguous
         self.sf_knn_idx = _as(sf.knn_indices, i32, dev)
         self.sf_knn_w = _as(sf.knn_w, sdt, dev)
         self.ed_points = _as(ed.points, sdt, dev)
         self.ed_knn_idx = _as(ed.knn_indices, i32, dev)
+        self.J = int(self.ed_points.shape[0])
+
+    @staticmethod
+    def _stamp(tensors):
+        return tuple((t.data_ptr(), tuple(t.shape), t.dtype, t._version) for t in tensors)
+
+    def matches(self, sf, device, state):
+        ed = sf.ED_nodes
+        return (self.device == device and self.state_dtype == state_dtype(sf, state) and
+                self.stamp == self._stamp((sf.points, sf.knn_indices, sf.knn_w, ed.points, ed.knn_indices)))
+
+    def fill(self, fr: SlmFrame):
+        fr.N, fr.J = int(self.sf_points.shape[0]), self.J
+        fr.K, fr.K_ED = int(self.sf_knn_idx.shape[1]), int(self.ed_knn_idx.shape[1])
+        for name in self.FIELDS:
+            setattr(fr, name, _dev_ptr(getattr(self, name)))
+        fr.state_f64 = 1 if self.state_dtype == torch.float64 else 0
+
+
+class BoundFrame:
+    """Device-resident, ABI-layout view of what LM reads from ``sf`` / ``inputs`` /
+    ``new_data``.  Holds the tensors alive while the library uses them.
+    ``model``: a ``ModelView`` of the same ``sf`` made earlier (``LM_Solver.prepare_model``)."""
+
+    def __init__(self, sf, inputs, new_data, device=None, state=None, model=None):
+        dev = device if device is not None else sf.points.device
+        if dev.type != "cuda":
+            raise _lib.SuperLMError("super_amd needs tensors on a HIP device (no CPU fallback)")
+        f32, i32 = torch.float32, torch.int32
+        mv = model if model is not None else ModelView(sf, dev, state)
+        self.model = mv
+        self.device = dev
+        self.state_dtype = mv.state_dtype
+        for name in ModelView.FIELDS:
+            setattr(self, name, getattr(mv, name))
         self.tgt_points = _as(new_data.points, f32, dev)
         self.tgt_norms = _as(new_data.norms, f32, dev)
         self.index_map = _as(new_data.index_map, i32, dev)
@@ -75,16 +115,14 @@ class BoundFrame:
         H, W = inputs[("color", 0)].shape[-2:]
         K = inputs["K"]
         Kh = K[0].detach().to("cpu", torch.float32)        # one tiny D2H read per frame
-        self.J = int(self.ed_points.shape[0])
+        self.J = mv.J
         fr = SlmFrame()
-        fr.N, fr.J, fr.T = int(self.sf_points.shape[0]), self.J, int(self.tgt_points.shape[0])
+        mv.fill(fr)
+        fr.T = int(self.tgt_points.shape[0])
         fr.H, fr.W = int(H), int(W)
-        fr.K, fr.K_ED = int(self.sf_knn_idx.shape[1]), int(self.ed_knn_idx.shape[1])
         fr.fx, fr.fy, fr.cx, fr.cy = float(Kh[0, 0]), float(Kh[1, 1]), float(Kh[0, 2]), float(Kh[1, 2])
-        for name in ("sf_points", "sf_knn_idx", "sf_knn_w", "ed_points", "ed_knn_idx", "tgt_points",
-                     "tgt_norms", "index_map", "tgt_valid"):
+        for name in ("tgt_points", "tgt_norms", "index_map", "tgt_valid"):
             setattr(fr, name, _dev_ptr(getattr(self, name)))
-        fr.state_f64 = 1 if sdt == torch.float64 else 0
         self.c = fr
 
 
@@ -109,6 +147,7 @@ class LM_Solver():
         self.max_frames = max_frames
         self._solvers = {}                           # (u, v, minimal_loss) -> handle
         self._bound = [None] * max_frames
+        self._prepared = [None] * max_frames         # (handle, ModelView) of a pending slm_prepare_model per slot
         self.last_records = None
         self.rank, self.world = 0, 1
         self.sharded = bool(shard_surfels or world is not None)   # (a world of one rank runs the same protocol)
@@ -162,11 +201,33 @@ class LM_Solver():
             pass
 
     def _bind(self, h, slot, sf, inputs, new_data):
-        bf = BoundFrame(sf, inputs, new_data, state=getattr(self.opt, "slm_state_dtype", None))
+        state = getattr(self.opt, "slm_state_dtype", None)
+        dev = sf.points.device
+        prepared = self._prepared[slot]
+        self._prepared[slot] = None                    # a prepared model serves one bind
+        mv = None
+        if prepared is not None and prepared[0] is h and prepared[1].matches(sf, dev, state):
+            mv = prepared[1]                           # same arrays, untouched since: the library only binds the target side
+        bf = BoundFrame(sf, inputs, new_data, state=state, model=mv)
         _lib.check(self.lib.slm_bind_frame(h, slot, C.byref(bf.c), _stream_ptr(bf.device)),
                    "slm_bind_frame")
         self._bound[slot] = bf
         return bf
+
+    def prepare_model(self, sf, slot=0, u=10, v=7.5, minimal_loss=1e10):
+        """The model-side half of the NEXT frame's ``loss_term.prepare`` (reference ``super/loss.py:212-220,408-426``),
+        ahead of time: call it when the current frame is done with the model -- after ``sf.update`` /
+        ``fuseInputData`` / ``prepareStableIndexNSwapAllModel`` (``super/super.py:66-73``) -- and the next ``LM()`` on the
+        same, untouched ``sf`` only binds its target (``slm_prepare_model``: the sort, the size read-backs and any
+        symbolic analysis run on the library's worker thread and stream while the caller fetches the next frame).
+        Optional: ``LM()`` alone does everything, as the reference does.  Not for surfel-sharded solvers' first bind
+        order; harmless when the model changes after all (the bind then prepares in full)."""
+        h = self._handle(u, v, minimal_loss)
+        mv = ModelView(sf, state=getattr(self.opt, "slm_state_dtype", None))
+        fr = SlmFrame()
+        mv.fill(fr)
+        _lib.check(self.lib.slm_prepare_model(h, slot, C.byref(fr), _stream_ptr(mv.device)), "slm_prepare_model")
+        self._prepared[slot] = (h, mv)
 
     # ---- reference surface -------------------------------------------------------------
     @staticmethod

@@ -35,7 +35,7 @@ EXPORTS = [
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set", "slm_lm_exchange_ptr",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
     "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read", "slm_debug_dag_trace",
-    "slm_abi_version", "slm_abi_check", "slm_debug_dag_timeout", "slm_debug_dag_abort",
+    "slm_abi_version", "slm_abi_check", "slm_debug_dag_timeout", "slm_debug_dag_abort", "slm_prepare_model",
 ]
 
 
@@ -176,6 +176,7 @@ def load():
         "slm_debug_last_solver_form": [vp],
         "slm_bind_frames": [vp, i32, i32, C.POINTER(SlmFrame), vp],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
+        "slm_prepare_model": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],
         "slm_get_plan_info": [vp, i32, C.POINTER(C.c_double), i32],

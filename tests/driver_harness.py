@@ -85,6 +85,8 @@ class FrameLoop:
             self.sf = first_frame_model(opt, models, inputs, target)
             if test:
                 self.sf.prepareStableIndexNSwapAllModel(inputs, target)
+            if self.lm is not None and getattr(opt, "slm_prepare_ahead", True):
+                self.lm.prepare_model(self.sf)
             self.deform_param = None
             return None
         if self.lm is not None:
@@ -95,5 +97,9 @@ class FrameLoop:
         if test:
             self.sf.fuseInputData(inputs, target)
             self.sf.prepareStableIndexNSwapAllModel(inputs, target)
+        # the model is final for the next frame: its model-side prepare starts now, on the library's worker thread and
+        # stream, while the caller fetches the next frame (optional -- LM() alone does it all)
+        if self.lm is not None and getattr(opt, "slm_prepare_ahead", True):
+            self.lm.prepare_model(self.sf)
         self.deform_param = warp
         return warp

@@ -24,10 +24,12 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 
 VARIANTS = [("single", {})]
-for cap in (48, 64, 96, 128, 160):
-    VARIANTS.append((f"groups2 sync cap{cap}", {"SLM_GROUPS": "2", "SLM_DAG_CAP": str(cap), "SLM_GROUP_SYNC": "1"}))
-for cap in (64, 96, 128):
-    VARIANTS.append((f"groups2 free cap{cap}", {"SLM_GROUPS": "2", "SLM_DAG_CAP": str(cap), "SLM_GROUP_SYNC": "0"}))
+for G, caps in ((2, (128, 160, 192, 0)), (3, (96, 128)), (4, (64, 96, 128))):
+    for cap in caps:
+        VARIANTS.append((f"G{G} free cap{cap}", {"SLM_GROUPS": str(G), "SLM_DAG_CAP": str(cap), "SLM_GROUP_SYNC": "0"}))
+for cap in (128, 192):
+    VARIANTS.append((f"G2 stagger cap{cap}", {"SLM_GROUPS": "2", "SLM_DAG_CAP": str(cap), "SLM_GROUP_SYNC": "2"}))
+VARIANTS.append(("G2 sync cap96", {"SLM_GROUPS": "2", "SLM_DAG_CAP": "96", "SLM_GROUP_SYNC": "1"}))
 VARIANTS.append(("single (again)", {}))
 if os.environ.get("AB_VARIANTS"):
     keep = os.environ["AB_VARIANTS"].split(",")
@@ -77,7 +79,17 @@ for name, env in VARIANTS:
           f"reg {phases['reg_grad']:.3f} loss {phases['data_loss']:.3f} accept {phases['accept']:.3f}; "
           f"max|beta - single| {err:.2e} flags_equal {same_flags}", flush=True)
 
-# bitwise check on the run-to-run reproducible data path
-b0 = run_variant({}, data_path=2)[3]
-b1 = run_variant({"SLM_GROUPS": "2", "SLM_DAG_CAP": "96"}, data_path=2)[3]
-print("data_path 2: grouped beta bitwise equal to single:", all(np.array_equal(a, b) for a, b in zip(b0, b1)), flush=True)
+# bitwise check on the run-to-run reproducible data path: a frame sees the launches of a batch of its GROUP's size
+if B % 2 == 0 and not os.environ.get("AB_VARIANTS"):
+    b1 = run_variant({"SLM_GROUPS": "2", "SLM_DAG_CAP": "96"}, data_path=2)[3]
+    half = B // 2
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    ok = True
+    for g in range(2):
+        eng = Engine(dev, max_frames=half, data_path=2)
+        eng.bind_batch(frames[g * half:(g + 1) * half])
+        eng.run(half)
+        ok = ok and all(np.array_equal(eng.beta(i).cpu().numpy(), b1[g * half + i]) for i in range(half))
+        eng.close()
+    print("data_path 2: grouped beta bitwise equal to the two half batches run one after the other:", ok, flush=True)

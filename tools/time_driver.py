@@ -35,6 +35,8 @@ opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, 
                       th_cosine_ang=0.4, th_time_steps=30, disable_merging_new_surfels=False,
                       disable_merging_exist_surfels=False, disable_adding_new_surfels=False,
                       disable_removing_unstable_surfels=False)
+if os.environ.get("DRIVER_PREPARE_AHEAD") == "0":      # A/B: the whole prepare inside LM(), as in rounds 1-3
+    opt.slm_prepare_ahead = False
 if os.environ.get("DRIVER_SOLVER_PATH"):
     opt.slm_solver_path = int(os.environ["DRIVER_SOLVER_PATH"])
 model = drv.FrameLoop(opt)
@@ -88,6 +90,7 @@ else:
 frames = int(os.environ.get("DRIVER_FRAMES", "12"))
 tot = []
 events = []
+accept_log = []
 if "--nogc" in sys.argv:
     import gc
     gc.disable()
@@ -104,6 +107,8 @@ for k in range(frames):
     model(SimpleNamespace(), inputs)
     torch.cuda.synchronize()
     tot.append((time.perf_counter() - t0) * 1e3)
+    if derived and model.lm.last_records:
+        accept_log.append("".join("T" if r["accepted"] else ("F" if r["status"] == 0 else "x") for r in model.lm.last_records[0]))
     import ctypes
     from super_amd import _lib
     cnt = (ctypes.c_int64 * 4)()
@@ -126,5 +131,11 @@ if stat1:
           "| throttled ms:", (stat1.get("throttled_usec", 0) - stat0.get("throttled_usec", 0)) // 1000)
 print("slow frames:", [(i, round(tot[i], 1), "reallocs", int(d[i - 1][0]), "MB", int(d[i - 1][1]) >> 20, "plan builds", int(d[i - 1][2])) for i in slow[:25]])
 print("totals: reallocs", ev[-1][0], "plan builds", ev[-1][2], "plan reuses", ev[-1][3])
+if accept_log:
+    n_it = sum(len(a) for a in accept_log)
+    n_rej = sum(a.count("F") for a in accept_log)
+    n_rej_followed = sum(sum(1 for i, c in enumerate(a[:-1]) if c == "F") for a in accept_log)
+    print(f"LM accept patterns: {n_rej} of {n_it} iterations rejected ({100.0 * n_rej / max(n_it, 1):.1f} %), {n_rej_followed} of them "
+          f"followed by another iteration of the same frame (what a speculative second solve could save); first frames: {accept_log[:12]}")
 for k, v in stages.items():
     print(f"  {k:22s} {np.mean(v[3:]):7.2f} ms   per frame: {[round(x, 1) for x in v]}")
