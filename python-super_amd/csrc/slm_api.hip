@@ -20,6 +20,7 @@ void launch_data_grad(const FrameDev*, int, int, double, hipStream_t);
 void launch_data_loss(const FrameDev*, int, int, double, int, hipStream_t);
 void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
 void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t, const int* reuse = nullptr);
+void launch_data_eval(const FrameDev*, int, int, double, int mode, hipStream_t, const int* reuse = nullptr);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_assemble(const FrameDev*, int, int, hipStream_t);
@@ -118,7 +119,7 @@ constexpr int kRegBlocksMax = 64;
 
 struct Slot {
   FrameDev h{};                 // host mirror of the device descriptor
-  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0, cap_npk = 0, cap_tpn = 0;
+  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0, cap_npk = 0, cap_tpn = 0, cap_ev = 0;
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
   // nested-dissection plan: host copy + device mirrors (grow-only)
   NDPlanHost nd;
@@ -517,6 +518,7 @@ int slm_destroy(slm_solver* s) {
     if (h.rec) (void)hipFree(h.rec);
     if (h.node_pk) (void)hipFree(h.node_pk);
     if (h.tgt_pn) (void)hipFree(h.tgt_pn);
+    if (h.ev_rc) (void)hipFree(h.ev_rc);
     plan_free(sl.plan);
     if (sl.h_pin) (void)hipHostFree(sl.h_pin);
     sl.h_pairs.release();
@@ -698,11 +700,13 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.blk_key = sl.plan.blk_key;
       h.blk_start = sl.plan.blk_start;
       h.blk_entry = sl.plan.blk_entry;
+      HIPCHK(grow(h.ev_rc, sl.cap_ev, (size_t)4 * sz.n_pos));   // evaluation buffer {r, c} per position
       h.v1_ready = 1;
       // workgroup-merged records (default); data_path 2 keeps the per-run slab
       h.v2_ready = 0;
       if (s->cfg.data_path == 0 && sz.n_wblk > 0 && sz.max_wblk_per_wg <= SLM_LB_MAX) {
         h.n_wblk = sz.n_wblk;
+        h.max_wblk = sz.max_wblk_per_wg;
         h.wg_first = sl.plan.wg_first;
         h.wg_last = sl.plan.wg_last;
         h.run_lidx = sl.plan.run_lidx;
@@ -1159,6 +1163,7 @@ struct BatchDims {
   int max_pos = 0, max_blocks = 0, maxP = 0;
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
   int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
+  int max_wblk = 0;        // most (workgroup, pair) records of one workgroup over the batch (LDS of k_data_gram)
   bool nd = true;   // every slot of the batch has a nested-dissection plan
   int max_tasks = 0;   // tasks of the persistent task-graph solver (maximum over the batch)
   // hybrid solve: every slot has the same number of levels and the same top-of-tree cut (-1: not available)
@@ -1177,6 +1182,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.max_blocks = std::max(d.max_blocks, h.n_blocks);
     d.v1 = d.v1 && h.v1_ready;
     if (h.v1_ready) d.gram_variants |= h.v2_ready ? 1 : 2;
+    if (h.v1_ready && h.v2_ready) d.max_wblk = std::max(d.max_wblk, h.max_wblk);
     d.nd = d.nd && h.nd_ready;
     d.max_tasks = std::max(d.max_tasks, h.nd_ready ? h.n_dag_tasks : 0);
     if (h.nd_ready) {
@@ -1266,6 +1272,7 @@ hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims&
   const FrameDev* fr = s->frames_dev + first;
   launch_iter_begin_nd(fr, n, st);   // zeroes the pivot columns of the fronts of all n slots in one launch
   if (s->cfg.use_data) {
+    launch_data_eval(fr, n, kLossBlocks, s->cfg.w_data, 2, st);   // {r, c} at the current beta (clobbers the loss partials)
     launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
   }
@@ -1278,6 +1285,7 @@ void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims&
   launch_iter_begin(fr, n, st);
   if (s->cfg.use_data) {
     if (d.v1) {
+      launch_data_eval(fr, n, kLossBlocks, s->cfg.w_data, 2, st);
       launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
       launch_band_assemble(fr, n, d.max_blocks, st);
     } else {
@@ -1344,6 +1352,7 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   const int* reuse = (s->cfg.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
   launch_iter_begin_nd(fr, n_frames, st, reuse);
   if (s->cfg.use_data) {
+    launch_data_eval(fr, n_frames, kLossBlocks, s->cfg.w_data, 1, st, reuse);   // (only slots whose buffer is not the current beta's)
     launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st, reuse);
     launch_pair_reduce(fr, n_frames, d.max_blocks, st);
   }
@@ -1375,7 +1384,7 @@ int slm_lm_loss_local(slm_solver* s, int32_t n_frames, void* stream) {
   const slm_config& c = s->cfg;
   if (c.use_data) {
     launch_make_trial(fr, n_frames, d.maxJKe, st);
-    launch_data_loss(fr, n_frames, kLossBlocks, c.w_data, 1, st);
+    launch_data_eval(fr, n_frames, kLossBlocks, c.w_data, 0, st);   // this rank's positions: loss partials + the evaluation buffer
   }
   if (d.n_reg_part > 0)
     launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
@@ -1449,7 +1458,7 @@ int slm_lm_exchange_set(slm_solver* s, int32_t slot, int32_t what, const double*
 // One LM iteration of slots [first, first + n) on `st`.  `between` (grouped run): called once the launches of the
 // assembly and of the per-level part of the solve are enqueued.
 static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st, bool counts,
-                                 int dag_cap, const std::function<void()>* between) {
+                                 int dag_cap, const std::function<void()>* between, bool first_iteration) {
   const FrameDev* fr = s->frames_dev + first;
   const slm_config& c = s->cfg;
   std::vector<hipEvent_t>* evs = nullptr;
@@ -1475,8 +1484,16 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   }
   mark();
   if (c.use_data) {
-    if (d.v1) launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
-    else launch_data_grad(fr, n, d.maxN, c.w_data, st);
+    if (d.v1) {
+      // The Jacobian pass reads {r, c} of every position from the evaluation buffer.  Inside the loop the buffer is
+      // what the loss pass of the previous iteration left at the accepted trial point (a rejected step reuses the
+      // records and runs no Jacobian pass at all); a pass of its own is only needed at the first iteration of a run
+      // (skipped on the device for slots whose buffer is valid) and after a reject when records are not reused.
+      if (first_iteration || (c.phase_test && !reuse)) launch_data_eval(fr, n, kLossBlocks, c.w_data, 1, st, reuse);
+      launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
+    } else {
+      launch_data_grad(fr, n, d.maxN, c.w_data, st);
+    }
   }
   mark();
   if (d.nd) {
@@ -1492,7 +1509,10 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   else launch_band_solve(fr, n, d.nt_max, d.wb_cap, -1.0, st);
   if (c.use_data) launch_make_trial(fr, n, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
   mark();
-  if (c.use_data) launch_data_loss(fr, n, kLossBlocks, c.w_data, 1, st);
+  if (c.use_data) {
+    if (d.v1) launch_data_eval(fr, n, kLossBlocks, c.w_data, 0, st);   // the loss pass; its {r, c} feed the next Jacobian pass
+    else launch_data_loss(fr, n, kLossBlocks, c.w_data, 1, st);
+  }
   mark();
   if (d.n_reg_part > 0)
     launch_reg_loss(fr, n, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
@@ -1544,7 +1564,7 @@ static int run_grouped(slm_solver* s, int G, const int first[], const int cnt[],
       hipError_t rec_err = hipSuccess;
       const bool need_ev_rec = s->group_sync == 1 || (s->group_sync == 2 && it == 0);
       const std::function<void()> between = [&]() { if (need_ev_rec) rec_err = hipEventRecord(evA(g, it), q[g]); };
-      enqueue_lm_iteration(s, first[g], cnt[g], d[g], q[g], g == 0, s->dag_cap, &between);
+      enqueue_lm_iteration(s, first[g], cnt[g], d[g], q[g], g == 0, s->dag_cap, &between, it == 0);
       if (need_ev_rec && s->last_solver_form != 2) rec_err = hipEventRecord(evA(g, it), q[g]);   // (no per-level part: after the iteration)
       HIPCHK(rec_err);
     }
@@ -1596,7 +1616,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     }
     d = dims_of(s, 0, n_frames);
   }
-  for (int it = 0; it < c.num_iterations; ++it) enqueue_lm_iteration(s, 0, n_frames, d, st, true, 0, nullptr);
+  for (int it = 0; it < c.num_iterations; ++it) enqueue_lm_iteration(s, 0, n_frames, d, st, true, 0, nullptr, it == 0);
   // The reuse flag of a slot says "the Gram records in HBM were computed at the slot's CURRENT beta".  k_accept keeps it
   // on every path that writes records (banded path included: a later multifrontal run may then reuse them); a run that
   // wrote none (per-entry atomics) leaves nothing to reuse.

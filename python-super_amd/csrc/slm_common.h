@@ -49,6 +49,11 @@ struct LMState {
   int32_t chol_fail;     // set by the factorisation of the current iteration
   int32_t m_grad_local;  // surfel-sharded frames: this rank's own share of m_grad (k_pair_scatter puts the all-reduced count into
                          // m_grad; a Jacobian pass reused after a rejected step sends the share again, not the global count)
+  // ---- evaluation buffer of the tuple-sorted data path (k_data_eval, slm_data_v1.hip) ----
+  int32_t eval_valid;    // 1: fd.ev_rc holds the evaluation (r, c per position) at the slot's CURRENT beta
+  int32_t m_eval;        // matched surfels (of this rank's share) of the evaluation in fd.ev_rc
+  unsigned long long eval_acc;   // k_data_eval: blocks done << 32 | sum of their matched counts, ONE relaxed atomic per block
+                                 // (no fence: a release / acquire at agent scope writes back / invalidates the XCD's whole L2)
 };
 
 // Per-slot descriptor, resident in HBM as an array indexed by blockIdx.y.
@@ -94,12 +99,19 @@ struct FrameDev {
   //      (workgroup, node pair) goes to HBM instead of one 768-double Gram per run ----
   int32_t v2_ready;
   int32_t n_wblk;          // (workgroup, pair) records
+  int32_t max_wblk;        // most records of one workgroup
+  int32_t pad5;
   GP<const int32_t> wg_first; // (n_wg) first record of each workgroup
   GP<const int32_t> wg_last;  // (n_wg) last record (first-1 if none)
   GP<const uint8_t> run_lidx; // (n_runs,10) local record index of the run's 10 node pairs
   GP<double> wgslab;          // (n_wblk, 56): 49 block entries (row-major ca,cb) + 7 entries of -J^T r
   GP<const int32_t> blk2_start;  // (n_blocks+1) CSR over blk2_entry, same pair order as blk_key
   GP<const int32_t> blk2_entry;  // record ids
+  // ---- evaluation buffer: per tuple-sorted position {r, c.x, c.y, c.z} (r = lambda n.(T(p) - o), c = dr/dT(p)/lambda; zeros
+  //      where unmatched / padding).  Written by every evaluation pass (k_data_eval: the loss pass of the LM loop, at the
+  //      trial point), read by the Jacobian pass of the NEXT iteration when the step was accepted: the target-side half of
+  //      the per-surfel work (projection, match test, 8 bilinear taps) is done once per iteration, not twice ----
+  GP<double> ev_rc;
   // ---- one frame sharded over several GPUs (slm_set_shard): this rank evaluates the workgroups
   //      [wg_lo, wg_hi) of the Jacobian pass and the surfels [sf_lo, sf_hi) of the loss pass; the
   //      per-pair sums travel through pairbuf (n_blocks x 56 doubles + matched count) ----

@@ -11,16 +11,41 @@ struct SurfelEval {
   bool match;
   double r;            // lambda * n.(T(p) - o)
   int id[SLM_K];       // node ids of the four neighbours
-  double row[SLM_K * 7];  // lambda * [w_k c.Jq_k | w_k c]  (GRAD only)
+  double row[SLM_K * 7];  // lambda * [w_k c.Jq_k | w_k c]  (MODE 1 only)
+  double c[3];         // c = d r / d T(p) / lambda (MODE >= 1): everything of the row that depends on the TARGET
   int taps[4];         // target rows of the four bilinear taps (-1 invalid)
 };
+
+// The 28 Jacobian-row entries of a surfel from c (reference super/loss.py:258-288): lambda * [w_k c^T dR(q_k)(p - g_k)/dq_k | w_k c]
+// for its four nodes.  Needs the surfel and its nodes only -- no projection, no target table.
+__device__ __forceinline__ void rows_from_c(const d3 p, const int id[4], const double w[4], double lam,
+                                            const double* __restrict__ npk, const d3 c, double row[SLM_K * 7]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double2* nq = reinterpret_cast<const double2*>(npk + (size_t)SLM_NPK * id[k]);
+    const double2 n0 = nq[0], n1 = nq[1], n3 = nq[3], n4 = nq[4];
+    const d3 g = {n3.y, n4.x, n4.y};
+    double jq[4];
+    quat_jac_row(n0.x, {n0.y, n1.x, n1.y}, p - g, c, jq);
+    const double lw = lam * w[k];
+    row[7 * k + 0] = lw * jq[0];
+    row[7 * k + 1] = lw * jq[1];
+    row[7 * k + 2] = lw * jq[2];
+    row[7 * k + 3] = lw * jq[3];
+    row[7 * k + 4] = lw * c.x;
+    row[7 * k + 5] = lw * c.y;
+    row[7 * k + 6] = lw * c.z;
+  }
+}
 
 // npk: packed node table (fd.node_pk at beta, fd.node_pk_try at the trial point beta + delta).
 // sf_pts / sf_idx / sf_w: the surfel streams to read (caller order or tuple-sorted copies).
 // The evaluation is a chain of dependent gathers (surfel -> its 4 nodes -> projected pixel ->
 // 4 target rows); the loads of each stage are issued together, and callers that can fetch the
 // surfel stream entries early pass them in (eval_surfel_core).
-template <bool GRAD>
+// MODE 0: residual only (loss pass); 1: residual + the 28 row entries; 2: residual + c (the evaluation pass that feeds
+// the tuple-sorted Jacobian pass, slm_data_v1.hip)
+template <int MODE>
 __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p, int4 ids, const double w[4],
                                                  double lam, const double* __restrict__ npk, SurfelEval& out) {
   const FrameIn& f = frame_in(fd);
@@ -91,7 +116,7 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p,
     const double wv = an * am;
     o = {o.x + P.x * wv, o.y + P.y * wv, o.z + P.z * wv};
     n = {n.x + Nn.x * wv, n.y + Nn.y * wv, n.z + Nn.z * wv};
-    if (GRAD) {
+    if (MODE) {
       const double sn = dn >= 0.0 ? 1.0 : -1.0, sm = dm >= 0.0 ? 1.0 : -1.0;
       const double gu = an * sm, gv = am * sn;   // d/du, d/dv weights
       dou = {dou.x + P.x * gu, dou.y + P.y * gu, dou.z + P.z * gu};
@@ -106,7 +131,7 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p,
   const d3 e = T - o;
   out.match = true;
   out.r = lam * dot(n, e);
-  if (!GRAD) return;
+  if (!MODE) return;
 
   // ---- c = n^T (I - A) + e^T B, A = do/d(u,v) Pi, B = dn/d(u,v) Pi (loss.py:257-281) ----
   const double Z = T.z;   // no epsilon in dPi (loss.py:161-173)
@@ -116,6 +141,10 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p,
   const double s1 = dot(e, dnv) - dot(n, dov);
   const d3 c = {n.x + s0 * Pi0.x + s1 * Pi1.x, n.y + s0 * Pi0.y + s1 * Pi1.y,
                 n.z + s0 * Pi0.z + s1 * Pi1.z};
+  out.c[0] = c.x;
+  out.c[1] = c.y;
+  out.c[2] = c.z;
+  if (MODE == 2) return;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     double jq[4];
@@ -131,7 +160,7 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p,
   }
 }
 
-template <bool GRAD>
+template <int MODE>
 __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const void* __restrict__ sf_pts,
                                                const int* __restrict__ sf_idx,
                                                const void* __restrict__ sf_w, double lam,
@@ -139,12 +168,12 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const void* _
                                                SurfelEval& out) {
   double w[4];
   ld_state4(sf_w, (size_t)i, fd.f.state_f64, w);
-  eval_surfel_core<GRAD>(fd, ld_state3(sf_pts, (size_t)i, fd.f.state_f64),
+  eval_surfel_core<MODE>(fd, ld_state3(sf_pts, (size_t)i, fd.f.state_f64),
                          *reinterpret_cast<const int4*>(sf_idx + 4 * (size_t)i), w, lam, npk, out);
 }
 
-template <bool GRAD>
+template <int MODE>
 __device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* npk, int i,
                                             SurfelEval& out) {
-  eval_surfel_at<GRAD>(fd, frame_in(fd).sf_points, frame_in(fd).sf_knn_idx, frame_in(fd).sf_knn_w, lam, npk, i, out);
+  eval_surfel_at<MODE>(fd, frame_in(fd).sf_points, frame_in(fd).sf_knn_idx, frame_in(fd).sf_knn_w, lam, npk, i, out);
 }

@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(256) k_data_grad(const FrameDev* __restrict__ 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   SurfelEval ev;
   ev.match = false;
-  if (i < fd.f.N) eval_surfel<true>(fd, lam, fd.node_pk, i, ev);
+  if (i < fd.f.N) eval_surfel<1>(fd, lam, fd.node_pk, i, ev);
 
   // matched-surfel count: one atomic per wave
   unsigned long long m = __ballot(ev.match);
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) k_data_loss(const FrameDev* __restrict__ 
   // [sf_lo, sf_hi) = all surfels unless the frame is sharded over several GPUs
   for (int i = fd.sf_lo + blockIdx.x * blockDim.x + threadIdx.x; i < fd.sf_hi; i += gridDim.x * blockDim.x) {
     SurfelEval ev;
-    eval_surfel<false>(fd, lam, use_delta ? fd.node_pk_try : fd.node_pk, i, ev);
+    eval_surfel<0>(fd, lam, use_delta ? fd.node_pk_try : fd.node_pk, i, ev);
     if (ev.match) {
       acc += ev.r * ev.r;
       ++cnt;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_data_resid(const FrameDev* __restrict__
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= fd.f.N) return;
   SurfelEval ev;
-  eval_surfel<false>(fd, lam, fd.node_pk, i, ev);
+  eval_surfel<0>(fd, lam, fd.node_pk, i, ev);
   if (r_out) r_out[i] = ev.match ? ev.r : 0.0;
   if (match_out) match_out[i] = ev.match ? 1 : 0;
   if (taps_out) {

@@ -1,9 +1,13 @@
 // slm_data_v1.hip -- tuple-sorted data-term Jacobian pass (JtJ / jtl of the point-to-plane
 // term, reference super/loss.py:222-288 + 200-205), no per-entry atomics on the matrix:
 //
-//   k_data_gram     one wave per 64 tuple-sorted surfel positions: every lane evaluates
-//                   its surfel (skin -> project -> match -> bilinear -> residual -> 28
-//                   Jacobian entries, f64), writes the augmented row [J(28) | r | 0 0 0]
+//   k_data_eval     the TARGET-side half of the per-surfel work, one thread per tuple-sorted position: skin ->
+//                   project -> match -> 8 bilinear taps -> residual r and c = dr/dT(p); {r, c} go to the evaluation
+//                   buffer (32 B per position), sum r^2 / the matched count to the loss partials.  It IS the loss
+//                   pass of the LM loop (trial point beta + delta); when the step is accepted its output is what the
+//                   next Jacobian pass needs, so the projection and the taps are done once per iteration, not twice.
+//   k_data_gram     one wave per 64 tuple-sorted surfel positions: every lane forms the 28 Jacobian entries of
+//                   its surfel from {r, c} and its four nodes (no target access), writes the augmented row [J(28) | r | 0 0 0]
 //                   (node slots in ascending-id order) to LDS, and the wave contracts
 //                   groups of 4 surfels on the f64 MFMA:  G += row^T row  (32 x 32 as the
 //                   three 16x16 tiles 00, 10, 11).  G[28][0..27] = J^T r and G[28][28] =
@@ -21,6 +25,65 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define ROW_STRIDE 17   // doubles per surfel half-row in LDS (odd: conflict-free 64-bit writes)
+
+// Evaluation pass over the tuple-sorted positions [256 wg_lo, min(n_pos, 256 wg_hi)) of every slot (the whole frame unless
+// it is sharded over several GPUs).  grid = (n_blocks, n_frames), grid-stride; partial sums per block in a fixed order
+// (bitwise reproducible).  mode 0: trial point (node_pk_try), always runs -- the loss pass; 1: current beta, only slots whose
+// buffer is not valid (first iteration of a frame; after a reject when records are not reused); 2: current beta, always
+// (parity entry points).  The LAST block of a slot (ticket) publishes the matched count of the pass (m_eval) and, for the
+// passes at the current beta, marks the buffer valid; for the trial pass k_accept decides (valid iff accepted).
+__global__ void __launch_bounds__(256) k_data_eval(const FrameDev* __restrict__ frames, double lam, int mode,
+                                                    const int* __restrict__ reuse) {
+  __shared__ double sm[16];
+  __shared__ int s_skip;
+  if (mode == 1 && reuse && reuse[blockIdx.y]) return;   // the Jacobian pass that would read the buffer is skipped too
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.v1_ready || fd.st->stopped) return;
+  if (mode == 1) {
+    // (uniform per slot for the whole launch: only the last block to FINISH changes the flag)
+    if (threadIdx.x == 0) s_skip = __hip_atomic_load(&fd.st->eval_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+    __syncthreads();
+    if (s_skip) return;
+  }
+  const double* npk = mode == 0 ? fd.node_pk_try.get() : fd.node_pk.get();
+  const int p0 = 256 * fd.wg_lo, p1 = min(fd.n_pos, 256 * fd.wg_hi);
+  double acc = 0.0;
+  int cnt = 0;
+  for (int pos = p0 + blockIdx.x * blockDim.x + threadIdx.x; pos < p1; pos += gridDim.x * blockDim.x) {
+    const int4 ids = *reinterpret_cast<const int4*>(fd.s_idx + 4 * (size_t)pos);
+    double2 o0 = make_double2(0.0, 0.0), o1 = make_double2(0.0, 0.0);
+    if (ids.x >= 0) {
+      double wk[4];
+      ld_state4(fd.s_w, (size_t)pos, fd.f.state_f64, wk);
+      const d3 pp = ld_state3(fd.s_pts, (size_t)pos, fd.f.state_f64);
+      SurfelEval ev;
+      eval_surfel_core<2>(fd, pp, ids, wk, lam, npk, ev);
+      if (ev.match) {
+        acc += ev.r * ev.r;
+        ++cnt;
+        o0 = make_double2(ev.r, ev.c[0]);
+        o1 = make_double2(ev.c[1], ev.c[2]);
+      }
+    }
+    double2* out = reinterpret_cast<double2*>(fd.ev_rc.get() + 4 * (size_t)pos);
+    out[0] = o0;
+    out[1] = o1;
+  }
+  const double s = block_sum(acc, sm);
+  const double c = block_sum((double)cnt, sm);
+  if (threadIdx.x == 0) {
+    fd.loss_part[2 * blockIdx.x] = s;
+    fd.loss_part[2 * blockIdx.x + 1] = c;
+    LMState* st = fd.st;
+    const unsigned long long old = __hip_atomic_fetch_add(&st->eval_acc, (1ull << 32) | (unsigned long long)(unsigned)(int)c,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)(old >> 32) == (int)gridDim.x - 1) {            // the last block of the slot to finish
+      st->m_eval = (int)(unsigned)(old & 0xFFFFFFFFull) + (int)c;
+      __hip_atomic_store(&st->eval_acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mode != 0) __hip_atomic_store(&st->eval_valid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 // grid = (ceil(max n_pos / 256), n_frames), 256 threads = 4 waves, one 64-position chunk each
 // dbg (diagnostic build only): bit0 skip slab stores, bit1 skip MFMA, bit2 skip surfel evaluation
@@ -51,6 +114,8 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int base = (blockIdx.x * 4 + w) * 64;
   if (blockIdx.x * 256 >= fd.n_pos) return;
+  // the matched count of this pass is the one of the evaluation it consumes (this rank's share of it when sharded)
+  if (blockIdx.x == 0 && threadIdx.x == 0) fd.st->m_grad = fd.st->m_eval;
   if ((int)blockIdx.x < fd.wg_lo || (int)blockIdx.x >= fd.wg_hi) return;   // another rank's share
   const bool wact = base < fd.n_pos;
   const int pos = base + l;
@@ -65,8 +130,12 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   int4 ids = {-1, -1, -1, -1};
   double wk[4] = {0, 0, 0, 0};
   d3 pp = {0, 0, 0};
+  double2 e0 = make_double2(0.0, 0.0), e1 = make_double2(0.0, 0.0);   // {r, c.x}, {c.y, c.z} of the position
   if (wact) {
     my_run = fd.grp_run[(base >> 2) + lc];   // lane (l & 15) holds the run of group (l & 15)
+    const double2* e2 = reinterpret_cast<const double2*>(fd.ev_rc.get() + 4 * (size_t)pos);
+    e0 = e2[0];
+    e1 = e2[1];
     ids = *reinterpret_cast<const int4*>(fd.s_idx + 4 * (size_t)pos);
     ld_state4(fd.s_w, (size_t)pos, fd.f.state_f64, wk);
     pp = ld_state3(fd.s_pts, (size_t)pos, fd.f.state_f64);
@@ -87,9 +156,10 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
     for (int i = threadIdx.x; i < nrec * SLM_WREC; i += 256) recs[i] = 0.0;
   double* myrow = &rows[w][l * ROW_STRIDE];
 
-  // ---- per-surfel evaluation -----------------------------------------------------
+  // ---- the surfel's row from the evaluation buffer: no projection, no target access --------------
   SurfelEval ev;
   ev.match = false;
+  ev.r = 0.0;
   ev.id[0] = ev.id[1] = ev.id[2] = ev.id[3] = -1;
   const bool live = wact && ids.x >= 0;
 #ifdef SLM_STAMPS
@@ -97,7 +167,13 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
 #else
   if (live)
 #endif
-    eval_surfel_core<true>(fd, pp, ids, wk, lam, fd.node_pk, ev);
+  {
+    ev.id[0] = ids.x; ev.id[1] = ids.y; ev.id[2] = ids.z; ev.id[3] = ids.w;
+    // (an unmatched surfel has {r, c} = 0: its row is zero and it adds nothing to the Gram)
+    ev.match = e0.x != 0.0 || e0.y != 0.0 || e1.x != 0.0 || e1.y != 0.0;
+    ev.r = e0.x;
+    if (ev.match) rows_from_c(pp, ev.id, wk, lam, fd.node_pk, {e0.y, e1.x, e1.y}, ev.row);
+  }
   if (MERGE && wact) {
     lidx[w][l] = lv0;
     lidx[w][l + 64] = lv1;
@@ -105,8 +181,6 @@ __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict
   }
   if (MERGE) __syncthreads();   // accumulators zeroed, record numbers in place
   if (wact) {
-  const unsigned long long mm = __ballot(ev.match);
-  if (l == 0 && mm) atomicAdd(&fd.st->m_grad, __popcll(mm));
 
   // canonical slot of neighbour k = number of neighbour ids smaller than id[k]
   int slot[4];
@@ -260,6 +334,11 @@ void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, dou
   const dim3 grid((max_pos + 255) / 256, n_frames);
   if (variants & 1) hipLaunchKernelGGL(k_data_gram<true>, grid, dim3(256), 0, st, frames_dev, lam, dbg, reuse);
   if (variants & 2) hipLaunchKernelGGL(k_data_gram<false>, grid, dim3(256), 0, st, frames_dev, lam, dbg, reuse);
+}
+
+void launch_data_eval(const FrameDev* frames_dev, int n_frames, int n_blocks, double lam, int mode, hipStream_t st,
+                      const int* reuse) {
+  hipLaunchKernelGGL(k_data_eval, dim3(n_blocks, n_frames), dim3(256), 0, st, frames_dev, lam, mode, reuse);
 }
 
 void launch_band_assemble(const FrameDev* frames_dev, int n_frames, int max_blocks, hipStream_t st) {

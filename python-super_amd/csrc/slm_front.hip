@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restric
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // (a reused Jacobian pass keeps its matched count -- on a surfel-sharded frame the rank's OWN share of it, which
     //  k_pair_scatter set aside before it stored the all-reduced count)
-    if (!(reuse && reuse[blockIdx.y])) fd.st->m_grad = 0;
+    if (!(reuse && reuse[blockIdx.y])) fd.st->m_grad = 0;   // (k_data_gram takes the count of the evaluation it consumes)
     else if (fd.pairbuf) fd.st->m_grad = fd.st->m_grad_local;
     fd.st->chol_fail = 0;
   }

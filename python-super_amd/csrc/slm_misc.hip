@@ -38,6 +38,9 @@ __global__ void __launch_bounds__(256) k_init_slot(const FrameDev* __restrict__ 
     s.m_loss = 0;
     s.chol_fail = 0;
     s.m_grad_local = 0;
+    s.eval_valid = 0;
+    s.m_eval = 0;
+    s.eval_acc = 0;
     *fd.st = s;
   }
 }
@@ -120,6 +123,7 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
     st->iter = it + 1;
     s_accept = acc;
     if (reuse) reuse[blockIdx.y] = acc ? 0 : 1;   // rejected: the next Jacobian pass would repeat this one (k_data_gram)
+    st->eval_valid = acc;                         // the loss pass evaluated the TRIAL point: the current beta only if accepted
   }
   __syncthreads();
   if (s_accept) {
