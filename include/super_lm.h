@@ -641,6 +641,13 @@ int slm_debug_dag_timeout(int64_t ticks);
 int slm_debug_dag_abort(slm_solver* s, int32_t n_frames, void* stream);
 int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, int64_t max_doubles,
                    int64_t* n_doubles, void* stream);
+/* Diagnostics / tests: copies one array of the slot's per-frame assembly plan (the output of the preparation, slm_prep.hip) to
+ * HOST memory as raw bytes (synchronises `stream`): what = 0 s_idx, 1 grp_run, 2 run_nodes, 3 s_w, 4 blk_key, 5 blk_start,
+ * 6 blk_entry, 7 wg_first, 8 wg_last, 9 run_lidx, 10 blk2_start, 11 blk2_entry, 12 s_pts.  *n_bytes receives the array's
+ * length; at most max_bytes are copied.  (tests/test_gpu_prepare_binned.py: the binned preparation against the rocPRIM
+ * pipeline, array by array.) */
+int slm_debug_read_plan(slm_solver* s, int32_t slot, int32_t what, void* host_out, int64_t max_bytes, int64_t* n_bytes,
+                        void* stream);
 
 #ifdef __cplusplus
 }

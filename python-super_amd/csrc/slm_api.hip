@@ -437,6 +437,40 @@ int slm_debug_read(slm_solver* s, int32_t slot, int32_t what, double* host_out, 
   return SLM_OK;
 }
 
+int slm_debug_read_plan(slm_solver* s, int32_t slot, int32_t what, void* host_out, int64_t max_bytes, int64_t* n_bytes, void* stream) {
+  if (!s || slot < 0 || slot >= (int)s->slots.size() || !n_bytes) return fail(SLM_ERR_INVALID, "slm_debug_read_plan: bad argument");
+  int rc = check_slots_fwd(s, slot, 1);
+  if (rc) return rc;
+  const Slot& sl = s->slots[slot];
+  const FrameDev& h = sl.h;
+  if (!h.v1_ready) return fail(SLM_ERR_UNSUPPORTED, "slm_debug_read_plan: the slot has no tuple-sorted plan");
+  const size_t esz = h.f.state_f64 ? 8 : 4;
+  const size_t n_wg = (size_t)h.n_pos / 256 + ((h.n_pos % 256) ? 1 : 0);
+  const void* src = nullptr;
+  size_t n = 0;
+  switch (what) {
+    case 0: src = h.s_idx.get(); n = sizeof(int32_t) * 4 * (size_t)h.n_pos; break;
+    case 1: src = h.grp_run.get(); n = sizeof(int32_t) * (size_t)h.n_pos / 4; break;
+    case 2: src = h.run_nodes.get(); n = sizeof(int32_t) * 4 * (size_t)h.n_runs; break;
+    case 3: src = h.s_w.get(); n = esz * 4 * (size_t)h.n_pos; break;
+    case 4: src = h.blk_key.get(); n = sizeof(int32_t) * (size_t)h.n_blocks; break;
+    case 5: src = h.blk_start.get(); n = sizeof(int32_t) * ((size_t)h.n_blocks + 1); break;
+    case 6: src = h.blk_entry.get(); n = sizeof(int32_t) * 10 * (size_t)h.n_runs; break;
+    case 7: src = h.v2_ready ? h.wg_first.get() : nullptr; n = h.v2_ready ? sizeof(int32_t) * n_wg : 0; break;
+    case 8: src = h.v2_ready ? h.wg_last.get() : nullptr; n = h.v2_ready ? sizeof(int32_t) * n_wg : 0; break;
+    case 9: src = h.v2_ready ? h.run_lidx.get() : nullptr; n = h.v2_ready ? 10 * (size_t)h.n_runs : 0; break;
+    case 10: src = h.v2_ready ? h.blk2_start.get() : nullptr; n = h.v2_ready ? sizeof(int32_t) * ((size_t)h.n_blocks + 1) : 0; break;
+    case 11: src = h.v2_ready ? h.blk2_entry.get() : nullptr; n = h.v2_ready ? sizeof(int32_t) * (size_t)h.n_wblk : 0; break;
+    case 12: src = h.s_pts.get(); n = esz * 3 * (size_t)h.n_pos; break;
+    default: return fail(SLM_ERR_INVALID, "slm_debug_read_plan: unknown array");
+  }
+  *n_bytes = (int64_t)n;
+  const size_t m = n < (size_t)(max_bytes > 0 ? max_bytes : 0) ? n : (size_t)(max_bytes > 0 ? max_bytes : 0);
+  if (m > 0 && host_out && src) HIPCHK(hipMemcpyAsync(host_out, src, m, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return SLM_OK;
+}
+
 int slm_abi_version(void) { return SLM_ABI_VERSION; }
 
 int slm_abi_check(int32_t abi_version, int32_t sz_config, int32_t sz_frame, int32_t sz_gf_config, int32_t sz_gf_frame,

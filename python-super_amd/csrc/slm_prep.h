@@ -27,6 +27,7 @@ struct V1Plan {
   int32_t* blk2_start = nullptr;
   int32_t* blk2_entry = nullptr;
   int32_t nt_hint = 0;            // distinct KNN tuples of the frame this plan was last built for (0: none yet)
+  bool legacy = false;            // a bin of this plan's frames did not fit the LDS sort of the binned preparation: rocPRIM pipeline from then on
   size_t cap_rchunk = 0, cap_wg = 0, cap_lidx = 0, cap_wgslab = 0, cap_b2start = 0, cap_b2entry = 0;
   size_t cap_pts = 0, cap_idx = 0, cap_w = 0, cap_grp = 0, cap_runs = 0, cap_slab = 0, cap_bkey = 0,
          cap_bstart = 0, cap_bentry = 0;
