@@ -22,7 +22,7 @@ PHASE_KERNELS = {
     "reg_grad": ["k_front_assemble", "k_reg_grad_nd", "k_front_load_rhs"],
     "solve": ["k_fL11", "k_fL21", "k_fpanel", "k_fpotrf", "k_ftrsm", "k_ftrail", "k_fschur", "k_fpull", "k_fdag", "k_dag_reset",
               "k_dag_check", "k_fback_prep", "k_fbacksub", "k_make_trial"],
-    "data_loss": ["k_data_loss"],
+    "data_loss": ["k_data_loss", "k_data_eval"],   # (round 4: k_data_eval is the loss pass on the tuple-sorted path)
     "accept": ["k_reg_loss", "k_accept"],
 }
 
