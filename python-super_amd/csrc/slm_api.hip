@@ -316,8 +316,9 @@ struct slm_solver {
   // substitution, capped to dag_cap workgroups) runs UNDER the bandwidth-bound per-level launches of the other.
   int groups = 1;               // SLM_GROUPS
   int group_min_frames = 6;     // batches below this stay in one group
-  int dag_cap = 96;             // SLM_DAG_CAP: workgroups of a group's task-graph launch
-  int group_sync = 1;           // SLM_GROUP_SYNC: 1 = the groups' assembly + per-level phases alternate (events), 0 = free-running
+  int dag_cap = 128;            // SLM_DAG_CAP: workgroups of a group's task-graph launch (the best of the measured caps)
+  int group_sync = 0;           // SLM_GROUP_SYNC: 0 = free-running (the fastest measured), 1 = the groups' assembly + per-level phases
+                                // alternate (events), 2 = staggered start only
   std::vector<hipStream_t> group_streams; // groups 1.. (group 0 runs on the caller's stream)
   std::vector<hipEvent_t> group_events;   // fork, joins, and one per (group, iteration)
   bool profile = false;
@@ -740,7 +741,6 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.v2_ready = 0;
       if (s->cfg.data_path == 0 && sz.n_wblk > 0 && sz.max_wblk_per_wg <= SLM_LB_MAX) {
         h.n_wblk = sz.n_wblk;
-        h.max_wblk = sz.max_wblk_per_wg;
         h.wg_first = sl.plan.wg_first;
         h.wg_last = sl.plan.wg_last;
         h.run_lidx = sl.plan.run_lidx;
@@ -1197,7 +1197,6 @@ struct BatchDims {
   int max_pos = 0, max_blocks = 0, maxP = 0;
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
   int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
-  int max_wblk = 0;        // most (workgroup, pair) records of one workgroup over the batch (LDS of k_data_gram)
   bool nd = true;   // every slot of the batch has a nested-dissection plan
   int max_tasks = 0;   // tasks of the persistent task-graph solver (maximum over the batch)
   // hybrid solve: every slot has the same number of levels and the same top-of-tree cut (-1: not available)
@@ -1216,7 +1215,6 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.max_blocks = std::max(d.max_blocks, h.n_blocks);
     d.v1 = d.v1 && h.v1_ready;
     if (h.v1_ready) d.gram_variants |= h.v2_ready ? 1 : 2;
-    if (h.v1_ready && h.v2_ready) d.max_wblk = std::max(d.max_wblk, h.max_wblk);
     d.nd = d.nd && h.nd_ready;
     d.max_tasks = std::max(d.max_tasks, h.nd_ready ? h.n_dag_tasks : 0);
     if (h.nd_ready) {

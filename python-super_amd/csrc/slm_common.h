@@ -99,8 +99,6 @@ struct FrameDev {
   //      (workgroup, node pair) goes to HBM instead of one 768-double Gram per run ----
   int32_t v2_ready;
   int32_t n_wblk;          // (workgroup, pair) records
-  int32_t max_wblk;        // most records of one workgroup
-  int32_t pad5;
   GP<const int32_t> wg_first; // (n_wg) first record of each workgroup
   GP<const int32_t> wg_last;  // (n_wg) last record (first-1 if none)
   GP<const uint8_t> run_lidx; // (n_runs,10) local record index of the run's 10 node pairs

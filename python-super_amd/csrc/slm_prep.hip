@@ -330,21 +330,36 @@ __device__ void lds_sort_pairs(unsigned long long* k, unsigned* v, int n) {
     }
 }
 // in-place exclusive scan of a[0..n) (LDS or global, one block of NT threads); returns the total; tmp: NT ints of LDS
+// (per-thread chunk sums, a shuffle scan inside every wave, the wave totals scanned by the first wave: three barriers)
 template <int NT>
 __device__ int block_excl_scan(int* a, int n, int* tmp) {
   const int chunk = (n + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, n);
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   int s = 0;
   for (int i = b0; i < b1; ++i) s += a[i];
-  tmp[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 1; off < NT; off <<= 1) {
-    const int x = (int)threadIdx.x >= off ? tmp[threadIdx.x - off] : 0;
-    __syncthreads();
-    tmp[threadIdx.x] += x;
-    __syncthreads();
+  int inc = s;                                   // inclusive scan over the wave's 64 chunk sums
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int x = __shfl_up(inc, off, 64);
+    if (l >= off) inc += x;
   }
-  const int total = tmp[NT - 1];
-  int run = tmp[threadIdx.x] - s;
+  __syncthreads();                               // (tmp may still be read by a previous scan's last step)
+  if (l == 63) tmp[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    const int nw = NT / 64;
+    int t = l < nw ? tmp[l] : 0, ti = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int x = __shfl_up(ti, off, 64);
+      if (l >= off) ti += x;
+    }
+    if (l < nw) tmp[l] = ti - t;                 // waves before this one
+    if (l == nw - 1) tmp[NT / 64] = ti;          // total
+  }
+  __syncthreads();
+  const int total = tmp[NT / 64];
+  int run = tmp[w] + inc - s;
   for (int i = b0; i < b1; ++i) {
     const int x = a[i];
     a[i] = run;

@@ -81,7 +81,7 @@ for name, env in VARIANTS:
 
 # bitwise check on the run-to-run reproducible data path: a frame sees the launches of a batch of its GROUP's size
 if B % 2 == 0 and not os.environ.get("AB_VARIANTS"):
-    b1 = run_variant({"SLM_GROUPS": "2", "SLM_DAG_CAP": "96"}, data_path=2)[3]
+    b1 = run_variant({"SLM_GROUPS": "2", "SLM_DAG_CAP": "128", "SLM_GROUP_SYNC": "0"}, data_path=2)[3]
     half = B // 2
     for k in KNOBS:
         os.environ.pop(k, None)
