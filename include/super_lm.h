@@ -171,6 +171,12 @@ int slm_bind_frames(slm_solver* s, int32_t first_slot, int32_t n_frames, const s
  * returned by the bind that consumes it.  Replaces the model-side part of loss_term.prepare, super/loss.py:212-220,
  * 408-426, moved to where its inputs become final. */
 int slm_prepare_model(slm_solver* s, int32_t slot, const slm_frame* model, void* stream);
+/* Drops the slot's queued / finished preparation: the next slm_bind_frame binds in full whatever its pointers are.  The
+ * library can only compare SIZES and POINTERS of the model arrays; a caller that knows the arrays were rewritten in place
+ * after slm_prepare_model (same buffers, new values -- the host mirror sees it in the tensors' version counters) calls
+ * this before the bind, otherwise the bind would consume a plan sorted from the old values.  Joins the worker; the bind
+ * that follows is ordered behind the preparation's launches either way. */
+int slm_discard_prepared(slm_solver* s, int32_t slot);
 
 /* -- the LM loop ------------------------------------------------------------------ */
 /* Enqueues num_iterations damped accept/reject iterations for slots [0,n_frames),

@@ -44,7 +44,7 @@ void launch_iter_begin(const FrameDev*, int, hipStream_t);
 void launch_pack_nodes(const FrameDev*, int, int, hipStream_t);
 void launch_make_trial(const FrameDev*, int, int, hipStream_t);
 void launch_pack_target(int, const float*, const float*, float4*, hipStream_t);
-void launch_accept(const FrameDev*, int, int, int, int, hipStream_t, int* reuse = nullptr);
+void launch_accept(const FrameDev*, int, int, int, int, hipStream_t, int* reuse = nullptr, int eval_pass = 0);
 void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
 void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
@@ -161,6 +161,7 @@ struct Slot {
   slm_frame prep_model{};          // the model fields it was prepared for
   unsigned long long prep_ticket = 0;   // job number on the worker (0: none pending)
   int prep_rc = SLM_OK;
+  bool prep_recorded = false;      // prep_done was recorded on the solver's stream and nothing has waited for it yet
   std::string prep_err;
   hipEvent_t prep_fork = nullptr, prep_done = nullptr;
 };
@@ -996,9 +997,15 @@ static int bind_frame_impl(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   // frame's update / fusion rewrites them in place afterwards.
   const bool prepared = sl.model_ready && same_model(sl.prep_model, *f);
   sl.model_ready = false;
+  // Whatever becomes of the preparation, its launches ran on the solver's own stream and wrote this slot's plan buffers
+  // (and read the caller's arrays): everything the bind enqueues comes after them -- also when the preparation is NOT
+  // used (another model, slm_discard_prepared) and the full bind rewrites the same buffers.
+  if (sl.prep_recorded) {
+    sl.prep_recorded = false;
+    HIPCHK(hipStreamWaitEvent(st, sl.prep_done, 0));
+  }
   if (prepared) {
     if (sl.prep_rc != SLM_OK) return fail(sl.prep_rc, sl.prep_err.c_str());
-    HIPCHK(hipStreamWaitEvent(st, sl.prep_done, 0));     // the preparation ran on the solver's own stream
     g_bt.n = 0;
     bt_mark();
   } else {
@@ -1041,8 +1048,12 @@ int slm_prepare_model(slm_solver* s, int32_t slot, const slm_frame* model, void*
           rc = fail(SLM_ERR_HIP, "slm_prepare_model: worker setup failed");
         } else {
           rc = bind_model_part(s, slot, &w.prep_model, s->prep_stream, s->prep_async);
-          if (rc == SLM_OK && hipEventRecord(w.prep_done, s->prep_stream) != hipSuccess)
-            rc = fail(SLM_ERR_HIP, "slm_prepare_model: hipEventRecord failed");
+          // (recorded after a failed preparation too: its launches up to the failure still touch the slot)
+          if (hipEventRecord(w.prep_done, s->prep_stream) != hipSuccess) {
+            if (rc == SLM_OK) rc = fail(SLM_ERR_HIP, "slm_prepare_model: hipEventRecord failed");
+          } else {
+            w.prep_recorded = true;
+          }
         }
         if (rc != SLM_OK) w.prep_err = g_err;          // (thread-local text of the worker)
       } catch (...) {
@@ -1056,6 +1067,14 @@ int slm_prepare_model(slm_solver* s, int32_t slot, const slm_frame* model, void*
     sl.prep_ticket = 0;
     return fail(SLM_ERR_HIP, "slm_prepare_model: could not start the worker");
   }
+  return SLM_OK;
+}
+
+int slm_discard_prepared(slm_solver* s, int32_t slot) {
+  if (!s) return fail(SLM_ERR_INVALID, "slm_discard_prepared: null argument");
+  if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_discard_prepared: bad slot");
+  join_prepare(s, slot);
+  s->slots[slot].model_ready = false;   // (prep_recorded stays: the next bind of the slot still orders itself behind the launches)
   return SLM_OK;
 }
 
@@ -1429,7 +1448,7 @@ int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream) {
   int rc = shard_dims(s, n_frames, d);
   if (rc) return rc;
   launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, std::max(s->cfg.num_iterations, 1), (hipStream_t)stream,
-                s->cfg.phase_test ? s->reuse_dev : nullptr);
+                s->cfg.phase_test ? s->reuse_dev : nullptr, s->cfg.use_data ? 1 : 0);   // (slm_lm_loss_local ran k_data_eval)
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -1549,7 +1568,7 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   if (d.n_reg_part > 0)
     launch_reg_loss(fr, n, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
   launch_accept(fr, n, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st,
-                (d.v1 && c.phase_test) ? s->reuse_dev + first : nullptr);
+                (d.v1 && c.phase_test) ? s->reuse_dev + first : nullptr, (c.use_data && d.v1) ? 1 : 0);
   mark();
 }
 

@@ -69,8 +69,11 @@ __global__ void __launch_bounds__(256) k_iter_begin(const FrameDev* __restrict__
 // A failed factorisation stops the loop with beta unchanged.  grid = (1, n_frames), 1024 thr.
 // Records are kept for the first n_rec iterations after the bind (the capacity of fd.rec): running again
 // without binding continues the loop from the current state and records nothing more.
+// eval_pass: the loss pass of this iteration was k_data_eval (it wrote the slot's evaluation buffer at the trial point);
+// 0 when the batch took k_data_loss (one slot without a tuple-sorted plan sends all of them there): ev_rc then still
+// holds an OLDER evaluation and must not be marked valid.
 __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ frames, int phase_test,
-                                                  int n_reg_part, int n_rec, int* __restrict__ reuse) {
+                                                  int n_reg_part, int n_rec, int* __restrict__ reuse, int eval_pass) {
   __shared__ double sm[16];
   __shared__ int s_accept;
   const FrameDev& fd = frames[blockIdx.y];
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(1024) k_accept(const FrameDev* __restrict__ fr
     st->iter = it + 1;
     s_accept = acc;
     if (reuse) reuse[blockIdx.y] = acc ? 0 : 1;   // rejected: the next Jacobian pass would repeat this one (k_data_gram)
-    st->eval_valid = acc;                         // the loss pass evaluated the TRIAL point: the current beta only if accepted
+    st->eval_valid = eval_pass ? acc : 0;         // the loss pass evaluated the TRIAL point: the current beta only if accepted
   }
   __syncthreads();
   if (s_accept) {
@@ -497,9 +500,9 @@ void launch_iter_begin(const FrameDev* frames_dev, int n_frames, hipStream_t st)
 }
 
 void launch_accept(const FrameDev* frames_dev, int n_frames, int phase_test, int n_reg_part, int n_rec,
-                   hipStream_t st, int* reuse) {
+                   hipStream_t st, int* reuse, int eval_pass) {
   hipLaunchKernelGGL(k_accept, dim3(1, n_frames), dim3(1024), 0, st, frames_dev, phase_test,
-                     n_reg_part, n_rec, reuse);
+                     n_reg_part, n_rec, reuse, eval_pass);
 }
 
 void launch_loss_out(const FrameDev* frames_dev, int slot, int n_reg_part, double* out,

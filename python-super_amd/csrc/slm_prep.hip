@@ -713,7 +713,12 @@ __global__ void __launch_bounds__(256) kb_wg_records(int n_wg, int J, int RB, co
   const int r1 = wgr1[wg], r0 = r1 > 0 ? RB - wgr0x[wg] : 0;
   const int n = 10 * (r1 - r0);
   if (n <= 0 || n > 1024) {                              // (<= 64 runs per workgroup by construction: 640 entries)
-    if (threadIdx.x == 0) nrec[wg] = 0;
+    if (threadIdx.x == 0) {
+      nrec[wg] = 0;
+      // an invariant of the layout, not of the data: should it ever break, the plan would silently miss records --
+      // hand the slot to the rocPRIM pipeline instead (the final read-back sees the flag)
+      if (n > 1024) const_cast<int*>(scal)[15] = 1;
+    }
     return;
   }
   for (int j = threadIdx.x; j < n; j += 256) {
@@ -834,7 +839,10 @@ __global__ void __launch_bounds__(256) kb_rec_sort(int J, const int* __restrict_
   }
   const int base = startC[b], n = startC[b + 1] - base;
   if (n <= 0) return;
-  if (n > BIN_CAP) return;                                 // (never: records of a node <= its entries, checked in phase B)
+  if (n > BIN_CAP) {                                       // (never: records of a node <= its entries, checked in phase B)
+    if (threadIdx.x == 0) const_cast<int*>(scal)[15] = 1;  // ... and if it ever happens: the rocPRIM pipeline, not a plan with holes
+    return;
+  }
   for (int i = threadIdx.x; i < n; i += 256) {
     k[i] = rkey[base + i];
     v[i] = (unsigned)ru[base + i];

@@ -208,6 +208,11 @@ class LM_Solver():
         mv = None
         if prepared is not None and prepared[0] is h and prepared[1].matches(sf, dev, state):
             mv = prepared[1]                           # same arrays, untouched since: the library only binds the target side
+        elif prepared is not None:
+            # The model changed after prepare_model (other tensors, or the same buffers rewritten in place: the version
+            # counters moved).  The library compares sizes and pointers only -- with no-copy inputs (int32 tables, state
+            # dtype, contiguous) it would take the stale plan for this frame's: drop it explicitly.
+            _lib.check(self.lib.slm_discard_prepared(prepared[0], slot), "slm_discard_prepared")
         bf = BoundFrame(sf, inputs, new_data, state=state, model=mv)
         _lib.check(self.lib.slm_bind_frame(h, slot, C.byref(bf.c), _stream_ptr(bf.device)),
                    "slm_bind_frame")
@@ -221,7 +226,8 @@ class LM_Solver():
         same, untouched ``sf`` only binds its target (``slm_prepare_model``: the sort, the size read-backs and any
         symbolic analysis run on the library's worker thread and stream while the caller fetches the next frame).
         Optional: ``LM()`` alone does everything, as the reference does.  Not for surfel-sharded solvers' first bind
-        order; harmless when the model changes after all (the bind then prepares in full)."""
+        order.  When the model changes after all -- other tensors or an in-place write, seen in the tensors' version
+        counters -- the next ``LM()`` drops the preparation (``slm_discard_prepared``) and prepares in full."""
         h = self._handle(u, v, minimal_loss)
         mv = ModelView(sf, state=getattr(self.opt, "slm_state_dtype", None))
         fr = SlmFrame()

@@ -35,7 +35,7 @@ EXPORTS = [
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set", "slm_lm_exchange_ptr",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
     "slm_apply_update_f64", "slm_apply_update_gf_f64", "slm_debug_read", "slm_debug_dag_trace",
-    "slm_abi_version", "slm_abi_check", "slm_debug_dag_timeout", "slm_debug_dag_abort", "slm_prepare_model", "slm_debug_read_plan",
+    "slm_abi_version", "slm_abi_check", "slm_debug_dag_timeout", "slm_debug_dag_abort", "slm_prepare_model", "slm_discard_prepared", "slm_debug_read_plan",
 ]
 
 
@@ -177,6 +177,7 @@ def load():
         "slm_bind_frames": [vp, i32, i32, C.POINTER(SlmFrame), vp],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_prepare_model": [vp, i32, C.POINTER(SlmFrame), vp],
+        "slm_discard_prepared": [vp, i32],
         "slm_debug_read_plan": [vp, i32, i32, vp, C.c_int64, C.POINTER(C.c_int64), vp],
         "slm_run": [vp, i32, vp],
         "slm_profile_enable": [vp, i32],

@@ -61,7 +61,9 @@ def init_track_pts(sf, sfdata, filename, th=0.2):
                 d[~sf.isStable] = 1e13
             if float(d.min()) < th:
                 sf.track_id[k] = int(torch.argmin(d))
-        # like the reference this indexes with the id the point had at the top of the loop body
+        # ``tid`` is a 0-d VIEW of track_id[k] (the reference iterates the tensor: ``for k, tid in enumerate(self.track_id)``),
+        # so it shows the id assigned just above; a point that stays unassigned indexes projdata[-1] / [-2] like the reference
+        # (pinned by tests/golden/track_48x64.npz, recorded from the reference with a non-empty gt)
         sf.track_rsts[filename][k, 0:2] = sf.projdata[int(tid)]
         sf.track_rsts[filename][k, 2] = 1
 

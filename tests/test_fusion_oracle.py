@@ -152,3 +152,50 @@ def test_tracking_ground_truth_format_and_error(tmp_path):
     assert d2[0] == -1 / 480 and d2[1] == -1 / 480
     with pytest.raises(ValueError):
         ev.get_gt(SimpleNamespace(data_dir=str(tmp_path), tracking_gt_file="missing.npy"))
+
+
+def test_tracking_host_functions_against_the_reference_golden(tmp_path):
+    """Row f4 pinned by the reference itself: ``tests/golden/track_48x64.npz`` holds what the
+    reference's ``get_gt`` / ``evaluate`` / ``Surfels.init_track_pts`` / ``update_track_pts`` (``utils/utils.py:360-392``,
+    ``super/nodes.py:17-34,225-265``) return for a synthetic pickled ground-truth file and a NON-empty ``gt`` on the
+    fusion scene; the host mirror must reproduce it: ids bit-exact, values 1e-12."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "python-super_amd"))
+    from super_amd import evaluation as ev
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_48x64.npz"))
+    keys = ["000010", "000020", "000030"]
+    gt = {k: g["gtfile_" + k] for k in keys}
+    blob = {"gt": gt, "super_cpp": {k: v + 0.5 for k, v in gt.items()}, "SURF": {k: v - 0.25 for k, v in gt.items()}}
+    np.save(tmp_path / "tracked_pts.npy", blob, allow_pickle=True)
+    every, gt_m, ik, sk, arr = ev.get_gt(SimpleNamespace(data_dir=str(tmp_path), tracking_gt_file="tracked_pts.npy"))
+    np.testing.assert_array_equal(np.array(ik), g["gt_intkeys"])
+    np.testing.assert_array_equal(np.array([int(s) for s in sk]), g["gt_strkeys"])
+    assert sk == keys
+    np.testing.assert_array_equal(arr, g["gt_array"])
+    np.testing.assert_array_equal([len(every["gt"]), len(every["super_cpp"]), len(every["SURF"])], g["gt_methods"])
+    # evaluate: plain / ignored ids (1-based) / normalised
+    est = g["eval_est"]
+    np.testing.assert_allclose(ev.evaluate(gt["000020"].copy(), est.copy()), g["eval_plain"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ev.evaluate(gt["000020"].copy(), est.copy(), igonored_ids=[1, 4, 20]), g["eval_ignored"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ev.evaluate(gt["000020"].copy(), est.copy(), normalize=True), g["eval_norm"], rtol=0, atol=1e-12)
+    assert (g["eval_plain"] == -1).sum() > 0 and (g["eval_ignored"] == -1).sum() > (g["eval_plain"] == -1).sum()
+    # init_track_pts / update_track_pts with a non-empty gt
+    t = lambda a: torch.from_numpy(np.array(a, copy=True))
+    sf = SimpleNamespace(points=t(g["in_sf_points"]), isStable=t(g["in_sf_isStable"]), projdata=t(g["projdata"]),
+                         track_id=t(g["track_id0"]), track_num=20, gt=gt_m, gt_strkeys=sk, track_rsts={})
+    sfdata = SimpleNamespace(points=t(g["in_new_points"]), index_map=t(g["in_new_index_map"]))
+    ev.init_track_pts(sf, sfdata, "000010", th=0.2)
+    np.testing.assert_array_equal(sf.track_id.numpy(), g["init_track_id"])
+    np.testing.assert_allclose(sf.track_rsts["000010"].numpy(), g["init_rsts"], rtol=0, atol=1e-12)
+    assert (g["init_track_id"] != g["track_id0"]).sum() >= 5            # points were attached ...
+    assert (g["init_track_id"][[7, 14]] >= 0).all()                      # ... the deleted ones (-2 < 0) too, like the reference
+    ev.update_track_pts(sf, sfdata, "000015")                            # not a key frame
+    assert set(sf.track_rsts) == {"000010"}
+    ev.update_track_pts(sf, sfdata, "000020", th=0.05)                   # new key frame -> init with th
+    np.testing.assert_array_equal(sf.track_id.numpy(), g["upd20_track_id"])
+    np.testing.assert_allclose(sf.track_rsts["000020"].numpy(), g["upd20_rsts"], rtol=0, atol=1e-12)
+    sf.projdata = t(g["projdata2"])
+    ev.update_track_pts(sf, sfdata, "000010")                            # seen before: the update loop
+    np.testing.assert_array_equal(sf.track_id.numpy(), g["upd10_track_id"])
+    np.testing.assert_allclose(sf.track_rsts["000010"].numpy(), g["upd10_rsts"], rtol=0, atol=1e-12)

@@ -89,6 +89,57 @@ def test_a_preparation_for_another_model_is_discarded():
     np.testing.assert_allclose(beta.cpu().numpy(), g1["lm_beta"], rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("data_path", [0, 2])
+def test_no_copy_model_rewritten_in_place_after_the_preparation(data_path):
+    """with inputs that need NO conversion copy (int32 KNN tables, float64 contiguous state) the ModelView
+    made by ``LM()`` holds the very pointers ``prepare_model`` passed, so the library's pointer comparison cannot see an
+    in-place rewrite -- the mirror must drop the preparation (``slm_discard_prepared``), otherwise the bind consumes a
+    plan sorted from the OLD values.  The model is changed for real: surfel rows permuted (points, KNN rows and weights
+    together: the same problem in another surfel order, so the stale tuple-sorted streams are wrong row for row)."""
+    import torch
+    g, sc, opt = load_golden("s120x160_j108")
+    sf, inputs, new_data = torch_frame(sc)
+    sf.knn_indices = sf.knn_indices.to(torch.int32)          # no-copy inputs
+    sf.ED_nodes.knn_indices = sf.ED_nodes.knn_indices.to(torch.int32)
+    lm = _solver(opt, slm_data_path=data_path)
+    lm.prepare_model(sf)
+    mv = lm._prepared[0][1]
+    assert mv.sf_points.data_ptr() == sf.points.data_ptr() and mv.sf_knn_idx.data_ptr() == sf.knn_indices.data_ptr()
+    torch.cuda.synchronize()                                 # (the worker has read the old values)
+    perm = torch.from_numpy(np.random.default_rng(5).permutation(sc.N)).to(sf.points.device)
+    sf.points.copy_(sf.points[perm])
+    sf.knn_indices.copy_(sf.knn_indices[perm])
+    sf.knn_w.copy_(sf.knn_w[perm])
+    sf.norms.copy_(sf.norms[perm])
+    got = lm.LM(sf, inputs, new_data).cpu().numpy()
+    fresh = _solver(opt, slm_data_path=data_path)
+    want = fresh.LM(sf, inputs, new_data).cpu().numpy()
+    if data_path == 2:
+        np.testing.assert_array_equal(got, want)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(got, g["lm_beta"], rtol=0, atol=1e-7)   # a permutation of the surfels: the same problem
+    # C level: slm_discard_prepared makes the next bind a full one although every pointer is the prepared one
+    from super_amd import _lib
+    from super_amd.LM import BoundFrame, ModelView, _stream_ptr
+    h = lm._handle()
+    mv = ModelView(sf)
+    fr = _lib.SlmFrame()
+    mv.fill(fr)
+    _lib.check(lm.lib.slm_prepare_model(h, 0, C.byref(fr), _stream_ptr(mv.device)), "prepare")
+    torch.cuda.synchronize()
+    inv = torch.argsort(perm)
+    for t in (sf.points, sf.knn_indices, sf.knn_w, sf.norms):
+        t.copy_(t[inv])                                      # back to the original order, in place
+    _lib.check(lm.lib.slm_discard_prepared(h, 0), "discard")
+    bf = BoundFrame(sf, inputs, new_data, model=mv)          # the prepared pointers
+    _lib.check(lm.lib.slm_bind_frame(h, 0, C.byref(bf.c), _stream_ptr(bf.device)), "bind")
+    _lib.check(lm.lib.slm_run(h, 1, _stream_ptr(bf.device)), "run")
+    beta = torch.empty((bf.J, 7), dtype=torch.float64, device=bf.device)
+    _lib.check(lm.lib.slm_get_beta(h, 0, beta.data_ptr(), _stream_ptr(bf.device)), "beta")
+    np.testing.assert_allclose(beta.cpu().numpy(), g["lm_beta"], rtol=0, atol=1e-7)
+    assert lm.lib.slm_discard_prepared(h, 5) == _lib.SLM_ERR_INVALID
+
+
 def test_an_error_of_the_preparation_surfaces_at_the_bind():
     from super_amd import _lib
     g, sc, opt = load_golden("s60x80_j48")
