@@ -30,7 +30,7 @@ void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hip
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse = nullptr);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
-void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1, int max_wg = 0);
+void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
 hipError_t set_dag_timeout_ticks(long long);
 void launch_dag_abort_check(const FrameDev*, int, hipStream_t);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
@@ -312,21 +312,9 @@ struct slm_solver {
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
-  // Grouped run (slm_run, batches in the hybrid form): the frames of a launch are split into two groups whose LM loops
-  // run on two streams, phase-shifted, so that the latency-bound task-graph launch of one group (top of the tree + back
-  // substitution, capped to dag_cap workgroups) runs UNDER the bandwidth-bound per-level launches of the other.
-  int groups = 1;               // SLM_GROUPS
-  int group_min_frames = 6;     // batches below this stay in one group
-  int dag_cap = 128;            // SLM_DAG_CAP: workgroups of a group's task-graph launch (the best of the measured caps)
-  int group_sync = 0;           // SLM_GROUP_SYNC: 0 = free-running (the fastest measured), 1 = the groups' assembly + per-level phases
-                                // alternate (events), 2 = staggered start only
-  std::vector<hipStream_t> group_streams; // groups 1.. (group 0 runs on the caller's stream)
-  std::vector<hipEvent_t> group_events;   // fork, joins, and one per (group, iteration)
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
-  std::vector<char> ev_counts;                // ... and whether the entry counts as an iteration (the second group of a
-                                              // grouped run adds its phase times to the first group's iteration)
   slm_config cfg{};
   std::vector<Slot> slots;
   FrameDev* frames_dev = nullptr;
@@ -530,10 +518,6 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
   if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
-  if (const char* e = getenv("SLM_GROUPS")) s->groups = std::min(std::max(atoi(e), 1), 4);
-  if (const char* e = getenv("SLM_GROUP_MIN")) s->group_min_frames = std::max(2, atoi(e));
-  if (const char* e = getenv("SLM_DAG_CAP")) s->dag_cap = std::max(0, atoi(e));
-  if (const char* e = getenv("SLM_GROUP_SYNC")) s->group_sync = atoi(e);
   *out = s;
   return SLM_OK;
 }
@@ -587,8 +571,6 @@ int slm_destroy(slm_solver* s) {
       if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
   if (s->drain_event) (void)hipEventDestroy(s->drain_event);
-  for (hipEvent_t e : s->group_events) (void)hipEventDestroy(e);
-  for (hipStream_t q : s->group_streams) (void)hipStreamDestroy(q);
   if (s->frames_dev) (void)hipFree(s->frames_dev);
   if (s->bw_dev) (void)hipFree(s->bw_dev);
   if (s->reuse_dev) (void)hipFree(s->reuse_dev);
@@ -1295,24 +1277,20 @@ static bool solve_is_hybrid(const slm_solver* s, int n, const BatchDims& d) {
   return !solve_is_task_graph(s, n) && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
          d.hybrid_cut >= 0 && d.hybrid_levels == (int)d.sched.size() && d.hybrid_cut + 1 < d.hybrid_levels;
 }
-// dag_cap > 0: workgroups of the task-graph launch (grouped run); `between` runs after the per-level launches of the
-// hybrid form have been enqueued, before the task-graph launch
-void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st,
-                         int dag_cap = 0, const std::function<void()>* between = nullptr) {
+void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
   const bool dag = solve_is_task_graph(s, n);
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
   const bool hybrid = solve_is_hybrid(s, n, d);
   s->last_solver_form = dag ? 1 : (hybrid ? 2 : 0);
   if (dag) {
-    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1, dag_cap);
+    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1);
   } else if (hybrid) {
     const int n_levels = (int)d.sched.size(), l_cut = n_levels - 1 - d.hybrid_cut;
     launch_front_levels(fr, n, d.sched.data(), n_levels, l_cut, 0, u_override, st);
-    if (between) (*between)();
     // the task graph: the fronts above the cut, then the back substitution of the WHOLE tree (the list dag_top_tasks
     // ends with the BACKB / BACK tasks of the deeper fronts -- 24 small per-level launches, 0.25 ms at C2, otherwise)
-    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut, dag_cap);
+    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut);
   } else {
     launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
   }
@@ -1506,16 +1484,13 @@ int slm_lm_exchange_set(slm_solver* s, int32_t slot, int32_t what, const double*
   return SLM_OK;
 }
 
-// One LM iteration of slots [first, first + n) on `st`.  `between` (grouped run): called once the launches of the
-// assembly and of the per-level part of the solve are enqueued.
-static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st, bool counts,
-                                 int dag_cap, const std::function<void()>* between, bool first_iteration) {
+// One LM iteration of slots [first, first + n) on `st`.
+static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st, bool first_iteration) {
   const FrameDev* fr = s->frames_dev + first;
   const slm_config& c = s->cfg;
   std::vector<hipEvent_t>* evs = nullptr;
   if (s->profile) {
     s->ev_runs.emplace_back();
-    s->ev_counts.push_back(counts ? 1 : 0);
     evs = &s->ev_runs.back();
   }
   auto mark = [&]() {
@@ -1556,7 +1531,7 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
     launch_reg_grad(fr, n, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
   }
   mark();
-  if (d.nd) enqueue_front_solve(s, fr, n, d, -1.0, st, dag_cap, between);
+  if (d.nd) enqueue_front_solve(s, fr, n, d, -1.0, st);
   else launch_band_solve(fr, n, d.nt_max, d.wb_cap, -1.0, st);
   if (c.use_data) launch_make_trial(fr, n, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
   mark();
@@ -1572,61 +1547,6 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   mark();
 }
 
-// Grouped run: the slots are split into G contiguous groups; group 0 runs on the caller's stream, the others on the
-// solver's own streams, forked from / joined into the caller's.  group_sync 1 (two groups): the throughput phases A
-// (zeroing, Jacobian pass, assembly, per-level launches) of the two groups ALTERNATE -- A(0,i), A(1,i), A(0,i+1), ...
-// chained by events -- and each group's latency phase D (task graph for the top of the tree and the back substitution,
-// loss pass, accept) runs under the other group's next A.  group_sync 2: only the FIRST iteration is staggered (group g
-// starts its assembly when group g-1 has enqueued its per-level part), then the groups run free.  group_sync 0: free.
-// Every frame sees exactly the launches it would see in a batch of its group's size.
-static int run_grouped(slm_solver* s, int G, const int first[], const int cnt[], const BatchDims d[], hipStream_t st) {
-  const int n_it = s->cfg.num_iterations;
-  try {
-    s->group_streams.reserve(8);
-    s->group_events.reserve(1 + 8 + 8 * (size_t)std::max(n_it, 1));
-  } catch (...) {
-    return fail(SLM_ERR_HIP, "slm_run: out of host memory");
-  }
-  while ((int)s->group_streams.size() < G - 1) {
-    hipStream_t q = nullptr;
-    HIPCHK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-    s->group_streams.push_back(q);
-  }
-  const size_t need_ev = 1 + 8 + 8 * (size_t)std::max(n_it, 1);
-  while (s->group_events.size() < need_ev) {
-    hipEvent_t e = nullptr;
-    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    s->group_events.push_back(e);
-  }
-  hipStream_t q[8];
-  q[0] = st;
-  for (int g = 1; g < G; ++g) q[g] = s->group_streams[g - 1];
-  auto evA = [&](int g, int it) { return s->group_events[9 + 8 * (size_t)it + g]; };
-  HIPCHK(hipEventRecord(s->group_events[0], st));                       // fork
-  for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(q[g], s->group_events[0], 0));
-  for (int it = 0; it < n_it; ++it) {
-    for (int g = 0; g < G; ++g) {
-      if (s->group_sync == 1 && G == 2) {
-        if (g == 0 && it > 0) HIPCHK(hipStreamWaitEvent(q[0], evA(1, it - 1), 0));
-        if (g == 1) HIPCHK(hipStreamWaitEvent(q[1], evA(0, it), 0));
-      } else if (s->group_sync == 2 && it == 0 && g > 0) {
-        HIPCHK(hipStreamWaitEvent(q[g], evA(g - 1, 0), 0));
-      }
-      hipError_t rec_err = hipSuccess;
-      const bool need_ev_rec = s->group_sync == 1 || (s->group_sync == 2 && it == 0);
-      const std::function<void()> between = [&]() { if (need_ev_rec) rec_err = hipEventRecord(evA(g, it), q[g]); };
-      enqueue_lm_iteration(s, first[g], cnt[g], d[g], q[g], g == 0, s->dag_cap, &between, it == 0);
-      if (need_ev_rec && s->last_solver_form != 2) rec_err = hipEventRecord(evA(g, it), q[g]);   // (no per-level part: after the iteration)
-      HIPCHK(rec_err);
-    }
-  }
-  for (int g = 1; g < G; ++g) {                                          // join
-    HIPCHK(hipEventRecord(s->group_events[g], q[g]));
-    HIPCHK(hipStreamWaitEvent(st, s->group_events[g], 0));
-  }
-  return SLM_OK;
-}
-
 int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
   int rc = check_slots(s, 0, n_frames);
   if (rc) return rc;
@@ -1636,25 +1556,6 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
                 "slm_lm_accept with the exchanges between them");
   hipStream_t st = (hipStream_t)stream;
   const slm_config& c = s->cfg;
-  if (s->groups >= 2 && n_frames >= s->group_min_frames && n_frames >= 2 * s->groups && c.num_iterations > 0) {
-    const int G = s->groups;
-    int first[8], cnt[8];
-    BatchDims dg[8];
-    bool ok = true;
-    for (int g = 0, at = 0; g < G; ++g) {
-      first[g] = at;
-      cnt[g] = n_frames / G + (g < n_frames % G ? 1 : 0);
-      at += cnt[g];
-      dg[g] = dims_of(s, first[g], cnt[g]);
-      ok = ok && dg[g].nd && dg[g].v1;
-    }
-    if (ok) {
-      rc = run_grouped(s, G, first, cnt, dg, st);
-      if (rc) return rc;
-      HIPCHK(hipGetLastError());
-      return SLM_OK;
-    }
-  }
   BatchDims d = dims_of(s, 0, n_frames);
   if (!d.nd) {
     // A batch runs ONE solver form.  When some slot has no nested-dissection plan (a frame without surfels, a graph
@@ -1667,7 +1568,7 @@ int slm_run(slm_solver* s, int32_t n_frames, void* stream) {
     }
     d = dims_of(s, 0, n_frames);
   }
-  for (int it = 0; it < c.num_iterations; ++it) enqueue_lm_iteration(s, 0, n_frames, d, st, true, 0, nullptr, it == 0);
+  for (int it = 0; it < c.num_iterations; ++it) enqueue_lm_iteration(s, 0, n_frames, d, st, it == 0);
   // The reuse flag of a slot says "the Gram records in HBM were computed at the slot's CURRENT beta".  k_accept keeps it
   // on every path that writes records (banded path included: a later multifrontal run may then reuse them); a run that
   // wrote none (per-entry atomics) leaves nothing to reuse.
@@ -1721,7 +1622,6 @@ int slm_profile_read(slm_solver* s, double* ms_out, int64_t* count_out) {
   }
   for (size_t r = 0; r < s->ev_runs.size(); ++r) {
     auto& evs = s->ev_runs[r];
-    const bool counts = r >= s->ev_counts.size() || s->ev_counts[r] != 0;
     if ((int)evs.size() == SLM_PH_COUNT + 1 && evs.back()) {
       HIPCHK(hipEventSynchronize(evs.back()));
       for (int p = 0; p < SLM_PH_COUNT; ++p) {
@@ -1729,14 +1629,13 @@ int slm_profile_read(slm_solver* s, double* ms_out, int64_t* count_out) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, evs[p], evs[p + 1]));
         ms_out[p] += ms;
-        if (counts) count_out[p] += 1;
+        count_out[p] += 1;
       }
     }
     for (hipEvent_t e : evs)
       if (e) s->ev_pool.push_back(e);
   }
   s->ev_runs.clear();
-  s->ev_counts.clear();
   return SLM_OK;
 }
 

@@ -1329,10 +1329,9 @@ void launch_dag_abort_check(const FrameDev* fr, int n_frames, hipStream_t st) {
 hipError_t set_dag_timeout_ticks(long long ticks) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_dag_timeout_ticks), &ticks, sizeof(ticks));
 }
-// max_wg > 0 caps the persistent launch's grid: a launch that shares the GPU with the per-level launches of ANOTHER group
-// of frames (slm_api.hip, grouped run) must leave CUs to them -- a workgroup of this kernel owns its CU (one wave per SIMD
-// with the whole register file).  Tickets make any grid size deadlock-free.
-void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut, int max_wg) {
+// (a workgroup of this kernel owns its CU -- one wave per SIMD with most of the register file; tickets make any grid size
+//  deadlock-free)
+void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
   // per device: the dynamic-LDS attribute is a property of the kernel ON a device, and so is the CU count (host threads
@@ -1351,7 +1350,6 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
     n_wg = cus * (per_cu > 0 ? per_cu : 1);
     if (tracked) n_wg_dev[dev].store(n_wg, std::memory_order_release);
   }
-  if (max_wg > 0 && max_wg < n_wg) n_wg = max_wg;
   hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);

@@ -3,9 +3,9 @@
 * ``bench.py``'s headline is 8 C2 frames per launch x 10 LM iterations in the hybrid solver form.  Iterations 4-10 are
   where the damping has fallen to 1e-5 ... 1e-6 and where steps get rejected: here all ten are compared with
   ``oracle.lm_oracle.lm`` for the first and the last slot of the batch (beta <= 1e-4 -- north_star's bar --, loss trace
-  1e-6 relative, match counts equal, accept flags equal where the decision is not a rounding-level tie), in the
-  single-group form and in the grouped form (two phase-shifted groups of four frames on two streams inside one
-  ``slm_run``: slots 0 and 7 are in different groups).  Reference: ``super/LM.py:95-117``.
+  1e-6 relative, match counts equal, accept flags equal where the decision is not a rounding-level tie).  (Round 4's
+  opt-in grouped run -- two phase-shifted groups on two streams -- was removed in round 5: one code path.)
+  Reference: ``super/LM.py:95-117``.
 * BASELINE configs[4]'s size (C4: 500 k surfels / 4 k nodes, 9 tree levels) with the LM terms: three iterations at one
   frame per launch (task graph) and in a three-frame batch (hybrid) against the oracle with its sparse solve
   (``solve="sparse"``: SuperLU on the block-sparse JtJ + uI; pinned to the dense path and to the reference's goldens in
@@ -71,12 +71,10 @@ def _check(recs, beta, want, trace, tag):
     return err
 
 
-@pytest.mark.parametrize("groups", ["1", "2"])
-def test_c2_eight_frames_ten_iterations_match_the_oracle(groups, monkeypatch):
+def test_c2_eight_frames_ten_iterations_match_the_oracle():
     """bench.py's configuration: 8 frames per launch, solver_path 0 (hybrid form), 10 iterations."""
     import torch
     from super_amd.engine import Engine
-    monkeypatch.setenv("SLM_GROUPS", groups)
     seeds = list(range(8))
     eng = Engine(torch.device("cuda", 0), max_frames=8, num_iterations=10)
     eng.bind_batch([_dframe(_scene("C2", s)) for s in seeds])
@@ -84,7 +82,7 @@ def test_c2_eight_frames_ten_iterations_match_the_oracle(groups, monkeypatch):
     assert eng.lib.slm_debug_last_solver_form(eng.h) == 2
     for slot in (0, 7):
         want, trace = _oracle("C2", seeds[slot], 10)
-        err = _check(eng.records(slot), eng.beta(slot).cpu().numpy(), want, trace, f"C2 B=8 groups={groups} slot {slot}")
+        err = _check(eng.records(slot), eng.beta(slot).cpu().numpy(), want, trace, f"C2 B=8 slot {slot}")
         assert err < 1e-6          # observed ~1e-11; anything near the bar would be a defect
     eng.close()
 

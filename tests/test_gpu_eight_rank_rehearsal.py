@@ -33,8 +33,6 @@ def test_eight_ranks_share_one_gpu_and_gather_the_single_rank_betas(tmp_path):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(BENCH_SHARE_GPU="1", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="2",
                BENCH_DUMP_BETAS=str(tmp_path / "betas.npy"))
-    for k in ("SLM_GROUPS", "SLM_DAG_CAP", "SLM_GROUP_SYNC"):
-        env.pop(k, None)
     port = 29500 + (os.getpid() % 400)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(WORLD), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "3",
