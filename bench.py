@@ -761,6 +761,7 @@ def main():
     # worst per-iteration status over all slots of this rank (0 = every iteration ran; 3 = SLM_ITER_SOLVER_TIMEOUT)
     worst_status = max(r["status"] for e in engs for i in range(Bs) for r in e.records(i))
     cpu_busy_all = cpu_busy
+    per_rank_steps = None
     if use_dist:
         t = torch.tensor([elapsed, float(worst_status)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -768,6 +769,13 @@ def main():
         t = torch.tensor([cpu_busy], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         cpu_busy_all = float(t.item())
+        # per-rank step durations (one extra all-gather): a first real N-GPU run must show WHICH rank is slow and how --
+        # min / median / max of every rank's per-step times on its own GPU timeline, and its wall time of the timed region
+        mine = torch.tensor([step_ms[0], step_ms[len(step_ms) // 2], step_ms[-1], 1e3 * (t_end - t0)], dtype=torch.float64,
+                            device=device if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_steps = [[round(float(x), 3) for x in r.tolist()] for r in every]
         # test hook (tests/test_gpu_eight_rank_rehearsal.py): the betas rank 0 holds after the last end-of-frame all-gather
         dump = os.environ.get("BENCH_DUMP_BETAS")
         if dump and rank == 0 and gathered[0] is not None:
@@ -806,6 +814,9 @@ def main():
                             "launched_by": "torchrun" if launched else None},
             "worst_iter_status_all_ranks": worst_status,
         }
+        if per_rank_steps is not None:
+            out["distributed"]["per_rank_step_ms"] = {"columns": ["min", "median", "max", "timed_region_wall_ms"],
+                                                      "ranks": per_rank_steps}
         if prof is not None:
             info = eng.plan_info(0)
             flops = Bs * info["factor_flops"]          # padded dense-front FLOPs of one factorisation (what the MFMAs execute)

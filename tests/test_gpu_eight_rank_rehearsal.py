@@ -43,7 +43,11 @@ def test_eight_ranks_share_one_gpu_and_gather_the_single_rank_betas(tmp_path):
     assert len(lines) == 1, lines                      # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["n_gpus"] == WORLD and out["steps"] == 3 and out["value"] > 0
-    assert out["distributed"] == {"backend": "gloo", "world": WORLD, "launched_by": "torchrun"}
+    d = dict(out["distributed"])
+    per_rank = d.pop("per_rank_step_ms")                 # (round 5) every rank's min / median / max step and its wall time
+    assert d == {"backend": "gloo", "world": WORLD, "launched_by": "torchrun"}
+    assert per_rank["columns"] == ["min", "median", "max", "timed_region_wall_ms"] and len(per_rank["ranks"]) == WORLD
+    assert all(0 < r[0] <= r[1] <= r[2] and r[3] > 0 for r in per_rank["ranks"]), per_rank
     assert out["config"]["frames_per_gpu"] == B and out["config"]["global_frames"] == WORLD * B
     assert out["worst_iter_status_all_ranks"] == 0, out["worst_iter_status_all_ranks"]   # 3 would be SLM_ITER_SOLVER_TIMEOUT
     assert out["lm_iterations_ok_frame0"] == 10
