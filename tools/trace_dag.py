@@ -93,3 +93,15 @@ if "--transition" in sys.argv:
     print(f"  root POTRF(0): start {a[0]:.1f}, stage 0 done (mark4) {a[4]:.1f}, factor {a[8]:.1f} .. {a[20]:.1f}")
     mc0 = (front == root) & (typ == 1) & (s == 0)
     print(f"  root COL(r,0): ready {rd[mc0].min():.1f} .. {rd[mc0].max():.1f}, end {en[mc0].min():.1f} .. {en[mc0].max():.1f}")
+if "--kids" in sys.argv:
+    # the chains of the root's two children (the fronts below the root with the most pivot columns): per POTRF start / ready / end,
+    # and when the COL tasks of each column ran -- at 8 frames per launch these chains compete for workgroups with 7 other slots
+    npt_of = {f: len(v) for f, v in lvl_front.items()}
+    kids = sorted((f for f in npt_of if f != root), key=lambda f: -npt_of[f])[:2]
+    for k in kids:
+        print(f"child front {k} (npt {npt_of[k]}): s | POTRF start ready end wg | COL tasks: n, first ready, last end")
+        for sc in range(npt_of[k]):
+            i = np.nonzero((typ == 0) & (front == k) & (s == sc))[0][0]
+            mc = (typ == 1) & (front == k) & (s == sc)
+            extra = f"{mc.sum():3d} {rd[mc].min():8.1f} {en[mc].max():8.1f} (start {st[mc].min():.1f} .. {st[mc].max():.1f})" if mc.any() else ""
+            print(f"   s={sc}  {st[i]:8.1f} {rd[i]:8.1f} {en[i]:8.1f} wg {tr[i, 3]:3d} | {extra}")
