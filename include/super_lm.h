@@ -51,7 +51,7 @@ enum {
   SLM_ERR_HIP = 2,          /* a HIP runtime call failed (slm_last_error has the text) */
   SLM_ERR_NO_DEVICE = 3,    /* no gfx950 device / kernels cannot run */
   SLM_ERR_UNBOUND = 4,      /* slot used before slm_bind_frame */
-  SLM_ERR_UNSUPPORTED = 5   /* e.g. num_neighbors != 4 */
+  SLM_ERR_UNSUPPORTED = 5   /* e.g. num_neighbors outside 1..8, frames of one batch with different num_neighbors */
 };
 
 /* per-iteration status in slm_iter_record.status */
@@ -109,7 +109,9 @@ typedef struct slm_frame {
   int32_t J;                /* ED nodes (sf.ED_nodes.num) */
   int32_t T;                /* rows of the target tables */
   int32_t H, W;             /* image size (inputs[("color",0)] shape) */
-  int32_t K;                /* surfel->node neighbours (opt.num_neighbors); must be 4 */
+  int32_t K;                /* surfel->node neighbours (opt.num_neighbors, README.md:175 / options.py:49): 1..8.  4, the reference's
+                             * default, takes the tuple-sorted MFMA path + multifrontal solve; other values the per-entry-atomics data
+                             * path + block-banded solve (what data_path = 1 runs); the frames of one batch share their K */
   int32_t K_ED;             /* node->node neighbours (opt.num_ED_neighbors), 1..8 */
   float fx, fy, cx, cy;     /* inputs["K"][0] entries [0,0],[1,1],[0,2],[1,2] (float32 like the reference) */
   const void* sf_points;      /* device (N,3)      sf.points            float32, or float64 with state_f64 */

@@ -294,7 +294,7 @@ def jacobian_coo(fr: Frame, beta, opt):
     if use_d:
         t = data_term(fr, beta, opt.sf_point_plane_weight, grad=True)
         M = len(t.r)
-        rows = np.repeat(np.arange(M), 28)
+        rows = np.repeat(np.arange(M), 7 * t.nodes.shape[1])     # (K = num_neighbors columns blocks of 7 per residual)
         cols = (7 * t.nodes[:, :, None] + np.arange(7)[None, None, :]).reshape(-1)
         out["data"] = (rows, cols, t.Jrow.reshape(-1), M, t.r, t)
     if use_a:

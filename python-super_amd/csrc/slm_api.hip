@@ -16,9 +16,9 @@
 #include "slm_prep.h"
 
 // launchers defined next to their kernels
-void launch_data_grad(const FrameDev*, int, int, double, hipStream_t);
-void launch_data_loss(const FrameDev*, int, int, double, int, hipStream_t);
-void launch_data_resid(const FrameDev*, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
+void launch_data_grad(const FrameDev*, int, int, int, double, hipStream_t);
+void launch_data_loss(const FrameDev*, int, int, int, double, int, hipStream_t);
+void launch_data_resid(const FrameDev*, int, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
 void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t, const int* reuse = nullptr);
 void launch_data_eval(const FrameDev*, int, int, double, int mode, hipStream_t, const int* reuse = nullptr);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
@@ -47,9 +47,9 @@ void launch_pack_target(int, const float*, const float*, float4*, hipStream_t);
 void launch_accept(const FrameDev*, int, int, int, int, hipStream_t, int* reuse = nullptr, int eval_pass = 0);
 void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
-void launch_update(int, int, float*, float*, const int*, const float*, float*, float*, const double*,
+void launch_update(int, int, int, float*, float*, const int*, const float*, float*, float*, const double*,
                    hipStream_t);
-void launch_update64(int, int, double*, double*, const int*, const double*, double*, double*, const double*,
+void launch_update64(int, int, int, double*, double*, const int*, const double*, double*, double*, const double*,
                      hipStream_t);
 void launch_knn(int, int, int, int, const float*, const float*, int*, float*, hipStream_t);
 void launch_knn64(int, int, int, int, const double*, const double*, const int*, const int*, int*, double*, int*,
@@ -143,6 +143,11 @@ struct Slot {
   NDFront* d_fronts = nullptr;
   NDTileItem* d_items = nullptr;   // work lists of the pull-form kernels
   size_t cap_items = 0;
+  uint8_t* d_tile_kind = nullptr;  // FrameDev::tile_kind / zero_tiles (slm_common.h): per tile 1 = pure fill; the tiles to zero
+  long long* d_zero_tiles = nullptr;
+  size_t cap_tile_kind = 0, cap_zero_tiles = 0;
+  std::vector<uint8_t> h_tile_kind;      // host sources of the two uploads (kept: the copies are asynchronous)
+  std::vector<long long> h_zero_tiles;
   int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos | ... | dag_tasks | front_nin
   long long* d_dag_trace = nullptr; // diagnostics
   size_t cap_dag_trace = 0;
@@ -547,6 +552,8 @@ int slm_destroy(slm_solver* s) {
     sl.h_pts64.release();
     if (sl.d_fronts) (void)hipFree(sl.d_fronts);
     if (sl.d_items) (void)hipFree(sl.d_items);
+    if (sl.d_tile_kind) (void)hipFree(sl.d_tile_kind);
+    if (sl.d_zero_tiles) (void)hipFree(sl.d_zero_tiles);
     if (sl.d_ints) (void)hipFree(sl.d_ints);
     if (sl.d_dests) (void)hipFree(sl.d_dests);
     if (sl.d_cur_dests) (void)hipFree(sl.d_cur_dests);
@@ -637,7 +644,10 @@ int slm_bind_frame(slm_solver* s, int32_t slot, const slm_frame* f, void* stream
 // grow-only work buffers).  Leaves the slot UNBOUND; bind_target_part completes it.
 static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipStream_t st, PrepBuffers* prep) {
   if (slot < 0 || slot >= (int)s->slots.size()) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad slot");
-  if (f->K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_neighbors must be 4");
+  // num_neighbors (reference options.py:49, README.md:175; super/loss.py:213-220 and super/utils.py:30-36 are K-generic):
+  // 4 takes the tuple-sorted MFMA path; any other value in 1..8 the per-entry-atomics data path with the block-banded
+  // solve (what data_path = 1 runs), like a frame of >= 65 536 nodes
+  if (f->K < 1 || f->K > 8) return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_neighbors must be in 1..8");
   if (f->K_ED < 1 || f->K_ED > SLM_MAX_KED)
     return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: num_ED_neighbors must be in 1..8");
   if (f->N < 0 || f->J < 1) return fail(SLM_ERR_INVALID, "slm_bind_frame: bad sizes");
@@ -696,7 +706,7 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   // tuple-sorted data-term assembly plan (DataLoss.prepare analogue)
   h.v1_ready = 0;
   uint64_t dev_knn_hash = 0, dev_graph_hash = 0;   // coupling-graph hashes computed by prep_v1 on the device
-  if (s->cfg.use_data && s->cfg.data_path != 1 && f->J < 65536 && f->N > 0) {
+  if (s->cfg.use_data && s->cfg.data_path != 1 && f->K == SLM_K && f->J < 65536 && f->N > 0) {
     V1Sizes sz;
     HIPCHK(prep_v1(prep, *f, sl.plan, &sz, st));
     if (sz.bad_knn)
@@ -824,6 +834,58 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       if (e != hipSuccess) sl.nd_hash = 0;
       return e;
     };
+    // Pivot-column tiles by what reaches them (FrameDev::tile_kind, slm_common.h).  From the PLAN's destination list --
+    // every pair seen since the node graph last changed, fill-position pairs included: a superset of this frame's --,
+    // the ARAP pair blocks and the nodes' diagonal blocks (a 7 x 7 block can straddle a tile boundary: its four
+    // corners decide).  A tile that none of them reaches and that some child maps into (a pull item) is pure fill.
+    auto upload_tile_kinds = [&]() -> hipError_t {
+      const NDPlanHost& nd = sl.nd;
+      const size_t n_tiles = (size_t)(nd.tile_doubles / (SLM_NB * SLM_NB));
+      {   // (an earlier upload from these vectors may still be in flight)
+        const hipError_t e0 = hipStreamSynchronize(st);
+        if (e0 != hipSuccess) return e0;
+      }
+      std::vector<uint8_t>& kind = sl.h_tile_kind;
+      std::vector<long long>& zero = sl.h_zero_tiles;
+      kind.assign(n_tiles + 1, 0);
+      zero.clear();
+      std::vector<uint8_t> assembled(n_tiles + 1, 0), pulled(n_tiles + 1, 0);
+      auto nbase = [](const NDFront& fr, int pos) { return pos < fr.nv ? 7 * pos : fr.n1p + 7 * (pos - fr.nv); };
+      auto mark = [&](int front, int prow, int pcol) {
+        if (front < 0 || front >= (int)nd.fronts.size()) return;
+        const NDFront& fr = nd.fronts[front];
+        const int rb = nbase(fr, prow), cb = nbase(fr, pcol);
+        for (int x = 0; x < 7; x += 6)
+          for (int y = 0; y < 7; y += 6) {
+            int i = rb + x, j = cb + y;
+            if (i < j) std::swap(i, j);
+            const int r = i >> 6, c = j >> 6;
+            if (c < fr.npt && r < fr.nt) assembled[(size_t)fr.tile_first + (size_t)c * fr.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c)] = 1;
+          }
+      };
+      for (const NDDest& d : nd.block_dest) mark(d.front, d.prow, d.pcol);
+      for (const NDDest& d : nd.pair_dest) mark(d.front, d.prow, d.pcol);
+      for (size_t j = 0; j < nd.node_front.size(); ++j) mark(nd.node_front[j], nd.node_pos[j], nd.node_pos[j]);
+      for (size_t l = 0; l + 1 < nd.level_start.size(); ++l)
+        for (int k = nd.item_off[2 * l + 1]; k < nd.item_off[2 * l + 2]; ++k) pulled[(size_t)nd.tile_items[k].pad0] = 1;
+      for (const NDFront& fr : nd.fronts)
+        for (int c = 0; c < fr.npt; ++c)
+          for (int r = c; r < fr.nt; ++r) {
+            const size_t ix = (size_t)c * fr.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c), t = (size_t)fr.tile_first + ix;
+            kind[t] = (!assembled[t] && pulled[t]) ? 1 : 0;
+            if (!kind[t]) zero.push_back((long long)fr.tile_off + (long long)ix * (SLM_NB * SLM_NB));
+          }
+      hipError_t e = grow(sl.d_tile_kind, sl.cap_tile_kind, n_tiles + 1);
+      if (e == hipSuccess) e = grow(sl.d_zero_tiles, sl.cap_zero_tiles, zero.size() + 1);
+      if (e == hipSuccess) e = hipMemcpyAsync(sl.d_tile_kind, kind.data(), n_tiles + 1, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess && !zero.empty())
+        e = hipMemcpyAsync(sl.d_zero_tiles, zero.data(), sizeof(long long) * zero.size(), hipMemcpyHostToDevice, st);
+      h.tile_kind = sl.d_tile_kind;
+      h.zero_tiles = sl.d_zero_tiles;
+      h.n_zero_tiles = (int32_t)zero.size();
+      if (e != hipSuccess) { sl.cur_n_blocks = -1; sl.nd_hash = 0; }
+      return e;
+    };
     if (sl.nd_valid && sl.nd_knn_hash != knn_hash) {   // another node graph: nothing of the old plan applies
       sl.nd_valid = false;
       sl.plan_pairs.clear();
@@ -834,6 +896,7 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     } else if (sl.nd_valid && dests_from_plan()) {
       ++g_plan_reuses;
       HIPCHK(upload_cur_dests());
+      HIPCHK(upload_tile_kinds());   // (the plan's destination list may have grown by fill-position pairs)
       h.nd_ready = 1;
       sl.nd_hash = hash;
     } else if ([&] {
@@ -900,6 +963,7 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       h.pair_dest = sl.d_dests + nd.block_dest.size();
       if (!dests_from_plan()) return fail(SLM_ERR_INVALID, "slm_bind_frame: internal error (pair missing from its own plan)");
       HIPCHK(upload_cur_dests());
+      HIPCHK(upload_tile_kinds());
       h.fronts = sl.d_fronts;
       h.n_fronts = (int)nd.fronts.size();
       h.n_levels = (int)nd.level_start.size() - 1;
@@ -1188,6 +1252,9 @@ static int check_slots(slm_solver* s, int first, int n) {
   for (int i = first; i < first + n; ++i) {
     join_prepare(s, i);             // (a queued slm_prepare_model owns the slot until it is done; it leaves it unbound)
     if (!s->slots[i].h.bound) return fail(SLM_ERR_UNBOUND, "slot used before slm_bind_frame");
+    // the slots of one launch share their per-surfel kernels, which are instantiated per num_neighbors
+    if (s->slots[i].h.f.K != s->slots[first].h.f.K)
+      return fail(SLM_ERR_UNSUPPORTED, "the frames of one batch must have the same num_neighbors");
   }
   return SLM_OK;
 }
@@ -1196,6 +1263,7 @@ namespace {
 struct BatchDims {
   int maxN = 0, maxJKe = 0, nt_max = 0, wb_cap = 0, n_reg_part = 0;
   int max_pos = 0, max_blocks = 0, maxP = 0;
+  int K = 0;        // num_neighbors of the batch's slots (-1: they differ -- refused by the callers of the per-surfel kernels)
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
   int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
   bool nd = true;   // every slot of the batch has a nested-dissection plan
@@ -1209,6 +1277,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
   for (int i = first; i < first + n; ++i) {
     const FrameDev& h = s->slots[i].h;
     d.maxN = std::max(d.maxN, h.f.N);
+    d.K = (d.K == 0 || d.K == h.f.K) ? h.f.K : -1;
     d.maxJKe = std::max(d.maxJKe, h.f.J * h.f.K_ED);
     d.nt_max = std::max(d.nt_max, h.nt);
     d.wb_cap = std::max(d.wb_cap, h.wb);
@@ -1318,7 +1387,7 @@ void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims&
       launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
       launch_band_assemble(fr, n, d.max_blocks, st);
     } else {
-      launch_data_grad(fr, n, d.maxN, s->cfg.w_data, st);
+      launch_data_grad(fr, n, d.maxN, d.K, s->cfg.w_data, st);
     }
   }
   launch_reg_grad(fr, n, d.maxJKe, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
@@ -1326,7 +1395,7 @@ void enqueue_assemble(slm_solver* s, const FrameDev* fr, int n, const BatchDims&
 
 void enqueue_loss(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, int use_delta,
                   hipStream_t st) {
-  if (s->cfg.use_data) launch_data_loss(fr, n, kLossBlocks, s->cfg.w_data, use_delta, st);
+  if (s->cfg.use_data) launch_data_loss(fr, n, kLossBlocks, d.K, s->cfg.w_data, use_delta, st);
   if (d.n_reg_part > 0)
     launch_reg_loss(fr, n, d.n_reg_part, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot,
                     s->cfg.w_rot, use_delta, st);
@@ -1518,7 +1587,7 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
       if (first_iteration || (c.phase_test && !reuse)) launch_data_eval(fr, n, kLossBlocks, c.w_data, 1, st, reuse);
       launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
     } else {
-      launch_data_grad(fr, n, d.maxN, c.w_data, st);
+      launch_data_grad(fr, n, d.maxN, d.K, c.w_data, st);
     }
   }
   mark();
@@ -1537,7 +1606,7 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   mark();
   if (c.use_data) {
     if (d.v1) launch_data_eval(fr, n, kLossBlocks, c.w_data, 0, st);   // the loss pass; its {r, c} feed the next Jacobian pass
-    else launch_data_loss(fr, n, kLossBlocks, c.w_data, 1, st);
+    else launch_data_loss(fr, n, kLossBlocks, d.K, c.w_data, 1, st);
   }
   mark();
   if (d.n_reg_part > 0)
@@ -1795,7 +1864,7 @@ int slm_data_residuals(slm_solver* s, int32_t slot, double* r, uint8_t* match, i
   int rc = check_slots(s, slot, 1);
   if (rc) return rc;
   const FrameDev& h = s->slots[slot].h;
-  launch_data_resid(s->frames_dev, slot, h.f.N, s->cfg.w_data, r, match, taps, (hipStream_t)stream);
+  launch_data_resid(s->frames_dev, slot, h.f.N, h.f.K, s->cfg.w_data, r, match, taps, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -1803,11 +1872,11 @@ int slm_data_residuals(slm_solver* s, int32_t slot, double* r, uint8_t* match, i
 int slm_apply_update(int32_t N, int32_t J, int32_t K, float* sf_points, float* sf_norms,
                      const int32_t* sf_knn_idx, const float* sf_knn_w, float* ed_points,
                      float* ed_norms, const double* beta, void* stream) {
-  if (K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_apply_update: num_neighbors must be 4");
+  if (K < 1 || K > 8) return fail(SLM_ERR_UNSUPPORTED, "slm_apply_update: num_neighbors must be in 1..8");
   if (N < 0 || J < 1 || !ed_points || !ed_norms || !beta || (N > 0 && (!sf_points || !sf_norms ||
       !sf_knn_idx || !sf_knn_w)))
     return fail(SLM_ERR_INVALID, "slm_apply_update: bad argument");
-  launch_update(N, J, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, beta,
+  launch_update(N, J, K, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, beta,
                 (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return SLM_OK;
@@ -1816,11 +1885,11 @@ int slm_apply_update(int32_t N, int32_t J, int32_t K, float* sf_points, float* s
 int slm_apply_update_f64(int32_t N, int32_t J, int32_t K, double* sf_points, double* sf_norms,
                          const int32_t* sf_knn_idx, const double* sf_knn_w, double* ed_points,
                          double* ed_norms, const double* beta, void* stream) {
-  if (K != SLM_K) return fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_f64: num_neighbors must be 4");
+  if (K < 1 || K > 8) return fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_f64: num_neighbors must be in 1..8");
   if (N < 0 || J < 1 || !ed_points || !ed_norms || !beta || (N > 0 && (!sf_points || !sf_norms ||
       !sf_knn_idx || !sf_knn_w)))
     return fail(SLM_ERR_INVALID, "slm_apply_update_f64: bad argument");
-  launch_update64(N, J, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, beta,
+  launch_update64(N, J, K, sf_points, sf_norms, sf_knn_idx, sf_knn_w, ed_points, ed_norms, beta,
                   (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return SLM_OK;

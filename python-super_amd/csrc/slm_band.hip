@@ -23,9 +23,12 @@ __global__ void __launch_bounds__(256) k_bandwidth(slm_frame f, int* __restrict_
   int wmax = 0;
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < f.N; i += stride) {
-    const int4 id = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * i);
-    int lo = min(min(id.x, id.y), min(id.z, id.w));
-    int hi = max(max(id.x, id.y), max(id.z, id.w));
+    int lo = f.sf_knn_idx[(size_t)f.K * i], hi = lo;
+    for (int k = 1; k < f.K; ++k) {   // (K = num_neighbors, any value)
+      const int id = f.sf_knn_idx[(size_t)f.K * i + k];
+      lo = min(lo, id);
+      hi = max(hi, id);
+    }
     wmax = max(wmax, (7 * hi + 6) / NB - (7 * lo) / NB);
   }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < f.J * f.K_ED; t += stride) {

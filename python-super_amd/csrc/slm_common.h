@@ -138,6 +138,16 @@ struct FrameDev {
   GP<double> flinv;               // inverses of the diagonal Cholesky blocks of the fronts
   GP<double> fmail;               // task graph: per pivot tile column a mailbox of SLM_MAIL_DOUBLES (slm_tile.h) for the streamed hand-off
   long long zero_tile_doubles;    // leading part of ftiles / all of fvec that k_iter_begin_nd zeroes before an assembly
+  // Pivot-column tiles by what reaches them (round 5; per slot, from the plan's destinations -- slm_api.hip):
+  //   tile_kind[tile number] = 1: PURE FILL -- no assembled block lands in the tile (data term, ARAP, Rot, node diagonal
+  //   blocks) and some child maps into it.  Such a tile is never zeroed; its first toucher -- the pull that gathers the
+  //   children's updates (k_fpull, or the tile's own task of the task graph) -- starts from zero and STORES the whole tile.
+  //   0: everything else (zeroed before the assembly, added into).  zero_tiles lists the offsets (doubles) of the kind-0
+  //   pivot-column tiles: what k_iter_begin_nd zeroes.
+  GP<const uint8_t> tile_kind;
+  GP<const long long> zero_tiles;
+  int32_t n_zero_tiles;
+  int32_t pad6;
   long long zero_vec_doubles;
   // ---- persistent task-graph solver (slm_dag.hip): task list of the plan + per-iteration flags ----
   GP<const int32_t> dag_tasks;    // (n_dag_tasks, 2) task words (slm_nd.h), in a topological order

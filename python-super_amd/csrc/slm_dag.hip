@@ -121,6 +121,7 @@ struct SS {   // scalar snapshot of the slot's buffers
   const int32_t *nd_nodes, *front_kids, *pull_off, *pullmap, *prng_off, *prng;
   const NDFront* fronts;
   int n_fronts;
+  const uint8_t* tile_kind;   // FrameDev::tile_kind (only the factor tasks read it)
 };
 
 struct DagFlags {
@@ -705,6 +706,13 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
     // the per-level launches): requested BEFORE the wait for what the task needs to start, not after it
     double4_t acc[4];
     load_c_frags1(tile_ptr(fd, f, tr_, ts_), acc);
+    // a PURE-FILL tile (FrameDev::tile_kind: nothing assembled into it, never zeroed) starts from zero: what the load
+    // returned is whatever the previous iteration left there
+    fd.tile_kind = unip(fdr.tile_kind);
+    if (uni((int)fd.tile_kind[tile_index(f, tr_, ts_)]) != 0) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
     double bvec = 0.0, tsum = 0.0;
     if (type == ND_T_POTRF && threadIdx.x < NB) bvec = ld1(vecs + (size_t)ts_ * NB + threadIdx.x);
     dag_pull_maps(fd, fi, tr_, ts_, d.np, maps);   // (static plan data: also before the wait)
@@ -726,6 +734,10 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         // formed here as soon as the factor of column s-1 is out, and goes into the update of (s,s) from LDS
         double4_t accl[4];
         load_c_frags1(tile_ptr(fd, f, s, s - 1), accl);
+        if (uni((int)fd.tile_kind[tile_index(f, s, s - 1)]) != 0) {   // (pure fill: see above)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) accl[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+        }
         double dummy = 0.0;
         dag_pull<false>(fd, fi, s, s - 1, accl, dummy, d.np2, maps);
         {

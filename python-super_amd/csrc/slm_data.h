@@ -7,14 +7,20 @@
 #pragma once
 #include "slm_common.h"
 
-struct SurfelEval {
+// KK = surfel -> node neighbours (opt.num_neighbors).  4 (SLM_K) is the reference's default and the only value the
+// tuple-sorted MFMA path handles; the per-entry-atomics path (data_path 1: k_data_grad / k_data_loss / k_data_resid) is
+// instantiated for 1..SLM_KMAX (reference: super/loss.py:213-220 and super/utils.py:30-36 are K-generic).
+#define SLM_KMAX 8
+template <int KK>
+struct SurfelEvalT {
   bool match;
   double r;            // lambda * n.(T(p) - o)
-  int id[SLM_K];       // node ids of the four neighbours
-  double row[SLM_K * 7];  // lambda * [w_k c.Jq_k | w_k c]  (MODE 1 only)
+  int id[KK];          // node ids of the neighbours
+  double row[KK * 7];  // lambda * [w_k c.Jq_k | w_k c]  (MODE 1 only)
   double c[3];         // c = d r / d T(p) / lambda (MODE >= 1): everything of the row that depends on the TARGET
   int taps[4];         // target rows of the four bilinear taps (-1 invalid)
 };
+typedef SurfelEvalT<SLM_K> SurfelEval;
 
 // The 28 Jacobian-row entries of a surfel from c (reference super/loss.py:258-288): lambda * [w_k c^T dR(q_k)(p - g_k)/dq_k | w_k c]
 // for its four nodes.  Needs the surfel and its nodes only -- no projection, no target table.
@@ -45,17 +51,16 @@ __device__ __forceinline__ void rows_from_c(const d3 p, const int id[4], const d
 // surfel stream entries early pass them in (eval_surfel_core).
 // MODE 0: residual only (loss pass); 1: residual + the 28 row entries; 2: residual + c (the evaluation pass that feeds
 // the tuple-sorted Jacobian pass, slm_data_v1.hip)
-template <int MODE>
-__device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p, int4 ids, const double w[4],
-                                                 double lam, const double* __restrict__ npk, SurfelEval& out) {
+template <int MODE, int KK>
+__device__ __forceinline__ void eval_surfel_coreT(const FrameDev& fd, const d3 p, const int id[KK], const double w[KK],
+                                                  double lam, const double* __restrict__ npk, SurfelEvalT<KK>& out) {
   const FrameIn& f = frame_in(fd);
-  const int id[4] = {ids.x, ids.y, ids.z, ids.w};
 
-  double qw[4];
-  d3 qv[4], dk[4];
+  double qw[KK];
+  d3 qv[KK], dk[KK];
   d3 T = {0.0, 0.0, 0.0};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KK; ++k) {
     out.id[k] = id[k];
     const double2* nq = reinterpret_cast<const double2*>(npk + (size_t)SLM_NPK * id[k]);
     const double2 n0 = nq[0], n1 = nq[1], n2 = nq[2], n3 = nq[3], n4 = nq[4];
@@ -146,7 +151,7 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p,
   out.c[2] = c.z;
   if (MODE == 2) return;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KK; ++k) {
     double jq[4];
     quat_jac_row(qw[k], qv[k], dk[k], c, jq);
     const double lw = lam * w[k];
@@ -158,6 +163,14 @@ __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p,
     out.row[7 * k + 5] = lw * c.y;
     out.row[7 * k + 6] = lw * c.z;
   }
+}
+
+// the K = 4 form (one 16-byte load of the ids, what every caller of the tuple-sorted path uses)
+template <int MODE>
+__device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p, int4 ids, const double w[4],
+                                                 double lam, const double* __restrict__ npk, SurfelEval& out) {
+  const int id[4] = {ids.x, ids.y, ids.z, ids.w};
+  eval_surfel_coreT<MODE, SLM_K>(fd, p, id, w, lam, npk, out);
 }
 
 template <int MODE>
@@ -172,8 +185,21 @@ __device__ __forceinline__ void eval_surfel_at(const FrameDev& fd, const void* _
                          *reinterpret_cast<const int4*>(sf_idx + 4 * (size_t)i), w, lam, npk, out);
 }
 
-template <int MODE>
-__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* npk, int i,
-                                            SurfelEval& out) {
-  eval_surfel_at<MODE>(fd, frame_in(fd).sf_points, frame_in(fd).sf_knn_idx, frame_in(fd).sf_knn_w, lam, npk, i, out);
+// surfel i of the caller's own arrays with KK neighbours per surfel (rows of KK ids / weights)
+template <int MODE, int KK>
+__device__ __forceinline__ void eval_surfel(const FrameDev& fd, double lam, const double* npk, int i, SurfelEvalT<KK>& out) {
+  const FrameIn& f = frame_in(fd);
+  if constexpr (KK == SLM_K) {
+    eval_surfel_at<MODE>(fd, f.sf_points, f.sf_knn_idx, f.sf_knn_w, lam, npk, i, out);
+  } else {
+    double wk[KK];
+    int idk[KK];
+    const void* wp = f.sf_knn_w;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      idk[k] = f.sf_knn_idx[(size_t)KK * i + k];
+      wk[k] = fd.f.state_f64 ? static_cast<const double*>(wp)[(size_t)KK * i + k] : (double)static_cast<const float*>(wp)[(size_t)KK * i + k];
+    }
+    eval_surfel_coreT<MODE, KK>(fd, ld_state3(f.sf_points, (size_t)i, fd.f.state_f64), idk, wk, lam, npk, out);
+  }
 }

@@ -435,14 +435,15 @@ __device__ __forceinline__ void zero_pieces(double* base, size_t n_pieces, size_
 __device__ __forceinline__ size_t front_piv_tiles(const NDFront& f) {
   return (size_t)f.npt * f.nt - (size_t)f.npt * (f.npt - 1) / 2;
 }
-// what: 1 = pivot columns, 2 = F22 blocks, 3 = both, of every front of the slot; workgroup b of nb
-__device__ __forceinline__ void zero_fronts(const FrameDev& fd, int what, int b, int nb) {
-  const int nf = fd.n_fronts, slices = 16;
-  for (int u = b; u < nf * slices; u += nb) {
-    const NDFront& f = fd.fronts[u % nf];
-    const size_t piv = front_piv_tiles(f), all = f.is_leaf ? piv : (size_t)f.nt * (f.nt + 1) / 2;
-    const size_t t0 = (what & 1) ? 0 : piv, t1 = (what & 2) ? all : piv;
-    if (t1 > t0) zero_pieces(fd.ftiles.get() + f.tile_off + t0 * TILE, (t1 - t0) * 2, (size_t)(u / nf), (size_t)slices);
+// the slot's kind-0 pivot-column tiles (FrameDev::zero_tiles: assembled into, or touched by nothing at all), 16 KB pieces
+// strided over the launch's workgroups; pure-fill tiles (tile_kind 1) are not zeroed: their first toucher stores them
+__device__ __forceinline__ void zero_fronts(const FrameDev& fd, int b, int nb) {
+  const dvec2_t zz = {0.0, 0.0};
+  const int n = fd.n_zero_tiles;
+  for (int pc = b; pc < 2 * n; pc += nb) {
+    dvec2_t* q = reinterpret_cast<dvec2_t*>(fd.ftiles.get() + fd.zero_tiles[pc >> 1]) + (size_t)(pc & 1) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(zz, q + 256 * k);
   }
 }
 // Start of an iteration on the multifrontal path: zero the PIVOT columns of the fronts (the assembly adds into them; the
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restric
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
   const double2 z = make_double2(0.0, 0.0);
   if (fd.nd_ready) {
-    zero_fronts(fd, 1, blockIdx.x, gridDim.x);
+    zero_fronts(fd, blockIdx.x, gridDim.x);
     double2* v2 = reinterpret_cast<double2*>(fd.fvec.get());
     const size_t nv2 = (size_t)fd.zero_vec_doubles / 2;
     for (size_t e = tid; e < nv2; e += nthr) v2[e] = z;
@@ -1041,10 +1042,13 @@ __global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ fram
   const bool wave_on = 16 * w < vrow;
   pull_maps(fd, it, maps);
   double* T = item_tile(fd, it, it.r, it.c);
+  // pure-fill tile (FrameDev::tile_kind): nothing was assembled into it and nothing zeroed it -- start from zero and store
+  // the WHOLE tile (its padding too: the factor kernels read full tiles)
+  const bool pure = __builtin_amdgcn_readfirstlane((int)fd.tile_kind[it.pad0]) != 0;
   double4_t acc[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-  if (wave_on) {
+  if (wave_on && !pure) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       if (ni < nblk) {
@@ -1053,8 +1057,10 @@ __global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ fram
       }
   }
   __syncthreads();
-  if (wave_on) {
-    pull_tile(fd, it, maps, acc);
+  if (wave_on) pull_tile(fd, it, maps, acc);
+  if (pure) {
+    store_c_frags(T, acc);
+  } else if (wave_on) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
       if (ni < nblk) {

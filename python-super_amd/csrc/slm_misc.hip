@@ -210,7 +210,7 @@ __global__ void k_zero_reg_part(const FrameDev* __restrict__ frames, int n_reg_p
 // arrays (RT).  Note the reference rotates the normals with the 7-wide beta, so the translation b_k
 // is ADDED to the rotated normal before blending and normalising (nodes.py:207-213).
 template <typename RT>
-__global__ void __launch_bounds__(256) k_update_surfels(int N, RT* __restrict__ pts,
+__global__ void __launch_bounds__(256) k_update_surfels(int N, int K, RT* __restrict__ pts,
                                                          RT* __restrict__ nrm,
                                                          const int* __restrict__ knn_idx,
                                                          const RT* __restrict__ knn_w,
@@ -221,23 +221,20 @@ __global__ void __launch_bounds__(256) k_update_surfels(int N, RT* __restrict__ 
   const size_t i3 = 3 * (size_t)i;
   const d3 p = {(double)pts[i3], (double)pts[i3 + 1], (double)pts[i3 + 2]};
   const d3 n0 = {(double)nrm[i3], (double)nrm[i3 + 1], (double)nrm[i3 + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(knn_idx + 4 * (size_t)i);
-  const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-  const RT* wp = knn_w + 4 * (size_t)i;
-  const double w[4] = {(double)wp[0], (double)wp[1], (double)wp[2], (double)wp[3]};
   d3 T = {0, 0, 0}, Nn = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const double* b = beta + 7 * id[k];
-    const d3 g = {(double)ed_pts[3 * id[k]], (double)ed_pts[3 * id[k] + 1],
-                  (double)ed_pts[3 * id[k] + 2]};
+  // (K = opt.num_neighbors, 1..8; the sums run k = 0, 1, ... like the reference's sum over dim 1)
+  for (int k = 0; k < K; ++k) {
+    const int id = knn_idx[(size_t)K * i + k];
+    const double wk = (double)knn_w[(size_t)K * i + k];
+    const double* b = beta + 7 * id;
+    const d3 g = {(double)ed_pts[3 * id], (double)ed_pts[3 * id + 1], (double)ed_pts[3 * id + 2]};
     const d3 qv = {b[1], b[2], b[3]};
     d3 t = quat_apply(b[0], qv, p - g);
     t = {t.x + b[4] + g.x, t.y + b[5] + g.y, t.z + b[6] + g.z};
-    T = {T.x + w[k] * t.x, T.y + w[k] * t.y, T.z + w[k] * t.z};
+    T = {T.x + wk * t.x, T.y + wk * t.y, T.z + wk * t.z};
     d3 rn = quat_apply(b[0], qv, n0);
     rn = {rn.x + b[4], rn.y + b[5], rn.z + b[6]};
-    Nn = {Nn.x + w[k] * rn.x, Nn.y + w[k] * rn.y, Nn.z + w[k] * rn.z};
+    Nn = {Nn.x + wk * rn.x, Nn.y + wk * rn.y, Nn.z + wk * rn.z};
   }
   const double nl = fmax(sqrt(dot(Nn, Nn)), 1e-12);   // F.normalize eps
   pts[i3] = (RT)T.x;
@@ -515,22 +512,22 @@ void launch_zero_reg_part(const FrameDev* frames_dev, int n_frames, int n_reg_pa
 }
 
 template <typename RT>
-static void launch_update_t(int N, int J, RT* pts, RT* nrm, const int* knn_idx, const RT* knn_w,
+static void launch_update_t(int N, int J, int K, RT* pts, RT* nrm, const int* knn_idx, const RT* knn_w,
                             RT* ed_pts, RT* ed_nrm, const double* beta, hipStream_t st) {
   if (N > 0)
-    hipLaunchKernelGGL(k_update_surfels<RT>, dim3((N + 255) / 256), dim3(256), 0, st, N, pts, nrm,
+    hipLaunchKernelGGL(k_update_surfels<RT>, dim3((N + 255) / 256), dim3(256), 0, st, N, K, pts, nrm,
                        knn_idx, knn_w, (const RT*)ed_pts, beta);
   if (J > 0)
     hipLaunchKernelGGL(k_update_nodes<RT>, dim3((J + 255) / 256), dim3(256), 0, st, J, ed_pts, ed_nrm,
                        beta);
 }
-void launch_update(int N, int J, float* pts, float* nrm, const int* knn_idx, const float* knn_w,
+void launch_update(int N, int J, int K, float* pts, float* nrm, const int* knn_idx, const float* knn_w,
                    float* ed_pts, float* ed_nrm, const double* beta, hipStream_t st) {
-  launch_update_t<float>(N, J, pts, nrm, knn_idx, knn_w, ed_pts, ed_nrm, beta, st);
+  launch_update_t<float>(N, J, K, pts, nrm, knn_idx, knn_w, ed_pts, ed_nrm, beta, st);
 }
-void launch_update64(int N, int J, double* pts, double* nrm, const int* knn_idx, const double* knn_w,
+void launch_update64(int N, int J, int K, double* pts, double* nrm, const int* knn_idx, const double* knn_w,
                      double* ed_pts, double* ed_nrm, const double* beta, hipStream_t st) {
-  launch_update_t<double>(N, J, pts, nrm, knn_idx, knn_w, ed_pts, ed_nrm, beta, st);
+  launch_update_t<double>(N, J, K, pts, nrm, knn_idx, knn_w, ed_pts, ed_nrm, beta, st);
 }
 
 void launch_knn(int Nq, int Nn, int K, int skip_self, const float* q, const float* nodes, int* idx,

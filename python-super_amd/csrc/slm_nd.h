@@ -66,7 +66,7 @@ struct NDTileItem {
   int32_t r, c;         // tile row / column in the front's numbering (Schur items: both >= npt)
   int32_t nt, npt;      // the front's tiles per side / pivot tile columns
   int32_t n1, n2;       // true pivot / boundary scalars (7 nv, 7 nb)
-  int32_t pad0;
+  int32_t pad0;         // number of tile (r, c) in the slot's per-tile tables: NDFront::tile_first + its index in the front
   int64_t tile_off;     // NDFront::tile_off, f22_base, vec_off of the front
   int64_t f22_base;
   int64_t vec_off;

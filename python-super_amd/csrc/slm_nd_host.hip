@@ -435,6 +435,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       NDTileItem it{};
       it.front = i; it.r = r; it.c = c; it.nt = f.nt; it.npt = f.npt; it.n1 = f.n1; it.n2 = 7 * f.nb;
       it.tile_off = f.tile_off; it.f22_base = f.f22_base; it.vec_off = f.vec_off;
+      it.pad0 = f.tile_first + c * f.nt - c * (c - 1) / 2 + (r - c);   // the tile's number in the slot's per-tile tables (FrameDev::tile_kind)
       const int32_t* pr = out.prng.data() + out.prng_off[i];
       for (int k = 0; k < 2; ++k) {
         NDTileKid& kd = it.kid[k];

@@ -50,11 +50,11 @@ __global__ void __launch_bounds__(256) k_tuple_keys(int N, int J, const int* __r
 }
 
 // the same range test on its own, for the frames that do not take the tuple-sorted path (data_path 1, J >= 65536)
-__global__ void __launch_bounds__(256) k_check_knn(int N, int J, const int* __restrict__ knn, int* __restrict__ bad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int4 v = *reinterpret_cast<const int4*>(knn + 4 * i);
-  if ((unsigned)v.x >= (unsigned)J || (unsigned)v.y >= (unsigned)J || (unsigned)v.z >= (unsigned)J || (unsigned)v.w >= (unsigned)J) *bad = 1;
+// (n = N * K table entries: any num_neighbors)
+__global__ void __launch_bounds__(256) k_check_knn(long long n, int J, const int* __restrict__ knn, int* __restrict__ bad) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if ((unsigned)knn[i] >= (unsigned)J) *bad = 1;
 }
 
 __global__ void __launch_bounds__(256) k_padded_counts(const int* __restrict__ d_nt,
@@ -989,7 +989,8 @@ hipError_t prep_check_knn(PrepBuffers* p, const slm_frame& f, bool* bad, hipStre
   *bad = false;
   if (f.N <= 0) return hipSuccess;
   PCHK(hipMemsetAsync(p->scal + 13, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_check_knn, dim3((f.N + 255) / 256), dim3(256), 0, st, f.N, f.J, f.sf_knn_idx, p->scal + 13);
+  const long long n_ent = (long long)f.N * f.K;
+  hipLaunchKernelGGL(k_check_knn, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0, st, n_ent, f.J, f.sf_knn_idx, p->scal + 13);
   PCHK(hipMemcpyAsync(p->scal_host + 13, p->scal + 13, sizeof(int), hipMemcpyDeviceToHost, st));
   PCHK(hipStreamSynchronize(st));
   *bad = p->scal_host[13] != 0;

@@ -44,6 +44,10 @@ SCENES = {
     # large motion (dphi) so that some LM steps are rejected
     "s60x80_j48_reject": (dict(N=1500, J=48, H=60, W=80, seed=4, src_border=5, tgt_border=2,
                                dphi=0.9), dict(), False),
+    # num_neighbors = 6 (README.md:175 / options.py:49: a documented tunable; loss.py:213-220 and utils.py:30-36 are
+    # K-generic): 42-wide Jacobian rows, 21 coupled node pairs per surfel
+    "s60x80_j48_k6": (dict(N=1500, J=48, H=60, W=80, seed=6, src_border=5, tgt_border=3, tgt_holes=0.01,
+                           n_neighbors=6), dict(num_neighbors=6), True),
     # Semantic-SuPer: 3 wavy class bands, target segmentation moved 6 px (configs[4] terms)
     "s60x80_j48_semantic": (dict(N=1500, J=48, H=60, W=80, seed=5, src_border=5, tgt_border=2,
                                  semantic=True), dict(), False),

@@ -60,7 +60,7 @@ def test_batch_bind_reports_the_failing_frame():
     fr = _frames(dev)[:3]
     eng = Engine(dev, max_frames=3)
     cs = [f.c_struct() for _, f in fr]
-    cs[1].K = 5                                           # num_neighbors must be 4
+    cs[1].K = 9                                           # num_neighbors must be in 1..8 (round 5: any K there, tests/test_gpu_num_neighbors.py)
     arr = (_lib.SlmFrame * 3)(*cs)
     rc = eng.lib.slm_bind_frames(eng.h, 0, 3, arr, eng.stream)
     assert rc != 0

@@ -4,12 +4,12 @@ import numpy as np
 import pytest
 
 from oracle import lm_oracle as orc
-from helpers import GOLDENS, coo_dense, load_golden
+from helpers import GOLDENS, GOLDENS_K, coo_dense, load_golden
 
 TOL = 1e-9   # f64 restatement vs f64 reference: only reduction order differs
 
 
-@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("name", GOLDENS + GOLDENS_K)
 @pytest.mark.parametrize("tag", ["b0", "b1"])
 def test_terms_match_reference(name, tag):
     g, sc, opt = load_golden(name)
@@ -55,7 +55,7 @@ def test_projection_intermediates(name):
     np.testing.assert_array_equal(t.coords, g["b0_coords"])
 
 
-@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("name", GOLDENS + GOLDENS_K)
 def test_lm_trace_matches_reference(name):
     g, sc, opt = load_golden(name)
     fr = orc.Frame.from_scene(sc)
@@ -69,7 +69,7 @@ def test_lm_trace_matches_reference(name):
     assert not g["lm_accepted"].all() or name != "s60x80_j48_reject"
 
 
-@pytest.mark.parametrize("name", GOLDENS)
+@pytest.mark.parametrize("name", GOLDENS + GOLDENS_K)
 def test_sparse_solve_option_reproduces_the_reference_trace(name):
     """``lm(..., solve="sparse")`` (SuperLU on the block-sparse JtJ + uI -- what the full-size checks at 4 k nodes use)
     against the reference's own trace and against the dense path, delta by delta."""
