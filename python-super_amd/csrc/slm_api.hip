@@ -28,9 +28,10 @@ void launch_pair_reduce(const FrameDev*, int, int, hipStream_t);
 void launch_pair_scatter(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hipStream_t);
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
-void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse = nullptr);
+void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse, int dag_cut);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
-void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut = -1);
+void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut, bool reset, bool check);
+void launch_after_solve(const FrameDev*, int, int, int, int, double, int, double, int, hipStream_t);
 hipError_t set_dag_timeout_ticks(long long);
 void launch_dag_abort_check(const FrameDev*, int, hipStream_t);
 void launch_front_levels(const FrameDev*, int, const NDLevelSched*, int, int, int, double, hipStream_t);
@@ -1346,20 +1347,30 @@ static bool solve_is_hybrid(const slm_solver* s, int n, const BatchDims& d) {
   return !solve_is_task_graph(s, n) && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
          d.hybrid_cut >= 0 && d.hybrid_levels == (int)d.sched.size() && d.hybrid_cut + 1 < d.hybrid_levels;
 }
-void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st) {
+// what this batch's solve needs reset before its task-graph launch (k_iter_begin_nd's dag_cut): -1 the whole tree, >= 0 the
+// fronts of depth <= the hybrid cut, -2 nothing (per-level launches only)
+static int dag_cut_of(const slm_solver* s, int n, const BatchDims& d) {
+  if (solve_is_task_graph(s, n)) return -1;
+  return solve_is_hybrid(s, n, d) ? d.hybrid_cut : -2;
+}
+// dag_reset_done: this iteration's k_iter_begin_nd already reset the task graph's flags / mailboxes (launched with
+// dag_cut_of(...)); otherwise launch_front_solve_dag resets them with a launch of its own
+// dag_check_later: the caller's next launch (k_after_solve) settles a timed-out task-graph launch instead of k_dag_check
+void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st,
+                         bool dag_reset_done = false, bool dag_check_later = false) {
   const bool dag = solve_is_task_graph(s, n);
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
   const bool hybrid = solve_is_hybrid(s, n, d);
   s->last_solver_form = dag ? 1 : (hybrid ? 2 : 0);
   if (dag) {
-    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1);
+    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1, !dag_reset_done, !dag_check_later);
   } else if (hybrid) {
     const int n_levels = (int)d.sched.size(), l_cut = n_levels - 1 - d.hybrid_cut;
     launch_front_levels(fr, n, d.sched.data(), n_levels, l_cut, 0, u_override, st);
     // the task graph: the fronts above the cut, then the back substitution of the WHOLE tree (the list dag_top_tasks
     // ends with the BACKB / BACK tasks of the deeper fronts -- 24 small per-level launches, 0.25 ms at C2, otherwise)
-    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut);
+    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut, !dag_reset_done, !dag_check_later);
   } else {
     launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
   }
@@ -1368,14 +1379,14 @@ void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDi
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
 hipError_t enqueue_assemble_nd(slm_solver* s, int first, int n, const BatchDims& d, hipStream_t st) {
   const FrameDev* fr = s->frames_dev + first;
-  launch_iter_begin_nd(fr, n, st);   // zeroes the pivot columns of the fronts of all n slots in one launch
+  launch_iter_begin_nd(fr, n, st, nullptr, -2);   // zeroes the pivot columns of the fronts of all n slots in one launch
   if (s->cfg.use_data) {
     launch_data_eval(fr, n, kLossBlocks, s->cfg.w_data, 2, st);   // {r, c} at the current beta (clobbers the loss partials)
     launch_data_gram(fr, n, d.max_pos, s->cfg.w_data, d.gram_variants, st);
     launch_front_assemble(fr, n, d.max_blocks, st);
   }
   launch_reg_grad_nd(fr, n, d.maxP / 7, s->cfg.use_arap, s->cfg.w_arap, s->cfg.use_rot, s->cfg.w_rot, st);
-  launch_front_load_rhs(fr, n, d.maxP, st);
+  if (!s->cfg.use_arap && !s->cfg.use_rot) launch_front_load_rhs(fr, n, d.maxP, st);   // (else k_reg_grad_nd did it)
   return hipSuccess;
 }
 
@@ -1448,7 +1459,7 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const FrameDev* fr = s->frames_dev;
   const int* reuse = (s->cfg.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
-  launch_iter_begin_nd(fr, n_frames, st, reuse);
+  launch_iter_begin_nd(fr, n_frames, st, reuse, -2);
   if (s->cfg.use_data) {
     launch_data_eval(fr, n_frames, kLossBlocks, s->cfg.w_data, 1, st, reuse);   // (only slots whose buffer is not the current beta's)
     launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st, reuse);
@@ -1467,7 +1478,7 @@ int slm_lm_solve(slm_solver* s, int32_t n_frames, void* stream) {
   const slm_config& c = s->cfg;
   if (c.use_data) launch_pair_scatter(fr, n_frames, d.max_blocks, st);
   launch_reg_grad_nd(fr, n_frames, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
-  launch_front_load_rhs(fr, n_frames, d.maxP, st);
+  if (!c.use_arap && !c.use_rot) launch_front_load_rhs(fr, n_frames, d.maxP, st);   // (else k_reg_grad_nd did it)
   enqueue_front_solve(s, fr, n_frames, d, -1.0, st);
   HIPCHK(hipGetLastError());
   return SLM_OK;
@@ -1573,7 +1584,7 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   //  re-reads them; the banded path adds into the band in place)
   const int* reuse = (d.nd && d.v1 && c.phase_test && !s->no_reuse) ? s->reuse_dev + first : nullptr;
   if (d.nd) {
-    launch_iter_begin_nd(fr, n, st, reuse);
+    launch_iter_begin_nd(fr, n, st, reuse, dag_cut_of(s, n, d));
   } else {
     launch_iter_begin(fr, n, st);
   }
@@ -1594,23 +1605,25 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   if (d.nd) {
     if (c.use_data) launch_front_assemble(fr, n, d.max_blocks, st);
     launch_reg_grad_nd(fr, n, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
-    launch_front_load_rhs(fr, n, d.maxP, st);
+    if (!s->cfg.use_arap && !s->cfg.use_rot) launch_front_load_rhs(fr, n, d.maxP, st);   // (else k_reg_grad_nd did it)
   } else {
     if (c.use_data && d.v1) launch_band_assemble(fr, n, d.max_blocks, st);
     launch_reg_grad(fr, n, d.maxJKe, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
   }
   mark();
-  if (d.nd) enqueue_front_solve(s, fr, n, d, -1.0, st);
+  // the trial point beta + delta (node_pk_try), the regularisers' loss there and the task graph's abort check: one launch
+  const bool tail = c.use_data || d.n_reg_part > 0;
+  if (d.nd) enqueue_front_solve(s, fr, n, d, -1.0, st, true, tail);
   else launch_band_solve(fr, n, d.nt_max, d.wb_cap, -1.0, st);
-  if (c.use_data) launch_make_trial(fr, n, d.maxJKe, st);   // trial point beta + delta (maxJKe >= J)
+  if (tail)
+    launch_after_solve(fr, n, c.use_data ? d.maxP / 7 : 0, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot,
+                       (d.nd && dag_cut_of(s, n, d) >= -1) ? 1 : 0, st);
   mark();
   if (c.use_data) {
     if (d.v1) launch_data_eval(fr, n, kLossBlocks, c.w_data, 0, st);   // the loss pass; its {r, c} feed the next Jacobian pass
     else launch_data_loss(fr, n, kLossBlocks, d.K, c.w_data, 1, st);
   }
   mark();
-  if (d.n_reg_part > 0)
-    launch_reg_loss(fr, n, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
   launch_accept(fr, n, c.phase_test, d.n_reg_part, std::max(c.num_iterations, 1), st,
                 (d.v1 && c.phase_test) ? s->reuse_dev + first : nullptr, (c.use_data && d.v1) ? 1 : 0);
   mark();

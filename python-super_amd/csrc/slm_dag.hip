@@ -1343,7 +1343,7 @@ hipError_t set_dag_timeout_ticks(long long ticks) {
 }
 // (a workgroup of this kernel owns its CU -- one wave per SIMD with most of the register file; tickets make any grid size
 //  deadlock-free)
-void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut) {
+void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut, bool reset, bool check) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
   // per device: the dynamic-LDS attribute is a property of the kernel ON a device, and so is the CU count (host threads
@@ -1362,9 +1362,12 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
     n_wg = cus * (per_cu > 0 ? per_cu : 1);
     if (tracked) n_wg_dev[dev].store(n_wg, std::memory_order_release);
   }
-  hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
+  // reset = false: the flags and mailboxes were reset by this iteration's k_iter_begin_nd (launch_iter_begin_nd(..., dag_cut):
+  // slm_run's loop); true: by a launch of their own here (the host-driven sharded loop, slm_solve)
+  if (reset) hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);
   hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut);
-  hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
+  // (check = false: the caller's next launch settles an aborted launch itself -- k_after_solve, slm_reg.hip)
+  if (check) hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
 }

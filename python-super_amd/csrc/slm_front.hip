@@ -404,6 +404,13 @@ __global__ void __launch_bounds__(256) k_reg_grad_nd(const FrameDev* __restrict_
 #pragma unroll
   for (int q = 0; q < 5; ++q)
     if (dst[q]) *dst[q] = cur[q] + add[q];
+  // the node's right-hand side is final here (data term + regularisers): it goes to the pivot part of its front's vector in
+  // the same pass (k_front_load_rhs was a launch of its own; it still runs when no regulariser is enabled)
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int e = slot + RG_LANES * q;
+    if (e >= 28 && e < 35) fd.fvec[fj.vec_off + 7 * fd.node_pos[j] + (e - 28)] = cur[q] + add[q];
+  }
 }
 
 // global jtl -> the pivot part of each front's vector (boundary parts stay zero)
@@ -450,9 +457,27 @@ __device__ __forceinline__ void zero_fronts(const FrameDev& fd, int b, int nb) {
 // boundary blocks are written once by their own Schur kernels / tasks, never zeroed), the front vectors, rhs and the
 // counters, for ALL slots of the batch in one launch (one hipMemsetAsync pair per slot cost
 // ~25 us each, back to back).  grid = (blocks, n_frames); contiguous 16 KB pieces per workgroup.
-__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames, const int* __restrict__ reuse) {
+// dag_cut: what the task-graph launch of this iteration's solve needs reset -- its flags (ticket, abort, per-tile and
+// per-column flags) and the mailboxes of the pivot tile columns it factors: -1 all fronts (whole-tree task graph),
+// >= 0 the fronts of depth <= dag_cut (hybrid form), -2 none (per-level launches only).  This used to be a launch of its
+// own in front of k_fdag (k_dag_reset, 6-9 us of mostly launch latency per iteration); here it rides on a kernel that
+// runs anyway, after the previous iteration's k_dag_check has read the flags.  A stopped slot is reset too: slot 0's
+// flags carry the ticket of the whole batch.
+__global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames, const int* __restrict__ reuse, int dag_cut) {
   const FrameDev& fd = frames[blockIdx.y];
-  if (!fd.bound || fd.st->stopped) return;
+  if (!fd.bound) return;
+  if (dag_cut >= -1 && fd.nd_ready && fd.dag_flags) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fd.dag_n_flags; i += gridDim.x * blockDim.x) fd.dag_flags[i] = 0;
+    typedef __attribute__((address_space(1))) long long gll;
+    gll* mail = (gll*)(double*)fd.fmail;
+    for (int fi = blockIdx.x; fi < fd.n_fronts; fi += gridDim.x) {
+      const NDFront& f = fd.fronts[fi];
+      if (dag_cut >= 0 && f.depth > dag_cut) continue;
+      const size_t base = (size_t)(f.linv_off / TILE) * SLM_MAIL_DOUBLES, n = (size_t)f.npt * SLM_MAIL_DOUBLES;
+      for (size_t e = threadIdx.x; e < n; e += blockDim.x) mail[base + e] = SLM_MAIL_EMPTY;
+    }
+  }
+  if (fd.st->stopped) return;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
   const double2 z = make_double2(0.0, 0.0);
   if (fd.nd_ready) {
@@ -1291,12 +1316,13 @@ void launch_reg_grad_nd(const FrameDev* fr, int n_frames, int maxJ, int use_arap
                      lam_a, use_rot, lam_r);
 }
 
+// (only when no regulariser is enabled: k_reg_grad_nd loads the front vectors itself)
 void launch_front_load_rhs(const FrameDev* fr, int n_frames, int maxP, hipStream_t st) {
   hipLaunchKernelGGL(k_front_load_rhs, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, fr);
 }
 
-void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st, const int* reuse) {
-  hipLaunchKernelGGL(k_iter_begin_nd, dim3(1024, n_frames), dim3(256), 0, st, fr, reuse);
+void launch_iter_begin_nd(const FrameDev* fr, int n_frames, hipStream_t st, const int* reuse, int dag_cut) {
+  hipLaunchKernelGGL(k_iter_begin_nd, dim3(1024, n_frames), dim3(256), 0, st, fr, reuse, dag_cut);
 }
 
 // Level schedule shared by all slots of a batch (they may have different plans: the host

@@ -149,6 +149,76 @@ __global__ void __launch_bounds__(256) k_reg_loss(const FrameDev* __restrict__ f
   }
 }
 
+// What follows the solve of an LM iteration, in ONE launch (round 5; k_make_trial, k_reg_loss and k_dag_check were three
+// launches of 4-5 us each, mostly launch latency): blocks [0, n_trial) pack the trial point beta + delta (node_pk_try: what the
+// data term's loss pass reads), blocks [n_trial, n_trial + n_reg) evaluate the regularisers' loss there (they read beta and
+// delta themselves), and block 0 of every slot first settles a timed-out task-graph launch (dag_check: the abort flag, kept
+// with the ticket in slot 0's flags, marks the slots whose solve did not finish -- k_dag_check, slm_dag.hip).
+// grid = (n_trial + n_reg, n_frames)
+__global__ void __launch_bounds__(256) k_after_solve(const FrameDev* __restrict__ frames, int n_trial, int n_reg, int use_arap,
+                                                      double lam_a, int use_rot, double lam_r, int dag_check) {
+  __shared__ double sm[16];
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound) return;
+  if (dag_check && blockIdx.x == 0 && threadIdx.x < 64) {
+    const FrameDev& fd0 = frames[0];
+    if (fd0.bound && fd0.nd_ready && fd0.dag_flags && fd0.dag_flags[1] != 0 && fd.nd_ready && fd.dag_flags) {
+      const int* px = fd.dag_flags.get() + 8 + fd.dag_n_tiles + fd.dag_n_pcols;
+      bool done = true;
+      for (int fi = threadIdx.x; fi < fd.n_fronts; fi += 64) {
+        const NDFront& f = fd.fronts[fi];
+        if (f.npt > 0 && px[(int)(f.linv_off / (SLM_NB * SLM_NB))] == 0) done = false;
+      }
+      if (!__all(done) && threadIdx.x == 0 && fd.st->chol_fail == 0) fd.st->chol_fail = 2;
+    }
+  }
+  if (fd.st->stopped) return;
+  if ((int)blockIdx.x < n_trial) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= fd.f.J) return;
+    double bb[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) bb[c] = fd.beta[7 * j + c] + fd.delta[7 * j + c];
+    pack_node(fd.node_pk_try + (size_t)SLM_NPK * j, bb, ld_state3(frame_in(fd).ed_points, (size_t)j, fd.f.state_f64));
+    return;
+  }
+  const int b = blockIdx.x - n_trial;
+  const int Ke = fd.f.K_ED;
+  double sa = 0.0, sr = 0.0;
+  for (int t = b * blockDim.x + threadIdx.x; t < fd.f.J * Ke; t += n_reg * blockDim.x) {
+    const int j = t / Ke, slot = t % Ke;
+    if (use_arap) {
+      const int k = frame_in(fd).ed_knn_idx[j * Ke + slot];
+      double r[3], bk[7];
+      d3 d;
+      arap_residual(fd, fd.beta, fd.delta, j, k, lam_a, r, bk, d);
+      sa += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    }
+    if (use_rot && slot == 0) {
+      double bb[7];
+      load_beta(fd.beta, fd.delta, j, bb);
+      float q[4];
+      const float r = rot_residual32(bb, (float)lam_r, q);
+      sr += (double)sq32(r);
+    }
+  }
+  double a = block_sum(sa, sm);
+  double bsum = block_sum(sr, sm);
+  if (threadIdx.x == 0) {
+    double* out = fd.loss_part + 2 * (size_t)fd.n_loss_part;
+    out[2 * b] = a;
+    out[2 * b + 1] = bsum;
+  }
+}
+
+void launch_after_solve(const FrameDev* frames_dev, int n_frames, int maxJ, int n_reg, int use_arap, double lam_a, int use_rot,
+                        double lam_r, int dag_check, hipStream_t st) {
+  const int n_trial = maxJ > 0 ? (maxJ + 255) / 256 : 0;
+  if (n_trial + n_reg <= 0) return;
+  hipLaunchKernelGGL(k_after_solve, dim3(n_trial + n_reg, n_frames), dim3(256), 0, st, frames_dev, n_trial, n_reg, use_arap, lam_a,
+                     use_rot, lam_r, dag_check);
+}
+
 void launch_reg_grad(const FrameDev* frames_dev, int n_frames, int maxJKe, int use_arap, double lam_a,
                      int use_rot, double lam_r, hipStream_t st) {
   if (maxJKe <= 0 || (!use_arap && !use_rot)) return;
