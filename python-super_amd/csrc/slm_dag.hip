@@ -584,7 +584,7 @@ __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4
 // whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
 // base inside the function, so their address space stays known.
 extern __shared__ double dag_lds[];
-__device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, long long* trc) {
+__device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, long long* trc, int nblk) {
   double* S = dag_lds;
   double* M = dag_lds + TILE;
   double* dinv = dag_lds + 2 * TILE;
@@ -592,7 +592,7 @@ __device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, lo
   double* xch = wt + 3 * 256;                   // vec | yv: not live while a tile is being factored
   int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
   int* pf = s_ok + 16;                          // 16 hand-off flags of the trailing waves
-  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_mail, g_early, trc);
+  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_mail, g_early, trc, nblk);
 }
 
 }  // namespace
@@ -848,7 +848,8 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
         double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
         const bool ok = dag_factor_tile(stream ? fd.fmail + (size_t)(f.pcol0 + s) * SLM_MAIL_DOUBLES : nullptr,
                                        s > 0 ? g.tile + tile_index(f, s, s - 1) : nullptr,    // L(s, s-1) goes out during the first 16 pivots
-                                       trc ? trc + 8 : nullptr);
+                                       trc ? trc + 8 : nullptr,
+                                       min(4, (f.n1 - s * NB + 15) >> 4));   // 16-pivot blocks with real pivots (the front's last column: fewer)
         DAG_MARK(6);
         if (!ok && threadIdx.x == 0) lmst->chol_fail = 1;
 #pragma unroll

@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(256) k_fpanel(const FrameDev* __restrict__ fra
   SLM_STAMP(fd, stamp, 1);
   // (factor + inverse in the pipelined form of the task graph; the row blocks d > 0 only need L and the diagonal-block
   //  inverses, which are complete at the same time as with potrf64)
-  const bool ok = factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf);
+  const bool ok = factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, nullptr, nullptr, nullptr, min(4, (f.n1 - c * NB + 15) >> 4));
   SLM_STAMP(fd, stamp, 14);
 
   if (d == 0) {
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(256) k_fpotrf(const FrameDev* __restrict__ fra
     }
   }
   __syncthreads();
-  const bool ok = factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf);
+  const bool ok = factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, nullptr, nullptr, nullptr, min(4, (f.n1 - c * NB + 15) >> 4));
   if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
   double* linv = fd.flinv + f.linv_off + (size_t)c * TILE;
   for (int e = threadIdx.x; e < TILE; e += blockDim.x) linv[e] = M[e];
@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(256, 2) k_fL11(const FrameDev* __restrict__ fr
     __syncthreads();
     // factor + inverse in the pipelined form of the task graph (wave 0 runs the pivot chain, waves 1-3 trail with the
     // panel / trailing / inverse blocks): 11.7 us per tile against ~14 for potrf64 + inverse_assemble64
-    const bool ok = factor_inverse64p(S, M, dinv, wt, vec, s_ok, pf);
+    const bool ok = factor_inverse64p(S, M, dinv, wt, vec, s_ok, pf, nullptr, nullptr, nullptr, min(4, (f.n1 - c * NB + 15) >> 4));
     if (!ok && threadIdx.x == 0) fd.st->chol_fail = 1;
     if (threadIdx.x < NB) vec[threadIdx.x] = rhs_c;
     __syncthreads();

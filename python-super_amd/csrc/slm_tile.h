@@ -314,9 +314,12 @@ __device__ __forceinline__ void publish_blocks16(const double* S, const double* 
     }
 }
 
+// nblk (1..4): 16-pivot blocks of the tile that hold real pivots.  The blocks beyond are the identity padding of a front's
+// last pivot tile column (unit diagonal, zero rows): their "factorisation" is known -- the pivot chain skips diag16 for
+// them (1.7 us each on the critical path) and only writes the identity inverse; everything else runs unchanged.
 __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* dinv, double* wt, double* xch,
                                                   int* s_ok, int* pf, double* g_mail = nullptr, int* g_early = nullptr,
-                                                  long long* trc = nullptr) {
+                                                  long long* trc = nullptr, int nblk = 4) {
 #define FTRC(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
   const int w = threadIdx.x >> 6;
   const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
@@ -329,8 +332,18 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
   for (int kb = 0; kb < 4; ++kb) {
     FTRC(3 * kb);
     if (w == 0) {
-      const bool ok = diag16(S + kb * 16 * (LD + 1), dinv + kb * 256, xch);
-      if (!ok && (threadIdx.x & 63) == 0) *s_ok = 0;
+      if (kb < nblk) {
+        const bool ok = diag16(S + kb * 16 * (LD + 1), dinv + kb * 256, xch);
+        if (!ok && (threadIdx.x & 63) == 0) *s_ok = 0;
+      } else {   // identity block: L = I is in place, its inverse is I
+        const int l = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = l + 64 * j;
+          dinv[kb * 256 + e] = ((e & 15) == (e >> 4)) ? 1.0 : 0.0;
+        }
+        wave_sync();
+      }
       FTRC(3 * kb + 1);
     } else if (kb == 0) {
       for (int e = threadIdx.x - 64; e < TILE; e += 192) M[e] = 0.0;   // blocks above the diagonal stay zero
