@@ -1122,7 +1122,10 @@ __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ 
   // true sizes: rows of this tile row / columns of this tile column that are boundary scalars
   const int vrow = min(NB, it.n2 - NB * tr), vcol = min(NB, it.n2 - NB * tc);
   const bool wave_on = 16 * w < vrow;
-  const int nblk = (vcol + 15) >> 4;             // 16-column blocks with real columns
+  // 16-column blocks with real columns -- and, in a DIAGONAL tile of the (symmetric) update matrix, not beyond this wave's
+  // own row block: the blocks strictly above the diagonal are never read (the gathers take row >= column only), so they
+  // are neither computed nor stored (6 of a full tile's 16 blocks)
+  const int nblk = (tr == tc) ? min((vcol + 15) >> 4, w + 1) : (vcol + 15) >> 4;
   const bool kids = it.kid[0].front >= 0 || it.kid[1].front >= 0;
   pull_maps(fd, it, maps);
   // The B operand (L21 tile of block-row sc) passes through LDS in HALF tiles of 32 inner columns,
