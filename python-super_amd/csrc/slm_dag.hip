@@ -311,8 +311,13 @@ __device__ __forceinline__ TD task_deps(const SS& fd, const FS& f, int fi, int t
     d.pcol_parent = (int)(uni64(fd.fronts[f.parent].linv_off) / TILE);
     d.n0 = d.n = 1;
   } else {
-    // BACK(f): y_c (and its boundary part) of every column, and every tile L(r,c), c < r < npt
-    d.n0 = d.n = f.npt * (1 + (f.nb > 0 ? 1 : 0)) + f.npt * (f.npt - 1) / 2;
+    // BACK(f): y_c (and its boundary part) of every column, and every tile L(r,c), c < r < npt.  The FUSED form (word 1 of
+    // the task = 1: the task subtracts the boundary part itself) waits for the parent's solution in place of the npt flags
+    // of its BACKB tasks.
+    const bool fusedf = s == 1 && f.nb > 0;   // (word 1 of a BACK task: 0 or 1)
+    d.r = fusedf ? 1 : 0;
+    if (fusedf) d.pcol_parent = (int)(uni64(fd.fronts[f.parent].linv_off) / TILE);
+    d.n0 = d.n = f.npt + (f.nb > 0 ? (fusedf ? 1 : f.npt) : 0) + f.npt * (f.npt - 1) / 2;
   }
   return d;
 }
@@ -360,8 +365,13 @@ __device__ __forceinline__ const int* dep_flag(const TD& d, const FS& f, const D
   if (i < d.npt) return g.py + f.pcol0 + i;
   i -= d.npt;
   if (d.nb > 0) {
-    if (i < d.npt) return g.pb + f.pcol0 + i;
-    i -= d.npt;
+    if (d.r == 1) {                 // fused: the parent's solution
+      if (i < 1) return g.px + d.pcol_parent;
+      i -= 1;
+    } else {
+      if (i < d.npt) return g.pb + f.pcol0 + i;
+      i -= d.npt;
+    }
   }
   // tiles (r, c), c < r < npt, row by row: i = r (r - 1) / 2 + c
   int r = 1;
@@ -1165,7 +1175,10 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     // stage 0 in two steps: the factorisation's outputs (y of every column, the tiles of the pivot block) are there long
     // before the boundary part of the right-hand side (BACKB, which waits for the parent's solution): wait for the
     // former, request the first three tiles of the chain, and only then wait for the latter
-    const int nb_flags = f.nb > 0 ? f.npt : 0;
+    // FUSED form (word 1 = 1, fronts with few pivot tile columns): no BACKB tasks -- this task waits for the parent's
+    // solution itself and subtracts the boundary part before the chain
+    const bool fusedf = ts_ == 1 && f.nb > 0;
+    const int nb_flags = f.nb > 0 ? (fusedf ? 1 : f.npt) : 0;
     const bool prefactored = cut >= 0 && uni(fd.fronts[fi].depth) > cut;   // (hybrid solve: factored by the per-level launches)
     if (!prefactored) {
       if (!dag_wait_deps(d, f, g, 0, f.npt, abort_flag, s_abort)) return;
@@ -1201,9 +1214,11 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
     load_tile_regs2(op_addr(lc, lj), LV);                                                 \
     op_next(lc, lj);                                                                      \
   } while (0)
-    BACK_LOAD(l0);
-    BACK_LOAD(l1);
-    BACK_LOAD(l2);
+    if (!fusedf) {
+      BACK_LOAD(l0);
+      BACK_LOAD(l1);
+      BACK_LOAD(l2);
+    }
     if (!dag_wait_deps(d, f, g, f.npt, f.npt + nb_flags, abort_flag, s_abort)) return;
 
   {
@@ -1219,6 +1234,52 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc8[e] = 0.0;
       const int m2 = 2 * (l & 31), n_ = 2 * w + (l >> 5) + 8 * ((l >> 2) & 7);
+      if (fusedf) {
+        // ---- the boundary part (what the BACKB tasks do for the fronts that have them): y_c -= sum_r L(r,c)^T x_r over the
+        // boundary tile rows, x of the boundary nodes gathered ONCE from the global solution (all ancestors are solved)
+        double* xb = M;   // n2p doubles
+        const int* nodes = fd.nd_nodes + f.nodes_off + f.nv;
+        for (int i = threadIdx.x; i < f.n2p; i += blockDim.x) xb[i] = (i < 7 * f.nb) ? ld1(fd.delta + 7 * nodes[i / 7] + i % 7) : 0.0;
+        __syncthreads();   // xb and ya complete
+        // the npt x (nt - npt) boundary tiles in column-major order, two in use while the next two are in flight (requests
+        // past the end repeat the last tile and count for nothing: unconditional loads keep the wait counts exact)
+        const int nbt = f.nt - f.npt, nbops = f.npt * nbt;
+        auto b_addr = [&](int k) -> const double* {
+          const int kk = min(k, nbops - 1), c = kk / nbt;
+          return tile_ptr(fd, f, f.npt + (kk - c * nbt), c);
+        };
+        double t0[16], t1[16], t2[16], t3[16];
+        load_tile_regs2(b_addr(0), t0);
+        load_tile_regs2(b_addr(1), t1);
+#define BNDRY_USE(LV, K)                                                                       \
+  do {                                                                                         \
+    const int k_ = (K);                                                                        \
+    const bool on_ = k_ < nbops;                                                               \
+    const int kk_ = min(k_, nbops - 1), c_ = kk_ / nbt, rb_ = kk_ - c_ * nbt;                   \
+    const double x0_ = on_ ? xb[(size_t)rb_ * NB + m2] : 0.0, x1_ = on_ ? xb[(size_t)rb_ * NB + m2 + 1] : 0.0; \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) acc8[e] = fma(LV[2 * e + 1], x1_, fma(LV[2 * e], x0_, acc8[e])); \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(acc8[e]) :: "memory");   \
+    if (on_ && rb_ == nbt - 1) {            /* the column's last tile: finish y_c */              \
+      const double a_ = col_reduce8(acc8);                                                     \
+      if ((l & 3) == 0) ya[(size_t)c_ * NB + n_] -= a_;                                        \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) acc8[e] = 0.0;                             \
+    }                                                                                          \
+  } while (0)
+        for (int k = 0; k < nbops; k += 4) {
+          load_tile_regs2(b_addr(k + 2), t2);
+          load_tile_regs2(b_addr(k + 3), t3);
+          BNDRY_USE(t0, k);
+          BNDRY_USE(t1, k + 1);
+          load_tile_regs2(b_addr(k + 4), t0);
+          load_tile_regs2(b_addr(k + 5), t1);
+          BNDRY_USE(t2, k + 2);
+          BNDRY_USE(t3, k + 3);
+        }
+#undef BNDRY_USE
+        BACK_LOAD(l0);
+        BACK_LOAD(l1);
+        BACK_LOAD(l2);
+      }
 #define BACK_OP(LV, K)                                                                    \
   do {                                                                                    \
     const int c_ = oc, j_ = oj;                                                           \

@@ -555,12 +555,20 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       double st0 = fact_done[i];
       if (f.parent >= 0) st0 = std::max(st0, back_done[f.parent] + HOP);
       else for (int k = 0; k < T; ++k) st0 = std::max(st0, fact_done[k]);   // the root starts when everything is factored
-      // BACKB(f,c) for every pivot column in parallel, then ONE task per front for the chain over its columns
+      // BACKB(f,c) for every pivot column in parallel, then ONE task per front for the chain over its columns.  Fronts with
+      // few pivot tile columns (round 5: <= SLM_BACK_FUSE_NPT, default 2 -- the five deepest levels at C2) get
+      // ONE task that does both (word 1 = 1): the boundary's x is gathered once instead of once per column, one hand-off
+      // per tree level instead of two, and a third as many tasks to take tickets for.
+      static const int fuse_npt = [] {
+        const char* e = getenv("SLM_BACK_FUSE_NPT");
+        return e ? atoi(e) : 2;
+      }();
+      const bool fused = f.nb > 0 && f.npt <= fuse_npt;
       for (int c = f.npt - 1; c >= 0; --c)
-        if (f.nb > 0) tasks.push_back({st0, (ND_T_BACKB << 24) | i, (c << 8) | c});
-      const double stc = st0 + (f.nb > 0 ? 2.0 + 0.5 * (f.nt - f.npt) : 0.0);
-      tasks.push_back({stc, (ND_T_BACK << 24) | i, 0});
-      double prev = stc + 2.0 + 0.25 * f.npt * (f.npt + 1) / 2;
+        if (f.nb > 0 && !fused) tasks.push_back({st0, (ND_T_BACKB << 24) | i, (c << 8) | c});
+      const double stc = st0 + ((f.nb > 0 && !fused) ? 2.0 + 0.5 * (f.nt - f.npt) : 0.0);
+      tasks.push_back({stc, (ND_T_BACK << 24) | i, fused ? 1 : 0});
+      double prev = stc + 2.0 + 0.25 * f.npt * (f.npt + 1) / 2 + (fused ? 1.0 + 0.45 * (f.nt - f.npt) * f.npt : 0.0);
       back_done[i] = prev;
       t_end = std::max(t_end, prev);
     }
