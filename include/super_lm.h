@@ -69,7 +69,7 @@ enum {
  * the five structs that carry pointers or were extended (returns SLM_OK or SLM_ERR_INVALID with the mismatch in
  * slm_last_error()).  Bindings call it once after loading the library (super_amd/_lib.py does). */
 #define SLM_ABI_VERSION 3
-#define SLM_PLAN_INFO_DOUBLES 12
+#define SLM_PLAN_INFO_DOUBLES 14
 int slm_abi_version(void);
 int slm_abi_check(int32_t abi_version, int32_t sizeof_slm_config, int32_t sizeof_slm_frame, int32_t sizeof_slm_gf_config,
                   int32_t sizeof_slm_gf_frame, int32_t sizeof_slm_iter_record);
@@ -201,7 +201,9 @@ int slm_get_records(slm_solver* s, int32_t slot, slm_iter_record* host_out, int3
  * [3] FLOPs of one factorisation (padded dense fronts, or P*w^2 for the band),
  * [4] factor storage bytes, [5] distinct KNN tuples, [6] Gram runs, [7] coupled node pairs,
  * [8] workgroup-merged (workgroup, pair) records (0: one Gram per run in HBM), [9] padded positions,
- * [10] FLOPs of one factorisation without the padding of the fronts to 64, [11] tasks of the task-graph solver. */
+ * [10] FLOPs of one factorisation without the padding of the fronts to 64, [11] tasks of the task-graph solver,
+ * [12] pivot-column tiles of the fronts, [13] of them PURE FILL: no assembled block reaches them, some child maps into
+ *      them -- neither zeroed per iteration nor read by their first toucher (0 with SLM_PURE_FILL=0). */
 int slm_get_plan_info(slm_solver* s, int32_t slot, double* info_out, int32_t capacity);
 
 /* -- one LARGE frame sharded over the GPUs of a node ----------------

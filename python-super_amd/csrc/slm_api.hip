@@ -147,6 +147,7 @@ struct Slot {
   uint8_t* d_tile_kind = nullptr;  // FrameDev::tile_kind / zero_tiles (slm_common.h): per tile 1 = pure fill; the tiles to zero
   long long* d_zero_tiles = nullptr;
   size_t cap_tile_kind = 0, cap_zero_tiles = 0;
+  int n_piv_tiles = 0, n_pure_tiles = 0;  // pivot-column tiles of the plan / of them pure fill (slm_get_plan_info)
   std::vector<uint8_t> h_tile_kind;      // host sources of the two uploads (kept: the copies are asynchronous)
   std::vector<long long> h_zero_tiles;
   int32_t* d_ints = nullptr;    // level_start | nodes | eamap | node_front | node_pos | ... | dag_tasks | front_nin
@@ -318,6 +319,7 @@ struct slm_solver {
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
+  bool pure_fill = true;        // SLM_PURE_FILL=0 (tests): every pivot-column tile is zeroed and read-modify-written, as in rounds 1-4
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
   std::vector<std::vector<hipEvent_t>> ev_runs;  // per recorded iteration: SLM_PH_COUNT+1 events
@@ -524,6 +526,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
   if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
+  if (const char* pf = getenv("SLM_PURE_FILL")) s->pure_fill = atoi(pf) != 0;     // tests: differential check of the pure-fill tiles
   *out = s;
   return SLM_OK;
 }
@@ -850,6 +853,7 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       std::vector<long long>& zero = sl.h_zero_tiles;
       kind.assign(n_tiles + 1, 0);
       zero.clear();
+      sl.n_piv_tiles = sl.n_pure_tiles = 0;
       std::vector<uint8_t> assembled(n_tiles + 1, 0), pulled(n_tiles + 1, 0);
       auto nbase = [](const NDFront& fr, int pos) { return pos < fr.nv ? 7 * pos : fr.n1p + 7 * (pos - fr.nv); };
       auto mark = [&](int front, int prow, int pcol) {
@@ -873,7 +877,9 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
         for (int c = 0; c < fr.npt; ++c)
           for (int r = c; r < fr.nt; ++r) {
             const size_t ix = (size_t)c * fr.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c), t = (size_t)fr.tile_first + ix;
-            kind[t] = (!assembled[t] && pulled[t]) ? 1 : 0;
+            kind[t] = (s->pure_fill && !assembled[t] && pulled[t]) ? 1 : 0;
+            ++sl.n_piv_tiles;
+            sl.n_pure_tiles += kind[t];
             if (!kind[t]) zero.push_back((long long)fr.tile_off + (long long)ix * (SLM_NB * SLM_NB));
           }
       hipError_t e = grow(sl.d_tile_kind, sl.cap_tile_kind, n_tiles + 1);
@@ -1675,6 +1681,8 @@ int slm_get_plan_info(slm_solver* s, int32_t slot, double* out_caller, int32_t c
     out[10] = sl.nd.flops_exact;
     out[11] = (double)sl.nd.dag_tasks.size() / 2.0;
     out[4] = 8.0 * (double)sl.nd.tile_doubles;
+    out[12] = (double)sl.n_piv_tiles;
+    out[13] = (double)sl.n_pure_tiles;
   } else {
     out[0] = 1.0;
     const double w = (double)h.wb * SLM_NB;

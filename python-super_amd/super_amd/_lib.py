@@ -15,7 +15,7 @@ SLM_OK = 0
 SLM_ERR_INVALID, SLM_ERR_HIP, SLM_ERR_NO_DEVICE, SLM_ERR_UNBOUND, SLM_ERR_UNSUPPORTED = 1, 2, 3, 4, 5   # include/super_lm.h:48-53
 SLM_ITER_OK, SLM_ITER_SOLVER_FAILED, SLM_ITER_NOT_RUN, SLM_ITER_SOLVER_TIMEOUT = 0, 1, 2, 3
 SLM_ABI_VERSION = 3          # SLM_ABI_VERSION of include/super_lm.h this binding was written against
-PLAN_INFO_DOUBLES = 12
+PLAN_INFO_DOUBLES = 14
 SLM_X_PAIR_BLOCKS, SLM_X_DELTA, SLM_X_DATA_LOSS = 0, 1, 2
 PHASES = ["zero", "data_grad", "reg_grad", "solve", "data_loss", "accept"]
 

@@ -148,7 +148,7 @@ class Engine:
         out = (C.c_double * _lib.PLAN_INFO_DOUBLES)()
         _lib.check(self.lib.slm_get_plan_info(self.h, slot, out, _lib.PLAN_INFO_DOUBLES), "slm_get_plan_info")
         keys = ("solver", "fronts", "levels", "factor_flops", "factor_bytes", "tuples", "runs", "pairs",
-                "merged_records", "positions", "factor_flops_unpadded", "solver_tasks")
+                "merged_records", "positions", "factor_flops_unpadded", "solver_tasks", "pivot_tiles", "pure_fill_tiles")
         d = {k: out[i] for i, k in enumerate(keys)}
         d["solver"] = "nested-dissection multifrontal" if d["solver"] == 0 else "band"
         return d
