@@ -217,6 +217,48 @@ def latency_b1(dims, device, iters, steps=6):
     return out
 
 
+def batch_depth(scenes, device, iters, depths=(16, 32), steps=3):
+    """The headline's step (bind + 10 LM iterations + Surfels.update per frame) at DEEPER batches than the headline's 8 frames per
+    launch -- BASELINE `configs[3]`'s 64 frames on ONE GPU would be two launches of 32.  The pivot chains of the solve are
+    latency-bound and shared by every frame of a launch, so the rate grows with the depth; reported beside the headline, never as it.
+    The frames are the bench's own scenes, repeated over the slots (every slot owns its state arrays)."""
+    import torch
+    from super_amd.engine import DeviceFrame, Engine
+    fields = ("sf_points", "sf_norms", "ed_points", "ed_norms")
+    out = {}
+    for depth in depths:
+        pristine = [DeviceFrame.from_scene(scenes[i % len(scenes)], device) for i in range(depth)]
+        work = [DeviceFrame.from_scene(scenes[i % len(scenes)], device) for i in range(depth)]
+        eng = Engine(device, max_frames=depth, num_iterations=iters)
+        betas = [torch.empty((scenes[0].J, 7), dtype=torch.float64, device=device) for _ in range(depth)]
+
+        def step():
+            for p, w in zip(pristine, work):
+                for nm in fields:
+                    getattr(w, nm).copy_(getattr(p, nm))
+            eng.bind_batch(work)
+            eng.run(depth)
+            for i in range(depth):
+                eng.beta(i, betas[i])
+                eng.apply_update(i, betas[i])
+
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        ok = all(r["status"] == 0 for i in range(depth) for r in eng.records(i))
+        out[str(depth)] = {"value": depth * iters / dt, "unit": "LM it/s", "ms_per_step": 1e3 * dt, "ms_per_frame": 1e3 * dt / depth,
+                           "frames_per_launch": depth, "all_iterations_ok": ok}
+        eng.close()
+        del pristine, work, betas
+    out["sample"] = f"{steps} steps per depth; the {len(scenes)} frames of the headline repeated over the slots"
+    return out
+
+
 def latency_b1_sequence(device, frames=48):
     """`latency_b1_sequence`: the one-frame-per-launch path as a TRACKER sees it -- not the always-warm re-bind of one
     frame that `latency_b1` times, but a moving surface at the SuPer image size (480 x 640, about 300 k surfels / 2.5 k
@@ -866,6 +908,8 @@ def main():
         if world == 1 and not a.no_profile and not a.no_latency_b1:
             out["latency_b1"] = latency_b1(dims, device, iters)
             out["latency_b1_sequence"] = latency_b1_sequence(device)
+            if a.workload in ("C1", "C2") and S == 1:
+                out["batch_depth"] = batch_depth(scenes, device, iters)
         out["host"] = host_info()
         out["host"]["cpu_cores_busy_per_rank"] = round(cpu_busy, 2)   # (rank 0; timed region; user + system time of all threads)
         out["host"]["cpu_cores_busy_all_ranks"] = round(cpu_busy_all, 2)   # (sum over the ranks: what the job costs of the node's CPU quota)
