@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(256) k_ftrsm(const FrameDev* __restrict__ fram
   double4_t acc[4];
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-  tile_ABt_regs<false>(areg, Bl, acc);   // A (L^-1)^T
+  tile_ABt_regs<false, true>(areg, Bl, acc);   // A (L^-1)^T
   store_c_frags(At, acc);
 }
 
@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(256, 2) k_fL11(const FrameDev* __restrict__ fr
       double4_t acc[4];
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-      tile_ABt_regs<false>(areg, M, acc);
+      tile_ABt_regs<false, true>(areg, M, acc);
       store_c_frags(At, acc);
       // rhs rows of this wave: sum_col L[row][col] y[col], reduced over the 4 lk lanes
       double sacc = 0.0;
@@ -891,7 +891,9 @@ __global__ void __launch_bounds__(256, 2) k_fL11(const FrameDev* __restrict__ fr
         load_a_frags(ftile(fd, f, r, c), areg);
         double4_t acc[4];
         load_c_frags(Ct, acc);
-        tile_ABt_regs<true>(areg, Bl, acc);
+        // (a diagonal tile is only ever read in its lower triangle: wave w leaves the blocks right of its own alone)
+        if (r == sc) tile_ABt_regs_trim<true>(areg, Bl, acc, 4, w + 1);
+        else tile_ABt_regs<true>(areg, Bl, acc);
         store_c_frags(Ct, acc);
       }
     }
@@ -966,7 +968,7 @@ __global__ void __launch_bounds__(256, 3) k_fL21(const FrameDev* __restrict__ fr
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) xa[ni] = double4_t{0.0, 0.0, 0.0, 0.0};
         if (wave_on) {
-          tile_ABt_regs_trim<false>(areg, Bl, xa, nblk, nblk);
+          tile_ABt_regs_trim<false, true>(areg, Bl, xa, nblk, nblk);
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
             if (ni < nblk) {

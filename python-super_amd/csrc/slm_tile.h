@@ -440,7 +440,9 @@ __device__ __forceinline__ void load_c_frags(const double* __restrict__ Cg, doub
     for (int r = 0; r < 4; ++r) acc[ni][r] = Cg[(16 * w + lr) + (size_t)(16 * ni + lk + 4 * r) * NB];
 }
 
-template <bool NEGATE>
+// LOWER_B: B is lower triangular by 16 x 16 blocks (the inverse of a tile factor: B[n][p] = 0 for p-block > n-block) -- the
+// block products above the diagonal are not issued (40 MFMAs per wave instead of 64; the sums are the same, minus additions of 0)
+template <bool NEGATE, bool LOWER_B = false>
 __device__ __forceinline__ void tile_ABt_regs(const double areg[16], const double* Bl,
                                               double4_t acc[4]) {
   const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
@@ -448,7 +450,7 @@ __device__ __forceinline__ void tile_ABt_regs(const double areg[16], const doubl
   for (int ks = 0; ks < 16; ++ks) {
     const double a = NEGATE ? -areg[ks] : areg[ks];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = LOWER_B ? (ks >> 2) : 0; ni < 4; ++ni) {
       const double b = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
       acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[ni], 0, 0, 0);
     }
@@ -463,7 +465,7 @@ __device__ __forceinline__ void tile_ABt_regs(const double areg[16], const doubl
 // the result (uniform bounds, 1..4): what lies beyond is known to be zero -- the padding of a front's last pivot tile
 // column.  The column-block count is a template parameter behind a switch and the inner blocks are whole branches: with
 // per-instruction predicates the compiler hoists every operand read of the product (250 VGPRs).
-template <bool NEGATE, int NBLK>
+template <bool NEGATE, int NBLK, bool LOWER_B>
 __device__ __forceinline__ void tile_ABt_regs_nblk(const double areg[16], const double* Bl, double4_t acc[4], int kblk) {
   const int l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
 #pragma unroll
@@ -474,7 +476,7 @@ __device__ __forceinline__ void tile_ABt_regs_nblk(const double areg[16], const 
         const int ks = 4 * kb + k4;
         const double a = NEGATE ? -areg[ks] : areg[ks];
 #pragma unroll
-        for (int ni = 0; ni < NBLK; ++ni) {
+        for (int ni = LOWER_B ? kb : 0; ni < NBLK; ++ni) {
           const double b = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
           acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[ni], 0, 0, 0);
         }
@@ -483,14 +485,14 @@ __device__ __forceinline__ void tile_ABt_regs_nblk(const double areg[16], const 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-template <bool NEGATE>
+template <bool NEGATE, bool LOWER_B = false>
 __device__ __forceinline__ void tile_ABt_regs_trim(const double areg[16], const double* Bl, double4_t acc[4], int kblk,
                                                    int nblk) {
   switch (nblk) {
-    case 1: tile_ABt_regs_nblk<NEGATE, 1>(areg, Bl, acc, kblk); break;
-    case 2: tile_ABt_regs_nblk<NEGATE, 2>(areg, Bl, acc, kblk); break;
-    case 3: tile_ABt_regs_nblk<NEGATE, 3>(areg, Bl, acc, kblk); break;
-    default: tile_ABt_regs_nblk<NEGATE, 4>(areg, Bl, acc, kblk); break;
+    case 1: tile_ABt_regs_nblk<NEGATE, 1, LOWER_B>(areg, Bl, acc, kblk); break;
+    case 2: tile_ABt_regs_nblk<NEGATE, 2, LOWER_B>(areg, Bl, acc, kblk); break;
+    case 3: tile_ABt_regs_nblk<NEGATE, 3, LOWER_B>(areg, Bl, acc, kblk); break;
+    default: tile_ABt_regs_nblk<NEGATE, 4, LOWER_B>(areg, Bl, acc, kblk); break;
   }
 }
 
