@@ -594,7 +594,10 @@ __device__ __forceinline__ double dag_reduce_rows(double tsum, double* part /* 4
 // whole kernel beyond 256 VGPRs (every path pays the maximum).  The LDS regions are derived from the dynamic LDS
 // base inside the function, so their address space stays known.
 extern __shared__ double dag_lds[];
-__device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, long long* trc, int nblk) {
+// look_ahead: wave 0 has staged the first diagonal block at dinv + 256 (ld 16) and the waves' row partials lie in wt
+// (factor_inverse64p's look-ahead entry); *la_sum receives their sums (threads < NB)
+__device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, long long* trc, int nblk, bool look_ahead = false,
+                                                double* la_sum = nullptr) {
   double* S = dag_lds;
   double* M = dag_lds + TILE;
   double* dinv = dag_lds + 2 * TILE;
@@ -602,7 +605,9 @@ __device__ __forceinline__ bool dag_factor_tile(double* g_mail, int* g_early, lo
   double* xch = wt + 3 * 256;                   // vec | yv: not live while a tile is being factored
   int* s_ok = reinterpret_cast<int*>(xch + 2 * NB);
   int* pf = s_ok + 16;                          // 16 hand-off flags of the trailing waves
-  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_mail, g_early, trc, nblk);
+  // (ONE inlined copy serves both entries: with two, each of them came out ~1.5 us slower per tile)
+  return factor_inverse64p(S, M, dinv, wt, xch, s_ok, pf, g_mail, g_early, trc, nblk, look_ahead ? dinv + 256 : nullptr,
+                           look_ahead ? wt : nullptr, la_sum);
 }
 
 }  // namespace
@@ -671,6 +676,9 @@ __device__ __forceinline__ bool mail_here(double v) { return __double_as_longlon
 // ---- the tasks.  Each kind is a function of its own (a real call): inlined into one loop, every path pays the
 // register demand of all of them, and the tile factorisation -- the critical path -- ends up spilling.
 // A task re-derives its descriptors from (ticket) itself; LDS regions come from the dynamic LDS base.
+// (DIAG: the POTRF tasks and the COL tasks are instantiations of their own -- 85 KB of code as one function, more than the
+//  instruction cache two CUs share; the pivot chain runs through the smaller one)
+template <bool DIAG>
 __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
@@ -692,7 +700,8 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
     const FrameDev& fdr = frames[slot];
     const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
-    const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
+    constexpr int type = DIAG ? ND_T_POTRF : ND_T_COL;   // (= w0 >> 24: the caller dispatched on it)
+    const int fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
@@ -732,7 +741,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
   {
       // ================= POTRF(f,s) / COL(f,r,s) ==================================================
       const int r = tr_, s = ts_;
-      const bool diag = type == ND_T_POTRF;
+      constexpr bool diag = DIAG;
       const double u = (u_override >= 0.0 || !diag) ? u_override : lmst->u;   // requested now, used after the updates
       // (stage 0: the children's update tiles and the operand columns c < s-1)
       // the children's contributions to this tile (and to the vector rows of a diagonal tile)
@@ -815,15 +824,44 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
               x4 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, t4[ks], x4, 0, 0, 0);
             }
             accl[kb] = x4;
+            if (kb < 3) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) Xs[(16 * w + lr) + (lk + 4 * rr) * LD] = x4[rr];
-            __syncthreads();
+              for (int rr = 0; rr < 4; ++rr) Xs[(16 * w + lr) + (lk + 4 * rr) * LD] = x4[rr];
+              __syncthreads();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              const double a = -Xs[(16 * w + lr) + (4 * ks + lk) * LD];
+              for (int ks = 0; ks < 4; ++ks) {
+                const double a = -Xs[(16 * w + lr) + (4 * ks + lk) * LD];
 #pragma unroll
-              for (int ni = 0; ni < 4; ++ni)
-                acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
+                for (int ni = 0; ni < 4; ++ni)
+                  acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 * ni + lr) + (4 * ks + lk) * LD], a, acc[ni], 0, 0, 0);
+              }
+            } else {
+              // LAST round, look-ahead layout: X(:, 48..63) goes to blocks of M that hold nothing any more (the row blocks of
+              // L(s-1,s-1) of the earlier rounds: (0,0) (1,0) (2,0) for rows 0..47, (1,1) for rows 48..63) instead of S, so
+              // that nothing below waits for the slowest reader of this strip: wave 0 -- the pivot chain -- updates ITS
+              // diagonal block only and leaves for the factorisation (dag_factor_tile(..., look_ahead)), the others finish
+              // the tile and write rows 16..63 of S behind it.
+              double* xrow = (w < 3) ? M + 16 * w : M + 16 + 16 * LD;      // this wave's 16 rows of the strip
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) xrow[lr + (lk + 4 * rr) * LD] = x4[rr];
+              __syncthreads();
+              if (w == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                  const double x0 = M[lr + (4 * ks + lk) * LD];
+                  acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, -x0, acc[0], 0, 0, 0);
+                }
+              } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                  const double a = -xrow[lr + (4 * ks + lk) * LD];
+#pragma unroll
+                  for (int ni = 0; ni < 4; ++ni) {
+                    const double b = (ni < 3) ? M[(16 * ni + lr) + (4 * ks + lk) * LD] : M[(16 + lr) + (16 + 4 * ks + lk) * LD];
+                    acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(b, a, acc[ni], 0, 0, 0);
+                  }
+                }
+              }
             }
           }
         }
@@ -840,26 +878,46 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
       }
       if (diag) {
         DAG_MARK(4);
-        const double t = dag_reduce_rows(tsum, part);      // (sum_{c<s-1} L(s,c) y_c)[row threadIdx.x & 63]
-        const double bt = bvec - t;                        // threads < NB: right-hand side of row threadIdx.x (minus L(s,s-1) y_{s-1}, below)
+        const bool la = s > 0;                             // look-ahead entry of the factorisation (see the last streamed round)
+        double t;
+        if (!la) {
+          t = dag_reduce_rows(tsum, part);                 // (sum_{c<s-1} L(s,c) y_c)[row threadIdx.x & 63]
+        } else {
+          part[(threadIdx.x >> 6) * NB + (threadIdx.x & 63)] = tsum;   // summed behind the first 16 pivots (dag_factor_tile)
+          t = 0.0;
+        }
         // updated tile -> S: lower triangle, damping on real pivots, identity on the padding rows
+        if (!la || w > 0) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int i = 16 * w + lr, k = 16 * ni + lk + 4 * rr;
+              double x = (i >= k) ? acc[ni][rr] : 0.0;
+              if (i == k) x = (s * NB + i < f.n1) ? x + u : 1.0;
+              S[i + k * LD] = x;
+            }
+        } else {
+          // wave 0: its diagonal block on its own (dinv + 256, ld 16: the mailbox copies there are spent)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const int i = 16 * w + lr, k = 16 * ni + lk + 4 * rr;
-            double x = (i >= k) ? acc[ni][rr] : 0.0;
+            const int i = lr, k = lk + 4 * rr;
+            double x = (i >= k) ? acc[0][rr] : 0.0;
             if (i == k) x = (s * NB + i < f.n1) ? x + u : 1.0;
-            S[i + k * LD] = x;
+            dinv[256 + i + 16 * k] = x;
           }
-        __syncthreads();
+          wave_sync();
+        }
+        if (!la) __syncthreads();
         DAG_MARK(5);
         const bool stream = s + 1 < f.nt;                  // POTRF(s+1) and the column's COL tasks follow the factorisation 16 pivots at a time
         double* linv = fd.flinv + f.linv_off + (size_t)s * TILE;
         const bool ok = dag_factor_tile(stream ? fd.fmail + (size_t)(f.pcol0 + s) * SLM_MAIL_DOUBLES : nullptr,
                                        s > 0 ? g.tile + tile_index(f, s, s - 1) : nullptr,    // L(s, s-1) goes out during the first 16 pivots
                                        trc ? trc + 8 : nullptr,
-                                       min(4, (f.n1 - s * NB + 15) >> 4));   // 16-pivot blocks with real pivots (the front's last column: fewer)
+                                       min(4, (f.n1 - s * NB + 15) >> 4),   // 16-pivot blocks with real pivots (the front's last column: fewer)
+                                       la, &t);
+        const double bt = bvec - t;                        // threads < NB: right-hand side of row threadIdx.x (minus L(s,s-1) y_{s-1}, below)
         DAG_MARK(6);
         if (!ok && threadIdx.x == 0) lmst->chol_fail = 1;
 #pragma unroll
@@ -1347,7 +1405,8 @@ __global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ fr
     const FrameDev& fq = frames[tk % n_frames];
     if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(cut >= 0 ? fq.n_dag_top_tasks : fq.n_dag_tasks)) continue;
     const int type = uni(unip(cut >= 0 ? fq.dag_top_tasks : fq.dag_tasks)[2 * (tk / n_frames)]) >> 24;
-    if (type <= ND_T_COL) dag_task_factor(frames, n_frames, tk, u_override, cut);
+    if (type == ND_T_POTRF) dag_task_factor<true>(frames, n_frames, tk, u_override, cut);
+    else if (type == ND_T_COL) dag_task_factor<false>(frames, n_frames, tk, u_override, cut);
     else if (type == ND_T_SCHUR) dag_task_schur(frames, n_frames, tk, u_override, cut);
     else if (type == ND_T_BACKB) dag_task_backb(frames, n_frames, tk, u_override, cut);
     else dag_task_back(frames, n_frames, tk, u_override, cut);

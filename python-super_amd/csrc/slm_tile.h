@@ -108,13 +108,15 @@ __device__ __forceinline__ double rsq1(double p) {
 //   * S -= W W^T and M -= W Bm for the rows below the block: lane 16q+i holds A[i][k=q] = -W[i][q]
 //     and B[k=q][n=i] = W[i][q] (resp. Bm[q][i]) -- ONE MFMA each, no further data movement.
 // Writes L (lower, zeros above) to Sd (LDS, ld LD) and L^-1 to Dinv (16x16, ld 16).
-__device__ __forceinline__ bool diag16(double* Sd, double* Dinv, double* xch) {
+// (LDD: leading dimension of the block at Sd -- LD inside a tile, 16 for a block staged on its own; a run-time value so
+//  that a caller with both kinds of block keeps ONE copy of this code in its loop)
+__device__ __forceinline__ bool diag16(double* Sd, double* Dinv, double* xch, const int LDD = LD) {
   const int l = threadIdx.x & 63, lc = l & 15, lq = l >> 4;
   double4_t S, M;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lq + 4 * r;
-    S[r] = (row >= lc) ? Sd[row + lc * LD] : Sd[lc + row * LD];   // symmetric from the lower part
+    S[r] = (row >= lc) ? Sd[row + lc * LDD] : Sd[lc + row * LDD];   // symmetric from the lower part
     M[r] = (row == lc) ? 1.0 : 0.0;
   }
   bool ok = true;
@@ -150,7 +152,7 @@ __device__ __forceinline__ bool diag16(double* Sd, double* Dinv, double* xch) {
     const double W = lq == 0 ? w0 : (lq == 1 ? w1 : (lq == 2 ? w2 : w3));
     const double Bm = lq == 0 ? b0 : (lq == 1 ? b1 : (lq == 2 ? b2 : b3));
     const int col = 4 * b + lq;
-    Sd[lc + col * LD] = (lc >= col) ? W : 0.0;        // L[i][4b+q]; zero the strict upper part
+    Sd[lc + col * LDD] = (lc >= col) ? W : 0.0;       // L[i][4b+q]; zero the strict upper part
     Dinv[col + 16 * lc] = (lc <= col) ? Bm : 0.0;     // L^-1[4b+q][n]
     if (b < 3) {
       const double a = (lc > 4 * b + 3) ? -W : 0.0;   // rows of finished blocks stay as they are
@@ -317,15 +319,22 @@ __device__ __forceinline__ void publish_blocks16(const double* S, const double* 
 // nblk (1..4): 16-pivot blocks of the tile that hold real pivots.  The blocks beyond are the identity padding of a front's
 // last pivot tile column (unit diagonal, zero rows): their "factorisation" is known -- the pivot chain skips diag16 for
 // them (1.7 us each on the critical path) and only writes the identity inverse; everything else runs unchanged.
+// LOOK-AHEAD entry (la_blk != nullptr; slm_dag.hip, POTRF(s > 0)): the caller's wave 0 has staged the first 16 x 16 diagonal
+// block on its own (la_blk, ld 16, lower triangle + damping) as soon as ITS rows of the tile were updated, and enters here
+// while the other waves are still writing rows 16..63 of S: there is no barrier in front of the first 16 pivots -- the one
+// behind them (which every wave reaches with its part of S in place) is the first.  Row block 0 of S is never read.
+// la_part (4 x 64 doubles, may alias wt): row partials the caller's waves stored before entering; their sums are
+// returned in *la_sum for the threads of wave 0 -- read right behind the first barrier, before wt is used as scratch.
 __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* dinv, double* wt, double* xch,
                                                   int* s_ok, int* pf, double* g_mail = nullptr, int* g_early = nullptr,
-                                                  long long* trc = nullptr, int nblk = 4) {
+                                                  long long* trc = nullptr, int nblk = 4, double* la_blk = nullptr,
+                                                  const double* la_part = nullptr, double* la_sum = nullptr) {
 #define FTRC(k) do { if (trc && threadIdx.x == 0) trace_put(trc, (k), wall_clock64()); } while (0)
   const int w = threadIdx.x >> 6;
   const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
   if (threadIdx.x < 16) pf[threadIdx.x] = 0;
   if (threadIdx.x == 0) *s_ok = 1;
-  __syncthreads();
+  if (!la_blk) __syncthreads();
   double* Wscr = wt + (w > 0 ? w - 1 : 0) * 256;
   int* vpf = pf;
 #pragma unroll 1   // one copy of diag16: the unrolled form needs ~250 VGPRs and spills on the critical path
@@ -333,7 +342,8 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
     FTRC(3 * kb);
     if (w == 0) {
       if (kb < nblk) {
-        const bool ok = diag16(S + kb * 16 * (LD + 1), dinv + kb * 256, xch);
+        const bool staged = kb == 0 && la_blk;
+        const bool ok = diag16(staged ? la_blk : S + kb * 16 * (LD + 1), dinv + kb * 256, xch, staged ? 16 : LD);
         if (!ok && (threadIdx.x & 63) == 0) *s_ok = 0;
       } else {   // identity block: L = I is in place, its inverse is I
         const int l = threadIdx.x & 63;
@@ -346,7 +356,11 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
       }
       FTRC(3 * kb + 1);
     } else if (kb == 0) {
-      for (int e = threadIdx.x - 64; e < TILE; e += 192) M[e] = 0.0;   // blocks above the diagonal stay zero
+      // the six blocks above the diagonal stay zero (everything else is written below)
+      for (int e = threadIdx.x - 64; e < 6 * 256; e += 192) {
+        const int b = e >> 8, ib = b < 3 ? 0 : (b < 5 ? 1 : 2), jb = b < 3 ? b + 1 : (b < 5 ? b - 1 : 3);
+        M[(16 * ib + (e & 15)) + (16 * jb + ((e >> 4) & 15)) * LD] = 0.0;
+      }
     } else if (kb == 1) {
       lds_wait_all(vpf + 0, 3);                    // panel blocks (1,0) (2,0) (3,0)
       if (w == 1) { blk_trail(S, 2, 1, 0); blk_trail(S, 3, 2, 0); }
@@ -385,6 +399,8 @@ __device__ __forceinline__ bool factor_inverse64p(double* S, double* M, double* 
     if (kb == 0 && g_early) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the caller's earlier stores (see g_early)
     __syncthreads();   // Dinv_kb and L(kb,kb) visible; the trailing work of the previous round is complete
     FTRC(3 * kb + 2);
+    if (kb == 0 && la_part && threadIdx.x < NB)
+      *la_sum = la_part[threadIdx.x] + la_part[NB + threadIdx.x] + la_part[2 * NB + threadIdx.x] + la_part[3 * NB + threadIdx.x];
     if (kb == 3) break;
     // the wave with the least trailing work in the coming round publishes
     if (g_mail && w == (kb == 0 ? 3 : 2)) publish_blocks16(S, dinv, kb, g_mail);
