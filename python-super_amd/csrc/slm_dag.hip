@@ -423,10 +423,11 @@ __device__ __forceinline__ int dag_wait_prefix(const TD& d, const FS& f, const D
 // children's update tiles that map into it -- child 0 first, then child 1: a fixed order, so the sum does not
 // depend on which workgroup ran when.  (The update tiles are complete: their flags are part of the task's stage 0.)
 // VEC (diagonal tiles): bvec (threads < NB, row threadIdx.x of tile row r) += the children's vector rows.
-// maps: 128 ints of LDS (rows | columns).
-// the pull maps of tile (r,s) -- static plan data -- into LDS: [128 k + 0..63] the child's boundary scalar of every tile
-// row, [128 k + 64..127] of every tile column, child k
-__device__ __forceinline__ void dag_pull_maps(const SS& fd, int fi, int r, int s, const int np[2], int* maps) {
+// maps: 256 int2 of LDS per tile: [128 k + 0..63] the rows of tile row r, [128 k + 64..127] the columns of tile column s, child k:
+// .x = the child's boundary scalar that maps there (-1: none), .y = the BYTE offset of that row (resp. column) inside the
+// child's update block -- an entry's address is block + row offset + column offset (one add per gather instead of the
+// tile arithmetic: 1 KB of code per pulled tile instead of 5).  Static plan data, written before the task's wait.
+__device__ __forceinline__ void dag_pull_maps(const SS& fd, int fi, int r, int s, const int np[2], int2* maps) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (np[0] == 0 && np[1] == 0) return;
   __syncthreads();   // earlier readers of maps are done
@@ -435,14 +436,23 @@ __device__ __forceinline__ void dag_pull_maps(const SS& fd, int fi, int r, int s
     if (np[k] == 0) continue;
     const int ch = uni(fd.front_kids[2 * fi + k]);
     const int32_t* pm = fd.pullmap + uni(fd.pull_off[ch]);
-    if (threadIdx.x < 128) maps[128 * k + threadIdx.x] = pm[64 * (w == 0 ? r : s) + l];
+    const int cnpt = uni(fd.fronts[ch].npt), cnt = uni(fd.fronts[ch].nt);
+    if (threadIdx.x < 128) {
+      const int c = pm[64 * (w == 0 ? r : s) + l];
+      int off = 0;
+      if (c >= 0) {
+        const int t = cnpt + (c >> 6);      // tile row / tile column of the child's front
+        off = (w == 0) ? (t * TILE + (c & 63)) * 8 : ((t * cnt - t * (t - 1) / 2 - t) * TILE + (c & 63) * NB) * 8;
+      }
+      maps[128 * k + threadIdx.x] = make_int2(c, off);
+    }
   }
   __syncthreads();
 }
 
 template <bool VEC>
 __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, double4_t acc[4], double& bvec, const int np[2],
-                                         int* maps, bool maps_loaded = false) {
+                                         int2* maps, bool maps_loaded = false) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   if (np[0] == 0 && np[1] == 0) return;
   // both children's maps first (or already in LDS: dag_pull_maps before the task's wait), then ALL gathers in flight
@@ -455,23 +465,24 @@ __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, dou
     for (int e = 0; e < 16; ++e) v[k][e] = 0.0;
     if (np[k] == 0) continue;
     const int ch = uni(fd.front_kids[2 * fi + k]);
-    const FS cf = front_snapshot(fd.fronts[ch]);
-    const double* ct = fd.ftiles + cf.f22_base;   // the child's update tiles live in its boundary block
-    const int* mk = maps + 128 * k;
+    const long long cbase = uni64(fd.fronts[ch].f22_base);   // the child's update tiles live in its boundary block
+    const char* ct = reinterpret_cast<const char*>(fd.ftiles + cbase);
+    const int2* mk = maps + 128 * k;
+    const int2 rw = mk[16 * w + lr];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int ci = mk[16 * w + lr], cj = mk[64 + 16 * ni + lk + 4 * rr];
-        if (ci >= 0 && cj >= 0 && ci >= cj) {
-          const int tr = cf.npt + (ci >> 6), tc = cf.npt + (cj >> 6);
-          const size_t t = (size_t)tc * cf.nt - (size_t)tc * (tc - 1) / 2 + (size_t)(tr - tc);
-          v[k][4 * ni + rr] = ld1(ct + t * TILE + (ci & 63) + (size_t)(cj & 63) * NB);
-        }
+        const int2 cl = mk[64 + 16 * ni + lk + 4 * rr];
+        if (cl.x >= 0 && rw.x >= cl.x) v[k][4 * ni + rr] = ld1(reinterpret_cast<const double*>(ct + (unsigned)(rw.y + cl.y)));
       }
     if (VEC && threadIdx.x < NB) {
-      const int ci = mk[threadIdx.x];
-      if (ci >= 0) bv[k] = ld1(fd.fvec + cf.vec_off + (size_t)cf.npt * NB + ci);
+      const int ci = mk[threadIdx.x].x;
+      if (ci >= 0) {
+        const long long cvec = uni64(fd.fronts[ch].vec_off);
+        const int cnpt = uni(fd.fronts[ch].npt);
+        bv[k] = ld1(fd.fvec + cvec + (size_t)cnpt * NB + ci);
+      }
     }
   }
 #pragma unroll
@@ -692,7 +703,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
   int* s_cnt = s_ok + 3;
-  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  int2* maps = reinterpret_cast<int2*>(dinv);   // 256 int2: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
@@ -1016,7 +1027,7 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
   int* s_cnt = s_ok + 3;
-  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  int2* maps = reinterpret_cast<int2*>(dinv);   // 256 int2: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
@@ -1098,7 +1109,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
   int* s_cnt = s_ok + 3;
-  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  int2* maps = reinterpret_cast<int2*>(dinv);   // 256 int2: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
@@ -1202,7 +1213,7 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
   int* s_cnt = s_ok + 3;
-  int* maps = reinterpret_cast<int*>(dinv);   // 128 ints: pull maps of the tile being loaded (not live in a factorisation)
+  int2* maps = reinterpret_cast<int2*>(dinv);   // 256 int2: pull maps of the tile being loaded (not live in a factorisation)
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
