@@ -333,6 +333,9 @@ struct slm_solver {
   int rank = 0, world = 1;      // surfel sharding of every frame (slm_set_shard)
   bool shard_mode = false;      // slm_set_shard was called (world == 1 included): slots carry the exchange buffers
 };
+namespace {
+bool solve_is_task_graph(const slm_solver* s, int n);   // (below: which form of the solver a launch of n frames takes)
+}
 
 // diagnostics (slm_debug_counters): device reallocations and symbolic analyses since the library was loaded
 static std::atomic<long long> g_reallocs{0}, g_realloc_bytes{0}, g_plan_builds{0}, g_plan_reuses{0}, g_plan_fill_hits{0};   // (binds may run on worker threads)
@@ -911,8 +914,11 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
                  all_pairs.resize(sl.plan_pairs.size() + sl.h_pairs.size());
                  all_pairs.resize(std::set_union(sl.plan_pairs.begin(), sl.plan_pairs.end(), sl.h_pairs.begin(),
                                                  sl.h_pairs.end(), all_pairs.begin()) - all_pairs.begin());
+                 // (a solver that runs its launches as one task graph -- at most two slots, or solver_path 2 -- takes the
+                 //  larger leaves: SLM_ND_LEAF_LATENCY, slm_nd.h)
                  return nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), all_pairs.data(),
-                                      (int)all_pairs.size(), sl.nd);
+                                      (int)all_pairs.size(), sl.nd,
+                                      solve_is_task_graph(s, (int)s->slots.size()) ? SLM_ND_LEAF_LATENCY : SLM_ND_LEAF);
                }()) {
       sl.nd_valid = false;
       ++g_plan_builds;

@@ -15,6 +15,11 @@
 #include <vector>
 
 #define SLM_ND_LEAF 18   // stop bisecting at this many nodes (18 x 7 = 126 scalars: two 64-wide tiles)
+// ... and for a solver that runs the whole tree as ONE persistent task graph (one or two frames per launch: the drop-in
+// case): fewer, larger leaves -- a leaf's six pivot columns chain inside one front at ~14 us each, while every tree level
+// saved is a ~13 us transition (last column -> boundary rows -> update tiles -> the parent's gather) off the critical path.
+// C2, one frame per launch, ms per LM iteration at 18 / 30 / 42 / 50 / 60 / 72 nodes: 0.888 / 0.859 / 0.846 / 0.840 / 0.851 / 0.861.
+#define SLM_ND_LEAF_LATENCY 50
 
 // One front, device + host view.  Local node positions: [0,nv) pivots (elimination order),
 // [nv, nv+nb) boundary (ancestor separator nodes, elimination order).  Scalar layout:
@@ -142,8 +147,9 @@ struct NDPlanHost {
 
 // Host symbolic analysis.  pairs: unique coupled node pairs key = a*J + b (a >= b) of the data
 // term; ed_knn: (J,K_ED); pts: (J,3).  Returns false when the graph cannot be handled.
+// leaf_nodes: stop bisecting at this many nodes (0: SLM_ND_LEAF); the environment variable SLM_ND_LEAF overrides both (tests).
 bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, const uint32_t* pairs,
-                   int n_pairs, NDPlanHost& out);
+                   int n_pairs, NDPlanHost& out, int leaf_nodes = 0);
 
 // Destination of the 7x7 block of node pair key = a*J + b (a >= b) in an existing plan.  Also succeeds for
 // pairs the plan was NOT built from when the later-eliminated node lies in the front of the earlier one

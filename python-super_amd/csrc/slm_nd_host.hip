@@ -26,6 +26,7 @@ struct Builder {
   std::vector<TreeNode> tree;
   std::vector<char> side;   // scratch: 1 = A, 2 = B
   std::vector<int> idx_scratch;   // scratch: index of a node inside its boundary layer
+  int leaf_max = SLM_ND_LEAF;     // stop bisecting at this many nodes
   static bool use_cover() {
     static const bool on = [] {
       const char* e = getenv("SLM_ND_COVER");
@@ -38,10 +39,6 @@ struct Builder {
     const int id = (int)tree.size();
     tree.emplace_back();
     tree[id].depth = depth;
-    static const int leaf_max = [] {
-      const char* e = getenv("SLM_ND_LEAF");
-      return e ? atoi(e) : SLM_ND_LEAF;
-    }();
     if ((int)nodes.size() <= leaf_max) {
       tree[id].vars = nodes;
       return id;
@@ -160,9 +157,14 @@ inline int round64(int x) { return (x + 63) / 64 * 64; }
 }  // namespace
 
 bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, const uint32_t* pairs,
-                   int n_pairs, NDPlanHost& out) {
+                   int n_pairs, NDPlanHost& out, int leaf_nodes) {
   if (J < 1) return false;
   Builder b;
+  static const int leaf_env = [] {
+    const char* e = getenv("SLM_ND_LEAF");
+    return e ? atoi(e) : 0;
+  }();
+  b.leaf_max = leaf_env > 0 ? leaf_env : (leaf_nodes > 0 ? leaf_nodes : SLM_ND_LEAF);
   b.J = J;
   b.pts = pts;
   b.side.assign(J, 0);

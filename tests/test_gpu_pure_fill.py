@@ -46,7 +46,8 @@ def test_pure_fill_tiles_change_nothing_bitwise(monkeypatch, form):
     on, off = out[True][2], out[False][2]
     assert on["pivot_tiles"] == off["pivot_tiles"] > 0
     assert off["pure_fill_tiles"] == 0
-    assert 0.2 * on["pivot_tiles"] < on["pure_fill_tiles"] < 0.7 * on["pivot_tiles"]     # (C1: a third of the tiles; C2: 41 %)
+    # (C1: a third of the tiles with the throughput plan, C2: 41 %; fewer with the task-graph solver's larger leaves -- a leaf has no children)
+    assert 0.05 * on["pivot_tiles"] < on["pure_fill_tiles"] < 0.7 * on["pivot_tiles"]
     for a, b in zip(out[True][0], out[False][0]):
         np.testing.assert_array_equal(a, b)
     assert out[True][1] == out[False][1]
