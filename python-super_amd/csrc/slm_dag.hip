@@ -499,10 +499,12 @@ __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, dou
 // one tile when ra == rb) with tile-linear, fully coalesced sc1 loads, and the next column's tiles are in
 // flight (registers) under the MFMAs.  VEC (needs ra == rb): also tsum += (L(ra,c) y_c)[row threadIdx.x & 63] over
 // the 16 inner columns of this thread's quarter; y_c is read from the front's vector.
+// The front's LAST pivot tile column only counts up to its true pivots (blocks of 16: the padding columns of L are zero).
 template <bool VEC>
 __device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra, int rb, int c0, int c1,
                                                double4_t acc[4], double* Bl, double* Al, double* yv, double& tsum) {
   if (c0 >= c1) return;
+  const int kb_last = min(4, (f.n1 - NB * (f.npt - 1) + 15) >> 4);   // 16-column blocks with true pivots in column npt - 1
   const bool two = ra != rb;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   double breg[16], areg[16];
@@ -522,13 +524,20 @@ __device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra
       if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
     }
     __syncthreads();
+    const int kblk = (c == f.npt - 1) ? kb_last : 4;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const double a = -Ar[(16 * w + lr) + (4 * ks + lk) * LD];
+    for (int kb = 0; kb < 4; ++kb) {
+      if (kb < kblk) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const double bv = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
-        acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, a, acc[ni], 0, 0, 0);
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const int ks = 4 * kb + k4;
+          const double a = -Ar[(16 * w + lr) + (4 * ks + lk) * LD];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const double bv = Bl[(16 * ni + lr) + (4 * ks + lk) * LD];
+            acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, a, acc[ni], 0, 0, 0);
+          }
+        }
       }
     }
     if (VEC) {
