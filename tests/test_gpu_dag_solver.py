@@ -257,3 +257,29 @@ def test_an_aborted_task_graph_stops_every_unfinished_slot_of_a_large_batch():
     eng.run(B)
     assert all(r["status"] == _lib.SLM_ITER_OK for i in range(B) for r in eng.records(i))
     eng.close()
+
+
+def test_leaf_size_follows_the_solver_form_and_changes_nothing_but_the_plan():
+    """Round 5: a solver that runs its launches as ONE task graph (at most two slots, or solver_path 2) dissects down to
+    50-node leaves (SLM_ND_LEAF_LATENCY), the per-level / hybrid forms to 18 (SLM_ND_LEAF): fewer, larger fronts -- and the
+    same iterations (the elimination order is not part of the result: 1e-9 on beta, accept sequence equal), both against the
+    oracle.  The look-ahead entry of the tile factorisation (POTRF(s > 0)) runs in every task-graph solve of this file."""
+    from super_amd import synth
+    sc = synth.make_scene(N=20000, J=400, H=240, W=320, seed=77, src_border=8, tgt_border=4, dphi=0.2)
+    out = {}
+    for name, kw in (("graph1", dict(max_frames=1)), ("levels8", dict(max_frames=8, solver_path=3)), ("graph8", dict(max_frames=8, solver_path=2))):
+        e = _engine(**kw)
+        e.bind(0, _dframe(sc))
+        e.run(1)
+        out[name] = (e.beta(0).cpu().numpy(), e.records(0), e.plan_info(0))
+        e.close()
+    assert out["graph1"][2]["fronts"] < out["levels8"][2]["fronts"]          # larger leaves: fewer fronts, fewer levels
+    assert out["graph1"][2]["levels"] <= out["levels8"][2]["levels"]
+    assert out["graph8"][2]["fronts"] == out["graph1"][2]["fronts"]          # solver_path 2 is a task graph at any slot count
+    ob = orc.lm(orc.Frame.from_scene(sc), orc.default_opt())
+    for name in out:
+        b, r, _ = out[name]
+        assert all(x["status"] == 0 for x in r)
+        assert [x["accepted"] for x in r] == [x["accepted"] for x in out["levels8"][1]]
+        np.testing.assert_allclose(b, out["levels8"][0], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(b, ob, rtol=0, atol=1e-6)
