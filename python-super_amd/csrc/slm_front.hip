@@ -714,19 +714,30 @@ __device__ __forceinline__ double* item_tile(const FrameDev& fd, const NDTileIte
 }
 // maps -> LDS: [128 k + 0..63] child k's boundary scalar of every row of tile row r, [128 k + 64..127] of tile row c.
 // Needs a __syncthreads() before the first use (the callers have one on their way).
-__device__ __forceinline__ void pull_maps(const FrameDev& fd, const NDTileItem& it, int* maps) {
+// maps: 256 int2 of LDS: [128 k + 0..63] the rows of the item's tile row, [128 k + 64..127] the columns of its tile column, child k:
+// .x = the child's boundary scalar that maps there (-1: none), .y = the offset (in doubles) of that row (resp. column) inside the
+// child's update block -- an entry's address is block + row offset + column offset: one add per gathered entry instead of
+// the tile arithmetic (the same layout as the task graph's pull maps, slm_dag.hip)
+__device__ __forceinline__ void pull_maps(const FrameDev& fd, const NDTileItem& it, int2* maps) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (it.kid[k].front >= 0 && threadIdx.x < 128) {
       const int32_t* pm = fd.pullmap + it.kid[k].pull_off;
-      maps[128 * k + threadIdx.x] = pm[64 * (threadIdx.x < 64 ? it.r : it.c) + (threadIdx.x & 63)];
+      const bool row = threadIdx.x < 64;
+      const int c = pm[64 * (row ? it.r : it.c) + (threadIdx.x & 63)];
+      int off = 0;
+      if (c >= 0) {
+        const int t = it.kid[k].npt + (c >> 6);      // tile row / tile column of the child's front
+        off = row ? t * TILE + (c & 63) : (t * it.kid[k].nt - t * (t - 1) / 2 - t) * TILE + (c & 63) * NB;
+      }
+      maps[128 * k + threadIdx.x] = make_int2(c, off);
     }
   }
 }
 // acc (the item's tile in accumulator layout: wave w rows 16w.., see load_c_frags) += the children's entries.  All 16
 // gathers of a child are in flight together; the sum order is child 0, then child 1.  (One child at a time, fenced
 // for the instruction scheduler: both children's 32 values in flight cost 64 more registers.)
-__device__ __forceinline__ void pull_tile(const FrameDev& fd, const NDTileItem& it, const int* maps, double4_t acc[4]) {
+__device__ __forceinline__ void pull_tile(const FrameDev& fd, const NDTileItem& it, const int2* maps, double4_t acc[4]) {
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -734,24 +745,20 @@ __device__ __forceinline__ void pull_tile(const FrameDev& fd, const NDTileItem& 
     __builtin_amdgcn_sched_barrier(0);   // (the 16 gather addresses are formed here, not hoisted above the caller's barrier)
     double v[16];
     const double* ct = fd.ftiles + it.kid[k].f22_base;
-    const int cnt = it.kid[k].nt, cnpt = it.kid[k].npt;
-    const int* mk = maps + 128 * k;
-    const int ci = mk[16 * w + lr];
+    const int2* mk = maps + 128 * k;
+    const int2 rw = mk[16 * w + lr];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int cj = mk[64 + 16 * ni + lk + 4 * rr];
+        const int2 cl = mk[64 + 16 * ni + lk + 4 * rr];
         // The maps are monotone (a front lists its nodes in elimination order, and so does its parent): an entry of the
         // parent's lower triangle comes from the child's lower triangle.  ci < cj only occurs above the diagonal of a
         // diagonal tile, which nothing reads.
         // (branch-free: an entry nothing maps into reads the child's first word and drops it -- 16 loads back to back
         //  instead of 16 predicated branches with one load each)
-        const bool ok = ci >= 0 && cj >= 0 && ci >= cj;
-        const int tr = cnpt + (ci >> 6), tc = cnpt + (cj >> 6);
-        const int t = tc * cnt - tc * (tc - 1) / 2 + (tr - tc);
-        const int off = ok ? t * TILE + (ci & 63) + (cj & 63) * NB : 0;
-        const double x = ct[off];
+        const bool ok = cl.x >= 0 && rw.x >= cl.x;
+        const double x = ct[ok ? rw.y + cl.y : 0];
         v[4 * ni + rr] = ok ? x : 0.0;
       }
     __builtin_amdgcn_sched_barrier(0);
@@ -763,13 +770,13 @@ __device__ __forceinline__ void pull_tile(const FrameDev& fd, const NDTileItem& 
   }
 }
 // the children's boundary vector rows that map into tile row r of the front (threads < NB: row threadIdx.x)
-__device__ __forceinline__ double pull_vec(const FrameDev& fd, const NDTileItem& it, const int* maps) {
+__device__ __forceinline__ double pull_vec(const FrameDev& fd, const NDTileItem& it, const int2* maps) {
   double s = 0.0;
   if (threadIdx.x < NB) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (it.kid[k].front < 0) continue;
-      const int ci = maps[128 * k + threadIdx.x];
+      const int ci = maps[128 * k + threadIdx.x].x;
       if (ci >= 0) s += fd.fvec[it.kid[k].vec_boundary + ci];
     }
   }
@@ -1055,7 +1062,7 @@ __global__ void __launch_bounds__(256) k_ftrail(const FrameDev* __restrict__ fra
 // grid = (pull items of the level x frames, rounded to 8)
 __global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ frames, int level, int n_items, int items_at,
                                                 int n_frames) {
-  __shared__ int maps[256];
+  __shared__ int2 maps[256];
   const FrameDev* fdp;
   const NDTileItem* itp = tile_item(frames, level, 1, n_items, items_at, n_frames, fdp);
   if (!itp) return;
@@ -1111,7 +1118,7 @@ __global__ void __launch_bounds__(256) k_fpull(const FrameDev* __restrict__ fram
 __global__ void __launch_bounds__(256, 3) k_fschur(const FrameDev* __restrict__ frames, int level, int n_items,
                                                  int items_at, int n_frames) {
   __shared__ __attribute__((aligned(16))) double Bl[TILE];
-  __shared__ int maps[256];
+  __shared__ int2 maps[256];
   const FrameDev* fdp;
   const NDTileItem* itp = tile_item(frames, level, 0, n_items, items_at, n_frames, fdp);
   if (!itp) return;
