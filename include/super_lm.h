@@ -89,7 +89,8 @@ typedef struct slm_config {
                                used when J >= 65536); 2 = MFMA assembly with one Gram per run in HBM */
   int32_t solver_path;      /* 0..4, anything else is rejected by slm_create.  0 = nested-dissection multifrontal Cholesky (default, needs data_path 0); its numeric
                                phase runs as ONE persistent launch over a static task graph (per-tile flags instead
-                               of launch boundaries: the latency form) for one or two frames per launch, and as one
+                               of launch boundaries: the latency form) for small launches (one or two frames, or frames x nodes
+                               <= 8 000: three or four frames of 2 000 nodes, eight of 512), and as one
                                launch per level / tile column / phase for larger batches (the throughput form),
                                with the top of the tree (the root front and its children: a chain of dependent tile
                                columns) as a task graph over all frames when the frames' trees have the same depth

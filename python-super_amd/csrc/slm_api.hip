@@ -318,7 +318,8 @@ struct slm_solver {
   double drain_est_ms = 0.0;          // how long that wait took last time
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
-  bool hybrid_batches = true;   // solver_path 0, batches of >= 3 frames: per-level launches + task graph for the top levels
+  bool hybrid_batches = true;   // solver_path 0, larger batches: per-level launches + task graph for the top levels
+  long dag_max_nodes = 8000;    // solver_path 0: launches of at most this many frames x nodes run as ONE task graph (SLM_DAG_MAX_NODES)
   bool pure_fill = true;        // SLM_PURE_FILL=0 (tests): every pivot-column tile is zeroed and read-modify-written, as in rounds 1-4
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
@@ -334,7 +335,7 @@ struct slm_solver {
   bool shard_mode = false;      // slm_set_shard was called (world == 1 included): slots carry the exchange buffers
 };
 namespace {
-bool solve_is_task_graph(const slm_solver* s, int n);   // (below: which form of the solver a launch of n frames takes)
+bool solve_is_task_graph(const slm_solver* s, int n, int J);   // (below: which form of the solver a launch of n frames of J nodes takes)
 }
 
 // diagnostics (slm_debug_counters): device reallocations and symbolic analyses since the library was loaded
@@ -528,6 +529,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
     return SLM_ERR_HIP;
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
+  if (const char* dm = getenv("SLM_DAG_MAX_NODES")) s->dag_max_nodes = atol(dm);   // experiments / tests
   if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
   if (const char* pf = getenv("SLM_PURE_FILL")) s->pure_fill = atoi(pf) != 0;     // tests: differential check of the pure-fill tiles
   *out = s;
@@ -918,7 +920,7 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
                  //  larger leaves: SLM_ND_LEAF_LATENCY, slm_nd.h)
                  return nd_build_plan(f->J, f->K_ED, sl.h_pts.data(), sl.h_knn.data(), all_pairs.data(),
                                       (int)all_pairs.size(), sl.nd,
-                                      solve_is_task_graph(s, (int)s->slots.size()) ? SLM_ND_LEAF_LATENCY : SLM_ND_LEAF);
+                                      solve_is_task_graph(s, (int)s->slots.size(), f->J) ? SLM_ND_LEAF_LATENCY : SLM_ND_LEAF);
                }()) {
       sl.nd_valid = false;
       ++g_plan_builds;
@@ -1352,17 +1354,21 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
 // per-level launches (solver_path 0)
 // solver_path 0 picks by batch size: the task graph is a latency scheduler (one or two frames per launch: the
 // drop-in case, one frame at a time); larger batches are throughput-bound and run the per-level launches
-static bool solve_is_task_graph(const slm_solver* s, int n) {
-  return s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && n <= 2);
+// Round 5 (two workgroups per CU in the task graph): "small" is frames x nodes, not frames -- the task graph wins while its
+// tasks find workgroups.  C2 (2 000 nodes), ms per LM iteration, task graph / hybrid: 3 frames 1.290 / 1.481, 4 frames
+// 1.549 / 1.654, 6 frames 2.124 / 2.063, 8 frames 2.754 / 2.409; C1 (512 nodes) 8 frames 0.605 / 0.755; C4 (4 000 nodes)
+// 1 frame 1.396 / 1.753, 4 frames 3.510 / 3.330.
+static bool solve_is_task_graph(const slm_solver* s, int n, int J) {
+  return s->cfg.solver_path == 2 || (s->cfg.solver_path == 0 && (n <= 2 || (long)n * J <= s->dag_max_nodes));
 }
 static bool solve_is_hybrid(const slm_solver* s, int n, const BatchDims& d) {
-  return !solve_is_task_graph(s, n) && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
+  return !solve_is_task_graph(s, n, d.maxP / 7) && (s->cfg.solver_path == 4 || (s->cfg.solver_path == 0 && s->hybrid_batches)) &&
          d.hybrid_cut >= 0 && d.hybrid_levels == (int)d.sched.size() && d.hybrid_cut + 1 < d.hybrid_levels;
 }
 // what this batch's solve needs reset before its task-graph launch (k_iter_begin_nd's dag_cut): -1 the whole tree, >= 0 the
 // fronts of depth <= the hybrid cut, -2 nothing (per-level launches only)
 static int dag_cut_of(const slm_solver* s, int n, const BatchDims& d) {
-  if (solve_is_task_graph(s, n)) return -1;
+  if (solve_is_task_graph(s, n, d.maxP / 7)) return -1;
   return solve_is_hybrid(s, n, d) ? d.hybrid_cut : -2;
 }
 // dag_reset_done: this iteration's k_iter_begin_nd already reset the task graph's flags / mailboxes (launched with
@@ -1370,7 +1376,7 @@ static int dag_cut_of(const slm_solver* s, int n, const BatchDims& d) {
 // dag_check_later: the caller's next launch (k_after_solve) settles a timed-out task-graph launch instead of k_dag_check
 void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st,
                          bool dag_reset_done = false, bool dag_check_later = false) {
-  const bool dag = solve_is_task_graph(s, n);
+  const bool dag = solve_is_task_graph(s, n, d.maxP / 7);
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
   const bool hybrid = solve_is_hybrid(s, n, d);

@@ -1405,7 +1405,7 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
 
 // cut < 0: the whole tree (fd.dag_tasks).  cut >= 0: only the fronts of depth <= cut (fd.dag_top_tasks); the deeper
 // levels are factored before and back-substituted after this launch by the per-level kernels (slm_front.hip).
-__global__ void __launch_bounds__(256, 1) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
+__global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
                                                  double u_override, int cut) {
   int* s_ok = reinterpret_cast<int*>(dag_lds + 2 * TILE + 7 * 256 + 2 * NB);
   int* s_task = s_ok + 1;
@@ -1482,8 +1482,10 @@ void launch_dag_abort_check(const FrameDev* fr, int n_frames, hipStream_t st) {
 hipError_t set_dag_timeout_ticks(long long ticks) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_dag_timeout_ticks), &ticks, sizeof(ticks));
 }
-// (a workgroup of this kernel owns its CU -- one wave per SIMD with most of the register file; tickets make any grid size
-//  deadlock-free)
+// (TWO workgroups per CU since round 5 -- 248 VGPRs, 2 x 81 088 B of LDS: the bottom of the tree and the Schur tasks of a
+//  batch are short of workgroups, not of registers: C2 one frame per launch 0.830 -> 0.804 ms per LM iteration, eight frames
+//  2.462 -> 2.445; the build limited to 256 registers is itself 1 % faster at one workgroup per CU -- less scratch in the
+//  task functions' prologues.  Tickets make any grid size deadlock-free)
 void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut, bool reset, bool check) {
   if (max_tasks <= 0) return;
   const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
@@ -1499,7 +1501,7 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("SLM_DAG_WG_PER_CU");
-    const int per_cu = e ? atoi(e) : 1;
+    const int per_cu = e ? atoi(e) : 2;
     n_wg = cus * (per_cu > 0 ? per_cu : 1);
     if (tracked) n_wg_dev[dev].store(n_wg, std::memory_order_release);
   }

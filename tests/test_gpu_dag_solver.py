@@ -106,9 +106,10 @@ def test_c2_full_size_task_graph_solver():
 
 
 def test_hybrid_form_on_a_batch_equals_level_launches():
-    """batches of >= 3 frames whose trees have the same depth: per-level launches for the levels with many fronts,
-    the top of the tree as tasks of one persistent launch over all frames (solver_path 4, and what solver_path 0
-    picks) -- same iterations as the pure per-level form, different plans per frame"""
+    """batches whose trees have the same depth: per-level launches for the levels with many fronts, the top of the tree
+    as tasks of one persistent launch over all frames (solver_path 4, and what solver_path 0 picks for LARGE batches;
+    this one -- 4 frames x 400 nodes -- it runs as one task graph: frames x nodes <= SLM_DAG_MAX_NODES) -- same
+    iterations as the pure per-level form, different plans per frame"""
     from super_amd import synth
     scenes = [synth.make_scene(N=20000, J=400, H=240, W=320, seed=70 + k, src_border=8, tgt_border=4, dphi=0.15 + 0.05 * k)
               for k in range(4)]
@@ -118,7 +119,7 @@ def test_hybrid_form_on_a_batch_equals_level_launches():
         e.bind_batch([_dframe(sc) for sc in scenes])
         e.run(4)
         form = e.lib.slm_debug_last_solver_form(e.h)
-        assert form == {3: 0, 4: 2, 0: 2}[sp], (sp, form)
+        assert form == {3: 0, 4: 2, 0: 1}[sp], (sp, form)
         out[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(4)]
     for sp in (4, 0):
         for i in range(4):
@@ -160,22 +161,25 @@ def test_hybrid_form_failure_stops_like_the_reference():
 
 
 def test_c2_full_size_hybrid_batch():
-    """BASELINE C2 x 3 frames (different plans): the hybrid form solver_path 0 picks for a batch == per-level launches"""
+    """BASELINE C2 x 3 frames (different plans): the hybrid form (solver_path 4) and what solver_path 0 picks for this
+    batch -- one task graph over the three frames (3 x 2 000 nodes <= SLM_DAG_MAX_NODES; two workgroups per CU since
+    round 5) -- == per-level launches"""
     from super_amd import synth
     scenes = [synth.make_scene(seed=s, **synth.WORKLOADS["C2"]) for s in range(3)]
     res = {}
-    for sp in (3, 0):
+    for sp in (3, 4, 0):
         e = _engine(max_frames=3, solver_path=sp)
         e.bind_batch([_dframe(sc) for sc in scenes])
         e.run(3)
-        assert e.lib.slm_debug_last_solver_form(e.h) == (0 if sp == 3 else 2)
+        assert e.lib.slm_debug_last_solver_form(e.h) == {3: 0, 4: 2, 0: 1}[sp]
         res[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(3)]
         e.close()
-    for i in range(3):
-        assert all(r["status"] == 0 for r in res[0][i][1])
-        np.testing.assert_allclose([r["loss"] for r in res[0][i][1]], [r["loss"] for r in res[3][i][1]], rtol=1e-9)
-        assert [r["accepted"] for r in res[0][i][1]] == [r["accepted"] for r in res[3][i][1]]
-        np.testing.assert_allclose(res[0][i][0], res[3][i][0], rtol=0, atol=1e-9)
+    for sp in (4, 0):
+        for i in range(3):
+            assert all(r["status"] == 0 for r in res[sp][i][1])
+            np.testing.assert_allclose([r["loss"] for r in res[sp][i][1]], [r["loss"] for r in res[3][i][1]], rtol=1e-9)
+            assert [r["accepted"] for r in res[sp][i][1]] == [r["accepted"] for r in res[3][i][1]]
+            np.testing.assert_allclose(res[sp][i][0], res[3][i][0], rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("top_fronts", ["1", "4", "16"])

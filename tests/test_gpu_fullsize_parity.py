@@ -80,13 +80,15 @@ def test_c2_three_iterations_match_the_oracle_one_frame_per_launch(solver_path, 
     assert err < 1e-7          # observed ~1e-11: anything near the bar would be a defect
 
 
-def test_c2_three_frame_batch_hybrid_form_matches_the_oracle():
-    """What bench.py runs: a batch (>= 3 frames) under solver_path 0 takes the hybrid form."""
+@pytest.mark.parametrize("solver_path,form", [(4, 2), (0, 1)])
+def test_c2_three_frame_batch_matches_the_oracle(solver_path, form):
+    """A batch of three C2 frames: the hybrid form (what bench.py's 8 frames take under solver_path 0) and what
+    solver_path 0 picks for three -- one task graph over the batch (frames x nodes <= SLM_DAG_MAX_NODES)."""
     seeds = (0, 1, 2)
-    eng = _engine(num_iterations=3, max_frames=3)
+    eng = _engine(num_iterations=3, max_frames=3, solver_path=solver_path)
     eng.bind_batch([_dframe(_scene("C2", s)) for s in seeds])
     eng.run(3)
-    assert eng.lib.slm_debug_last_solver_form(eng.h) == 2
+    assert eng.lib.slm_debug_last_solver_form(eng.h) == form
     for i, s in enumerate(seeds):
         want, trace = _oracle("C2", s, 3)
         err = _check_against_oracle(eng.records(i), eng.beta(i).cpu().numpy(), want, trace, f"C2 B=3 slot {i}")
