@@ -586,7 +586,9 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     {
       static const int top_fronts = [] {
         const char* e = getenv("SLM_DAG_TOP_FRONTS");
-        return e && atoi(e) > 0 ? atoi(e) : 2;
+        // (2 through round 4; with two workgroups per CU in the task graph the 4-front level pays as tasks too: C2, 8 frames,
+        //  ms per LM iteration at 2 / 4 / 8 fronts per level: 2.448 / 2.397 / 2.429)
+        return e && atoi(e) > 0 ? atoi(e) : 4;
       }();
       int max_depth = 0;
       for (int i = 0; i < T; ++i) max_depth = std::max(max_depth, (int)out.fronts[i].depth);
