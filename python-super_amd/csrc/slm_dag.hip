@@ -122,6 +122,7 @@ struct SS {   // scalar snapshot of the slot's buffers
   const NDFront* fronts;
   int n_fronts;
   const uint8_t* tile_kind;   // FrameDev::tile_kind (only the factor tasks read it)
+  bool cached_ops;            // XCD-affine launch: operand tiles through the XCD's L2 (load_tile_regs2)
 };
 
 struct DagFlags {
@@ -233,9 +234,21 @@ __device__ __forceinline__ void load_tile_regs1(const double* __restrict__ T, do
 // the address path, not the memory, is the limit).  The language has no 16-byte atomic load, so these are buffer loads
 // with the same cache policy as ld1 (sc1: L1 and the non-coherent L2 bypassed); they follow the task's flag wait in
 // program order (a workgroup barrier with its fence stands between), which is all a hand-off needs.  T is uniform.
-__device__ __forceinline__ void load_tile_regs2(const double* T, double r[16]) {
+// cached (uniform): an OPERAND tile -- final, written by a task of the SAME frame -- in an XCD-affine launch (k_fdag): every task
+// of the frame runs on one XCD, whose L2 saw the tile's write-through stores; a plain load shares the tile among the frame's
+// tasks through that L2 instead of fetching it from HBM once per task.
+__device__ __forceinline__ void load_tile_regs2(const double* T, double r[16], bool cached = false) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T), 0, TILE * 8, 0x00020000);
+  if (cached) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * threadIdx.x + 4096 * e, 0, 0);
+      r[2 * e] = __hiloint2double(q.y, q.x);
+      r[2 * e + 1] = __hiloint2double(q.w, q.z);
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * threadIdx.x + 4096 * e, 0, 1 << 4 /* sc1 */);
@@ -474,7 +487,11 @@ __device__ __forceinline__ void dag_pull(const SS& fd, int fi, int r, int s, dou
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int2 cl = mk[64 + 16 * ni + lk + 4 * rr];
-        if (cl.x >= 0 && rw.x >= cl.x) v[k][4 * ni + rr] = ld1(reinterpret_cast<const double*>(ct + (unsigned)(rw.y + cl.y)));
+        if (cl.x >= 0 && rw.x >= cl.x) {
+          const double* src = reinterpret_cast<const double*>(ct + (unsigned)(rw.y + cl.y));
+          // (XCD-affine launch: the child's update tiles were written by tasks of this frame on this XCD, or by a launch before)
+          v[k][4 * ni + rr] = fd.cached_ops ? *(const gdouble*)src : ld1(src);
+        }
       }
     if (VEC && threadIdx.x < NB) {
       const int ci = mk[threadIdx.x].x;
@@ -508,8 +525,8 @@ __device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra
   const bool two = ra != rb;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   double breg[16], areg[16];
-  load_tile_regs2(tile_ptr(fd, f, rb, c0), breg);
-  if (two) load_tile_regs2(tile_ptr(fd, f, ra, c0), areg);
+  load_tile_regs2(tile_ptr(fd, f, rb, c0), breg, fd.cached_ops);
+  if (two) load_tile_regs2(tile_ptr(fd, f, ra, c0), areg, fd.cached_ops);
   double ynext = 0.0;
   if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)c0 * NB + threadIdx.x);
   const double* Ar = two ? Al : Bl;
@@ -519,8 +536,8 @@ __device__ __forceinline__ void dag_accumulate(const SS& fd, const FS& f, int ra
     if (two) store_tile_lds2(Al, areg);
     if (VEC && threadIdx.x < NB) yv[threadIdx.x] = ynext;
     if (c + 1 < c1) {
-      load_tile_regs2(tile_ptr(fd, f, rb, c + 1), breg);
-      if (two) load_tile_regs2(tile_ptr(fd, f, ra, c + 1), areg);
+      load_tile_regs2(tile_ptr(fd, f, rb, c + 1), breg, fd.cached_ops);
+      if (two) load_tile_regs2(tile_ptr(fd, f, ra, c + 1), areg, fd.cached_ops);
       if (VEC && threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
     }
     __syncthreads();
@@ -555,8 +572,8 @@ __device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s
   if (c0 >= c1) return;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   double breg[16], areg[16];
-  load_tile_regs2(tile_ptr(fd, f, s, c0), breg);
-  load_tile_regs2(tile_ptr(fd, f, s - 1, c0), areg);
+  load_tile_regs2(tile_ptr(fd, f, s, c0), breg, fd.cached_ops);
+  load_tile_regs2(tile_ptr(fd, f, s - 1, c0), areg, fd.cached_ops);
   double ynext = 0.0;
   if (threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)c0 * NB + threadIdx.x);
   for (int c = c0; c < c1; ++c) {
@@ -565,8 +582,8 @@ __device__ __forceinline__ void dag_accumulate2(const SS& fd, const FS& f, int s
     store_tile_lds2(Al, areg);
     if (threadIdx.x < NB) yv[threadIdx.x] = ynext;
     if (c + 1 < c1) {
-      load_tile_regs2(tile_ptr(fd, f, s, c + 1), breg);
-      load_tile_regs2(tile_ptr(fd, f, s - 1, c + 1), areg);
+      load_tile_regs2(tile_ptr(fd, f, s, c + 1), breg, fd.cached_ops);
+      load_tile_regs2(tile_ptr(fd, f, s - 1, c + 1), areg, fd.cached_ops);
       if (threadIdx.x < NB) ynext = ld1(fd.fvec + f.vec_off + (size_t)(c + 1) * NB + threadIdx.x);
     }
     __syncthreads();
@@ -699,7 +716,7 @@ __device__ __forceinline__ bool mail_here(double v) { return __double_as_longlon
 // (DIAG: the POTRF tasks and the COL tasks are instantiations of their own -- 85 KB of code as one function, more than the
 //  instruction cache two CUs share; the pivot chain runs through the smaller one)
 template <bool DIAG>
-__device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
+__device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames, int n_frames, int slot, int ti, double u_override, int cut, int mode) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -716,13 +733,13 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
-    const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
     const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     constexpr int type = DIAG ? ND_T_POTRF : ND_T_COL;   // (= w0 >> 24: the caller dispatched on it)
     const int fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
+    fd.cached_ops = (mode & 1) != 0;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
@@ -797,7 +814,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
             dag_accumulate<true>(fd, f, s, s, clast, clast + 1, acc, S, M, yv, tsum);       // leaves L(s,c) in S
             if (!dag_wait_deps(d, f, g, d.n0 + 3 * clast + 2, d.n0 + 3 * clast + 3, abort_flag, s_abort)) return;   // L(s-1,c)
             double areg[16];
-            load_tile_regs2(tile_ptr(fd, f, s - 1, clast), areg);
+            load_tile_regs2(tile_ptr(fd, f, s - 1, clast), areg, fd.cached_ops);
             store_tile_lds2(M, areg);
             __syncthreads();
 #pragma unroll
@@ -1023,7 +1040,7 @@ __device__ __noinline__ void dag_task_factor(const FrameDev* __restrict__ frames
   }
 }
 
-__device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
+__device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames, int n_frames, int slot, int ti, double u_override, int cut, int mode) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -1040,12 +1057,12 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
-    const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
     const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
+    fd.cached_ops = (mode & 1) != 0;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
@@ -1105,7 +1122,7 @@ __device__ __noinline__ void dag_task_schur(const FrameDev* __restrict__ frames,
   }
 }
 
-__device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
+__device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames, int n_frames, int slot, int ti, double u_override, int cut, int mode) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -1122,12 +1139,12 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
-    const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
     const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
+    fd.cached_ops = (mode & 1) != 0;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
@@ -1209,7 +1226,7 @@ __device__ __noinline__ void dag_task_backb(const FrameDev* __restrict__ frames,
   }
 }
 
-__device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, int n_frames, int tk, double u_override, int cut) {
+__device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, int n_frames, int slot, int ti, double u_override, int cut, int mode) {
   double* lds = dag_lds;
   double* S = lds;                 // tile being factored / B operand staging
   double* M = lds + TILE;          // inverse of the factored tile / second staging tile
@@ -1226,12 +1243,12 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
   int* abort_flag = unip(frames[0].dag_flags) + 1;
   (void)s_task; (void)S; (void)M; (void)dinv; (void)vec; (void)yv; (void)part; (void)maps; (void)s_cnt; (void)l; (void)w; (void)lr; (void)lk;
-    const int slot = tk % n_frames, ti = tk / n_frames;
     const FrameDev& fdr = frames[slot];
     const int32_t* tasks = unip(cut >= 0 ? fdr.dag_top_tasks : fdr.dag_tasks);
     const int w0 = uni(tasks[2 * ti]), w1 = uni(tasks[2 * ti + 1]);
     const int type = w0 >> 24, fi = w0 & 0xFFFFFF, tr_ = w1 >> 8, ts_ = w1 & 255;
     SS fd;
+    fd.cached_ops = (mode & 1) != 0;
     fd.ftiles = unip(fdr.ftiles); fd.fvec = unip(fdr.fvec); fd.flinv = unip(fdr.flinv); fd.fmail = unip(fdr.fmail); fd.delta = unip(fdr.delta);
     fd.nd_nodes = unip(fdr.nd_nodes); fd.front_kids = unip(fdr.front_kids); fd.pull_off = unip(fdr.pull_off);
     fd.pullmap = unip(fdr.pullmap); fd.prng_off = unip(fdr.prng_off); fd.prng = unip(fdr.prng);
@@ -1405,32 +1422,46 @@ __device__ __noinline__ void dag_task_back(const FrameDev* __restrict__ frames, 
 
 // cut < 0: the whole tree (fd.dag_tasks).  cut >= 0: only the fronts of depth <= cut (fd.dag_top_tasks); the deeper
 // levels are factored before and back-substituted after this launch by the per-level kernels (slm_front.hip).
+// mode bit 0: XCD-AFFINE launch (n_frames a multiple of 8; the hybrid's top at 8 frames per launch): the workgroups of XCD x
+// serve the frames x, x + 8, ... from a ticket stream of their own (the ticket word of frame x), so every task of a frame
+// runs on ONE XCD and the frame's final operand tiles are shared through that XCD's L2 (load_tile_regs2(..., cached)) instead
+// of being fetched from HBM by every task that multiplies with them.  Frames are independent: a task still waits on
+// smaller tickets of its own stream only.
 __global__ void __launch_bounds__(256, 2) k_fdag(const FrameDev* __restrict__ frames, int n_frames, int max_tasks,
-                                                 double u_override, int cut) {
+                                                 double u_override, int cut, int mode) {
   int* s_ok = reinterpret_cast<int*>(dag_lds + 2 * TILE + 7 * 256 + 2 * NB);
   int* s_task = s_ok + 1;
   int* s_abort = s_ok + 2;
   const FrameDev& fd0 = frames[0];
   if (!fd0.bound || !fd0.nd_ready) return;
-  int* ticket = unip(fd0.dag_flags);
+  const bool affine = (mode & 1) != 0;
+  const int xcc = affine ? (__builtin_amdgcn_s_getreg(63508) & 7) : 0;      // hwreg(HW_REG_XCC_ID)
+  const int per = affine ? n_frames / 8 : n_frames;                          // frames served by this ticket stream
+  int* ticket = unip(affine ? frames[xcc].dag_flags : fd0.dag_flags);
   if (threadIdx.x == 0) *s_abort = 0;
   __syncthreads();
-  const int total = n_frames * max_tasks;
+  const int total = per * max_tasks;
   for (;;) {
     if (threadIdx.x == 0) *s_task = addf(ticket, 1);
     __syncthreads();
     const int tk = uni(*s_task);   // provably uniform: descriptors stay in SGPRs
     __syncthreads();
     if (tk >= total || uni(*s_abort)) break;
-    const FrameDev& fq = frames[tk % n_frames];
-    if (!uni(fq.bound) || !uni(fq.nd_ready) || tk / n_frames >= uni(cut >= 0 ? fq.n_dag_top_tasks : fq.n_dag_tasks)) continue;
-    const int type = uni(unip(cut >= 0 ? fq.dag_top_tasks : fq.dag_tasks)[2 * (tk / n_frames)]) >> 24;
-    if (type == ND_T_POTRF) dag_task_factor<true>(frames, n_frames, tk, u_override, cut);
-    else if (type == ND_T_COL) dag_task_factor<false>(frames, n_frames, tk, u_override, cut);
-    else if (type == ND_T_SCHUR) dag_task_schur(frames, n_frames, tk, u_override, cut);
-    else if (type == ND_T_BACKB) dag_task_backb(frames, n_frames, tk, u_override, cut);
-    else dag_task_back(frames, n_frames, tk, u_override, cut);
+    const int slot = affine ? xcc + 8 * (tk % per) : tk % per, ti = tk / per;
+    const FrameDev& fq = frames[slot];
+    if (!uni(fq.bound) || !uni(fq.nd_ready) || ti >= uni(cut >= 0 ? fq.n_dag_top_tasks : fq.n_dag_tasks)) continue;
+    const int type = uni(unip(cut >= 0 ? fq.dag_top_tasks : fq.dag_tasks)[2 * ti]) >> 24;
+    if (type == ND_T_POTRF) dag_task_factor<true>(frames, n_frames, slot, ti, u_override, cut, mode);
+    else if (type == ND_T_COL) dag_task_factor<false>(frames, n_frames, slot, ti, u_override, cut, mode);
+    else if (type == ND_T_SCHUR) dag_task_schur(frames, n_frames, slot, ti, u_override, cut, mode);
+    else if (type == ND_T_BACKB) dag_task_backb(frames, n_frames, slot, ti, u_override, cut, mode);
+    else dag_task_back(frames, n_frames, slot, ti, u_override, cut, mode);
   }
+}
+
+// how many XCDs do the workgroups of a launch land on (HW_REG_XCC_ID)?  one bit per id seen
+__global__ void k_xcc_probe(unsigned* mask) {
+  if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg(63508) & 31));
 }
 
 // zero the flags of slots [0, n_frames) (ticket, abort, counters, tile / column flags) and empty the mailboxes of the
@@ -1510,7 +1541,26 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
   if (reset) hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);
-  hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut);
+  // XCD-affine ticket streams (k_fdag): the hybrid's top at a multiple of 8 frames per launch, on a device whose launches
+  // land on exactly the XCD ids 0..7 (probed once per device: a partitioned device must not wait for XCDs it does not have)
+  static std::atomic<int> xcd8_dev[64];   // 0 unknown, 1 yes, 2 no
+  int xcd8 = tracked ? xcd8_dev[dev].load(std::memory_order_acquire) : 2;
+  if (xcd8 == 0) {
+    static const bool off = [] { const char* e = getenv("SLM_DAG_XCD"); return e && atoi(e) == 0; }();
+    xcd8 = 2;
+    unsigned* d_mask = nullptr;
+    unsigned h_mask = 0;
+    if (!off && hipMalloc((void**)&d_mask, sizeof(unsigned)) == hipSuccess) {
+      if (hipMemset(d_mask, 0, sizeof(unsigned)) == hipSuccess) {
+        hipLaunchKernelGGL(k_xcc_probe, dim3(4096), dim3(64), 0, 0, d_mask);
+        if (hipMemcpy(&h_mask, d_mask, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && h_mask == 0xFFu) xcd8 = 1;
+      }
+      (void)hipFree(d_mask);
+    }
+    if (tracked) xcd8_dev[dev].store(xcd8, std::memory_order_release);
+  }
+  const int mode = (cut >= 0 && n_frames >= 8 && n_frames % 8 == 0 && xcd8 == 1 && grid == n_wg) ? 1 : 0;
+  hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut, mode);
   // (check = false: the caller's next launch settles an aborted launch itself -- k_after_solve, slm_reg.hip)
   if (check) hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
 }
