@@ -1559,7 +1559,7 @@ void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, dou
     }
     if (tracked) xcd8_dev[dev].store(xcd8, std::memory_order_release);
   }
-  const int mode = (cut >= 0 && n_frames >= 8 && n_frames % 8 == 0 && xcd8 == 1 && grid == n_wg) ? 1 : 0;
+  const int mode = (n_frames >= 8 && n_frames % 8 == 0 && xcd8 == 1 && grid == n_wg) ? 1 : 0;
   hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut, mode);
   // (check = false: the caller's next launch settles an aborted launch itself -- k_after_solve, slm_reg.hip)
   if (check) hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);

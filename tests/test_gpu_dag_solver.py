@@ -287,3 +287,30 @@ def test_leaf_size_follows_the_solver_form_and_changes_nothing_but_the_plan():
         assert [x["accepted"] for x in r] == [x["accepted"] for x in out["levels8"][1]]
         np.testing.assert_allclose(b, out["levels8"][0], rtol=0, atol=1e-9)
         np.testing.assert_allclose(b, ob, rtol=0, atol=1e-6)
+
+
+def test_eight_frames_as_one_task_graph_on_xcd_affine_ticket_streams():
+    """Round 5: at a multiple of 8 frames per launch every XCD serves the tasks of 'its' frames from a ticket stream of its
+    own (k_fdag mode bit 0): all tasks of a frame on one XCD, operand tiles and gathered update tiles through that XCD's L2.
+    8 frames x 400 nodes run as ONE task graph under solver_path 0 (frames x nodes <= SLM_DAG_MAX_NODES); same iterations
+    as the per-level launches, different plans per frame."""
+    from super_amd import synth
+    scenes = [synth.make_scene(N=20000, J=400, H=240, W=320, seed=120 + k, src_border=8, tgt_border=4, dphi=0.1 + 0.03 * k)
+              for k in range(8)]
+    frames = [_dframe(sc) for sc in scenes]
+    out = {}
+    for sp in (3, 0, 4):
+        e = _engine(max_frames=8, solver_path=sp)
+        e.bind_batch(frames)
+        e.run(8)
+        assert e.lib.slm_debug_last_solver_form(e.h) == {3: 0, 0: 1, 4: 2}[sp]
+        out[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(8)]
+        e.close()
+    for sp in (0, 4):
+        for i in range(8):
+            b0, r0 = out[3][i]
+            b, r = out[sp][i]
+            assert all(x["status"] == 0 for x in r)
+            np.testing.assert_allclose([x["loss"] for x in r], [x["loss"] for x in r0], rtol=1e-10)
+            assert [x["accepted"] for x in r] == [x["accepted"] for x in r0]
+            np.testing.assert_allclose(b, b0, rtol=0, atol=1e-10)
