@@ -512,14 +512,26 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
         }
         return t;
       };
-      double st_prev = 0.0;
-      for (int s = 0; s < f.npt; ++s) {
+      // Order inside a front: POTRF(0), POTRF(1), COL(., 0), POTRF(2), COL(., 1), ... -- the NEXT column's chain task is listed
+      // before this column's row solves (round 5).  It needs nothing from them (column s + 1 reads the columns <= s - 1 and
+      // follows the factor of column s through its mailbox), and listed behind them it takes its ticket only when a workgroup
+      // comes free: with several frames per launch a column's ~13 COL tasks per front hold the workgroups while they wait
+      // for the factor, the next POTRF starts when they are done, and its 15-30 us of own work (gathers, earlier columns) run
+      // AFTER the factor it should have followed instead of beside it (C2, 8 frames: 20-40 us per column against 14.4).
+      // The keys are made non-decreasing along this order so that the stable sort below keeps it.
+      double st_prev = 0.0, last_key = 0.0;
+      auto push = [&](double key, int32_t w0, int32_t w1) {   // returns the key the task got: the times derived from it stay consistent
+        last_key = std::max(last_key, key);
+        tasks.push_back({last_key, w0, w1});
+        return last_key;
+      };
+      auto potrf = [&](int s) {
         // POTRF(s) also owns the tile (s, s-1) left of the diagonal one: its row solve needs nothing but the
         // factor of column s-1, and its result feeds the update of (s,s) without leaving the workgroup
         double st = std::max(pulled(s, s), st_prev);
         if (s > 0) st = std::max(st, pulled(s, s - 1));
         for (int c = 0; c + 1 < s; ++c) st = std::max(st, std::max(done[tix(s, c)], done[tix(s - 1, c)]) + HOP);
-        tasks.push_back({st, (ND_T_POTRF << 24) | i, (s << 8) | s});
+        st = push(st, (ND_T_POTRF << 24) | i, (s << 8) | s);
         st_prev = st;
         double ready_at = st + 1.5 + 0.8 * s;
         if (s > 0) {
@@ -527,12 +539,19 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
           done[tix(s, s - 1)] = ready_at;
         }
         done[tix(s, s)] = ready_at + d_potrf(0);
+        return st;
+      };
+      std::vector<double> st_of(f.npt + 1, 0.0);
+      if (f.npt > 0) st_of[0] = potrf(0);
+      for (int s = 0; s < f.npt; ++s) {
+        if (s + 1 < f.npt) st_of[s + 1] = potrf(s + 1);
+        const double st = st_of[s];
         for (int r = s + 1; r < f.nt; ++r) {
           if (r == s + 1 && r < f.npt) continue;             // tile (s+1, s) belongs to POTRF(s+1)
           double sr = std::max(pulled(r, s), st);   // never listed before the POTRF it waits for
           for (int c = 0; c < s; ++c) sr = std::max(sr, std::max(done[tix(r, c)], done[tix(s, c)]) + HOP);
+          sr = push(sr, (ND_T_COL << 24) | i, (r << 8) | s);
           const double fin = std::max(sr + 1.5 + 0.8 * s, done[tix(s, s)] + HOP) + 2.5;
-          tasks.push_back({sr, (ND_T_COL << 24) | i, (r << 8) | s});
           done[tix(r, s)] = fin;
         }
       }
@@ -544,7 +563,7 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
           for (int sc = f.npt; sc <= r; ++sc) {
             double st = pulled(r, sc);
             for (int c = 0; c < f.npt; ++c) st = std::max(st, std::max(done[tix(r, c)], done[tix(sc, c)]) + HOP);
-            tasks.push_back({st, (ND_T_SCHUR << 24) | i, (r << 8) | sc});
+            st = push(st, (ND_T_SCHUR << 24) | i, (r << 8) | sc);
             done[tix(r, sc)] = st + d_schur(f.npt);
           }
       }

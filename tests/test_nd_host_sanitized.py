@@ -25,6 +25,8 @@ DRIVER = textwrap.dedent('''
                          len(pairs), out, fr.ctypes.data_as(C.c_void_p), 8192, None)
         assert n >= 1, (J, n)
         assert sum(int(f[1]) for f in fr[:n]) == J, "every node is a pivot of exactly one front"
+        rc = lib.nd_check_orders(J, K, pts.ctypes.data_as(C.c_void_p), knn.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p), len(pairs))
+        assert rc == 0, ("task list is not a valid ticket order (a task precedes something it waits for)", J, rc)
         return n
     run(1, 4, np.zeros((1, 3)), np.zeros((1, 4), np.int32), np.array([0]))
     run(2, 1, rng.normal(size=(2, 3)), np.array([[1], [0]]), np.array([0, 2, 3]))
