@@ -543,10 +543,12 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       };
       std::vector<double> st_of(f.npt + 1, 0.0);
       if (f.npt > 0) st_of[0] = potrf(0);
-      for (int s = 0; s < f.npt; ++s) {
-        if (s + 1 < f.npt) st_of[s + 1] = potrf(s + 1);
+      // ... and the BOUNDARY rows of a column (only the Schur tasks read them) one column later than its pivot rows (which the
+      // following chain tasks read): listed with them they hold ~10 workgroups per front idle until the column's factor
+      // is out; a column later that factor exists and they only work.
+      auto cols = [&](int s, int r0, int r1) {
         const double st = st_of[s];
-        for (int r = s + 1; r < f.nt; ++r) {
+        for (int r = r0; r < r1; ++r) {
           if (r == s + 1 && r < f.npt) continue;             // tile (s+1, s) belongs to POTRF(s+1)
           double sr = std::max(pulled(r, s), st);   // never listed before the POTRF it waits for
           for (int c = 0; c < s; ++c) sr = std::max(sr, std::max(done[tix(r, c)], done[tix(s, c)]) + HOP);
@@ -554,7 +556,15 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
           const double fin = std::max(sr + 1.5 + 0.8 * s, done[tix(s, s)] + HOP) + 2.5;
           done[tix(r, s)] = fin;
         }
+      };
+      static const int defer_boundary = [] { const char* e = getenv("SLM_DAG_DEFER_BOUNDARY"); return e ? atoi(e) : 2; }();   // columns of delay (0: none; C2, 8 frames, ms per LM iteration at 0 / 1 / 2 / all: 2.342 / 2.320 / 2.323 vs 2.335 / 2.334)
+      for (int s = 0; s < f.npt; ++s) {
+        if (s + 1 < f.npt) st_of[s + 1] = potrf(s + 1);
+        cols(s, s + 1, defer_boundary > 0 ? f.npt : f.nt);       // pivot rows of column s (all rows without the deferral)
+        if (defer_boundary > 0 && s >= defer_boundary) cols(s - defer_boundary, f.npt, f.nt);   // boundary rows of an earlier column
       }
+      if (defer_boundary > 0)
+        for (int s = std::max(0, f.npt - defer_boundary); s < f.npt; ++s) cols(s, f.npt, f.nt);
       double fd_ = 0.0;
       for (int s = 0; s < f.npt; ++s) fd_ = std::max(fd_, done[tix(s, s)]);
       fact_done[i] = fd_;
