@@ -543,9 +543,9 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       };
       std::vector<double> st_of(f.npt + 1, 0.0);
       if (f.npt > 0) st_of[0] = potrf(0);
-      // ... and the BOUNDARY rows of a column (only the Schur tasks read them) one column later than its pivot rows (which the
+      // ... and the BOUNDARY rows of a column (only the Schur tasks read them) two columns later than its pivot rows (which the
       // following chain tasks read): listed with them they hold ~10 workgroups per front idle until the column's factor
-      // is out; a column later that factor exists and they only work.
+      // is out; later that factor exists and they only work.
       auto cols = [&](int s, int r0, int r1) {
         const double st = st_of[s];
         for (int r = r0; r < r1; ++r) {
