@@ -314,3 +314,44 @@ def test_eight_frames_as_one_task_graph_on_xcd_affine_ticket_streams():
             np.testing.assert_allclose([x["loss"] for x in r], [x["loss"] for x in r0], rtol=1e-10)
             assert [x["accepted"] for x in r] == [x["accepted"] for x in r0]
             np.testing.assert_allclose(b, b0, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("env", [{"SLM_DAG_XCD": "0"}, {"SLM_DAG_WG_PER_CU": "1"}, {"SLM_DAG_DEFER_BOUNDARY": "0"},
+                                 {"SLM_DAG_DEFER_BOUNDARY": "9"}, {"SLM_DAG_MAX_NODES": "0"},
+                                 {"SLM_DAG_XCD": "0", "SLM_DAG_WG_PER_CU": "1", "SLM_DAG_DEFER_BOUNDARY": "0", "SLM_DAG_TOP_FRONTS": "2"}])
+def test_task_graph_switches_of_round_5_keep_the_result(env):
+    """The round-5 switches of the task graph (read once per process, hence the subprocess): no XCD-affine ticket streams,
+    one workgroup per CU, the boundary rows of a column listed with / far behind its pivot rows, no frames x nodes rule (the
+    hybrid form for a small batch), and the round-4 settings together -- 8 frames of different plans under solver_path 0 and
+    4, four iterations, against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{root!r}, {os.path.join(root, 'python-super_amd')!r}, {os.path.join(root, 'tests')!r}]\n"
+        "import torch\n"
+        "from oracle import lm_oracle as orc\n"
+        "from super_amd import synth\n"
+        "from super_amd.engine import DeviceFrame, Engine\n"
+        "dev = torch.device('cuda', 0)\n"
+        "scs = [synth.make_scene(N=20000, J=400, H=240, W=320, seed=140 + k, src_border=8, tgt_border=4, dphi=0.1 + 0.02 * k) for k in range(8)]\n"
+        "want = [orc.lm(orc.Frame.from_scene(sc), orc.default_opt(num_optimize_iterations=4)) for sc in scs[:2]]\n"
+        "res = []\n"
+        "for sp in (0, 4):\n"
+        "    e = Engine(dev, max_frames=8, solver_path=sp, num_iterations=4)\n"
+        "    e.bind_batch([DeviceFrame.from_scene(sc, dev) for sc in scs])\n"
+        "    e.run(8)\n"
+        "    ok = all(r['status'] == 0 for i in range(8) for r in e.records(i))\n"
+        "    err = max(float(np.abs(e.beta(i).cpu().numpy() - want[i]).max()) for i in range(2))\n"
+        "    res.append((e.lib.slm_debug_last_solver_form(e.h), ok, err))\n"
+        "    e.close()\n"
+        "print('RES', res[0][0], res[1][0], int(res[0][1] and res[1][1]), max(res[0][2], res[1][2]))\n")
+    full = dict(os.environ)
+    full.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=full, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    f0, f4, ok, err = out.stdout.strip().splitlines()[-1].split()[1:]
+    assert int(f0) == (2 if env.get("SLM_DAG_MAX_NODES") == "0" else 1) and int(f4) == 2, (env, f0, f4)
+    assert int(ok) == 1 and float(err) < 1e-6, (env, ok, err)
