@@ -83,7 +83,12 @@ typedef struct slm_config {
   int32_t use_data;         /* opt.sf_point_plane */
   int32_t use_arap;         /* opt.mesh_arap */
   int32_t use_rot;          /* opt.mesh_rot */
-  int32_t max_frames;       /* number of slots (>= 1) */
+  int32_t max_frames;       /* number of slots (>= 1).  Performance note (results do not depend on it): the symbolic plan of
+                             * a slot is built for the solver form this slot count implies -- a solver whose max_frames x J
+                             * fits ONE task-graph launch (<= 8 000 frames x nodes, or <= 2 slots) dissects down to 50-node
+                             * leaves, any other to 18-node leaves -- and cached plans keep the leaf size they were built
+                             * with, whatever n_frames a later slm_run passes.  Create the solver with the slot count it
+                             * will be run with. */
   int32_t data_path;        /* 0 = tuple-sorted MFMA assembly, node-pair blocks merged per workgroup in
                                LDS (default); 1 = per-entry f64 atomics (simple cross-check path, also
                                used when J >= 65536); 2 = MFMA assembly with one Gram per run in HBM */
@@ -633,6 +638,9 @@ int slm_graph_init_semantic(int32_t H, int32_t W, int32_t step, const uint8_t* v
  * launches, 1 = task graph (one persistent launch), 2 = hybrid (per-level launches below, task graph for the top of
  * the tree), -1 = none yet (block-banded path or nothing run). */
 int slm_debug_last_solver_form(slm_solver* s);
+/* Mode word of the last task-graph launch (k_fdag) this solver enqueued: bit 0 = XCD-affine ticket streams (a multiple of
+ * 8 frames per launch on a device whose launches land on the XCD ids 0..7); -1 = the last solve ran no task graph. */
+int slm_debug_last_dag_mode(slm_solver* s);
 int slm_debug_counters(int64_t out[4]);
 /* Diagnostics: copies a solver work buffer of the slot to HOST memory (synchronises `stream`): what = 0 front
  * tiles, 1 front vectors, 2 inverses of the diagonal factor blocks, 3 delta.  *n_doubles receives the buffer's

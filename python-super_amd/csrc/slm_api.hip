@@ -30,7 +30,9 @@ void launch_reg_grad_nd(const FrameDev*, int, int, int, double, int, double, hip
 void launch_front_load_rhs(const FrameDev*, int, int, hipStream_t);
 void launch_iter_begin_nd(const FrameDev*, int, hipStream_t, const int* reuse, int dag_cut);
 void launch_front_solve(const FrameDev*, int, const NDLevelSched*, int, double, hipStream_t);
-void launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut, bool reset, bool check);
+int launch_front_solve_dag(const FrameDev*, int, int, double, hipStream_t, int cut, bool reset, bool check);
+int dag_device_setup(int dev, int* xcd8_out);
+int dag_last_mode();
 void launch_after_solve(const FrameDev*, int, int, int, int, double, int, double, int, hipStream_t);
 hipError_t set_dag_timeout_ticks(long long);
 void launch_dag_abort_check(const FrameDev*, int, hipStream_t);
@@ -317,6 +319,7 @@ struct slm_solver {
   hipEvent_t drain_event = nullptr;   // slm_bind_frames' wait for the caller's stream (polled, see there)
   double drain_est_ms = 0.0;          // how long that wait took last time
   int last_solver_form = -1;    // diagnostics: 0 per-level launches, 1 task graph, 2 hybrid (slm_debug_last_solver_form)
+  int last_dag_mode = -1;       // diagnostics: mode word of the last task-graph launch (bit 0: XCD-affine), -1 none (slm_debug_last_dag_mode)
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, larger batches: per-level launches + task graph for the top levels
   long dag_max_nodes = 8000;    // solver_path 0: launches of at most this many frames x nodes run as ONE task graph (SLM_DAG_MAX_NODES)
@@ -372,6 +375,7 @@ extern "C" {
 const char* slm_last_error(void) { return g_err.c_str(); }
 
 int slm_debug_last_solver_form(slm_solver* s) { return s ? s->last_solver_form : -1; }
+int slm_debug_last_dag_mode(slm_solver* s) { return s ? s->last_dag_mode : -1; }
 
 int slm_debug_counters(int64_t out[4]) {
   if (!out) return fail(SLM_ERR_INVALID, "slm_debug_counters: null output");
@@ -527,6 +531,11 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
     g_err = std::string("slm_create: ") + hipGetErrorString(e);
     slm_destroy(s);
     return SLM_ERR_HIP;
+  }
+  {   // per-device set-up of the task-graph launch (LDS attribute, workgroup count, XCD probe): here, not inside an LM iteration
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)dag_device_setup(dev, nullptr);
   }
   if (const char* hb = getenv("SLM_HYBRID")) s->hybrid_batches = atoi(hb) != 0;   // experiments
   if (const char* dm = getenv("SLM_DAG_MAX_NODES")) s->dag_max_nodes = atol(dm);   // experiments / tests
@@ -1374,24 +1383,29 @@ static int dag_cut_of(const slm_solver* s, int n, const BatchDims& d) {
 // dag_reset_done: this iteration's k_iter_begin_nd already reset the task graph's flags / mailboxes (launched with
 // dag_cut_of(...)); otherwise launch_front_solve_dag resets them with a launch of its own
 // dag_check_later: the caller's next launch (k_after_solve) settles a timed-out task-graph launch instead of k_dag_check
-void enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st,
-                         bool dag_reset_done = false, bool dag_check_later = false) {
+// Returns the mode word of the task-graph launch (bit 0: XCD-affine ticket streams -- the caller's completion check must then
+// be unconditional, launch_front_solve_dag), -1 when the solve ran no task graph.
+int enqueue_front_solve(slm_solver* s, const FrameDev* fr, int n, const BatchDims& d, double u_override, hipStream_t st,
+                        bool dag_reset_done = false, bool dag_check_later = false) {
   const bool dag = solve_is_task_graph(s, n, d.maxP / 7);
   // batches: the levels with many fronts as launches (throughput-bound), the top of the tree -- a chain of ~20
   // dependent tile columns with a handful of fronts -- as tasks of ONE persistent launch for all frames
   const bool hybrid = solve_is_hybrid(s, n, d);
   s->last_solver_form = dag ? 1 : (hybrid ? 2 : 0);
+  int mode = -1;
   if (dag) {
-    launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1, !dag_reset_done, !dag_check_later);
+    mode = launch_front_solve_dag(fr, n, d.max_tasks, u_override, st, -1, !dag_reset_done, !dag_check_later);
   } else if (hybrid) {
     const int n_levels = (int)d.sched.size(), l_cut = n_levels - 1 - d.hybrid_cut;
     launch_front_levels(fr, n, d.sched.data(), n_levels, l_cut, 0, u_override, st);
     // the task graph: the fronts above the cut, then the back substitution of the WHOLE tree (the list dag_top_tasks
     // ends with the BACKB / BACK tasks of the deeper fronts -- 24 small per-level launches, 0.25 ms at C2, otherwise)
-    launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut, !dag_reset_done, !dag_check_later);
+    mode = launch_front_solve_dag(fr, n, d.max_top_tasks, u_override, st, d.hybrid_cut, !dag_reset_done, !dag_check_later);
   } else {
     launch_front_solve(fr, n, d.sched.data(), (int)d.sched.size(), u_override, st);
   }
+  s->last_dag_mode = mode;
+  return mode;
 }
 
 // zero the fronts of slots [first, first+n) and assemble JtJ / jtl into them
@@ -1631,11 +1645,12 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   mark();
   // the trial point beta + delta (node_pk_try), the regularisers' loss there and the task graph's abort check: one launch
   const bool tail = c.use_data || d.n_reg_part > 0;
-  if (d.nd) enqueue_front_solve(s, fr, n, d, -1.0, st, true, tail);
+  int dag_mode = -1;
+  if (d.nd) dag_mode = enqueue_front_solve(s, fr, n, d, -1.0, st, true, tail);
   else launch_band_solve(fr, n, d.nt_max, d.wb_cap, -1.0, st);
-  if (tail)
+  if (tail)   // (dag_check 2 behind an XCD-affine task-graph launch: the completion check runs whether or not the abort flag is up)
     launch_after_solve(fr, n, c.use_data ? d.maxP / 7 : 0, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot,
-                       (d.nd && dag_cut_of(s, n, d) >= -1) ? 1 : 0, st);
+                       (d.nd && dag_cut_of(s, n, d) >= -1) ? ((dag_mode > 0 && (dag_mode & 1)) ? 2 : 1) : 0, st);
   mark();
   if (c.use_data) {
     if (d.v1) launch_data_eval(fr, n, kLossBlocks, c.w_data, 0, st);   // the loss pass; its {r, c} feed the next Jacobian pass

@@ -1484,10 +1484,11 @@ __global__ void __launch_bounds__(256) k_dag_reset(const FrameDev* __restrict__ 
 // slot whose solve did not finish -- a front whose BACK task never published its solution -- with its own status
 // (chol_fail = 2 -> SLM_ITER_SOLVER_TIMEOUT, not "ill-posed system"); slots that were complete keep their result.
 // One workgroup per slot: grid = (n_frames).
-__global__ void __launch_bounds__(64) k_dag_check(const FrameDev* __restrict__ frames, int n_frames) {
+// always: an XCD-affine launch (launch_front_solve_dag) -- the check runs whether or not the abort flag is up.
+__global__ void __launch_bounds__(64) k_dag_check(const FrameDev* __restrict__ frames, int n_frames, int always) {
   const FrameDev& fd0 = frames[0];
   if (!fd0.bound || !fd0.nd_ready || !fd0.dag_flags) return;
-  if (fd0.dag_flags[1] == 0) return;
+  if (fd0.dag_flags[1] == 0 && !always) return;
   const FrameDev& fd = frames[blockIdx.x];
   if (!fd.bound || !fd.nd_ready || !fd.dag_flags) return;
   const int* px = fd.dag_flags.get() + 8 + fd.dag_n_tiles + fd.dag_n_pcols;
@@ -1508,59 +1509,83 @@ __global__ void k_dag_raise_abort(const FrameDev* __restrict__ frames) {
 void launch_dag_abort_check(const FrameDev* fr, int n_frames, hipStream_t st) {
   hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, -1);
   hipLaunchKernelGGL(k_dag_raise_abort, dim3(1), dim3(1), 0, st, fr);
-  hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
+  hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames, 0);
 }
 hipError_t set_dag_timeout_ticks(long long ticks) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_dag_timeout_ticks), &ticks, sizeof(ticks));
 }
-// (TWO workgroups per CU since round 5 -- 248 VGPRs, 2 x 81 088 B of LDS: the bottom of the tree and the Schur tasks of a
-//  batch are short of workgroups, not of registers: C2 one frame per launch 0.830 -> 0.804 ms per LM iteration, eight frames
-//  2.462 -> 2.445; the build limited to 256 registers is itself 1 % faster at one workgroup per CU -- less scratch in the
-//  task functions' prologues.  Tickets make any grid size deadlock-free)
-void launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut, bool reset, bool check) {
-  if (max_tasks <= 0) return;
-  const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
-  // per device: the dynamic-LDS attribute is a property of the kernel ON a device, and so is the CU count (host threads
-  // may drive different solvers on one device: atomics; a device id beyond the table is set up on every call)
-  static std::atomic<int> n_wg_dev[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
+// Per-device set-up of the task-graph launch: the dynamic-LDS attribute of k_fdag, the workgroup count (two per CU) and the
+// XCD probe -- do the workgroups of a launch land on exactly the XCD ids 0..7?  A partitioned device must not wait for
+// XCDs it does not have (k_fdag's XCD-affine mode).  slm_create calls this, so the probe (a hipMalloc, a launch on the null
+// stream, a blocking copy, a hipFree) never sits between the launches of an LM iteration; launch_front_solve_dag falls
+// back to it for a device it has not seen (a solver created on one device and driven on another).
+struct DagDevice {
+  std::atomic<int> n_wg{0};    // 0: not set up yet
+  std::atomic<int> xcd8{0};    // 0 unknown, 1 launches land on the XCD ids 0..7, 2 no (or SLM_DAG_XCD=0)
+};
+static DagDevice g_dag_dev[64];
+static std::atomic<int> g_last_dag_mode{-1};
+int dag_device_setup(int dev, int* xcd8_out) {
   const bool tracked = dev >= 0 && dev < 64;
-  int n_wg = tracked ? n_wg_dev[dev].load(std::memory_order_acquire) : 0;
+  int n_wg = tracked ? g_dag_dev[dev].n_wg.load(std::memory_order_acquire) : 0;
+  int xcd8 = tracked ? g_dag_dev[dev].xcd8.load(std::memory_order_acquire) : 2;
   if (n_wg == 0) {
-    if (hipFuncSetAttribute((const void*)k_fdag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;   // (the launch below would fail: hipGetLastError reports it)
+    const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
+    if (hipFuncSetAttribute((const void*)k_fdag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;   // (the launch would fail: hipGetLastError reports it)
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const char* e = getenv("SLM_DAG_WG_PER_CU");
     const int per_cu = e ? atoi(e) : 2;
     n_wg = cus * (per_cu > 0 ? per_cu : 1);
-    if (tracked) n_wg_dev[dev].store(n_wg, std::memory_order_release);
+    if (tracked && xcd8 == 0) {
+      static const bool off = [] { const char* e2 = getenv("SLM_DAG_XCD"); return e2 && atoi(e2) == 0; }();
+      xcd8 = 2;
+      unsigned* d_mask = nullptr;
+      unsigned h_mask = 0;
+      if (!off && hipMalloc((void**)&d_mask, sizeof(unsigned)) == hipSuccess) {
+        if (hipMemset(d_mask, 0, sizeof(unsigned)) == hipSuccess) {
+          hipLaunchKernelGGL(k_xcc_probe, dim3(4096), dim3(64), 0, 0, d_mask);
+          if (hipMemcpy(&h_mask, d_mask, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && h_mask == 0xFFu) xcd8 = 1;
+        }
+        (void)hipFree(d_mask);
+      }
+      g_dag_dev[dev].xcd8.store(xcd8, std::memory_order_release);
+    }
+    if (tracked) g_dag_dev[dev].n_wg.store(n_wg, std::memory_order_release);
   }
+  if (xcd8_out) *xcd8_out = xcd8;
+  return n_wg;
+}
+int dag_last_mode() { return g_last_dag_mode.load(std::memory_order_relaxed); }
+
+// (TWO workgroups per CU since round 5 -- 248 VGPRs, 2 x 81 088 B of LDS: the bottom of the tree and the Schur tasks of a
+//  batch are short of workgroups, not of registers: C2 one frame per launch 0.830 -> 0.804 ms per LM iteration, eight frames
+//  2.462 -> 2.445; the build limited to 256 registers is itself 1 % faster at one workgroup per CU -- less scratch in the
+//  task functions' prologues.  Tickets make any grid size deadlock-free)
+// Returns the launch's mode word (bit 0: XCD-affine ticket streams), -1 when nothing was launched.
+int launch_front_solve_dag(const FrameDev* fr, int n_frames, int max_tasks, double u_override, hipStream_t st, int cut, bool reset, bool check) {
+  if (max_tasks <= 0) return -1;
+  const size_t lds = DAG_LDS_DOUBLES * sizeof(double);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int xcd8 = 2;
+  const int n_wg = dag_device_setup(dev, &xcd8);
+  if (n_wg <= 0) return -1;
   // reset = false: the flags and mailboxes were reset by this iteration's k_iter_begin_nd (launch_iter_begin_nd(..., dag_cut):
   // slm_run's loop); true: by a launch of their own here (the host-driven sharded loop, slm_solve)
   if (reset) hipLaunchKernelGGL(k_dag_reset, dim3(64, n_frames), dim3(256), 0, st, fr, cut);
   const long total = (long)n_frames * max_tasks;
   const int grid = (int)(total < n_wg ? total : n_wg);
   // XCD-affine ticket streams (k_fdag): the hybrid's top at a multiple of 8 frames per launch, on a device whose launches
-  // land on exactly the XCD ids 0..7 (probed once per device: a partitioned device must not wait for XCDs it does not have)
-  static std::atomic<int> xcd8_dev[64];   // 0 unknown, 1 yes, 2 no
-  int xcd8 = tracked ? xcd8_dev[dev].load(std::memory_order_acquire) : 2;
-  if (xcd8 == 0) {
-    static const bool off = [] { const char* e = getenv("SLM_DAG_XCD"); return e && atoi(e) == 0; }();
-    xcd8 = 2;
-    unsigned* d_mask = nullptr;
-    unsigned h_mask = 0;
-    if (!off && hipMalloc((void**)&d_mask, sizeof(unsigned)) == hipSuccess) {
-      if (hipMemset(d_mask, 0, sizeof(unsigned)) == hipSuccess) {
-        hipLaunchKernelGGL(k_xcc_probe, dim3(4096), dim3(64), 0, 0, d_mask);
-        if (hipMemcpy(&h_mask, d_mask, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && h_mask == 0xFFu) xcd8 = 1;
-      }
-      (void)hipFree(d_mask);
-    }
-    if (tracked) xcd8_dev[dev].store(xcd8, std::memory_order_release);
-  }
+  // land on exactly the XCD ids 0..7.  The probe says what the DEVICE does; a stream with a CU mask, or a partition change
+  // behind the probe, could still leave an XCD without a workgroup of this launch -- the frames of its ticket stream would
+  // never be taken and no wait would time out.  The completion check of an affine launch is therefore UNCONDITIONAL (every
+  // front of every slot must have published its solution: k_dag_check / k_after_solve with mode 2), so such a launch ends
+  // as SLM_ITER_SOLVER_TIMEOUT, not with a stale delta.
   const int mode = (n_frames >= 8 && n_frames % 8 == 0 && xcd8 == 1 && grid == n_wg) ? 1 : 0;
   hipLaunchKernelGGL(k_fdag, dim3(grid), dim3(256), lds, st, fr, n_frames, max_tasks, u_override, cut, mode);
+  g_last_dag_mode.store(mode, std::memory_order_relaxed);
   // (check = false: the caller's next launch settles an aborted launch itself -- k_after_solve, slm_reg.hip)
-  if (check) hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames);
+  if (check) hipLaunchKernelGGL(k_dag_check, dim3(n_frames), dim3(64), 0, st, fr, n_frames, mode & 1);
+  return mode;
 }

@@ -20,6 +20,10 @@
 // saved is a ~13 us transition (last column -> boundary rows -> update tiles -> the parent's gather) off the critical path.
 // C2, one frame per launch, ms per LM iteration at 18 / 30 / 42 / 50 / 60 / 72 nodes: 0.888 / 0.859 / 0.846 / 0.840 / 0.851 / 0.861.
 #define SLM_ND_LEAF_LATENCY 50
+// Padded boundary scalars of a front that the substitution tasks can stage in LDS: the fused BACK task of the task graph
+// holds x of the boundary in ONE 64 x 64 tile (4 096 doubles), its BACKB tasks and the per-level k_fback_prep in two.
+#define ND_MAX_N2P_FUSED 4096
+#define ND_MAX_N2P 8192
 
 // One front, device + host view.  Local node positions: [0,nv) pivots (elimination order),
 // [nv, nv+nb) boundary (ancestor separator nodes, elimination order).  Scalar layout:

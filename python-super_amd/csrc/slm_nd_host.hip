@@ -308,6 +308,10 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
     f.n1 = 7 * f.nv;
     f.n1p = round64(f.n1);
     f.n2p = round64(7 * f.nb);
+    // the substitution tasks stage x of a front's boundary in LDS (slm_dag.hip BACKB: two tiles; slm_front.hip
+    // k_fback_prep: n2p doubles of dynamic LDS): a coupling graph whose front has a wider boundary (> 1 170 nodes -- no
+    // geometric ED graph comes near) is refused here and takes the block-banded solver
+    if (f.n2p > ND_MAX_N2P) return false;
     f.nt = (f.n1p + f.n2p) / 64;
     f.npt = f.n1p / 64;
     f.depth = t.depth;
@@ -594,7 +598,8 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
         const char* e = getenv("SLM_BACK_FUSE_NPT");
         return e ? atoi(e) : 2;
       }();
-      const bool fused = f.nb > 0 && f.npt <= fuse_npt;
+      // (the fused form stages the boundary's x in ONE tile of LDS -- dag_task_back's `xb = M`: n2p <= ND_MAX_N2P_FUSED)
+      const bool fused = f.nb > 0 && f.npt <= fuse_npt && f.n2p <= ND_MAX_N2P_FUSED;
       for (int c = f.npt - 1; c >= 0; --c)
         if (f.nb > 0 && !fused) tasks.push_back({st0, (ND_T_BACKB << 24) | i, (c << 8) | c});
       const double stc = st0 + ((f.nb > 0 && !fused) ? 2.0 + 0.5 * (f.nt - f.npt) : 0.0);

@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(256) k_after_solve(const FrameDev* __restrict_
   if (!fd.bound) return;
   if (dag_check && blockIdx.x == 0 && threadIdx.x < 64) {
     const FrameDev& fd0 = frames[0];
-    if (fd0.bound && fd0.nd_ready && fd0.dag_flags && fd0.dag_flags[1] != 0 && fd.nd_ready && fd.dag_flags) {
+    // (dag_check 2: an XCD-affine task-graph launch -- checked whether or not the abort flag is up, launch_front_solve_dag)
+    if (fd0.bound && fd0.nd_ready && fd0.dag_flags && (dag_check == 2 || fd0.dag_flags[1] != 0) && fd.nd_ready && fd.dag_flags) {
       const int* px = fd.dag_flags.get() + 8 + fd.dag_n_tiles + fd.dag_n_pcols;
       bool done = true;
       for (int fi = threadIdx.x; fi < fd.n_fronts; fi += 64) {

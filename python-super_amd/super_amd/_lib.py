@@ -30,7 +30,7 @@ EXPORTS = [
     "slm_gf_eval_losses", "slm_gf_step", "slm_gf_get_partial", "slm_gf_set_partial",
     "slm_depth_create", "slm_depth_destroy", "slm_depth_preprocess",
     "slm_graph_init", "slm_fuse_create", "slm_fuse_destroy", "slm_fuse_input_data", "slm_fuse_swap_stable",
-    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64", "slm_graph_init_semantic", "slm_debug_counters", "slm_debug_last_solver_form",
+    "slm_fuse_bind_semantic", "slm_knn_f64", "slm_knn_weights_f64", "slm_graph_init_semantic", "slm_debug_counters", "slm_debug_last_solver_form", "slm_debug_last_dag_mode",
     "slm_set_shard", "slm_lm_grad_local", "slm_lm_solve", "slm_lm_loss_local", "slm_lm_accept",
     "slm_lm_exchange_size", "slm_lm_exchange_get", "slm_lm_exchange_set", "slm_lm_exchange_ptr",
     "slm_gf_get_deform", "slm_gf_loss_grad", "slm_apply_update_gf",
@@ -174,6 +174,7 @@ def load():
         "slm_debug_read": [vp, i32, i32, vp, C.c_int64, C.POINTER(C.c_int64), vp],
         "slm_debug_dag_trace": [vp, i32, i32, vp],
         "slm_debug_last_solver_form": [vp],
+        "slm_debug_last_dag_mode": [vp],
         "slm_bind_frames": [vp, i32, i32, C.POINTER(SlmFrame), vp],
         "slm_bind_frame": [vp, i32, C.POINTER(SlmFrame), vp],
         "slm_prepare_model": [vp, i32, C.POINTER(SlmFrame), vp],

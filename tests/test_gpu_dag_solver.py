@@ -289,6 +289,15 @@ def test_leaf_size_follows_the_solver_form_and_changes_nothing_but_the_plan():
         np.testing.assert_allclose(b, ob, rtol=0, atol=1e-6)
 
 
+def _expect_affine():
+    """k_fdag's XCD-affine mode is taken on a device with 8 XCDs (MI355X: 256 CUs in 8 XCDs) unless SLM_DAG_XCD=0."""
+    import os
+    import torch
+    if os.environ.get("SLM_DAG_XCD") == "0":
+        return 0
+    return 1 if torch.cuda.get_device_properties(0).multi_processor_count == 256 else 0
+
+
 def test_eight_frames_as_one_task_graph_on_xcd_affine_ticket_streams():
     """Round 5: at a multiple of 8 frames per launch every XCD serves the tasks of 'its' frames from a ticket stream of its
     own (k_fdag mode bit 0): all tasks of a frame on one XCD, operand tiles and gathered update tiles through that XCD's L2.
@@ -304,6 +313,9 @@ def test_eight_frames_as_one_task_graph_on_xcd_affine_ticket_streams():
         e.bind_batch(frames)
         e.run(8)
         assert e.lib.slm_debug_last_solver_form(e.h) == {3: 0, 0: 1, 4: 2}[sp]
+        # the mode bit must really have been taken (a probe that says "not 8 XCDs" would silently test the
+        # non-affine path): 1 on an 8-XCD device, -1 when the solve ran no task graph
+        assert e.lib.slm_debug_last_dag_mode(e.h) == {3: -1, 0: _expect_affine(), 4: _expect_affine()}[sp]
         out[sp] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(8)]
         e.close()
     for sp in (0, 4):
@@ -345,13 +357,17 @@ def test_task_graph_switches_of_round_5_keep_the_result(env):
         "    e.run(8)\n"
         "    ok = all(r['status'] == 0 for i in range(8) for r in e.records(i))\n"
         "    err = max(float(np.abs(e.beta(i).cpu().numpy() - want[i]).max()) for i in range(2))\n"
-        "    res.append((e.lib.slm_debug_last_solver_form(e.h), ok, err))\n"
+        "    res.append((e.lib.slm_debug_last_solver_form(e.h), ok, err, e.lib.slm_debug_last_dag_mode(e.h)))\n"
         "    e.close()\n"
-        "print('RES', res[0][0], res[1][0], int(res[0][1] and res[1][1]), max(res[0][2], res[1][2]))\n")
+        "print('RES', res[0][0], res[1][0], int(res[0][1] and res[1][1]), max(res[0][2], res[1][2]), res[0][3], res[1][3])\n")
     full = dict(os.environ)
     full.update(env)
     out = subprocess.run([sys.executable, "-c", code], env=full, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    f0, f4, ok, err = out.stdout.strip().splitlines()[-1].split()[1:]
+    f0, f4, ok, err, m0, m4 = out.stdout.strip().splitlines()[-1].split()[1:]
     assert int(f0) == (2 if env.get("SLM_DAG_MAX_NODES") == "0" else 1) and int(f4) == 2, (env, f0, f4)
+    if env.get("SLM_DAG_XCD") == "0":
+        assert int(m0) == 0 and int(m4) == 0, (env, m0, m4)      # the switch really turns the XCD-affine streams off
+    else:
+        assert int(m0) == _expect_affine() and int(m4) == _expect_affine(), (env, m0, m4)
     assert int(ok) == 1 and float(err) < 1e-6, (env, ok, err)
