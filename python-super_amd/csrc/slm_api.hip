@@ -17,6 +17,7 @@
 
 // launchers defined next to their kernels
 void launch_data_grad(const FrameDev*, int, int, int, double, hipStream_t);
+void launch_data_grad_pairs(const FrameDev*, int, int, int, double, hipStream_t);
 void launch_data_loss(const FrameDev*, int, int, int, double, int, hipStream_t);
 void launch_data_resid(const FrameDev*, int, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
 void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t, const int* reuse = nullptr);
@@ -124,6 +125,7 @@ struct Slot {
   FrameDev h{};                 // host mirror of the device descriptor
   size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0, cap_npk = 0, cap_tpn = 0, cap_ev = 0;
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
+  PairPlan pplan;               // K-generic pair path (num_neighbors != 4): pair keys, per-surfel pair indices, surfel order
   // nested-dissection plan: host copy + device mirrors (grow-only)
   NDPlanHost nd;
   uint64_t nd_hash = 0;         // hash of the coupled-pair list + node KNN of the frame bound last
@@ -563,6 +565,7 @@ int slm_destroy(slm_solver* s) {
     if (h.tgt_pn) (void)hipFree(h.tgt_pn);
     if (h.ev_rc) (void)hipFree(h.ev_rc);
     plan_free(sl.plan);
+    pairplan_free(sl.pplan);
     if (sl.h_pin) (void)hipHostFree(sl.h_pin);
     sl.h_pairs.release();
     sl.h_knn.release();
@@ -723,6 +726,7 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
   }
   // tuple-sorted data-term assembly plan (DataLoss.prepare analogue)
   h.v1_ready = 0;
+  h.vk_ready = 0;
   uint64_t dev_knn_hash = 0, dev_graph_hash = 0;   // coupling-graph hashes computed by prep_v1 on the device
   if (s->cfg.use_data && s->cfg.data_path != 1 && f->K == SLM_K && f->J < 65536 && f->N > 0) {
     V1Sizes sz;
@@ -761,6 +765,23 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
         h.v2_ready = 1;
       }
     }
+  } else if (s->cfg.use_data && s->cfg.data_path != 1 && s->cfg.solver_path != 1 && f->J < 65536 && f->N > 0) {
+    // num_neighbors != 4 (round 6): the K-generic pair path -- the coupled-pair list and every surfel's pair indices from
+    // one sort (prep_pairs), the multifrontal solver on that list, the data term through per-pair records (pairbuf)
+    PairSizes sz;
+    HIPCHK(prep_pairs(prep, *f, sl.pplan, &sz, st));
+    if (sz.bad_knn)
+      return fail(SLM_ERR_INVALID, "slm_bind_frame: a surfel KNN index (sf_knn_idx) lies outside [0, J)");
+    dev_knn_hash = sz.knn_hash;
+    dev_graph_hash = sz.graph_hash;
+    bt_mark();
+    if (sz.n_blocks > 0) {
+      h.n_blocks = sz.n_blocks;
+      h.blk_key = sl.pplan.blk_key;
+      h.sf_pidx = sl.pplan.sf_pidx;
+      h.sf_perm = sl.pplan.sf_perm;
+      h.vk_ready = 1;
+    }
   } else if (s->cfg.use_data && f->N > 0) {
     // the per-entry atomics path (data_path 1, J >= 65536) dereferences the table too: same refusal
     bool bad = false;
@@ -776,19 +797,22 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
     h.sf_hi = (int32_t)((int64_t)f->N * (s->rank + 1) / s->world);
     h.pairbuf = nullptr;
     if (s->shard_mode) {
-      if (!h.v1_ready)
-        return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: sharded frames need the tuple-sorted data path "
-                                         "(data_path 0, num_neighbors 4, J < 65536)");
+      if (!h.v1_ready && !h.vk_ready)
+        return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: sharded frames need the multifrontal data paths "
+                                         "(data_path 0 or 2, J < 65536)");
       HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + 2));
       h.pairbuf = sl.pairbuf;
       // records (or per-run Grams) of the other ranks' workgroups stay zero for the whole frame
       if (h.v2_ready) HIPCHK(hipMemsetAsync(h.wgslab, 0, sizeof(double) * SLM_WREC * (size_t)h.n_wblk, st));
-      else HIPCHK(hipMemsetAsync(h.slab, 0, sizeof(double) * SLM_SLAB_STRIDE * (size_t)h.n_runs, st));
+      else if (h.v1_ready) HIPCHK(hipMemsetAsync(h.slab, 0, sizeof(double) * SLM_SLAB_STRIDE * (size_t)h.n_runs, st));
+    } else if (h.vk_ready) {   // the K-generic pair path always assembles through the pair records
+      HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + 2));
+      h.pairbuf = sl.pairbuf;
     }
   }
   // nested-dissection plan (symbolic analysis on the host from the coupled-pair list)
   h.nd_ready = 0;
-  if (h.v1_ready && s->cfg.solver_path != 1) {
+  if ((h.v1_ready || h.vk_ready) && s->cfg.solver_path != 1) {
     // The symbolic plan depends only on the coupling graph (node KNN table + coupled-pair list): reuse it while the
     // graph is unchanged.  The graph's hash comes from the device with the sizes (prep_v1's one read-back): a frame
     // whose graph is the slot's cached one reads nothing else back -- the lists only travel to the host when the
@@ -1289,6 +1313,7 @@ struct BatchDims {
   int max_pos = 0, max_blocks = 0, maxP = 0;
   int K = 0;        // num_neighbors of the batch's slots (-1: they differ -- refused by the callers of the per-surfel kernels)
   bool v1 = true;   // every slot of the batch has a tuple-sorted plan
+  bool vk = true;   // every slot of the batch takes the K-generic pair path (num_neighbors != 4 on the multifrontal solver)
   int gram_variants = 0;   // bit0: workgroup-merged records in use, bit1: per-run slab in use
   bool nd = true;   // every slot of the batch has a nested-dissection plan
   int max_tasks = 0;   // tasks of the persistent task-graph solver (maximum over the batch)
@@ -1308,6 +1333,7 @@ BatchDims dims_of(slm_solver* s, int first, int n) {
     d.max_pos = std::max(d.max_pos, h.n_pos);
     d.max_blocks = std::max(d.max_blocks, h.n_blocks);
     d.v1 = d.v1 && h.v1_ready;
+    d.vk = d.vk && h.vk_ready;
     if (h.v1_ready) d.gram_variants |= h.v2_ready ? 1 : 2;
     d.nd = d.nd && h.nd_ready;
     d.max_tasks = std::max(d.max_tasks, h.nd_ready ? h.n_dag_tasks : 0);
@@ -1479,8 +1505,8 @@ static int shard_dims(slm_solver* s, int n_frames, BatchDims& d) {
   int rc = check_slots(s, 0, n_frames);
   if (rc) return rc;
   d = dims_of(s, 0, n_frames);
-  if (!d.nd || !d.v1)
-    return fail(SLM_ERR_UNSUPPORTED, "sharded LM step: every slot needs the tuple-sorted data path and the ND solver");
+  if (!d.nd || !(d.v1 || d.vk))
+    return fail(SLM_ERR_UNSUPPORTED, "sharded LM step: every slot needs a multifrontal data path (tuple-sorted or K-generic) and the ND solver");
   return SLM_OK;
 }
 
@@ -1490,12 +1516,16 @@ int slm_lm_grad_local(slm_solver* s, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   const FrameDev* fr = s->frames_dev;
-  const int* reuse = (s->cfg.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
+  const int* reuse = (d.v1 && s->cfg.phase_test && !s->no_reuse) ? s->reuse_dev : nullptr;
   launch_iter_begin_nd(fr, n_frames, st, reuse, -2);
   if (s->cfg.use_data) {
-    launch_data_eval(fr, n_frames, kLossBlocks, s->cfg.w_data, 1, st, reuse);   // (only slots whose buffer is not the current beta's)
-    launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st, reuse);
-    launch_pair_reduce(fr, n_frames, d.max_blocks, st);
+    if (d.v1) {
+      launch_data_eval(fr, n_frames, kLossBlocks, s->cfg.w_data, 1, st, reuse);   // (only slots whose buffer is not the current beta's)
+      launch_data_gram(fr, n_frames, d.max_pos, s->cfg.w_data, d.gram_variants, st, reuse);
+      launch_pair_reduce(fr, n_frames, d.max_blocks, st);
+    } else {
+      launch_data_grad_pairs(fr, n_frames, d.maxN, d.K, s->cfg.w_data, st);   // K-generic: this rank's share of the surfel list, straight into the pair records
+    }
   }
   HIPCHK(hipGetLastError());
   return SLM_OK;
@@ -1525,7 +1555,8 @@ int slm_lm_loss_local(slm_solver* s, int32_t n_frames, void* stream) {
   const slm_config& c = s->cfg;
   if (c.use_data) {
     launch_make_trial(fr, n_frames, d.maxJKe, st);
-    launch_data_eval(fr, n_frames, kLossBlocks, c.w_data, 0, st);   // this rank's positions: loss partials + the evaluation buffer
+    if (d.v1) launch_data_eval(fr, n_frames, kLossBlocks, c.w_data, 0, st);   // this rank's positions: loss partials + the evaluation buffer
+    else launch_data_loss(fr, n_frames, kLossBlocks, d.K, c.w_data, 1, st);   // K-generic: this rank's surfels [sf_lo, sf_hi)
   }
   if (d.n_reg_part > 0)
     launch_reg_loss(fr, n_frames, d.n_reg_part, c.use_arap, c.w_arap, c.use_rot, c.w_rot, 1, st);
@@ -1538,7 +1569,7 @@ int slm_lm_accept(slm_solver* s, int32_t n_frames, void* stream) {
   int rc = shard_dims(s, n_frames, d);
   if (rc) return rc;
   launch_accept(s->frames_dev, n_frames, s->cfg.phase_test, d.n_reg_part, std::max(s->cfg.num_iterations, 1), (hipStream_t)stream,
-                s->cfg.phase_test ? s->reuse_dev : nullptr, s->cfg.use_data ? 1 : 0);   // (slm_lm_loss_local ran k_data_eval)
+                (d.v1 && s->cfg.phase_test) ? s->reuse_dev : nullptr, (s->cfg.use_data && d.v1) ? 1 : 0);   // (slm_lm_loss_local ran k_data_eval)
   HIPCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -1629,13 +1660,18 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
       // (skipped on the device for slots whose buffer is valid) and after a reject when records are not reused.
       if (first_iteration || (c.phase_test && !reuse)) launch_data_eval(fr, n, kLossBlocks, c.w_data, 1, st, reuse);
       launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
+    } else if (d.nd && d.vk) {
+      launch_data_grad_pairs(fr, n, d.maxN, d.K, c.w_data, st);   // K-generic: per-pair records (zeroed, then filled)
     } else {
       launch_data_grad(fr, n, d.maxN, d.K, c.w_data, st);
     }
   }
   mark();
   if (d.nd) {
-    if (c.use_data) launch_front_assemble(fr, n, d.max_blocks, st);
+    if (c.use_data) {
+      if (d.v1) launch_front_assemble(fr, n, d.max_blocks, st);
+      else launch_pair_scatter(fr, n, d.max_blocks, st);          // K-generic: records -> fronts + jtl
+    }
     launch_reg_grad_nd(fr, n, d.maxP / 7, c.use_arap, c.w_arap, c.use_rot, c.w_rot, st);
     if (!s->cfg.use_arap && !s->cfg.use_rot) launch_front_load_rhs(fr, n, d.maxP, st);   // (else k_reg_grad_nd did it)
   } else {

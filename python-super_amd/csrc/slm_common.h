@@ -116,6 +116,14 @@ struct FrameDev {
   int32_t wg_lo, wg_hi;
   int32_t sf_lo, sf_hi;
   GP<double> pairbuf;
+  // ---- K-generic pair path (num_neighbors != 4 on the multifrontal solver; slm_prep.hip prep_pairs): the data term's
+  //      7 x 7 blocks are added into pairbuf (n_blocks x 56 doubles + matched count) by k_data_grad_pairs -- per surfel
+  //      the record of each of its K(K+1)/2 canonical pair slots is known (sf_pidx), surfels are walked in neighbour-set
+  //      order (sf_perm) -- and placed into the fronts by k_pair_scatter, exactly like an all-reduced sharded frame ----
+  int32_t vk_ready;
+  int32_t pad7;
+  GP<const int32_t> sf_pidx;
+  GP<const int32_t> sf_perm;
   // ---- nested-dissection multifrontal solver (slm_nd_host.hip / slm_front.hip) ----
   int32_t nd_ready;      // 1 when the plan below is valid for this frame
   int32_t n_fronts;

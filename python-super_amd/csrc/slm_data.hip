@@ -81,6 +81,116 @@ __global__ void __launch_bounds__(256) k_data_resid(const FrameDev* __restrict__
   }
 }
 
+
+// ---- K-generic data term on the multifrontal path (num_neighbors != 4) ------------------------------------------------
+// The Jacobian row of a surfel has 7K entries; its outer product lands in the K(K+1)/2 node-pair blocks of the surfel.
+// One thread per surfel evaluates (as k_data_grad), then the WAVE turns round: the rows of its 64 surfels go to LDS in the
+// surfel's canonical neighbour order (ids ascending: slot (ra, rb <= ra) is the pair (c[ra], c[rb]), never transposed) and
+// every lane owns a fixed set of ENTRIES -- (slot, ca, cb) of the blocks and (node, c) of J^T r -- which it forms for the
+// wave's surfels one after the other, accumulating in a register while the destination record stays the same and issuing
+// one f64 atomic when it changes.  Surfels are walked in neighbour-set order (FrameDev::sf_perm), so the surfels of a set
+// are consecutive and their common blocks reach memory once per wave instead of once per surfel: K = 6 at C2 issues
+// ~945 atomics per RUN of surfels with one neighbour set instead of per surfel.  The records (pairbuf: 49 block entries
+// row-major (ca, cb) of the larger-id node's row index first + 7 entries of J^T r of the diagonal pair, as the wgslab
+// records of the tuple-sorted path) are placed into the fronts by k_pair_scatter (slm_front.hip).
+// grid = (ceil(max positions / 64), n_frames), ONE wave per workgroup
+template <int KK>
+__global__ void __launch_bounds__(64) k_data_grad_pairs(const FrameDev* __restrict__ frames, double lam) {
+  constexpr int NP = KK * (KK + 1) / 2, NR = 7 * KK, NB49 = NP * 49, NE = NB49 + NR, NPL = (NE + 63) / 64;
+  constexpr int LDR = (NR + 1) | 1;   // odd row stride: the lanes of one surfel's row spread over the banks
+  __shared__ double s_row[64 * LDR];
+  __shared__ int s_pi[64 * NP];
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || fd.st->stopped || fd.f.K != KK || !fd.vk_ready) return;
+  const int l = threadIdx.x;
+  const int pos = fd.sf_lo + blockIdx.x * 64 + l;   // [sf_lo, sf_hi): all positions unless the frame is sharded over several GPUs
+  SurfelEvalT<KK> ev;
+  ev.match = false;
+  int i = 0;
+  if (pos < fd.sf_hi) {
+    i = fd.sf_perm[pos];
+    eval_surfel<1, KK>(fd, lam, fd.node_pk, i, ev);
+  }
+  const unsigned long long m = __ballot(ev.match);
+  if (!m) return;
+  if (l == 0) {
+    atomicAdd(&fd.st->m_grad, __popcll(m));
+    atomic_add_f64(fd.pairbuf + (size_t)fd.n_blocks * SLM_WREC, (double)__popcll(m));   // (what k_pair_scatter reads back)
+  }
+  if (ev.match) {
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < KK; ++j) rank += (ev.id[j] < ev.id[k]) ? 1 : 0;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) s_row[l * LDR + 7 * rank + c] = ev.row[7 * k + c];
+    }
+    s_row[l * LDR + NR] = ev.r;
+#pragma unroll
+    for (int sl = 0; sl < NP; ++sl) s_pi[l * NP + sl] = fd.sf_pidx[(size_t)NP * i + sl];
+  }
+  __syncthreads();
+  // this lane's entries: e = l + 64 q
+  int desc[NPL];   // slot | rowa << 6 | rowb << 12 | off << 18 | active << 24
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    const int e = l + 64 * q;
+    int d = 0;
+    if (e < NB49) {
+      const int slot = e / 49, rem = e - 49 * slot, ca = rem / 7, cb = rem - 7 * ca;
+      int ra = 0;
+      while ((ra + 1) * (ra + 2) / 2 <= slot) ++ra;
+      const int rb = slot - ra * (ra + 1) / 2;
+      if (!(ra == rb && ca < cb))   // (a diagonal pair's block is symmetric: its lower part is what is placed)
+        d = slot | (7 * ra + ca) << 6 | (7 * rb + cb) << 12 | (7 * ca + cb) << 18 | 1 << 24;
+    } else if (e < NE) {
+      const int k = (e - NB49) / 7, c = (e - NB49) - 7 * k;
+      d = (k * (k + 1) / 2 + k) | (7 * k + c) << 6 | NR << 12 | (49 + c) << 18 | 1 << 24;
+    }
+    desc[q] = d;
+  }
+  double acc[NPL];
+  int prev[NPL];
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    acc[q] = 0.0;
+    prev[q] = -1;
+  }
+  double* pb = fd.pairbuf;
+  for (unsigned long long mm = m; mm; mm &= mm - 1) {
+    const int sidx = __builtin_ctzll(mm);   // uniform: the wave's matched surfels in list order
+    const double* rw = s_row + sidx * LDR;
+    const int* pi = s_pi + sidx * NP;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int d = desc[q];
+      if (d >> 24) {
+        const int dest = pi[d & 63] * SLM_WREC + ((d >> 18) & 63);
+        const double v = rw[(d >> 6) & 63] * rw[(d >> 12) & 63];
+        if (dest != prev[q]) {
+          if (prev[q] >= 0) atomic_add_f64(pb + prev[q], acc[q]);
+          prev[q] = dest;
+          acc[q] = v;
+        } else {
+          acc[q] += v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NPL; ++q)
+    if (prev[q] >= 0) atomic_add_f64(pb + prev[q], acc[q]);
+}
+
+// zero the pair records (+ the matched count behind them) of the slots that take the K-generic pair path
+__global__ void __launch_bounds__(256) k_zero_pairbuf(const FrameDev* __restrict__ frames) {
+  const FrameDev& fd = frames[blockIdx.y];
+  if (!fd.bound || !fd.vk_ready || !fd.pairbuf || fd.st->stopped) return;
+  const size_t n = (size_t)fd.n_blocks * SLM_WREC + 1;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) fd.pairbuf[e] = 0.0;
+}
+
 // ---- host launchers (called from slm_api.hip) ------------------------------------
 // K = the batch's num_neighbors (1..SLM_KMAX): one instantiation per value
 #define SLM_K_DISPATCH(K, CALL)                                        \
@@ -111,4 +221,12 @@ void launch_data_resid(const FrameDev* frames_dev, int slot, int N, int K, doubl
                        hipStream_t st) {
   if (N <= 0) return;
   SLM_K_DISPATCH(K, hipLaunchKernelGGL(k_data_resid<KK>, dim3((N + 255) / 256), dim3(256), 0, st, frames_dev, slot, lam, r, match, taps));
+}
+
+// the K-generic Jacobian pass of the multifrontal path: pair records zeroed, then filled (max_pos = the batch's largest surfel count)
+void launch_data_grad_pairs(const FrameDev* frames_dev, int n_frames, int max_pos, int K, double lam, hipStream_t st) {
+  if (max_pos <= 0) return;
+  hipLaunchKernelGGL(k_zero_pairbuf, dim3(128, n_frames), dim3(256), 0, st, frames_dev);
+  dim3 grid((max_pos + 63) / 64, n_frames);
+  SLM_K_DISPATCH(K, hipLaunchKernelGGL(k_data_grad_pairs<KK>, grid, dim3(64), 0, st, frames_dev, lam));
 }

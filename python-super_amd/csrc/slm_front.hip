@@ -175,9 +175,10 @@ __global__ void __launch_bounds__(256) k_pair_reduce(const FrameDev* __restrict_
   fd.pairbuf[(size_t)bi * SLM_WREC + l] = acc;
 }
 
+// (also the assembly of the K-generic pair path -- FrameDev::vk_ready: k_data_grad_pairs filled pairbuf)
 __global__ void __launch_bounds__(256) k_pair_scatter(const FrameDev* __restrict__ frames) {
   const FrameDev& fd = frames[blockIdx.y];
-  if (!fd.bound || !fd.v1_ready || !fd.nd_ready || fd.st->stopped) return;
+  if (!fd.bound || !(fd.v1_ready || fd.vk_ready) || !fd.nd_ready || fd.st->stopped) return;
   const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bi == 0 && (threadIdx.x & 63) == 0) {
     // the rank's own count is kept apart: after a rejected step the records -- and this count -- are sent again

@@ -75,24 +75,35 @@ __device__ __forceinline__ d3 quat_apply_t(double w, d3 v, d3 c) {
 }
 
 // deformed surfel i: T(p) = sum_k w_k [R(q_k)(p-g_k) + b_k + g_k], P = R(q_g) T + b_g
-// (deform_source, super/deform_mesh.py:198-221)
-struct GfSkin {
-  int id[4];
-  double w[4], qw[4];
-  d3 qv[4], dk[4], T, P;
+// (deform_source, super/deform_mesh.py:198-221; K-generic like the reference: KK = opt.num_neighbors, 1..8)
+template <int KK>
+struct GfSkinT {
+  int id[KK];
+  double w[KK], qw[KK];
+  d3 qv[KK], dk[KK], T, P;
   double gw;
   d3 gv;
 };
+typedef GfSkinT<SLM_K> GfSkin;
 
-__device__ __forceinline__ void gf_skin(const GfSlotDev& s, int i, GfSkin& k) {
+template <int KK>
+__device__ __forceinline__ void gf_skin(const GfSlotDev& s, int i, GfSkinT<KK>& k) {
   const FrameIn& f = s.f.base;
   const d3 p = ld_state3(f.sf_points, (size_t)i, f.state_f64);
-  const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * (size_t)i);
-  k.id[0] = ids.x; k.id[1] = ids.y; k.id[2] = ids.z; k.id[3] = ids.w;
-  ld_state4(f.sf_knn_w, (size_t)i, f.state_f64, k.w);
+  if constexpr (KK == SLM_K) {
+    const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * (size_t)i);
+    k.id[0] = ids.x; k.id[1] = ids.y; k.id[2] = ids.z; k.id[3] = ids.w;
+    ld_state4(f.sf_knn_w, (size_t)i, f.state_f64, k.w);
+  } else {
+#pragma unroll
+    for (int a = 0; a < KK; ++a) {
+      k.id[a] = f.sf_knn_idx[(size_t)KK * i + a];
+      k.w[a] = ld_state1(f.sf_knn_w, (size_t)KK * i + a, f.state_f64);
+    }
+  }
   k.T = {0, 0, 0};
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < KK; ++a) {
     const double* b = s.dv + 7 * k.id[a];
     const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
     k.qw[a] = b[0];
@@ -107,4 +118,24 @@ __device__ __forceinline__ void gf_skin(const GfSlotDev& s, int i, GfSkin& k) {
   k.gv = {bgl[1], bgl[2], bgl[3]};
   k.P = quat_apply(k.gw, k.gv, k.T);
   k.P = {k.P.x + bgl[4], k.P.y + bgl[5], k.P.z + bgl[6]};
+}
+
+// the deformed position alone, K at run time (the morphing term's pass: it needs P only) -- the same sums in the same order
+__device__ __forceinline__ d3 gf_skin_pos(const GfSlotDev& s, int i) {
+  const FrameIn& f = s.f.base;
+  const int K = f.K;
+  const d3 p = ld_state3(f.sf_points, (size_t)i, f.state_f64);
+  d3 T = {0, 0, 0};
+  for (int a = 0; a < K; ++a) {
+    const int id = f.sf_knn_idx[(size_t)K * i + a];
+    const double w = ld_state1(f.sf_knn_w, (size_t)K * i + a, f.state_f64);
+    const double* b = s.dv + 7 * id;
+    const d3 g = ld_state3(f.ed_points, (size_t)id, f.state_f64);
+    d3 t = quat_apply(b[0], {b[1], b[2], b[3]}, p - g);
+    t = {t.x + b[4] + g.x, t.y + b[5] + g.y, t.z + b[6] + g.z};
+    T = {T.x + w * t.x, T.y + w * t.y, T.z + w * t.z};
+  }
+  const double* bgl = s.dv + 7 * f.J;
+  d3 P = quat_apply(bgl[0], {bgl[1], bgl[2], bgl[3]}, T);
+  return {P.x + bgl[4], P.y + bgl[5], P.z + bgl[6]};
 }

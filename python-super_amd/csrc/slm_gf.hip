@@ -103,7 +103,9 @@ __device__ __forceinline__ void gf_flow_sample(const float* __restrict__ flow, i
 // seg_mode: 0 none, 1 hard, 2 soft semantic weight on the squared residual (loss.py:379-399);
 // pp_max > 0 (and no seg_mode): squared residuals >= pp_max are dropped (loss.py:369-370);
 // use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
+// KK = opt.num_neighbors of the launch's slots (deform_source is K-generic, super/deform_mesh.py:198-221)
 #define GF_TAB 128   // LDS gradient table: slots per workgroup (power of two)
+template <int KK>
 __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode,
                                                   double pp_max, int use_morph, double w_morph, int corr_mode,
                                                   double lam_c) {
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   __shared__ int tkey[GF_TAB];
   __shared__ double tval[GF_TAB * 7];
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
-  if (!s.bound) return;
+  if (!s.bound || s.f.base.K != KK) return;
   for (int t = threadIdx.x; t < GF_TAB; t += blockDim.x) tkey[t] = -1;
   for (int t = threadIdx.x; t < GF_TAB * 7; t += blockDim.x) tval[t] = 0.0;
   __syncthreads();
@@ -124,8 +126,8 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   const int J = f.J;
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0, lossc = 0.0, cntc = 0.0;
   if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
-    GfSkin k;
-    gf_skin(s, i, k);
+    GfSkinT<KK> k;
+    gf_skin<KK>(s, i, k);
     const d3 P = k.P;
     const double fx = (double)f.fx, fy = (double)f.fy, cx = (double)f.cx, cy = (double)f.cy;
     const double Ze = P.z + 1e-8;
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
       gb[2] = gP.z;
       const d3 cl = quat_apply_t(k.gw, k.gv, gP);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < KK; ++a) {
         quat_jac_row(k.qw[a], k.qv[a], k.dk[a], cl, jq);
         const double wk = k.w[a];
         const double v[7] = {wk * jq[0], wk * jq[1], wk * jq[2], wk * jq[3], wk * cl.x, wk * cl.y, wk * cl.z};
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(256) k_gf_init(GfSlot* __restrict__ slots, int
 
 // Surfels.update, autograd variant (super/nodes.py:193-223): T(p) + b_g (the global ROTATION is
 // applied to the normals only, exactly as the reference does), nodes += b_j + b_g.
-template <typename RT>
+template <typename RT, int KK>
 __global__ void __launch_bounds__(256) k_gf_update_surfels(int N, int J, RT* __restrict__ pts_,
                                                             RT* __restrict__ nrm_,
                                                             const int* __restrict__ knn_idx,
@@ -457,13 +459,16 @@ __global__ void __launch_bounds__(256) k_gf_update_surfels(int N, int J, RT* __r
   RT* nrm = nrm_ + 3 * (size_t)i - 3 * i;
   const d3 p = {(double)pts[3 * i], (double)pts[3 * i + 1], (double)pts[3 * i + 2]};
   const d3 n0 = {(double)nrm[3 * i], (double)nrm[3 * i + 1], (double)nrm[3 * i + 2]};
-  const int4 ids = *reinterpret_cast<const int4*>(knn_idx + 4 * (size_t)i);
-  const RT* wp = knn_w + 4 * (size_t)i;
-  const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-  const double w[4] = {(double)wp[0], (double)wp[1], (double)wp[2], (double)wp[3]};
+  int id[KK];
+  double w[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    id[k] = knn_idx[(size_t)KK * i + k];
+    w[k] = (double)knn_w[(size_t)KK * i + k];
+  }
   d3 T = {0, 0, 0}, Nn = {0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KK; ++k) {
     const double* b = dv + 7 * id[k];
     const d3 g = {(double)ed_pts[3 * id[k]], (double)ed_pts[3 * id[k] + 1], (double)ed_pts[3 * id[k] + 2]};
     const d3 qv = {b[1], b[2], b[3]};
@@ -508,7 +513,22 @@ __global__ void __launch_bounds__(256) k_gf_update_nodes(int J, RT* __restrict__
 // ---------------------------------------------------------------------------------------
 void slm_set_error_text(const char* msg);   // slm_api.hip
 
+// one instantiation of the per-surfel kernels per opt.num_neighbors (1..8)
+#define GF_K_DISPATCH(K, ...)                                          \
+  switch (K) {                                                         \
+    case 1: { constexpr int KK = 1; __VA_ARGS__; break; }                     \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; break; }                     \
+    case 3: { constexpr int KK = 3; __VA_ARGS__; break; }                     \
+    case 4: { constexpr int KK = 4; __VA_ARGS__; break; }                     \
+    case 5: { constexpr int KK = 5; __VA_ARGS__; break; }                     \
+    case 6: { constexpr int KK = 6; __VA_ARGS__; break; }                     \
+    case 7: { constexpr int KK = 7; __VA_ARGS__; break; }                     \
+    case 8: { constexpr int KK = 8; __VA_ARGS__; break; }                     \
+    default: break;                                                    \
+  }
+
 struct slm_gf {
+  int batch_K = SLM_K;       // num_neighbors of the slots of the launch being enqueued (gf_dims: they must agree)
   slm_gf_config cfg{};
   std::vector<GfSlot> host;
   std::vector<size_t> cap;
@@ -543,8 +563,8 @@ static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int max
   const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
   if ((use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0)
-    hipLaunchKernelGGL(k_gf_data, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
-                       c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr);
+    GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL(k_gf_data<KK>, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
+                                                 c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr));
   if (g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
     hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
                        c.use_rot, c.w_rot, c.use_face, c.w_face);
@@ -559,14 +579,14 @@ template <typename RT>
 static int apply_update_gf_t(int32_t N, int32_t J, int32_t K, RT* sf_points, RT* sf_norms,
                              const int32_t* sf_knn_idx, const RT* sf_knn_w, RT* ed_points, RT* ed_norms,
                              const double* deform, void* stream) {
-  if (K != SLM_K) return gf_fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_gf: num_neighbors must be 4");
+  if (K < 1 || K > 8) return gf_fail(SLM_ERR_UNSUPPORTED, "slm_apply_update_gf: num_neighbors must be in 1..8");
   if (N < 0 || J < 1 || !ed_points || !ed_norms || !deform ||
       (N > 0 && (!sf_points || !sf_norms || !sf_knn_idx || !sf_knn_w)))
     return gf_fail(SLM_ERR_INVALID, "slm_apply_update_gf: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (N > 0)
-    hipLaunchKernelGGL(k_gf_update_surfels<RT>, dim3((N + 255) / 256), dim3(256), 0, st, N, J, sf_points, sf_norms,
-                       sf_knn_idx, sf_knn_w, (const RT*)ed_points, deform);
+    GF_K_DISPATCH(K, hipLaunchKernelGGL((k_gf_update_surfels<RT, KK>), dim3((N + 255) / 256), dim3(256), 0, st, N, J, sf_points, sf_norms,
+                                        sf_knn_idx, sf_knn_w, (const RT*)ed_points, deform));
   hipLaunchKernelGGL(k_gf_update_nodes<RT>, dim3((J + 255) / 256), dim3(256), 0, st, J, ed_points, ed_norms, deform);
   GFCHK(hipGetLastError());
   return SLM_OK;
@@ -610,7 +630,7 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* fr, void* str
   if (!g || !fr) return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_frame: null argument");
   if (slot < 0 || slot >= (int)g->host.size()) return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_frame: bad slot");
   const slm_frame& f = fr->base;
-  if (f.K != SLM_K) return gf_fail(SLM_ERR_UNSUPPORTED, "slm_gf_bind_frame: num_neighbors must be 4");
+  if (f.K < 1 || f.K > 8) return gf_fail(SLM_ERR_UNSUPPORTED, "slm_gf_bind_frame: num_neighbors must be in 1..8");
   if (f.K_ED < 1 || f.K_ED > SLM_MAX_KED || f.N < 0 || f.J < 1 || f.H < 4 || f.W < 4)
     return gf_fail(SLM_ERR_INVALID, "slm_gf_bind_frame: bad sizes");
   if (!f.sf_points || !f.sf_knn_idx || !f.sf_knn_w || !f.ed_points || !f.ed_knn_idx || !f.tgt_points ||
@@ -714,12 +734,15 @@ static int gf_dims(slm_gf* g, int first, int n, int* maxN, int* maxReg, int* max
       return gf_fail(SLM_ERR_UNBOUND, "slm_gf: semantic terms enabled but slm_gf_bind_semantic was not called");
     if (g->cfg.corr_mode && !s.flow)
       return gf_fail(SLM_ERR_UNBOUND, "slm_gf: corr_mode set but slm_gf_bind_flow was not called");
+    if (s.f.base.K != g->host[first].f.base.K)
+      return gf_fail(SLM_ERR_UNSUPPORTED, "slm_gf: the frames of one batch must have the same num_neighbors");
     *maxN = std::max(*maxN, s.f.base.N);
     int reg = std::max(s.f.base.J * s.f.base.K_ED, s.f.base.J + 1);
     if (g->cfg.use_face) reg = std::max(reg, s.f.n_triangles);
     *maxReg = std::max(*maxReg, reg);
     *maxP = std::max(*maxP, (s.f.base.J + 1) * 7);
   }
+  g->batch_K = g->host[first].f.base.K;
   return SLM_OK;
 }
 

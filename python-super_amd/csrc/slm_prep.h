@@ -42,6 +42,29 @@ struct V1Sizes {
   bool bad_knn = false;          // a surfel KNN index outside [0, J) was seen: the frame must be refused
 };
 
+// ---- K-generic pair plan (any opt.num_neighbors in 1..8; reference super/loss.py:213-220 is K-generic) ----------------
+// What the multifrontal solver needs from a frame whose surfels have K != 4 neighbours (the tuple-sorted MFMA assembly is a
+// K = 4 structure): the sorted list of coupled node pairs (key a*J + b, a >= b -- the same list prep_v1 produces as blk_key)
+// and, per surfel, the position in that list of each of its K(K+1)/2 node pairs in CANONICAL slot order (the surfel's node
+// ids ascending c[0] < ... < c[K-1]; slot ra(ra+1)/2 + rb, rb <= ra, is the pair (c[ra], c[rb])), so that the per-iteration
+// kernel (k_data_grad_pairs, slm_data.hip) adds a surfel's 7 x 7 blocks into compact per-pair records without searching;
+// sf_perm lists the surfels ordered by their smallest ids -- surfels with the same neighbour set are adjacent there, and a
+// wave that walks the list accumulates their common blocks in registers before it touches memory.
+struct PairPlan {
+  int32_t* blk_key = nullptr;    // (n_blocks) sorted pair keys
+  int32_t* sf_pidx = nullptr;    // (N, K(K+1)/2) pair index of every (surfel, canonical slot)
+  int32_t* sf_perm = nullptr;    // (N) surfel ids in neighbour-set order
+  size_t cap_key = 0, cap_pidx = 0, cap_perm = 0;
+};
+struct PairSizes {
+  int n_blocks = 0;
+  uint64_t knn_hash = 0, graph_hash = 0;   // as V1Sizes
+  bool bad_knn = false;
+};
+// Stream-synchronising (one read-back).  f.K in 1..8, f.J < 65536.
+hipError_t prep_pairs(PrepBuffers*, const slm_frame& f, PairPlan& plan, PairSizes* out, hipStream_t st);
+void pairplan_free(PairPlan& plan);
+
 PrepBuffers* prep_create();
 void prep_destroy(PrepBuffers*);
 // Builds the plan for frame f (stream-synchronising: one small read-back, two for a plan's first frame).

@@ -283,6 +283,81 @@ __global__ void __launch_bounds__(256) k_plan_hash(int J, int K_ED, const int32_
   }
 }
 
+// ---- K-generic pair plan (prep_pairs) ---------------------------------------------------------------------------------
+// keys of the K(K+1)/2 node pairs of every surfel, slot (ka, kb <= ka) at ka(ka+1)/2 + kb: max(id)*J + min(id)
+template <int KK>
+__global__ void __launch_bounds__(256) k_pair_keys(int N, int J, const int* __restrict__ knn, unsigned* __restrict__ keys,
+                                                    int* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  constexpr int NP = KK * (KK + 1) / 2;
+  int id[KK];
+  bool b = false;
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    id[k] = knn[(size_t)KK * i + k];
+    if ((unsigned)id[k] >= (unsigned)J) {
+      b = true;
+      id[k] = min(max(id[k], 0), J - 1);
+    }
+  }
+  if (b) *bad = 1;
+#pragma unroll
+  for (int ka = 0; ka < KK; ++ka)
+#pragma unroll
+    for (int kb = 0; kb <= ka; ++kb) {
+      const int a = max(id[ka], id[kb]), c = min(id[ka], id[kb]);
+      keys[(size_t)NP * i + ka * (ka + 1) / 2 + kb] = (unsigned)a * (unsigned)J + (unsigned)c;
+    }
+}
+// Canonical neighbour order of a surfel: its K node ids ascending (they are distinct).  Slot (ra, rb <= ra) of the surfel is
+// the pair (c[ra], c[rb]) -- the larger id first, as in the pair keys -- so two surfels with the same neighbour SET have the
+// same pair in every slot whatever the distance order of their KNN lists, and no block is ever transposed.
+template <int KK>
+__device__ __forceinline__ void canon_ids(const int* __restrict__ knn, int i, int J, int c[KK]) {
+#pragma unroll
+  for (int k = 0; k < KK; ++k) c[k] = min(max(knn[(size_t)KK * i + k], 0), J - 1);
+#pragma unroll
+  for (int a = 1; a < KK; ++a)   // insertion sort, fully unrolled compare-exchanges
+#pragma unroll
+    for (int b = a; b > 0; --b) {
+      const int lo = min(c[b - 1], c[b]), hi = max(c[b - 1], c[b]);
+      c[b - 1] = lo;
+      c[b] = hi;
+    }
+}
+// per surfel: position of each canonical slot's pair in the sorted unique list (binary searches; once per bind) and the
+// 64-bit order key of the surfel (its four smallest ids): surfels with the same neighbour set become neighbours in sf_perm
+template <int KK>
+__global__ void __launch_bounds__(256) k_pair_index(int N, int J, int n_blocks, const int* __restrict__ knn,
+                                                     const unsigned* __restrict__ ukeys, int* __restrict__ pidx,
+                                                     unsigned long long* __restrict__ okey, int* __restrict__ oid) {
+  constexpr int NP = KK * (KK + 1) / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int c[KK];
+  canon_ids<KK>(knn, i, J, c);
+#pragma unroll
+  for (int ra = 0; ra < KK; ++ra)
+#pragma unroll
+    for (int rb = 0; rb <= ra; ++rb) {
+      const unsigned key = (unsigned)c[ra] * (unsigned)J + (unsigned)c[rb];
+      int lo = 0, hi = n_blocks - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ukeys[mid] < key) lo = mid + 1;
+        else hi = mid;
+      }
+      pidx[(size_t)NP * i + ra * (ra + 1) / 2 + rb] = lo;
+    }
+  unsigned long long k64 = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) k64 = (k64 << 16) | (unsigned long long)(k < KK ? c[k] : 0);
+  okey[i] = k64;
+  oid[i] = i;
+}
+__global__ void k_pair_count(int* __restrict__ scal, const unsigned* __restrict__ cnt) { scal[3] = (int)cnt[0]; }
+
 // blk2_start[n_blocks] = number of live records (end of the last live pair)
 __global__ void k_totals3(const int* __restrict__ scal, int* __restrict__ blk2_start) {
   blk2_start[scal[3]] = scal[6];
@@ -913,6 +988,12 @@ struct PrepBuffers {
   int *eval = nullptr, *ru = nullptr, *sp_uhead = nullptr, *nrec = nullptr;
   unsigned* reckey_sp = nullptr;
   size_t cap_ent = 0, cap_nwg = 0;
+  // ---- K-generic pair plan (prep_pairs) ----
+  unsigned *gk = nullptr, *gsk = nullptr;   // N * K(K+1)/2 pair keys, unsorted / sorted (gk again: the distinct ones)
+  unsigned* gcnt = nullptr;                 // their count
+  size_t cap_g = 0, q_g = 0, q_gN = 0;      // capacity; key / surfel counts the rocPRIM scratch requirement was last queried for
+  void* gtmp = nullptr;
+  size_t cap_gtmp = 0;
 };
 
 PrepBuffers* prep_create() {
@@ -931,7 +1012,7 @@ void prep_destroy(PrepBuffers* p) {
                   p->nruns, p->rstart, p->pkeys, p->spkeys, p->ukeys, p->pvals, p->bcount, p->tmp, p->scal,
                   p->wkeys, p->swkeys, p->uwkeys, p->wvals, p->swvals, p->wcount, p->wstart, p->pv2, p->spv2,
                   p->b2count, p->pk2, p->spk2, p->upk2, p->bins, p->binv, p->sp_head, p->sp_pcl, p->sp_rl, p->ekey, p->rkey,
-                  p->eval, p->ru, p->sp_uhead, p->nrec, p->reckey_sp};
+                  p->eval, p->ru, p->sp_uhead, p->nrec, p->reckey_sp, p->gk, p->gsk, p->gcnt, p->gtmp};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->scal_host) (void)hipHostFree(p->scal_host);
@@ -1344,4 +1425,97 @@ hipError_t prep_v1(PrepBuffers* p, const slm_frame& f, V1Plan& plan, V1Sizes* ou
     plan.nt_hint = 0;
   }
   return prep_v1_legacy(p, f, plan, out, st);
+}
+
+
+// ---- K-generic pair plan ---------------------------------------------------------------------------------------------
+void pairplan_free(PairPlan& plan) {
+  if (plan.blk_key) (void)hipFree(plan.blk_key);
+  if (plan.sf_pidx) (void)hipFree(plan.sf_pidx);
+  if (plan.sf_perm) (void)hipFree(plan.sf_perm);
+  plan = PairPlan();
+}
+
+#define SLM_PREP_K_DISPATCH(K, CALL)                                   \
+  switch (K) {                                                         \
+    case 1: { constexpr int KK = 1; CALL; break; }                     \
+    case 2: { constexpr int KK = 2; CALL; break; }                     \
+    case 3: { constexpr int KK = 3; CALL; break; }                     \
+    case 4: { constexpr int KK = 4; CALL; break; }                     \
+    case 5: { constexpr int KK = 5; CALL; break; }                     \
+    case 6: { constexpr int KK = 6; CALL; break; }                     \
+    case 7: { constexpr int KK = 7; CALL; break; }                     \
+    case 8: { constexpr int KK = 8; CALL; break; }                     \
+    default: break;                                                    \
+  }
+
+hipError_t prep_pairs(PrepBuffers* p, const slm_frame& f, PairPlan& plan, PairSizes* out, hipStream_t st) {
+  *out = PairSizes();
+  if (f.N <= 0 || f.K < 1 || f.K > 8 || f.J >= 65536) return hipSuccess;
+  const size_t NP = (size_t)f.K * (f.K + 1) / 2, n = (size_t)f.N * NP;
+  if (n > p->cap_g) {
+    size_t c;
+    c = p->cap_g; PCHK(grow_raw(p->gk, c, n));
+    c = p->cap_g; PCHK(grow_raw(p->gsk, c, n));
+    p->cap_g = c;
+  }
+  if (!p->gcnt) PCHK(hipMalloc((void**)&p->gcnt, sizeof(unsigned)));
+  // key bits: a*J + b < J*J
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < (unsigned long long)f.J * (unsigned long long)f.J) ++bits;
+  const size_t N = (size_t)f.N;
+  if (N > p->cap_n) {   // (the phase-A buffers of the tuple-sorted preparation: order keys / surfel ids, unsorted and sorted)
+    size_t c;
+    c = p->cap_n; PCHK(grow_raw(p->keys, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->skeys, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->tkeys, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->ids, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->sids, c, N));
+    c = p->cap_n; PCHK(grow_raw(p->tcount, c, N));
+    p->cap_n = c;
+  }
+  if (p->q_g != n || p->q_gN != N || !p->gtmp) {
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    PCHK(rocprim::radix_sort_keys(nullptr, b1, p->gk, p->gsk, n, 0, 32, st));
+    PCHK(rocprim::unique(nullptr, b2, p->gsk, p->gk, p->gcnt, n, rocprim::equal_to<unsigned>(), st));
+    PCHK(rocprim::radix_sort_pairs(nullptr, b3, p->keys, p->skeys, p->ids, p->sids, N, 0, 64, st));
+    b1 = b1 > b3 ? b1 : b3;
+    size_t need = (b1 > b2 ? b1 : b2), cap = p->cap_gtmp;
+    need += need / 4 + (1u << 16);
+    char* q = (char*)p->gtmp;
+    PCHK(grow_raw(q, cap, need));
+    p->gtmp = q;
+    p->cap_gtmp = cap;
+    p->q_g = n;
+    p->q_gN = N;
+  }
+  PCHK(hipMemsetAsync(p->scal, 0, 16 * sizeof(int), st));
+  const dim3 blk(256);
+  SLM_PREP_K_DISPATCH(f.K, hipLaunchKernelGGL(k_pair_keys<KK>, dim3((unsigned)((f.N + 255) / 256)), blk, 0, st, f.N, f.J, f.sf_knn_idx,
+                                              p->gk, p->scal + 13));
+  size_t b1 = p->cap_gtmp, b2 = p->cap_gtmp;
+  PCHK(rocprim::radix_sort_keys(p->gtmp, b1, p->gk, p->gsk, n, 0, bits, st));
+  PCHK(rocprim::unique(p->gtmp, b2, p->gsk, p->gk, p->gcnt, n, rocprim::equal_to<unsigned>(), st));
+  hipLaunchKernelGGL(k_pair_count, dim3(1), dim3(1), 0, st, p->scal, p->gcnt);
+  // the hashes the cached symbolic plan is compared with (same function as the tuple-sorted preparation's)
+  hipLaunchKernelGGL(k_plan_hash, dim3(16), blk, 0, st, f.J, f.K_ED, f.ed_knn_idx, reinterpret_cast<const int32_t*>(p->gk), p->scal,
+                     reinterpret_cast<unsigned long long*>(p->scal + 8));
+  PCHK(hipMemcpyAsync(p->scal_host, p->scal, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+  PCHK(hipStreamSynchronize(st));
+  out->bad_knn = p->scal_host[13] != 0;
+  if (out->bad_knn) return hipSuccess;
+  out->n_blocks = p->scal_host[3];
+  memcpy(&out->knn_hash, p->scal_host + 8, 8);
+  memcpy(&out->graph_hash, p->scal_host + 10, 8);
+  if (out->n_blocks <= 0) return hipSuccess;
+  PCHK(grow_raw(plan.blk_key, plan.cap_key, (size_t)out->n_blocks));
+  PCHK(grow_raw(plan.sf_pidx, plan.cap_pidx, n));
+  PCHK(grow_raw(plan.sf_perm, plan.cap_perm, N));
+  PCHK(hipMemcpyAsync(plan.blk_key, p->gk, sizeof(unsigned) * (size_t)out->n_blocks, hipMemcpyDeviceToDevice, st));
+  SLM_PREP_K_DISPATCH(f.K, hipLaunchKernelGGL(k_pair_index<KK>, dim3((unsigned)((N + 255) / 256)), blk, 0, st, f.N, f.J, out->n_blocks,
+                                              f.sf_knn_idx, reinterpret_cast<const unsigned*>(plan.blk_key), plan.sf_pidx,
+                                              p->keys, p->ids));
+  size_t b3 = p->cap_gtmp;
+  PCHK(rocprim::radix_sort_pairs(p->gtmp, b3, p->keys, p->skeys, p->ids, plan.sf_perm, N, 0, 64, st));
+  return hipGetLastError();
 }

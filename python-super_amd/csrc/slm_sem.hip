@@ -118,8 +118,14 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
   if (i < f.N) {
     double2 g = make_double2(0.0, 0.0);
     if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
-      GfSkin k;
-      gf_skin(s, i, k);
+      struct { d3 P; } k;
+      if (f.K == SLM_K) {   // (the default: the instantiation the other kernels use, operation for operation)
+        GfSkin k4;
+        gf_skin(s, i, k4);
+        k.P = k4.P;
+      } else {
+        k.P = gf_skin_pos(s, i);
+      }
       const int H = f.H, W = f.W, C = s.sem.num_classes;
       const double Ze = k.P.z + 1e-8;
       const double x = k.P.x * (double)f.fx / Ze + (double)f.cx, y = k.P.y * (double)f.fy / Ze + (double)f.cy;

@@ -299,3 +299,20 @@ def smooth_flow(H, W, seed, amp=(1.2, 0.9)):
     fx = amp[0] * np.sin(2 * np.pi * a[0] * uu / W + 0.3) * np.cos(2 * np.pi * a[1] * vv / H)
     fy = amp[1] * np.cos(2 * np.pi * a[2] * uu / W) * np.sin(2 * np.pi * a[3] * vv / H + 0.7)
     return np.stack([fx, fy])[None].astype(np.float32)
+
+
+def graphfit_options(**kw):
+    """An options object for ``GraphFit`` with the reference's option NAMES (``options.py:37-50,213-250,331-343``) and the
+    values the benchmarks and the synthetic driver runs use: point-plane + ARAP (weight 10) + Rot, 10 optimiser
+    iterations at learning rate 5e-5, no face / segmentation / morphing / correspondence term.  Product-side helper
+    (``bench.py`` and the tools build their GraphFit runs from it); the test oracle carries its own defaults."""
+    from types import SimpleNamespace
+    o = SimpleNamespace(sf_point_plane=True, sf_point_plane_weight=1.0, mesh_arap=True, mesh_arap_weight=10.0,
+                        mesh_rot=True, mesh_rot_weight=1.0, mesh_face=False, mesh_face_weight=1.0,
+                        num_optimize_iterations=10, optimizer="SGD", learning_rate=5e-5,
+                        sf_soft_seg_point_plane=False, sf_hard_seg_point_plane=False, sf_bn_morph=False,
+                        sf_bn_morph_weight=1.0, depth_model="monodepth2", sf_corr=False, sf_corr_weight=0.001,
+                        sf_corr_loss_type="point-point", deform_udpate_method="super_edg")
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o

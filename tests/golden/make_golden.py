@@ -224,7 +224,7 @@ def capture_graphfit(ref, sc, okw, variants):
         out[f"gf_{tag}_final"] = _np(dv)
         if tag == "sgd":   # Surfels.update, autograd variant (global row), on the reference
             sfu, _, _ = ref_shim.torch_frame(sc)
-            sfu.opt = ref_shim.ref_opt(use_derived_gradient=False)
+            sfu.opt = ref_shim.ref_opt(use_derived_gradient=False, num_neighbors=okw.get("num_neighbors", 4))
             ref.nodes.Surfels.update(sfu, dv.detach())
             out["gf_upd_points"], out["gf_upd_norms"] = _np(sfu.points), _np(sfu.norms)
             out["gf_upd_ed_points"], out["gf_upd_ed_norms"] = _np(sfu.ED_nodes.points), _np(sfu.ED_nodes.norms)
@@ -276,7 +276,7 @@ def main():
         g.update(capture_update(ref, sc, opt, g["lm_beta"]))
         g.update(capture_knn(ref, sc, opt))
         g["in_ed_triangles"], g["in_ed_triangle_areas"] = sc.ed_triangles, sc.ed_triangle_areas
-        if name in ("s60x80_j48", "s60x80_j48_reject"):
+        if name in ("s60x80_j48", "s60x80_j48_reject", "s60x80_j48_k6"):   # (k6, round 6: deform_source / get_losses at num_neighbors = 6)
             g.update(capture_graphfit(ref, sc, okw, GF_VARIANTS["plain"]))
         if sc.num_classes:
             for f in ("img_seg_conf", "img_seg", "tgt_seg_conf", "sf_seg", "sf_seg_conf"):

@@ -10,6 +10,8 @@ pytestmark = pytest.mark.gpu
 
 CASES = [("s60x80_j48", "sgd"), ("s60x80_j48", "adam"), ("s60x80_j48", "sgdface"),
          ("s60x80_j48_reject", "sgd"), ("s60x80_j48_reject", "adam")]
+# num_neighbors = 6 (round 6; deform_source / get_losses are K-generic in the reference: super/deform_mesh.py:198-230)
+CASES += [("s60x80_j48_k6", "sgd"), ("s60x80_j48_k6", "adam"), ("s60x80_j48_k6", "sgdface")]
 CASES += [("s60x80_j48_semantic", t) for t in GF_SEMANTIC_VARIANTS]   # Semantic-SuPer terms (configs[4])
 
 

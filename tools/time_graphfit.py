@@ -6,10 +6,10 @@ import numpy as np, torch
 from super_amd import synth
 from super_amd.deform_mesh import GraphFit
 from helpers import torch_frame
-from oracle import graphfit_oracle as gfo
+from super_amd import synth as _synth
 sc = synth.make_scene(seed=0, **synth.WORKLOADS["C2"])
 sf, inputs, new_data = torch_frame(sc)
-opt = gfo.default_opt(optimizer="Adam"); opt.deform_udpate_method = "super_edg"
+opt = _synth.graphfit_options(optimizer="Adam")
 gf = GraphFit(opt)
 bf = gf._bind(0, inputs, sf, new_data)
 st = torch.cuda.current_stream().cuda_stream
