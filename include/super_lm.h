@@ -537,10 +537,11 @@ typedef struct slm_surfel_model {  /* device pointers with room for `cap` rows; 
   float* confs;                   /* (cap)   sf.confs */
   float* time_stamp;              /* (cap)   sf.time_stamp */
   uint8_t* is_stable;             /* (cap)   sf.isStable */
-  int32_t* knn_idx;               /* (cap,4) sf.knn_indices */
-  double* knn_w;                  /* (cap,4) sf.knn_w */
+  int32_t* knn_idx;               /* (cap,K) sf.knn_indices */
+  double* knn_w;                  /* (cap,K) sf.knn_w */
   float* projdata;                /* (cap,2) sf.projdata */
-  int32_t J, pad;
+  int32_t J;
+  int32_t K;                      /* opt.num_neighbors, 1..8; 0 is read as 4 (the field was padding through ABI version 5) */
   const double* ed_points;        /* (J,3) sf.ED_nodes.points */
   const double* ed_radii;         /* (J)   sf.ED_nodes.radii */
   int32_t* merged_into;           /* (cap) or NULL.  slm_fuse_input_data: the surfel that absorbed row i

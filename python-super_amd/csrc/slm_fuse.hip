@@ -270,17 +270,24 @@ __global__ void __launch_bounds__(256) k_fu_apply_dead(int n, const uint8_t* __r
   if (i < n && dead[i]) stable[i] = 0;
 }
 
-__device__ __forceinline__ void fu_softmax4(const double d[4], const double r[4], double w[4]) {
-  double e[4], mx = -1e300, s = 0.0;
-  for (int k = 0; k < 4; ++k) {
+// K = opt.num_neighbors (slm_surfel_model::K; the reference's find_knn / weights are K-generic: super/nodes.py:170-191,466-509)
+#define FU_KMAX 8
+__device__ __forceinline__ int fu_K(const slm_surfel_model& m) { return m.K > 0 ? m.K : 4; }
+template <int KK>
+__device__ __forceinline__ void fu_softmaxk(const double d[KK], const double r[KK], double w[KK]) {
+  double e[KK], mx = -1e300, s = 0.0;
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
     e[k] = exp(-d[k] / r[k]);
     mx = fmax(mx, e[k]);
   }
-  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
     w[k] = exp(e[k] - mx);
     s += w[k];
   }
-  for (int k = 0; k < 4; ++k) w[k] /= s;
+#pragma unroll
+  for (int k = 0; k < KK; ++k) w[k] /= s;
 }
 
 // Jensen-Shannon divergence of two class distributions (utils/utils.py:244-254)
@@ -295,26 +302,32 @@ __device__ __forceinline__ double fu_jsd(const double* P, const double* Q, int C
 }
 
 // softmax(exp(-JSD)^(1/2) * exp(-d/r)^(1/2)) (nodes.py:472-477, power_arg = (1/2, 1/2))
-__device__ __forceinline__ void fu_softmax4_sem(const double d[4], const double r[4], const double js[4], double w[4]) {
-  double e[4], mx = -1e300, s = 0.0;
-  for (int k = 0; k < 4; ++k) {
+template <int KK>
+__device__ __forceinline__ void fu_softmaxk_sem(const double d[KK], const double r[KK], const double js[KK], double w[KK]) {
+  double e[KK], mx = -1e300, s = 0.0;
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
     e[k] = sqrt(exp(-js[k])) * sqrt(exp(-d[k] / r[k]));
     mx = fmax(mx, e[k]);
   }
-  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
     w[k] = exp(e[k] - mx);
     s += w[k];
   }
-  for (int k = 0; k < 4; ++k) w[k] /= s;
+#pragma unroll
+  for (int k = 0; k < KK; ++k) w[k] /= s;
 }
 
 // knn_w = softmax(exp(-dist / radius)) at the current positions (nodes.py:466-481)
+template <int KK>
 __global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m, slm_fuse_semantic sm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m.n) return;
-  double d[4], r[4], w[4];
-  for (int k = 0; k < 4; ++k) {
-    const int j = m.knn_idx[4 * (size_t)i + k];
+  double d[KK], r[KK], w[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    const int j = m.knn_idx[KK * (size_t)i + k];
     double s = 0.0;
     for (int a = 0; a < 3; ++a) {
       const double t = m.points[3 * (size_t)i + a] - m.ed_points[3 * (size_t)j + a];
@@ -325,14 +338,16 @@ __global__ void __launch_bounds__(256) k_fu_weights(slm_surfel_model m, slm_fuse
   }
   if (sm.num_classes > 0 && sm.soft_weights) {
     const int C = sm.num_classes;
-    double js[4];
-    for (int k = 0; k < 4; ++k)
-      js[k] = fu_jsd(sm.ed_seg_conf + (size_t)C * m.knn_idx[4 * (size_t)i + k], sm.seg_conf + (size_t)C * i, C);
-    fu_softmax4_sem(d, r, js, w);
+    double js[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+      js[k] = fu_jsd(sm.ed_seg_conf + (size_t)C * m.knn_idx[KK * (size_t)i + k], sm.seg_conf + (size_t)C * i, C);
+    fu_softmaxk_sem<KK>(d, r, js, w);
   } else {
-    fu_softmax4(d, r, w);
+    fu_softmaxk<KK>(d, r, w);
   }
-  for (int k = 0; k < 4; ++k) m.knn_w[4 * (size_t)i + k] = w[k];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) m.knn_w[KK * (size_t)i + k] = w[k];
 }
 
 // Bounding boxes of the ED nodes in runs of FU_RUN consecutive indices (the node graph is a mesh grid in
@@ -372,21 +387,43 @@ __device__ __forceinline__ double fu_box_d2(const double* __restrict__ bx, doubl
 // is scanned by the whole wavefront when any of its lanes needs it (neighbouring pixels need the same runs; a
 // lane that did not is not harmed by the extra insert tests) -- so node and box coordinates come through the
 // scalar cache (s_load) instead of 64 identical vector loads per step.
-__device__ __forceinline__ void fu_insert(double d2, int j, double bd[4], int bi[4]) {
-  if (d2 < bd[3] || (d2 == bd[3] && j < bi[3])) {
-    int k = 3;
-    while (k > 0 && (d2 < bd[k - 1] || (d2 == bd[k - 1] && j < bi[k - 1]))) {
-      bd[k] = bd[k - 1];
-      bi[k] = bi[k - 1];
-      --k;
+// (branch-free shift for the generic K: the list lives in registers, a run-time index into it would not)
+template <int KK>
+__device__ __forceinline__ void fu_insert(double d2, int j, double bd[KK], int bi[KK]) {
+  if constexpr (KK == 4) {
+    if (d2 < bd[3] || (d2 == bd[3] && j < bi[3])) {
+      int k = 3;
+      while (k > 0 && (d2 < bd[k - 1] || (d2 == bd[k - 1] && j < bi[k - 1]))) {
+        bd[k] = bd[k - 1];
+        bi[k] = bi[k - 1];
+        --k;
+      }
+      bd[k] = d2;
+      bi[k] = j;
     }
-    bd[k] = d2;
-    bi[k] = j;
+  } else {
+    if (d2 < bd[KK - 1] || (d2 == bd[KK - 1] && j < bi[KK - 1])) {
+#pragma unroll
+      for (int k = KK - 1; k >= 0; --k) {
+        // entry k takes the new item when it sorts before the old entry k and not before entry k - 1; the old entry k - 1
+        // when the new item sorts before that too
+        const bool before_k = d2 < bd[k] || (d2 == bd[k] && j < bi[k]);
+        const bool before_km1 = k > 0 && (d2 < bd[k - 1] || (d2 == bd[k - 1] && j < bi[k - 1]));
+        if (before_km1) {
+          bd[k] = bd[k - 1];
+          bi[k] = bi[k - 1];
+        } else if (before_k) {
+          bd[k] = d2;
+          bi[k] = j;
+        }
+      }
+    }
   }
 }
 
+template <int KK>
 __device__ __forceinline__ void fu_scan_run(const slm_surfel_model& m, const slm_fuse_semantic& sm, bool by_class, int cls,
-                                            int b, double px, double py, double pz, double bd[4], int bi[4]) {
+                                            int b, double px, double py, double pz, double bd[KK], int bi[KK]) {
   const int j0 = b * FU_RUN, j1 = min(j0 + FU_RUN, m.J);
   int j = j0;
   for (; j + 4 <= j1; j += 4) {          // four nodes per step: their 12 coordinates are requested together
@@ -406,19 +443,20 @@ __device__ __forceinline__ void fu_scan_run(const slm_surfel_model& m, const slm
       d2[e] = dx * dx + dy * dy + dz * dz;
       if (cl[e] != cls) d2[e] = 2e300;     // other class: never a neighbour (2e300 > every list entry)
     }
-    if (fmin(fmin(d2[0], d2[1]), fmin(d2[2], d2[3])) <= bd[3]) {
+    if (fmin(fmin(d2[0], d2[1]), fmin(d2[2], d2[3])) <= bd[KK - 1]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) fu_insert(d2[e], j + e, bd, bi);
+      for (int e = 0; e < 4; ++e) fu_insert<KK>(d2[e], j + e, bd, bi);
     }
   }
   for (; j < j1; ++j) {
     const double* g = m.ed_points + 3 * (size_t)j;
     const double dx = px - g[0], dy = py - g[1], dz = pz - g[2];
     const double d2 = dx * dx + dy * dy + dz * dz;
-    if (!(by_class && sm.ed_seg[j] != cls)) fu_insert(d2, j, bd, bi);
+    if (!(by_class && sm.ed_seg[j] != cls)) fu_insert<KK>(d2, j, bd, bi);
   }
 }
 
+template <int KK>
 __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_surfel_model m, slm_fuse_semantic sm,
                                                         slm_new_frame fr, int32_t* __restrict__ flag,
                                                         int32_t* __restrict__ cand_idx, double* __restrict__ cand_w,
@@ -438,8 +476,13 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
   }
   // lanes without a candidate follow the wave with a list nothing can enter
   const double init = act ? 1e300 : -1.0;
-  double bd[4] = {init, init, init, init};
-  int bi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  double bd[KK];
+  int bi[KK];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    bd[k] = init;
+    bi[k] = 0x7fffffff;
+  }
   const int n_runs = (m.J + FU_RUN - 1) / FU_RUN;
   int seed = -1;
   double seed_d2 = 1e300;
@@ -454,25 +497,26 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
   unsigned long long pend = __ballot(act && seed >= 0);
   while (pend) {
     const int sb = __builtin_amdgcn_readfirstlane(__shfl(seed, __ffsll((long long)pend) - 1));
-    fu_scan_run(m, sm, by_class, cls, sb, px, py, pz, bd, bi);
+    fu_scan_run<KK>(m, sm, by_class, cls, sb, px, py, pz, bd, bi);
     pend &= ~__ballot(seed == sb);
   }
   for (int b = 0; b < n_runs; ++b) {
-    const bool need = act && fu_box_d2(boxes + 6 * (size_t)b, px, py, pz) <= bd[3];   // equal: a tie with a lower index may be inside
+    const bool need = act && fu_box_d2(boxes + 6 * (size_t)b, px, py, pz) <= bd[KK - 1];   // equal: a tie with a lower index may be inside
     if (__ballot(need) == 0ull) continue;
     if (__ballot(act && seed == b) != 0ull) continue;     // scanned above as some lane's nearest run
-    fu_scan_run(m, sm, by_class, cls, b, px, py, pz, bd, bi);
+    fu_scan_run<KK>(m, sm, by_class, cls, b, px, py, pz, bd, bi);
   }
   if (!act) return;
-  if (bd[3] >= 1e300) bi[3] = -1;      // fewer than 4 nodes (of this class)
-  if (bi[3] < 0) {       // fewer than 4 nodes of this class: the reference asserts (utils/utils.py:237)
+  if (bd[KK - 1] >= 1e300) bi[KK - 1] = -1;      // fewer than K nodes (of this class)
+  if (bi[KK - 1] < 0) {       // fewer than 4 nodes of this class: the reference asserts (utils/utils.py:237)
     atomicAdd(&counters[1], 1);
     flag[pix] = 0;
     return;
   }
-  double d[4], r[4], w[4];
+  double d[KK], r[KK], w[KK];
   bool stable = false;
-  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
     d[k] = sqrt(bd[k]);
     r[k] = m.ed_radii[bi[k]];
     stable = stable || d[k] <= r[k];
@@ -483,15 +527,17 @@ __global__ void __launch_bounds__(256) k_fu_candidates(slm_fuse_config c, slm_su
   }
   if (sm.num_classes > 0 && sm.soft_weights && !sm.hard_seg) {
     const int C = sm.num_classes;
-    double js[4];
-    for (int k = 0; k < 4; ++k) js[k] = fu_jsd(sm.ed_seg_conf + (size_t)C * bi[k], sm.new_seg_conf + (size_t)C * t, C);
-    fu_softmax4_sem(d, r, js, w);
+    double js[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) js[k] = fu_jsd(sm.ed_seg_conf + (size_t)C * bi[k], sm.new_seg_conf + (size_t)C * t, C);
+    fu_softmaxk_sem<KK>(d, r, js, w);
   } else {
-    fu_softmax4(d, r, w);
+    fu_softmaxk<KK>(d, r, w);
   }
-  for (int k = 0; k < 4; ++k) {
-    cand_idx[4 * (size_t)pix + k] = bi[k];
-    cand_w[4 * (size_t)pix + k] = w[k];
+#pragma unroll
+  for (int k = 0; k < KK; ++k) {
+    cand_idx[KK * (size_t)pix + k] = bi[k];
+    cand_w[KK * (size_t)pix + k] = w[k];
   }
 }
 
@@ -512,9 +558,10 @@ __global__ void __launch_bounds__(256) k_fu_append(slm_fuse_config c, slm_surfel
   m.confs[o] = fr.confs[t];
   m.time_stamp[o] = (float)fr.time;
   m.is_stable[o] = 1;
-  for (int k = 0; k < 4; ++k) {
-    m.knn_idx[4 * o + k] = cand_idx[4 * (size_t)pix + k];
-    m.knn_w[4 * o + k] = cand_w[4 * (size_t)pix + k];
+  const int K = fu_K(m);
+  for (int k = 0; k < K; ++k) {
+    m.knn_idx[K * o + k] = cand_idx[K * (size_t)pix + k];
+    m.knn_w[K * o + k] = cand_w[K * (size_t)pix + k];
   }
   if (sm.num_classes > 0) {
     sm.seg[o] = sm.new_seg[t];
@@ -564,9 +611,10 @@ __global__ void __launch_bounds__(256) k_fu_compact(slm_surfel_model m, slm_fuse
   s.s_d1[o] = m.radii[i];
   s.s_f1[o] = m.confs[i];
   s.s_f1[(size_t)m.cap + o] = m.time_stamp[i];
-  for (int k = 0; k < 4; ++k) {
-    s.s_i4[4 * o + k] = m.knn_idx[4 * (size_t)i + k];
-    s.s_d4[4 * o + k] = m.knn_w[4 * (size_t)i + k];
+  const int K = fu_K(m);
+  for (int k = 0; k < K; ++k) {
+    s.s_i4[K * o + k] = m.knn_idx[K * (size_t)i + k];
+    s.s_d4[K * o + k] = m.knn_w[K * (size_t)i + k];
   }
   s.s_f2[2 * o] = m.projdata[2 * (size_t)i];
   s.s_f2[2 * o + 1] = m.projdata[2 * (size_t)i + 1];
@@ -577,6 +625,20 @@ __global__ void __launch_bounds__(256) k_fu_compact(slm_surfel_model m, slm_fuse
     s.s_d2e[o] = s.sem.dist2edge[i];
   }
 }
+
+#define FU_K_DISPATCH(K, ...)                                          \
+  switch (K) {                                                         \
+    case 1: { constexpr int KK = 1; __VA_ARGS__; break; }              \
+    case 2: { constexpr int KK = 2; __VA_ARGS__; break; }              \
+    case 3: { constexpr int KK = 3; __VA_ARGS__; break; }              \
+    case 4: { constexpr int KK = 4; __VA_ARGS__; break; }              \
+    case 5: { constexpr int KK = 5; __VA_ARGS__; break; }              \
+    case 6: { constexpr int KK = 6; __VA_ARGS__; break; }              \
+    case 7: { constexpr int KK = 7; __VA_ARGS__; break; }              \
+    case 8: { constexpr int KK = 8; __VA_ARGS__; break; }              \
+    default: break;                                                    \
+  }
+static inline size_t fu_Kh(const slm_surfel_model& m) { return (size_t)(m.K > 0 ? m.K : 4); }
 
 template <typename T>
 hipError_t falloc(T*& p, size_t n) {
@@ -632,18 +694,18 @@ int slm_fuse_create(int32_t H, int32_t W, int32_t max_surfels, slm_fuse** out) {
   if (e == hipSuccess) e = falloc(f->layers, FU_LAYERS * HW);
   if (e == hipSuccess) e = falloc(f->flag, nmax);
   if (e == hipSuccess) e = falloc(f->pos, nmax);
-  if (e == hipSuccess) e = falloc(f->cand_idx, 4 * HW);
-  if (e == hipSuccess) e = falloc(f->cand_w, 4 * HW);
+  if (e == hipSuccess) e = falloc(f->cand_idx, FU_KMAX * HW);
+  if (e == hipSuccess) e = falloc(f->cand_w, FU_KMAX * HW);
   if (e == hipSuccess) e = falloc(f->dead, cap);
   if (e == hipSuccess) e = falloc(f->counters, 4);
   if (e == hipSuccess) e = hipHostMalloc((void**)&f->h_counters, sizeof(int32_t) * 4, hipHostMallocDefault);
   if (e == hipSuccess) e = falloc(f->s_d3, 6 * cap);
   if (e == hipSuccess) e = falloc(f->s_d1, cap);
-  if (e == hipSuccess) e = falloc(f->s_d4, 4 * cap);
+  if (e == hipSuccess) e = falloc(f->s_d4, FU_KMAX * cap);
   if (e == hipSuccess) e = falloc(f->s_f3, 3 * cap);
   if (e == hipSuccess) e = falloc(f->s_f1, 2 * cap);
   if (e == hipSuccess) e = falloc(f->s_f2, 2 * cap);
-  if (e == hipSuccess) e = falloc(f->s_i4, 4 * cap);
+  if (e == hipSuccess) e = falloc(f->s_i4, FU_KMAX * cap);
   if (e == hipSuccess) e = falloc(f->s_seg, cap);
   if (e == hipSuccess) e = falloc(f->s_sc, SLM_MAX_CLASSES * cap);
   if (e == hipSuccess) e = falloc(f->s_d2e, cap);
@@ -689,8 +751,9 @@ static int fuse_check(slm_fuse* f, const slm_fuse_config* c, const slm_surfel_mo
   if (c->H != f->H || c->W != f->W) return ffail(SLM_ERR_INVALID, "slm_fuse: image size differs from slm_fuse_create");
   if (m->n < 0 || m->cap > f->cap || m->n > m->cap) return ffail(SLM_ERR_INVALID, "slm_fuse: model rows exceed the capacity");
   if (!m->points || !m->norms || !m->colors || !m->radii || !m->confs || !m->time_stamp || !m->is_stable ||
-      !m->knn_idx || !m->knn_w || !m->projdata || !m->ed_points || !m->ed_radii || m->J < 4)
-    return ffail(SLM_ERR_INVALID, "slm_fuse: null device pointer (or fewer than 4 ED nodes)");
+      !m->knn_idx || !m->knn_w || !m->projdata || !m->ed_points || !m->ed_radii || m->J < (int)fu_Kh(*m))
+    return ffail(SLM_ERR_INVALID, "slm_fuse: null device pointer (or fewer than num_neighbors ED nodes)");
+  if (m->K < 0 || m->K > FU_KMAX) return ffail(SLM_ERR_UNSUPPORTED, "slm_fuse: num_neighbors must be in 1..8 (0 = 4)");
   return SLM_OK;
 }
 
@@ -741,7 +804,8 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
     hipLaunchKernelGGL(k_fu_apply_dead, gs, blk, 0, st, n, f->dead, m.is_stable);
   }
   // 4. skinning weights at the fused positions
-  if (n > 0) hipLaunchKernelGGL(k_fu_weights, gs, blk, 0, st, m, sm);
+  const int K = (int)fu_Kh(m);
+  if (n > 0) FU_K_DISPATCH(K, hipLaunchKernelGGL(k_fu_weights<KK>, gs, blk, 0, st, m, sm));
   // 5. unmatched points with a nearby node become new surfels, in row-major pixel (= sfdata) order
   int n_new = 0;
   if (c.add_new && c.merge_new && n > 0) {   // (no surfel projects anywhere -> every flag is 0, nothing is added)
@@ -754,13 +818,13 @@ int slm_fuse_input_data(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mode
       f->cap_boxes = (size_t)n_runs;
     }
     hipLaunchKernelGGL(k_fu_node_boxes, dim3(n_runs), dim3(64), 0, st, m.J, m.ed_points, f->boxes);
-    hipLaunchKernelGGL(k_fu_candidates, gp, blk, 0, st, c, m, sm, *frame, f->flag, f->cand_idx, f->cand_w,
-                       f->counters, f->boxes);
+    FU_K_DISPATCH(K, hipLaunchKernelGGL(k_fu_candidates<KK>, gp, blk, 0, st, c, m, sm, *frame, f->flag, f->cand_idx, f->cand_w,
+                                        f->counters, f->boxes));
     FCHK(scan_flags(f, HW, st));
     int n_short = 0;
     FCHK(count_flags(f, HW, st, &n_new, &n_short));
     if (n_short > 0)
-      return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: hard_seg needs at least 4 ED nodes of every class that has new points");
+      return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: hard_seg needs at least num_neighbors ED nodes of every class that has new points");
     if (n + n_new > m.cap) return ffail(SLM_ERR_INVALID, "slm_fuse_input_data: model capacity too small for the new surfels");
     if (n_new > 0)
       hipLaunchKernelGGL(k_fu_append, gp, blk, 0, st, c, m, sm, *frame, f->flag, f->pos, f->cand_idx, f->cand_w);
@@ -799,8 +863,8 @@ int slm_fuse_swap_stable(slm_fuse* f, const slm_fuse_config* cfg, slm_surfel_mod
     FCHK(hipMemcpyAsync(m.radii, f->s_d1, sizeof(double) * k, hipMemcpyDeviceToDevice, st));
     FCHK(hipMemcpyAsync(m.confs, f->s_f1, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
     FCHK(hipMemcpyAsync(m.time_stamp, f->s_f1 + cap, sizeof(float) * k, hipMemcpyDeviceToDevice, st));
-    FCHK(hipMemcpyAsync(m.knn_idx, f->s_i4, sizeof(int32_t) * 4 * k, hipMemcpyDeviceToDevice, st));
-    FCHK(hipMemcpyAsync(m.knn_w, f->s_d4, sizeof(double) * 4 * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.knn_idx, f->s_i4, sizeof(int32_t) * fu_Kh(m) * k, hipMemcpyDeviceToDevice, st));
+    FCHK(hipMemcpyAsync(m.knn_w, f->s_d4, sizeof(double) * fu_Kh(m) * k, hipMemcpyDeviceToDevice, st));
     FCHK(hipMemcpyAsync(m.projdata, f->s_f2, sizeof(float) * 2 * k, hipMemcpyDeviceToDevice, st));
     FCHK(hipMemsetAsync(m.is_stable, 1, k, st));
     if (f->sem.num_classes > 0) {

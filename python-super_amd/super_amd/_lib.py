@@ -111,7 +111,7 @@ class SlmSurfelModel(C.Structure):
     _fields_ = [("n", C.c_int32), ("cap", C.c_int32), ("points", C.c_void_p), ("norms", C.c_void_p),
                 ("colors", C.c_void_p), ("radii", C.c_void_p), ("confs", C.c_void_p),
                 ("time_stamp", C.c_void_p), ("is_stable", C.c_void_p), ("knn_idx", C.c_void_p),
-                ("knn_w", C.c_void_p), ("projdata", C.c_void_p), ("J", C.c_int32), ("pad", C.c_int32),
+                ("knn_w", C.c_void_p), ("projdata", C.c_void_p), ("J", C.c_int32), ("K", C.c_int32),
                 ("ed_points", C.c_void_p), ("ed_radii", C.c_void_p), ("merged_into", C.c_void_p)]
 
 

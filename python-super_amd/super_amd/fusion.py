@@ -70,7 +70,13 @@ class _Model:
         n = int(sf.points.shape[0])
         self.n, self.cap, self.dev = n, cap, dev
         self.buf = {}
+        # opt.num_neighbors (K-generic like the reference's find_knn / skinning weights, super/nodes.py:170-191,466-509)
+        K = int(sf.knn_indices.shape[1]) if getattr(sf, "knn_indices", None) is not None and sf.knn_indices.dim() == 2 \
+            else int(getattr(sf.opt, "num_neighbors", 4))
+        if not 1 <= K <= 8:
+            raise NotImplementedError("super_amd.fusion: opt.num_neighbors must be in 1..8")
         for name, dt, width in self.FIELDS:
+            width = K if name in ("knn_indices", "knn_w") else width
             shape = (cap, width) if width else (cap,)
             b = torch.zeros(shape, dtype=dt, device=dev)
             src = getattr(sf, name, None)
@@ -87,6 +93,7 @@ class _Model:
                             ("knn_idx", "knn_indices"), ("knn_w", "knn_w"), ("projdata", "projdata")):
             setattr(m, cname, _dev_ptr(self.buf[name]))
         m.J = int(self.ed_points.shape[0])
+        m.K = K
         m.ed_points, m.ed_radii = _dev_ptr(self.ed_points), _dev_ptr(self.ed_radii)
         self.merged_into = None
         if hasattr(sf, "track_pts") or getattr(sf, "evaluate_tracking", False):

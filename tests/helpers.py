@@ -9,7 +9,7 @@ from super_amd import synth
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDENS = ["s60x80_j48", "s120x160_j108", "s60x80_j48_dataonly", "s60x80_j48_reject"]
-GOLDENS_K = ["s60x80_j48_k6"]   # num_neighbors != 4 (6): the per-entry-atomics data path + block-banded solve on the device
+GOLDENS_K = ["s60x80_j48_k6"]   # num_neighbors != 4 (6): the K-generic pair path on the multifrontal solver (round 6)
 
 
 def load_golden(name):

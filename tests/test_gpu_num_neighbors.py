@@ -1,8 +1,11 @@
 """``--num_neighbors`` other than 4: a documented tunable of the reference (``README.md:175``,
 ``options.py:49``; its code is K-generic: ``super/loss.py:213-220``, ``super/utils.py:30-36``, ``super/nodes.py:170-191``).
-The device path for K != 4 is the per-entry-atomics data term (``k_data_grad<K>`` / ``k_data_loss<K>``) with the
-block-banded float64 solve -- what ``slm_data_path = 1`` runs for K = 4 --, ``Surfels.update`` and the KNN feeder with
-runtime K.  Pinned by ``tests/golden/s60x80_j48_k6.npz``, recorded from the reference at ``num_neighbors = 6``
+Round 6: K != 4 is a first-class path -- the K-generic pair plan (``prep_pairs``: the coupled-pair list and every surfel's
+pair indices from one sort), the data term through per-pair records (``k_data_grad_pairs<K>``: lane = entry, run-length
+accumulation in neighbour-set order) and the SAME nested-dissection multifrontal solver K = 4 runs (task graph / per-level
+launches / hybrid); the surfel-sharded mode accepts it.  ``slm_data_path = 1`` / ``slm_solver_path = 1`` keep the round-5
+compatibility path (per-entry atomics into the band + block-banded solve) as a cross-check.  ``Surfels.update`` and the KNN
+feeder take K at run time.  Pinned by ``tests/golden/s60x80_j48_k6.npz``, recorded from the reference at ``num_neighbors = 6``
 (``tests/golden/make_golden.py``): match set and tap rows bit-exact, residuals 1e-9, JtJ / jtl against the reference's
 own sparse Jacobian, the ten-iteration LM trace, ``update`` and the feeder's tables.  Through the C ABI, on an MI355X."""
 import numpy as np
@@ -164,3 +167,58 @@ def test_k4_on_the_same_path_and_mixed_batches_are_refused():
     eng = Engine(dev, max_frames=1, num_iterations=1)
     eng.bind(0, fr9)                                        # 8 is the largest supported value
     eng.close()
+
+
+@pytest.mark.parametrize("K", [3, 6, 8])
+def test_every_solver_form_runs_the_k_generic_pair_path(K):
+    """Round 6: num_neighbors != 4 takes the multifrontal solver in every form (the plan is built from the coupling graph,
+    whatever K produced it): one frame as a task graph, a batch of 8 as one task graph / per-level launches / hybrid, and
+    the round-5 compatibility path (per-entry atomics + block-banded solve) -- the same four iterations, against the oracle."""
+    import torch
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+    dev = torch.device("cuda", 0)
+    scs = [synth.make_scene(N=12000, J=300, H=240, W=320, seed=300 + 10 * K + k, src_border=8, tgt_border=4, dphi=0.1 + 0.02 * k,
+                            n_neighbors=K) for k in range(8)]
+    opt = orc.default_opt(num_optimize_iterations=4)
+    want = [orc.lm(orc.Frame.from_scene(sc), opt) for sc in scs[:2]]
+    frames = [DeviceFrame.from_scene(sc, dev) for sc in scs]
+    out = {}
+    for name, kw, form in (("graph1", dict(max_frames=1), 1), ("graph8", dict(max_frames=8, solver_path=2), 1),
+                           ("levels8", dict(max_frames=8, solver_path=3), 0), ("hybrid8", dict(max_frames=8, solver_path=4), 2),
+                           ("band8", dict(max_frames=8, solver_path=1), -1)):
+        e = Engine(dev, num_iterations=4, **kw)
+        n = kw["max_frames"]
+        e.bind_batch(frames[:n]) if n > 1 else e.bind(0, frames[0])
+        e.run(n)
+        assert e.lib.slm_debug_last_solver_form(e.h) == form, (name, e.lib.slm_debug_last_solver_form(e.h))
+        out[name] = [(e.beta(i).cpu().numpy(), e.records(i)) for i in range(min(n, 2))]
+        e.close()
+    for name, res in out.items():
+        for i, (b, r) in enumerate(res):
+            assert all(x["status"] == 0 for x in r), name
+            np.testing.assert_allclose(b, want[i], rtol=0, atol=1e-7, err_msg=name)
+            assert [x["accepted"] for x in r] == [x["accepted"] for x in out["band8"][i][1]], name
+            np.testing.assert_allclose([x["loss"] for x in r], [x["loss"] for x in out["band8"][i][1]], rtol=1e-9, err_msg=name)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_surfel_sharded_lm_accepts_k6(world):
+    """The surfel-sharded LM mode at num_neighbors = 6 (it refused K != 4 through round 5): each emulated rank adds its
+    share of the neighbour-set-ordered surfel list into its pair records, the records are all-reduced, every rank solves --
+    identical parameters on every rank, the reference's golden trace."""
+    from test_gpu_parity import TOL_BETA, _run_emulated_ranks
+    g, o, betas, recs = _run_emulated_ranks("s60x80_j48_k6", world)
+    for b in betas[1:]:
+        np.testing.assert_array_equal(b, betas[0])
+    for r in recs[1:]:
+        assert [x["accepted"] for x in r] == [x["accepted"] for x in recs[0]]
+        assert [x["loss"] for x in r] == [x["loss"] for x in recs[0]]
+    np.testing.assert_allclose(betas[0], g["lm_beta"], rtol=0, atol=TOL_BETA)
+    np.testing.assert_allclose([x["loss"] for x in recs[0]], g["lm_loss"], rtol=1e-6)
+    best = np.minimum.accumulate(np.concatenate([[1e10], g["lm_loss"]]))[:-1]
+    decisive = np.abs(g["lm_loss"] - best) > 1e-6 * np.abs(best)
+    acc = np.array([x["accepted"] for x in recs[0]])
+    np.testing.assert_array_equal(acc[decisive], g["lm_accepted"][decisive])
+    assert recs[0][0]["M_grad"] == len(g["b0_match"])
+    assert all(x["M_grad"] == y["M_grad"] for r in recs for x, y in zip(r, recs[0]))
