@@ -3,7 +3,7 @@
 ``ref_shim``) on a seeded synthetic surfel model + new frame and record inputs and outputs per
 option variant.
 
-    python tests/golden/make_golden_fusion.py        ->  tests/golden/fu_48x64.npz
+    python tests/golden/make_golden_fusion.py        ->  tests/golden/fu_48x64.npz, fu_48x64_k6.npz (num_neighbors = 6, round 6)
 """
 from __future__ import annotations
 
@@ -46,10 +46,10 @@ STATE = ("points", "norms", "colors", "radii", "confs", "time_stamp", "isStable"
 SEG_STATE = ("seg", "seg_conf", "dist2edge")
 
 
-def make_inputs(seed=11):
+def make_inputs(seed=11, num_neighbors=4):
     """Surfel model (with several surfels on many pixels and a few unstable / stale ones) + new frame."""
     sc = synth.make_scene(N=1500, J=30, H=48, W=64, seed=seed, src_border=4, tgt_border=5, tgt_holes=0.02,
-                          jitter=0.49, semantic=True, num_classes=3)
+                          jitter=0.49, semantic=True, num_classes=3, n_neighbors=num_neighbors)
     rng = np.random.default_rng(seed)
     # surfels are sampled one per pixel: add perturbed copies so that many pixels carry 2-4 layers
     P0, N0, I0, W0 = sc.f64("sf_points"), sc.f64("sf_norms"), sc.sf_knn_idx, sc.f64("sf_knn_w")
@@ -62,7 +62,7 @@ def make_inputs(seed=11):
     sf_points, sf_norms = np.concatenate([P0, Pd]), np.concatenate([N0, Nd])
     sf_knn_idx, sf_knn_w = np.concatenate([I0, I0[dup]]), np.concatenate([W0, W0[dup]])
     N, T = len(sf_points), sc.T
-    base = dict(H=sc.H, W=sc.W, K=sc.K,
+    base = dict(H=sc.H, W=sc.W, K=sc.K, num_neighbors=num_neighbors,
                 sf_points=sf_points, sf_norms=sf_norms,
                 sf_colors=rng.uniform(0, 255, (N, 3)).astype(np.float32),
                 sf_radii=rng.uniform(0.002, 0.004, N),
@@ -104,7 +104,7 @@ def run_reference(ref, b, okw):
     opt = SimpleNamespace(height=int(b["H"]), width=int(b["W"]), th_dist=0.1, th_cosine_ang=0.4, th_time_steps=30,
                           disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
                           disable_adding_new_surfels=False, disable_removing_unstable_surfels=False,
-                          phase="test", method="super", data="superv2", num_neighbors=4, save_sample_freq=10 ** 9,
+                          phase="test", method="super", data="superv2", num_neighbors=int(b["num_neighbors"]), save_sample_freq=10 ** 9,
                           data_dir="")
     for k, v in okw.items():
         if not k.startswith("_"):
@@ -160,7 +160,7 @@ def run_knn(ref, b, okw):
     """``Surfels.update_ed`` + ``update_sfed_knn`` (super/nodes.py:154-191) as run once at frame 0, with the
     Semantic-SuPer branches (class-restricted neighbours, Jensen-Shannon weights)."""
     t = lambda a: torch.from_numpy(np.array(a, copy=True))
-    opt = SimpleNamespace(method=okw.get("method", "super"), num_neighbors=4, num_ED_neighbors=4,
+    opt = SimpleNamespace(method=okw.get("method", "super"), num_neighbors=int(b["num_neighbors"]), num_ED_neighbors=4,
                           num_classes=int(b["num_classes"]))
     ed = ref_shim.Data(points=t(b["ed_points"]), radii=t(b["ed_radii"]), seg=t(b["ed_seg"]), seg_conf=t(b["ed_seg_conf"]))
     n = len(b["sf_points"])
@@ -173,23 +173,30 @@ def run_knn(ref, b, okw):
                 ed_idx=ed.knn_indices.numpy(), ed_w=ed.knn_w.numpy())
 
 
-def main():
-    ref = ref_shim.install()
-    base = make_inputs()
+def record(ref, fname, num_neighbors, knn_modes, variants):
+    base = make_inputs(num_neighbors=num_neighbors)
     g = {"in_" + k: v for k, v in base.items()}
-    for tag, okw in KNN_MODES.items():
-        for k, v in run_knn(ref, base, okw).items():
+    for tag in knn_modes:
+        for k, v in run_knn(ref, base, KNN_MODES[tag]).items():
             g[f"knn_{tag}_{k}"] = v
         print("knn", tag, "unstable", int((~g[f"knn_{tag}_sf_stable"]).sum()))
-    for tag, okw in VARIANTS.items():
-        out = run_reference(ref, base, okw)
+    for tag in variants:
+        out = run_reference(ref, base, VARIANTS[tag])
         for k, v in out.items():
             g[f"{tag}_{k}"] = v
         print(tag, "surfels", len(base["sf_points"]), "->", len(out["fuse_points"]), "stable", int(out["fuse_isStable"].sum()),
               "->", len(out["swap_points"]) if "swap_points" in out else int(out["swap_count"]))
-    path = os.path.join(HERE, "fu_48x64.npz")
+    path = os.path.join(HERE, fname)
     np.savez_compressed(path, **g)
     print(path, os.path.getsize(path) // 1024, "KB")
+
+
+def main():
+    ref = ref_shim.install()
+    record(ref, "fu_48x64.npz", 4, list(KNN_MODES), list(VARIANTS))
+    # num_neighbors = 6 (round 6): find_knn / the skinning weights / the candidate search are K-generic in the reference
+    # (super/nodes.py:170-191,466-509); the option variants that exercise them
+    record(ref, "fu_48x64_k6.npz", 6, ["plain", "sem", "hard"], ["default", "tight", "track", "sem", "hard"])
 
 
 if __name__ == "__main__":

@@ -9,6 +9,10 @@ import pytest
 from oracle import fusion_oracle as fuo
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fu_48x64.npz")
+# num_neighbors = 6 (round 6): the same scene with six neighbours per surfel, recorded from the reference for the option
+# variants that exercise the K-generic pieces (find_knn, skinning weights, the candidate search of new surfels)
+GOLD_K6 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fu_48x64_k6.npz")
+K6_VARIANTS = ("default", "tight", "track", "sem", "hard")
 
 # same table as tests/golden/make_golden_fusion.py VARIANTS
 VARIANTS = {
@@ -58,11 +62,12 @@ def check(m, g, prefix):
         np.testing.assert_array_equal(m.dist2edge, g[prefix + "dist2edge"])
 
 
-@pytest.mark.parametrize("tag", list(VARIANTS))
-def test_fusion_matches_reference(tag):
-    g = np.load(GOLD)
+@pytest.mark.parametrize("tag,gold", [(t, GOLD) for t in VARIANTS] + [(t, GOLD_K6) for t in K6_VARIANTS])
+def test_fusion_matches_reference(tag, gold):
+    g = np.load(gold)
     b, m, new = load(g, seg=tag in SEG)
-    opt = fuo.default_opt(height=int(b["H"]), width=int(b["W"]), **VARIANTS[tag])
+    opt = fuo.default_opt(height=int(b["H"]), width=int(b["W"]), num_neighbors=int(b.get("num_neighbors", 4)), **VARIANTS[tag])
+    assert m.knn_indices.shape[1] == opt.num_neighbors
     tid = b["track_id"].copy() if tag == "track" else None
     fuo.fuse_input_data(m, opt, b["K"], new, int(b["time"]), track_id=tid)
     check(m, g, f"{tag}_fuse_")
@@ -106,12 +111,13 @@ def test_semantic_fixture_exercises_class_test_and_weights():
     assert (cls == g["hard_fuse_seg"][new_rows][:, None]).all()
 
 
+@pytest.mark.parametrize("gold", [GOLD, GOLD_K6])
 @pytest.mark.parametrize("mode", ["plain", "sem", "hard"])
-def test_knn_feeder_matches_reference(mode):
+def test_knn_feeder_matches_reference(mode, gold):
     """update_ed / update_sfed_knn at frame 0 incl. the Semantic-SuPer branches (nodes.py:154-191)."""
-    g = np.load(GOLD)
+    g = np.load(gold)
     b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
-    opt = SimpleNamespace(method="super" if mode == "plain" else "semantic-super", num_neighbors=4, num_ED_neighbors=4,
+    opt = SimpleNamespace(method="super" if mode == "plain" else "semantic-super", num_neighbors=int(b.get("num_neighbors", 4)), num_ED_neighbors=4,
                           num_classes=int(b["num_classes"]))
     hard = mode == "hard"
     idx, w = fuo.update_ed(b["ed_points"], b["ed_radii"], opt, hard, b["ed_seg"])

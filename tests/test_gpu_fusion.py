@@ -6,7 +6,7 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
-from test_fusion_oracle import GOLD, SEG, VARIANTS
+from test_fusion_oracle import GOLD, GOLD_K6, K6_VARIANTS, SEG, VARIANTS
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,7 @@ def _objects(b, okw, seg=False):
     opt = SimpleNamespace(height=int(b["H"]), width=int(b["W"]), th_dist=0.1, th_cosine_ang=0.4, th_time_steps=30,
                           disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
                           disable_adding_new_surfels=False, disable_removing_unstable_surfels=False,
-                          phase="test", method="super", num_neighbors=4)
+                          phase="test", method="super", num_neighbors=int(b.get("num_neighbors", 4)))
     for k, v in okw.items():
         setattr(opt, k, v)
     sf = SimpleNamespace(opt=opt, hard_seg=False, evaluate_tracking=False, logger=logging.getLogger("fusion"),
@@ -59,10 +59,10 @@ def _check(sf, g, prefix):
         np.testing.assert_array_equal(get("dist2edge"), g[prefix + "dist2edge"])
 
 
-@pytest.mark.parametrize("tag", list(VARIANTS))
-def test_fusion_matches_reference_goldens(tag):
+@pytest.mark.parametrize("tag,gold", [(t, GOLD) for t in VARIANTS] + [(t, GOLD_K6) for t in K6_VARIANTS])
+def test_fusion_matches_reference_goldens(tag, gold):
     from super_amd import fusion
-    g = np.load(GOLD)
+    g = np.load(gold)
     b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
     sf, inputs, sfdata = _objects(b, VARIANTS[tag], seg=tag in SEG)
     if tag == "track":
@@ -235,16 +235,17 @@ def test_fusion_full_size_matches_oracle(mode):
     np.testing.assert_allclose(w.sum(1), 1.0, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("gold", [GOLD, GOLD_K6])
 @pytest.mark.parametrize("mode", ["plain", "sem", "hard"])
-def test_knn_feeder_semantic_branches_match_reference(mode):
+def test_knn_feeder_semantic_branches_match_reference(mode, gold):
     """update_ed / update_sfed_knn (frame 0) with hard_seg class-restricted neighbours and the
-    Jensen-Shannon weights of Semantic-SuPer, against the reference's goldens."""
+    Jensen-Shannon weights of Semantic-SuPer, against the reference's goldens (num_neighbors 4 and 6)."""
     import torch
     from super_amd import nodes
-    g = np.load(GOLD)
+    g = np.load(gold)
     b = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
     t = lambda a: torch.from_numpy(np.array(a, copy=True)).cuda()
-    opt = SimpleNamespace(method="super" if mode == "plain" else "semantic-super", num_neighbors=4, num_ED_neighbors=4,
+    opt = SimpleNamespace(method="super" if mode == "plain" else "semantic-super", num_neighbors=int(b.get("num_neighbors", 4)), num_ED_neighbors=4,
                           num_classes=int(b["num_classes"]))
     ed = SimpleNamespace(points=t(b["ed_points"]), radii=t(b["ed_radii"]), seg=t(b["ed_seg"]), seg_conf=t(b["ed_seg_conf"]))
     sf = SimpleNamespace(opt=opt, hard_seg=mode == "hard", ED_nodes=ed, points=t(b["sf_points"]), seg=t(b["sf_seg"]),
@@ -285,7 +286,7 @@ def test_hard_seg_with_too_few_nodes_of_a_class_fails_loudly():
     b["ed_seg"][b["ed_seg"] == 2] = 0
     b["ed_seg"][keep] = 2                      # class 2 keeps 3 nodes only
     sf, inputs, sfdata = _objects(b, VARIANTS["hard"], seg=True)
-    with pytest.raises(SuperLMError, match="at least 4 ED nodes"):
+    with pytest.raises(SuperLMError, match="at least num_neighbors ED nodes"):
         fusion.fuseInputData(sf, inputs, sfdata)
 
 
