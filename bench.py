@@ -508,31 +508,193 @@ def cpu_baseline_autograd(dims, seed):
                       f"{sc.J}-node frame, PyTorch-CPU float64, {dt:.1f} s"}
 
 
-def graphfit_timing(dims, device):
-    """The device side of rows a18-a20 (GraphFit: 10 Adam iterations of point-plane + ARAP + Rot on one frame of
-    the bench workload) through the C ABI, beside cpu_baseline_autograd which times the same thing on the host."""
+def _graphfit_frames(sc, device, semantic=False):
+    """(sf, inputs, new_data) of one synthetic scene for the GraphFit mirror (the semantic fields when asked for)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import torch_frame
+    sf, inputs, new_data = torch_frame(sc, device)
+    if semantic:
+        t = lambda a: torch.from_numpy(a).to(device)
+        sf.ED_nodes.triangles = t(sc.ed_triangles)
+        sf.ED_nodes.triangles_areas = t(sc.ed_triangle_areas).double()
+        sf.seg, sf.seg_conf = t(sc.sf_seg), t(sc.sf_seg_conf)
+        new_data.seg_conf = t(sc.tgt_seg_conf)
+        inputs[("seg_conf", 0)] = t(sc.img_seg_conf)[None]
+        inputs[("seg", 0)] = t(sc.img_seg)[None, None]
+    return sf, inputs, new_data
+
+
+def _time_gf_run(gf, n_frames, device, reps=10):
+    """ms per slm_gf_run(n_frames) from HIP events on the launch stream (the current torch stream)."""
+    import torch
+    st = torch.cuda.current_stream(device).cuda_stream
+    for _ in range(2):
+        gf.lib.slm_gf_run(gf.h, n_frames, st)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        gf.lib.slm_gf_run(gf.h, n_frames, st)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) / reps
+
+
+def graphfit_timing(dims, device, B=8):
+    """The device side of rows a18-a20 (GraphFit: 10 Adam iterations of point-plane + ARAP + Rot per frame of the bench
+    workload) through the C ABI, beside cpu_baseline_autograd which times the same thing on the host: ONE frame per launch
+    (what `deform_superedg` delivers to run_super.py) and B frames per launch (blockIdx.y = slot in every GraphFit kernel --
+    the per-GPU share of BASELINE configs[3]), with the HBM roofline of the path on its ALGORITHMIC bytes (per
+    frame and optimiser iteration the surfel pass streams 72 N bytes -- SURVEY 8d's loss-pass figure: xyz, KNN ids and
+    weights, four target taps -- and the node pass reads / writes dv, grad, m1, m2 and the node KNN table: 440 J bytes)."""
     import torch
     from super_amd import synth
     from super_amd.deform_mesh import GraphFit
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import torch_frame
-    sc = synth.make_scene(seed=0, **dims)
-    sf, inputs, new_data = torch_frame(sc, device)
     opt = synth.graphfit_options(optimizer="Adam")
+    it = int(opt.num_optimize_iterations)
+    scs = [synth.make_scene(seed=s, **dims) for s in range(B)]
+    out = {}
+    for n in (1, B):
+        gf = GraphFit(opt, max_frames=n)
+        keep = [gf._bind(i, *_reorder(_graphfit_frames(scs[i], device))) for i in range(n)]
+        ms = _time_gf_run(gf, n, device)
+        alg = n * it * (72.0 * scs[0].N + 440.0 * scs[0].J)
+        gbs = alg / ms / 1e6
+        out[f"b{n}"] = {"ms_per_launch": ms, "ms_per_frame": ms / n, "value": n * it / (ms * 1e-3), "unit": "Adam it/s",
+                        "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                     "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                     "kernels": "k_gf_zero + k_gf_data + k_gf_reg + k_gf_step + k_gf_advance per iteration"}}
+        del keep, gf
+    out["sample"] = (f"{it} Adam iterations per frame on {scs[0].N}-surfel / {scs[0].J}-node frames, float64 arithmetic, C ABI; "
+                     f"b1 = one frame per slm_gf_run, b{B} = {B} frames per launch; HIP events on the launch stream")
+    # flat keys of rounds 1-5 (one frame per launch)
+    out["ms_per_frame"], out["value"], out["unit"] = out["b1"]["ms_per_frame"], out["b1"]["value"], "Adam it/s"
+    return out
+
+
+def _reorder(t):
+    sf, inputs, new_data = t
+    return inputs, sf, new_data
+
+
+def graphfit_c4_semantic(device):
+    """BASELINE configs[4]'s own workload on one GPU: the Semantic-SuPer GraphFit step (soft-segmentation point-plane +
+    face + boundary morphing + ARAP + Rot; reference super/deform_mesh.py:25-196,251-379) on a 500 k-surfel / 4 k-node
+    frame at 720 x 960, ten SGD iterations per frame through the C ABI, float64 (the fp16-residual mode is rejected on
+    evidence).  Parity of this very configuration: tests/test_gpu_edge_and_fullsize.py."""
+    from super_amd import synth
+    from super_amd.deform_mesh import GraphFit
+    sc = synth.make_scene(seed=0, semantic=True, seg_smooth=11, **synth.WORKLOADS["C4"])
+    opt = synth.graphfit_options(sf_soft_seg_point_plane=True, mesh_face=True, sf_bn_morph=True, sf_bn_morph_weight=0.1,
+                                 num_classes=3)
     gf = GraphFit(opt)
-    gf._bind(0, inputs, sf, new_data)
-    st = torch.cuda.current_stream(device).cuda_stream
-    for _ in range(2):
-        gf.lib.slm_gf_run(gf.h, 1, st)
-    torch.cuda.synchronize(device)
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        gf.lib.slm_gf_run(gf.h, 1, st)
-    torch.cuda.synchronize(device)
-    dt = (time.perf_counter() - t0) / n
-    return {"ms_per_frame": 1e3 * dt, "value": opt.num_optimize_iterations / dt, "unit": "Adam it/s",
-            "sample": f"10 Adam iterations per frame on one {sc.N}-surfel / {sc.J}-node frame, float64, C ABI"}
+    keep = gf._bind(0, *_reorder(_graphfit_frames(sc, device, semantic=True)))
+    ms = _time_gf_run(gf, 1, device, reps=5)
+    it = int(opt.num_optimize_iterations)
+    alg = it * (72.0 * sc.N + 440.0 * sc.J + 16.0 * sc.N)    # + the per-surfel morphing gradient (written, then read)
+    del keep
+    return {"ms_per_frame": ms, "value": it / (ms * 1e-3), "unit": "SGD it/s",
+            "achieved_GBps_on_algorithmic_bytes": alg / ms / 1e6, "hbm_frac": alg / ms / 1e6 / HBM_PEAK_GBS,
+            "boundary_pixels": list(gf.edge_counts) if gf.edge_counts else None,
+            "sample": f"one {sc.N}-surfel / {sc.J}-node frame at {sc.H}x{sc.W}, 3 classes, {it} SGD iterations per frame: soft-seg "
+                      "point-plane + mesh_face + sf_bn_morph + ARAP + Rot, float64, C ABI, HIP events"}
+
+
+def batch_sequence(device, surfaces=8, frames=20):
+    """`batch_sequence`: the headline's 8 frames per launch as a tracker of EIGHT surfaces sees them -- not the always-warm
+    re-bind of the same eight problems, but eight moving surfaces at the SuPer image size (phase-shifted against each other)
+    stepped in lock-step through the stage mirrors: depth preprocessing x 8 -> ONE LM_Solver.LM_batch over the eight
+    models (slm_bind_frame per slot + slm_run(8)) -> update / fuseInputData / swap x 8 -> the model-side prepare of the
+    next frame per slot (slm_prepare_model).  Real updates, fusion between frames, symbolic analyses and rejected
+    iterations where they fall.  Reported: LM it/s over the LM stage, LM-stage and whole-step ms per frame, the share of
+    (surface, frame) binds that needed a symbolic analysis, the share of rejected iterations."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import driver_harness as drv
+    from super_amd import _lib, synth
+    from super_amd.LM import LM_Solver
+    H, W = 480, 640
+    K = synth.intrinsics()
+    inv_K = np.linalg.pinv(K)
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    color = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (3, H, W)).astype(np.float32))[None].to(device)
+
+    def depth(s, k):
+        d = (0.2 * synth._surface(uu, vv, H, W, 0.3 + 0.3 * np.sin(0.05 * k + 0.7 * s))).astype(np.float32)
+        d[:4] = 0.0
+        d[:, :4] = 0.0
+        return torch.from_numpy(d)[None, None].to(device)
+
+    opt = SimpleNamespace(height=H, width=W, data="superv1", load_valid_mask=False, depth_model="monodepth2",
+                          dilate_invalid_kernel=0, normal_model="naive", phase="test", method="super", load_depth=True,
+                          deform_udpate_method="super_edg", mesh_step_size=11, use_derived_gradient=True,
+                          sf_point_plane=True, mesh_arap=True, mesh_rot=True, mesh_face=False, sf_point_plane_weight=1.0,
+                          mesh_arap_weight=10.0, mesh_rot_weight=1.0, mesh_face_weight=1.0, num_optimize_iterations=10,
+                          num_neighbors=4, num_ED_neighbors=4, th_dist=0.02, th_cosine_ang=0.4, th_time_steps=30,
+                          disable_merging_new_surfels=False, disable_merging_exist_surfels=False,
+                          disable_adding_new_surfels=False, disable_removing_unstable_surfels=False, slm_prepare_ahead=False)
+    loops = [drv.FrameLoop(opt) for _ in range(surfaces)]      # per-surface model state (their own solvers stay unused)
+    lm = LM_Solver(opt, max_frames=surfaces)
+    lib = _lib.load()
+    cnt = (C.c_int64 * 4)()
+
+    def inputs_of(s, k):
+        return {("depth", 0): depth(s, k), ("disp", 0): torch.zeros(1, 1, H, W, device=device),
+                "inv_K": torch.from_numpy(inv_K)[None].to(device), "K": torch.from_numpy(K)[None].to(device),
+                ("color", 0): color, "divterm": torch.tensor(1.0 / (2 * 0.6 * 0.6)), "filename": ["%06d" % k], "time": k,
+                "ID": torch.tensor([k])}
+
+    for s, loop in enumerate(loops):                            # frame 0: the models
+        loop(SimpleNamespace(), inputs_of(s, 0))
+        lm.prepare_model(loop.sf, slot=s)
+    lm_ms, step_ms, builds, rej, its = [], [], [], 0, 0
+    for k in range(1, frames):
+        ins = [inputs_of(s, k) for s in range(surfaces)]
+        torch.cuda.synchronize(device)
+        lib.slm_debug_counters(cnt)
+        b0 = cnt[2]
+        t0 = time.perf_counter()
+        tg = []
+        for s, loop in enumerate(loops):
+            target, ins[s] = drv.depth_preprocessing(opt, None, loop._to_device(ins[s]))
+            tg.append(target)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        betas = lm.LM_batch([(loop.sf, ins[s], tg[s]) for s, loop in enumerate(loops)])
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        for s, loop in enumerate(loops):
+            loop.sf.update(betas[s])
+            loop.sf.fuseInputData(ins[s], tg[s])
+            loop.sf.prepareStableIndexNSwapAllModel(ins[s], tg[s])
+            lm.prepare_model(loop.sf, slot=s)
+        torch.cuda.synchronize(device)
+        t3 = time.perf_counter()
+        lib.slm_debug_counters(cnt)
+        lm_ms.append((t2 - t1) * 1e3)
+        step_ms.append((t3 - t0) * 1e3)
+        builds.append(int(cnt[2] - b0))
+        for recs in lm.last_records:
+            its += len(recs)
+            rej += sum(1 for r in recs if r["status"] == 0 and not r["accepted"])
+    skip = 3
+    lmv, stv = np.array(lm_ms[skip:]), np.array(step_ms[skip:])
+    n_it = int(opt.num_optimize_iterations)
+    surf = [int(l.sf.points.shape[0]) for l in loops]
+    nodes = int(loops[0].sf.ED_nodes.num)
+    return {"value": surfaces * n_it / (float(np.median(lmv)) * 1e-3), "unit": "LM it/s (LM stage, median step)",
+            "lm_stage_ms_per_frame": float(np.median(lmv)) / surfaces, "lm_stage_ms": {"median": float(np.median(lmv)), "p99": float(np.percentile(lmv, 99)), "mean": float(lmv.mean())},
+            "step_ms_per_frame": float(np.median(stv)) / surfaces,
+            "cold_bind_share": float(sum(builds[skip:])) / (surfaces * len(builds[skip:])),
+            "rejected_iteration_share": rej / max(its, 1),
+            "sample": f"{surfaces} moving synthetic surfaces in lock-step, {frames - 1 - skip} counted frames each, {H}x{W}, "
+                      f"{min(surf)}..{max(surf)} surfels / {nodes} nodes at the end, {n_it} LM iterations per frame, one slm_run over "
+                      f"{surfaces} slots per step (hybrid solver); model-side prepare queued per slot after the swap; whole step = depth "
+                      "preprocessing + LM + update + fusion + swap of all surfaces, host-timed around stream syncs"}
 
 
 def next_row_timings(device):
@@ -908,6 +1070,8 @@ def main():
             out["latency_b1_sequence"] = latency_b1_sequence(device)
             if a.workload in ("C1", "C2") and S == 1:
                 out["batch_depth"] = batch_depth(scenes, device, iters)
+            if a.workload == "C2" and S == 1 and B == 8:
+                out["batch_sequence"] = batch_sequence(device)
         out["host"] = host_info()
         out["host"]["cpu_cores_busy_per_rank"] = round(cpu_busy, 2)   # (rank 0; timed region; user + system time of all threads)
         out["host"]["cpu_cores_busy_all_ranks"] = round(cpu_busy_all, 2)   # (sum over the ranks: what the job costs of the node's CPU quota)
@@ -918,7 +1082,9 @@ def main():
             out["parity_" + a.workload.lower()] = parity_check(dims, device, oracle_beta, oracle_trace, B)
             assert out["parity_" + a.workload.lower()]["ok"], out["parity_" + a.workload.lower()]
             out["cpu_baseline_autograd"] = cpu_baseline_autograd(dims, seed=0)
-            out["graphfit_gpu"] = graphfit_timing(dims, device)
+            out["graphfit_gpu"] = graphfit_timing(dims, device, B)
+            out["roofline_graphfit"] = out["graphfit_gpu"][f"b{B}"]["roofline"]
+            out["graphfit_c4_semantic"] = graphfit_c4_semantic(device)
             out["next_rows"] = next_row_timings(device)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -48,6 +48,7 @@ void launch_iter_begin(const FrameDev*, int, hipStream_t);
 void launch_pack_nodes(const FrameDev*, int, int, hipStream_t);
 void launch_make_trial(const FrameDev*, int, int, hipStream_t);
 void launch_pack_target(int, const float*, const float*, float4*, hipStream_t);
+void launch_pack_target_px(int, const int*, const uint8_t*, const float*, const float*, float4*, hipStream_t);
 void launch_accept(const FrameDev*, int, int, int, int, hipStream_t, int* reuse = nullptr, int eval_pass = 0);
 void launch_loss_out(const FrameDev*, int, int, double*, hipStream_t);
 void launch_zero_reg_part(const FrameDev*, int, int, hipStream_t);
@@ -123,7 +124,7 @@ constexpr int kRegBlocksMax = 64;
 
 struct Slot {
   FrameDev h{};                 // host mirror of the device descriptor
-  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0, cap_npk = 0, cap_tpn = 0, cap_ev = 0;
+  size_t cap_beta = 0, cap_vec = 0, cap_band = 0, cap_linv = 0, cap_npk = 0, cap_tpn = 0, cap_tpx = 0, cap_ev = 0;
   V1Plan plan;                  // tuple-sorted assembly buffers (grow-only)
   PairPlan pplan;               // K-generic pair path (num_neighbors != 4): pair keys, per-surfel pair indices, surfel order
   // nested-dissection plan: host copy + device mirrors (grow-only)
@@ -563,6 +564,7 @@ int slm_destroy(slm_solver* s) {
     if (h.rec) (void)hipFree(h.rec);
     if (h.node_pk) (void)hipFree(h.node_pk);
     if (h.tgt_pn) (void)hipFree(h.tgt_pn);
+    if (h.tgt_px) (void)hipFree(h.tgt_px);
     if (h.ev_rc) (void)hipFree(h.ev_rc);
     plan_free(sl.plan);
     pairplan_free(sl.pplan);
@@ -1044,6 +1046,8 @@ static int bind_target_part(slm_solver* s, int32_t slot, const slm_frame* f, hip
   h.f = *f;
   HIPCHK(grow(h.tgt_pn, sl.cap_tpn, (size_t)2 * (f->T > 0 ? f->T : 1)));
   launch_pack_target(f->T, f->tgt_points, f->tgt_norms, h.tgt_pn, st);
+  HIPCHK(grow(h.tgt_px, sl.cap_tpx, (size_t)2 * f->H * f->W));
+  launch_pack_target_px(f->H * f->W, f->index_map, f->tgt_valid, f->tgt_points, f->tgt_norms, h.tgt_px, st);
   h.bound = 1;
   // descriptor -> device through the slot's pinned mirror: no wait for the copy (the mirror always holds the newest
   // host state, and every change of it is followed by another copy on the stream)

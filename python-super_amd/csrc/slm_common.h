@@ -77,6 +77,11 @@ struct FrameDev {
   GP<double> node_pk;       // (J,10): beta[0..6], g.x, g.y, g.z (float64: exact for either state dtype)
   GP<double> node_pk_try;   // same at the trial point beta + delta (loss pass of the LM loop)
   GP<float4> tgt_pn;        // (T,2): target point xyz0, target normal xyz0
+  // (H*W,2) the same PER PIXEL (round 6): {point xyz, w = 1 where the pixel is mapped (index_map >= 0) else 0}, {normal xyz,
+  // w = 1 where tgt_valid}.  A bilinear tap of the evaluation pass (k_data_eval) is then ONE 32-byte gather instead of
+  // index_map -> row -> point/normal (two dependent sector reads per tap) and the validity of the rounded pixel -- which
+  // is one of the four taps -- needs no load of its own; the two taps of an image row are adjacent in memory.
+  GP<float4> tgt_px;
   GP<unsigned long long> dbg;  // diagnostic builds only (-DSLM_STAMPS): in-kernel s_memtime stamps
   // ---- tuple-sorted data-term assembly (slm_prep.hip / slm_data_v1.hip) ----
   int32_t v1_ready;      // 1 when the structures below are valid for this frame

@@ -51,7 +51,10 @@ __device__ __forceinline__ void rows_from_c(const d3 p, const int id[4], const d
 // surfel stream entries early pass them in (eval_surfel_core).
 // MODE 0: residual only (loss pass); 1: residual + the 28 row entries; 2: residual + c (the evaluation pass that feeds
 // the tuple-sorted Jacobian pass, slm_data_v1.hip)
-template <int MODE, int KK>
+// PX: the target taps come from the per-pixel table (FrameDev::tgt_px): one 32-byte gather per tap, the validity of the
+// rounded pixel from the tap that IS that pixel; out.taps is not filled (the evaluation pass of the LM loop does not
+// need the row numbers).  Same values, same sums: the match set and the residuals are those of the row-table form.
+template <int MODE, int KK, bool PX = false>
 __device__ __forceinline__ void eval_surfel_coreT(const FrameDev& fd, const d3 p, const int id[KK], const double w[KK],
                                                   double lam, const double* __restrict__ npk, SurfelEvalT<KK>& out) {
   const FrameIn& f = frame_in(fd);
@@ -88,34 +91,57 @@ __device__ __forceinline__ void eval_surfel_coreT(const FrameDev& fd, const d3 p
   // proj_valid (false for NaN): 0 <= v < H-1, 0 <= u < W-1
   const bool pv = vr >= 0.0 && vr < (double)(H - 1) && ur >= 0.0 && ur < (double)(W - 1);
   // valid_pair (loss.py:229-234) and the four bilinear taps (loss.py:107-129): one round trip
-  const int coords = pv ? (int)vr * W + (int)ur : 0;
   const double fv = floor(v_), cv = ceil(v_), fu = floor(u_), cu = ceil(u_);
   const double nn[4] = {fv, fv, cv, cv};
   const double mm[4] = {fu, cu, fu, cu};
-  const uint8_t tv = pv ? f.tgt_valid[coords] : (uint8_t)0;
-  int rows[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int ni = (int)nn[t], mi = (int)mm[t];
-    const bool inside = pv && (ni >= 0) && (ni < H) && (mi >= 0) && (mi < W);
-    rows[t] = inside ? f.index_map[ni * W + mi] : -1;
-  }
-  if (!tv) return;
-  bool all_ok = true;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    out.taps[t] = rows[t];
-    all_ok = all_ok && (rows[t] >= 0);
-  }
-  if (!all_ok) return;   // NaN fill -> surfel dropped (loss.py:241)
-
   d3 o = {0, 0, 0}, n = {0, 0, 0};
   d3 dou = {0, 0, 0}, dov = {0, 0, 0}, dnu = {0, 0, 0}, dnv = {0, 0, 0};
+  float4 tpv[4], tnv[4];
+  if constexpr (PX) {
+    bool all_ok = pv;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ni = (int)nn[t], mi = (int)mm[t];
+      const bool inside = pv && (ni >= 0) && (ni < H) && (mi >= 0) && (mi < W);
+      const float4* q = fd.tgt_px.get() + 2 * (size_t)(inside ? ni * W + mi : 0);
+      tpv[t] = q[0];
+      tnv[t] = q[1];
+      all_ok = all_ok && inside && tpv[t].w != 0.f;
+    }
+    // the rounded pixel is one of the taps: (vr, ur) in {fv, cv} x {fu, cu}
+    const int tr = ((vr != fv) ? 2 : 0) + ((ur != fu) ? 1 : 0);
+    const float tvf = tr == 0 ? tnv[0].w : (tr == 1 ? tnv[1].w : (tr == 2 ? tnv[2].w : tnv[3].w));
+    if (!pv || tvf == 0.f) return;
+    if (!all_ok) return;   // NaN fill -> surfel dropped (loss.py:241)
+  } else {
+    const int coords = pv ? (int)vr * W + (int)ur : 0;
+    const uint8_t tv = pv ? f.tgt_valid[coords] : (uint8_t)0;
+    int rows[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ni = (int)nn[t], mi = (int)mm[t];
+      const bool inside = pv && (ni >= 0) && (ni < H) && (mi >= 0) && (mi < W);
+      rows[t] = inside ? f.index_map[ni * W + mi] : -1;
+    }
+    if (!tv) return;
+    bool all_ok = true;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      out.taps[t] = rows[t];
+      all_ok = all_ok && (rows[t] >= 0);
+    }
+    if (!all_ok) return;   // NaN fill -> surfel dropped (loss.py:241)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      tpv[t] = fd.tgt_pn[2 * (size_t)rows[t]];
+      tnv[t] = fd.tgt_pn[2 * (size_t)rows[t] + 1];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const double dn = nn[t] - v_, dm = mm[t] - u_;
     const double an = fmax(1.0 - fabs(dn), 0.0), am = fmax(1.0 - fabs(dm), 0.0);
-    const float4 tp = fd.tgt_pn[2 * (size_t)rows[t]], tn = fd.tgt_pn[2 * (size_t)rows[t] + 1];
+    const float4 tp = tpv[t], tn = tnv[t];
     const d3 P = {(double)tp.x, (double)tp.y, (double)tp.z};
     const d3 Nn = {(double)tn.x, (double)tn.y, (double)tn.z};
     const double wv = an * am;
@@ -166,11 +192,11 @@ __device__ __forceinline__ void eval_surfel_coreT(const FrameDev& fd, const d3 p
 }
 
 // the K = 4 form (one 16-byte load of the ids, what every caller of the tuple-sorted path uses)
-template <int MODE>
+template <int MODE, bool PX = false>
 __device__ __forceinline__ void eval_surfel_core(const FrameDev& fd, const d3 p, int4 ids, const double w[4],
                                                  double lam, const double* __restrict__ npk, SurfelEval& out) {
   const int id[4] = {ids.x, ids.y, ids.z, ids.w};
-  eval_surfel_coreT<MODE, SLM_K>(fd, p, id, w, lam, npk, out);
+  eval_surfel_coreT<MODE, SLM_K, PX>(fd, p, id, w, lam, npk, out);
 }
 
 template <int MODE>

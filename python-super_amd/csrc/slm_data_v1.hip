@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_data_eval(const FrameDev* __restrict__ 
       ld_state4(fd.s_w, (size_t)pos, fd.f.state_f64, wk);
       const d3 pp = ld_state3(fd.s_pts, (size_t)pos, fd.f.state_f64);
       SurfelEval ev;
-      eval_surfel_core<2>(fd, pp, ids, wk, lam, npk, ev);
+      eval_surfel_core<2, true>(fd, pp, ids, wk, lam, npk, ev);   // (target taps from the per-pixel table)
       if (ev.match) {
         acc += ev.r * ev.r;
         ++cnt;

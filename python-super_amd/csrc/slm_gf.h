@@ -3,6 +3,15 @@
 #pragma once
 #include "slm_data.h"
 
+// Block partials of the per-slot scalars (the global row's gradient, the loss terms, the counts) go to GF_NCOPY spread copies
+// behind `terms` -- copy (blockIdx.x % GF_NCOPY), entry a: terms[SLM_GF_NTERMS + 16 copy + a] -- and k_gf_fold sums the copies
+// in a fixed order into grad[7J..] / terms[].  One global f64 atomic per block and scalar onto ONE address serialises in the
+// L2: 782 blocks x ~0.1 us = the whole 82 us of k_gf_data at C2 (round 6); spread over 64 addresses it is 12 per address.
+//   a = 0..6 global row (k_gf_data, k_gf_reg) | 7, 8 point-plane loss, kept | 9, 10 correspondence loss, kept |
+//   11, 12, 13 face, arap, rot | 14, 15 morphing sum, kept
+#define GF_NCOPY 64
+#define GF_PART_DOUBLES (16 * GF_NCOPY)
+
 struct GfSlot {
   slm_gf_frame f;
   int32_t bound;
@@ -110,6 +119,48 @@ __device__ __forceinline__ void gf_skin(const GfSlotDev& s, int i, GfSkinT<KK>& 
     k.qv[a] = {b[1], b[2], b[3]};
     k.dk[a] = p - g;
     d3 t = quat_apply(k.qw[a], k.qv[a], k.dk[a]);
+    t = {t.x + b[4] + g.x, t.y + b[5] + g.y, t.z + b[6] + g.z};
+    k.T = {k.T.x + k.w[a] * t.x, k.T.y + k.w[a] * t.y, k.T.z + k.w[a] * t.z};
+  }
+  const double* bgl = s.dv + 7 * f.J;
+  k.gw = bgl[0];
+  k.gv = {bgl[1], bgl[2], bgl[3]};
+  k.P = quat_apply(k.gw, k.gv, k.T);
+  k.P = {k.P.x + bgl[4], k.P.y + bgl[5], k.P.z + bgl[6]};
+}
+
+// The same without the per-neighbour state: ids, weights, p, T, P and the global row only.  k_gf_data keeps THIS across its
+// sampling phase (26 + 3 K registers instead of 30 + 17 K) and re-reads the nodes -- cache hits -- when it back-propagates:
+// with GfSkinT held live the kernel needed more than 256 VGPRs and ran at ONE wave per SIMD (round 6).
+template <int KK>
+struct GfSkinLight {
+  int id[KK];
+  double w[KK];
+  d3 p, T, P;
+  double gw;
+  d3 gv;
+};
+template <int KK>
+__device__ __forceinline__ void gf_skin_light(const GfSlotDev& s, int i, GfSkinLight<KK>& k) {
+  const FrameIn& f = s.f.base;
+  k.p = ld_state3(f.sf_points, (size_t)i, f.state_f64);
+  if constexpr (KK == SLM_K) {
+    const int4 ids = *reinterpret_cast<const int4*>(f.sf_knn_idx + 4 * (size_t)i);
+    k.id[0] = ids.x; k.id[1] = ids.y; k.id[2] = ids.z; k.id[3] = ids.w;
+    ld_state4(f.sf_knn_w, (size_t)i, f.state_f64, k.w);
+  } else {
+#pragma unroll
+    for (int a = 0; a < KK; ++a) {
+      k.id[a] = f.sf_knn_idx[(size_t)KK * i + a];
+      k.w[a] = ld_state1(f.sf_knn_w, (size_t)KK * i + a, f.state_f64);
+    }
+  }
+  k.T = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < KK; ++a) {
+    const double* b = s.dv + 7 * k.id[a];
+    const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
+    d3 t = quat_apply(b[0], {b[1], b[2], b[3]}, k.p - g);
     t = {t.x + b[4] + g.x, t.y + b[5] + g.y, t.z + b[6] + g.z};
     k.T = {k.T.x + k.w[a] * t.x, k.T.y + k.w[a] * t.y, k.T.z + k.w[a] * t.z};
   }

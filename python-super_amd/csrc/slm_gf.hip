@@ -16,12 +16,42 @@
 
 #include "slm_sem.h"
 
-__global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
+// advance: the optimiser step the previous iteration applied is counted HERE (slm_gf_run: k_gf_advance was a launch of its
+// own per iteration; nothing between k_gf_step and this kernel reads the counter)
+__global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots, int advance) {
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
+  if (advance && blockIdx.x == 0 && threadIdx.x == 0) s.step += 1;
   const int n = (s.f.base.J + 1) * 7;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) s.grad[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x < SLM_GF_NTERMS) s.terms[threadIdx.x] = 0.0;
+  if (blockIdx.x == 1 % gridDim.x)
+    for (int e = threadIdx.x; e < GF_PART_DOUBLES; e += blockDim.x) s.terms[SLM_GF_NTERMS + e] = 0.0;
+}
+
+// the spread block partials (slm_gf.h) -> grad[7J + 0..6] and terms[], copies summed in a fixed order, then cleared.
+// which: bit0 = the entries of k_gf_data / k_gf_reg (0..13), bit1 = those of k_gf_morph (14, 15).  grid = (1, n_frames), 64 threads
+__global__ void __launch_bounds__(64) k_gf_fold(GfSlot* __restrict__ slots, int which) {
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
+  if (!s.bound) return;
+  const int a = threadIdx.x;
+  if (a >= 16) return;
+  const bool mine = a < 14 ? (which & 1) != 0 : (which & 2) != 0;
+  if (!mine) return;
+  double* part = s.terms.get() + SLM_GF_NTERMS;
+  double t = 0.0;
+  for (int c = 0; c < GF_NCOPY; ++c) {
+    t += part[16 * c + a];
+    part[16 * c + a] = 0.0;
+  }
+  if (t == 0.0) return;
+  const int J = s.f.base.J;
+  if (a < 7) s.grad[7 * J + a] += t;
+  else {
+    // 7, 8 -> terms[3], [4]; 9, 10 -> [8], [9]; 11, 12, 13 -> [0], [1], [2]; 14, 15 -> [5], [6]
+    const int map[9] = {3, 4, 8, 9, 0, 1, 2, 5, 6};
+    s.terms[map[a - 7]] += t;
+  }
 }
 
 // 4-tap gather of the target maps at the float pixel (u_, v_) (bilinear_sample, loss.py:9-80, zero fill):
@@ -105,10 +135,15 @@ __device__ __forceinline__ void gf_flow_sample(const float* __restrict__ flow, i
 // use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
 // KK = opt.num_neighbors of the launch's slots (deform_source is K-generic, super/deform_mesh.py:198-221)
 #define GF_TAB 128   // LDS gradient table: slots per workgroup (power of two)
-template <int KK>
-__global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode,
-                                                  double pp_max, int use_morph, double w_morph, int corr_mode,
-                                                  double lam_c) {
+// EXTRA = false: the plain point-plane term only (no segmentation weight, clip, morphing or correspondence term) -- the
+// instantiation the default options run: those code paths, and the registers they hold, are compiled out (round 6: the
+// kernel ran at ONE wave per SIMD with everything in one body).
+template <int KK, bool EXTRA>
+__global__ void __launch_bounds__(256, 3) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode_,
+                                                     double pp_max_, int use_morph_, double w_morph, int corr_mode_,
+                                                     double lam_c) {
+  const int seg_mode = EXTRA ? seg_mode_ : 0, use_morph = EXTRA ? use_morph_ : 0, corr_mode = EXTRA ? corr_mode_ : 0;
+  const double pp_max = EXTRA ? pp_max_ : 0.0;
   __shared__ double sm[16];
   // The 256 surfels of a workgroup are neighbours on the image and share a few dozen ED nodes: their
   // gradient rows are summed in an LDS table keyed by node (ds_add_f64) and flushed with one global
@@ -116,6 +151,8 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   // and entry.  A slot taken by another node (direct-mapped, node & 127) falls back to global atomics.
   __shared__ int tkey[GF_TAB];
   __shared__ double tval[GF_TAB * 7];
+  __shared__ double s_gval[4][16][7 * KK];   // gradient rows of 16 surfels of each wave, canonical slot order
+  __shared__ int s_gid[4][16][KK];
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound || s.f.base.K != KK) return;
   for (int t = threadIdx.x; t < GF_TAB; t += blockDim.x) tkey[t] = -1;
@@ -125,9 +162,13 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int J = f.J;
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0}, loss = 0.0, cnt = 0.0, lossc = 0.0, cntc = 0.0;
+  bool has_grad = false;
+  d3 cl = {0, 0, 0};          // dL/dT(p) of this surfel (the global rotation undone): what its neighbours' rows are formed from
+  GfSkinLight<KK> k;
+#pragma unroll
+  for (int a = 0; a < KK; ++a) k.id[a] = 0;
   if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
-    GfSkinT<KK> k;
-    gf_skin<KK>(s, i, k);
+    gf_skin_light<KK>(s, i, k);
     const d3 P = k.P;
     const double fx = (double)f.fx, fy = (double)f.fy, cx = (double)f.cx, cy = (double)f.cy;
     const double Ze = P.z + 1e-8;
@@ -248,23 +289,78 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
       gb[0] = gP.x;
       gb[1] = gP.y;
       gb[2] = gP.z;
-      const d3 cl = quat_apply_t(k.gw, k.gv, gP);
+      cl = quat_apply_t(k.gw, k.gv, gP);
+      has_grad = true;
+    }
+  }
+  // ---- the local rows: the WAVE turns round (round 6).  One LDS atomic per surfel, neighbour and entry -- 28 per surfel,
+  // most of them onto the few addresses the wave's surfels share -- serialised inside every instruction (k_gf_data was 8x
+  // slower per surfel than the LM path's evaluation pass).  Now the gradient rows of 16 surfels at a time go to LDS in
+  // canonical slot order and lane e < 7 KK owns ENTRY (slot e / 7, component e % 7): it walks the surfels, accumulates in
+  // a register while the slot's node stays the same and adds to the workgroup's table when it changes -- one conflict-free
+  // add per run of surfels with a common node instead of one conflicting add per surfel.
+  {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long am = __ballot(has_grad);
+    const int slot = l / 7;
+    double acc = 0.0;
+    int prev = -1;
+    auto flush = [&]() {
+      if (prev < 0) return;
+      const int ts = prev & (GF_TAB - 1);
+      const int old = atomicCAS(&tkey[ts], -1, prev);
+      if (old == -1 || old == prev) unsafeAtomicAdd(&tval[7 * ts + (l - 7 * slot)], acc);
+      else atomic_add_f64(s.grad + 7 * prev + (l - 7 * slot), acc);
+    };
+    if (am) {
+#pragma unroll 1
+      for (int sb = 0; sb < 4; ++sb) {
+        const unsigned mask16 = (unsigned)((am >> (16 * sb)) & 0xFFFFull);
+        if (mask16 == 0u) continue;                       // (uniform)
+        if ((l >> 4) == sb && has_grad) {
+          // this sub-batch's surfels form their rows now and write them straight to LDS (nothing per neighbour was held
+          // across the sampling phase: the node rows / positions are read again -- cache hits)
+          const FrameIn& f = s.f.base;
 #pragma unroll
-      for (int a = 0; a < KK; ++a) {
-        quat_jac_row(k.qw[a], k.qv[a], k.dk[a], cl, jq);
-        const double wk = k.w[a];
-        const double v[7] = {wk * jq[0], wk * jq[1], wk * jq[2], wk * jq[3], wk * cl.x, wk * cl.y, wk * cl.z};
-        const int node = k.id[a], slot = node & (GF_TAB - 1);
-        const int old = atomicCAS(&tkey[slot], -1, node);
-        if (old == -1 || old == node) {
+          for (int a = 0; a < KK; ++a) {
+            const double* b = s.dv + 7 * k.id[a];
+            const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
+            double jq[4];
+            quat_jac_row(b[0], {b[1], b[2], b[3]}, k.p - g, cl, jq);
+            const double wk = k.w[a];
+            // canonical slot of neighbour a: its rank among the surfel's node ids (two surfels with the same neighbour SET
+            // have the same node in every slot, whatever the distance order of their KNN lists)
+            int rank = 0;
 #pragma unroll
-          for (int e = 0; e < 7; ++e) unsafeAtomicAdd(&tval[7 * slot + e], v[e]);
-        } else {
-          double* gr = s.grad + 7 * node;
-#pragma unroll
-          for (int e = 0; e < 7; ++e) atomic_add_f64(gr + e, v[e]);
+            for (int b2 = 0; b2 < KK; ++b2) rank += (k.id[b2] < k.id[a]) ? 1 : 0;
+            s_gid[w][l & 15][rank] = k.id[a];
+            double* dst = &s_gval[w][l & 15][7 * rank];
+            dst[0] = wk * jq[0]; dst[1] = wk * jq[1]; dst[2] = wk * jq[2]; dst[3] = wk * jq[3];
+            dst[4] = wk * cl.x;  dst[5] = wk * cl.y;  dst[6] = wk * cl.z;
+          }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (l < 7 * KK) {
+          for (unsigned mm = mask16; mm; mm &= mm - 1) {
+            const int si = __builtin_ctz(mm);
+            const int id = s_gid[w][si][slot];
+            const double v = s_gval[w][si][l];
+            if (id != prev) {
+              flush();
+              prev = id;
+              acc = v;
+            } else {
+              acc += v;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+      if (l < 7 * KK) flush();
     }
   }
   __syncthreads();
@@ -279,12 +375,8 @@ __global__ void __launch_bounds__(256) k_gf_data(GfSlot* __restrict__ slots, int
   for (int a = 0; a < 11; ++a) {
     if (a >= 9 && !corr_mode) break;
     const double t = block_sum(vals[a], sm);
-    if (threadIdx.x == 0 && t != 0.0) {
-      if (a < 7) atomic_add_f64(s.grad + 7 * J + a, t);
-      else if (a == 7) atomic_add_f64(s.terms + 3, t);
-      else if (a == 8) atomic_add_f64(s.terms + 4, t);
-      else atomic_add_f64(s.terms + (a - 1), t);   // [8] correspondence loss, [9] residuals kept
-    }
+    // (spread block partials, slm_gf.h: entries 0..6 global row, 7 / 8 point-plane loss / kept, 9 / 10 correspondence loss / kept)
+    if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(s.terms.get() + SLM_GF_NTERMS + 16 * (blockIdx.x % GF_NCOPY) + a, t);
   }
 }
 
@@ -383,10 +475,9 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
 #pragma unroll
   for (int a = 0; a < 10; ++a) {
     const double tt = block_sum(vals[a], sm);
-    if (threadIdx.x == 0 && tt != 0.0) {
-      if (a < 7) atomic_add_f64(s.grad + 7 * J + a, tt);
-      else atomic_add_f64(s.terms + (a - 7), tt);
-    }
+    // (spread block partials: 0..6 global row, 11 / 12 / 13 face / arap / rot)
+    if (threadIdx.x == 0 && tt != 0.0)
+      atomic_add_f64(s.terms.get() + SLM_GF_NTERMS + 16 * (blockIdx.x % GF_NCOPY) + (a < 7 ? a : a + 4), tt);
   }
 }
 
@@ -552,9 +643,12 @@ static int gf_fail(int code, const char* msg) {
 }
 
 // pass 1: zero the gradient / terms, then the morphing term's per-surfel pass (sum, count)
-static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStream_t st) {
-  hipLaunchKernelGGL(k_gf_zero, dim3(32, n), dim3(256), 0, st, slots);
-  if (g->cfg.use_bn_morph) launch_gf_morph(slots, n, maxN, st);
+static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStream_t st, int advance = 0) {
+  hipLaunchKernelGGL(k_gf_zero, dim3(32, n), dim3(256), 0, st, slots, advance);
+  if (g->cfg.use_bn_morph) {
+    launch_gf_morph(slots, n, maxN, st);
+    hipLaunchKernelGGL(k_gf_fold, dim3(1, n), dim3(64), 0, st, slots, 2);   // terms[5], [6]: what the back-propagation divides by
+  }
 }
 
 // pass 2: point-plane (+ morphing back-propagation, needs the GLOBAL kept count in terms[6]) and
@@ -563,15 +657,24 @@ static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int max
   const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
   if ((use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0)
-    GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL(k_gf_data<KK>, dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
-                                                 c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr));
+  {
+    const bool extra = c.seg_mode || c.use_bn_morph || c.corr_mode || c.pp_max > 0.0;
+    if (extra) {
+      GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, true>), dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
+                                                   c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr));
+    } else {
+      GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, false>), dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
+                                                   0, 0.0, 0, 0.0, 0, 0.0));
+    }
+  }
   if (g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
     hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
                        c.use_rot, c.w_rot, c.use_face, c.w_face);
+  hipLaunchKernelGGL(k_gf_fold, dim3(1, n), dim3(64), 0, st, slots, 1);
 }
 
-static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
-  gf_enqueue_morph(g, slots, n, maxN, st);
+static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, int advance = 0) {
+  gf_enqueue_morph(g, slots, n, maxN, st, advance);
   gf_enqueue_losses(g, slots, n, maxN, maxReg, st);
 }
 
@@ -643,7 +746,7 @@ int slm_gf_bind_frame(slm_gf* g, int32_t slot, const slm_gf_frame* fr, void* str
   if (n > g->cap[slot]) {
     if (s.dv) GFCHK(hipFree(s.dv));
     s.dv = nullptr;
-    GFCHK(hipMalloc((void**)&s.dv, sizeof(double) * (4 * n + SLM_GF_NTERMS)));
+    GFCHK(hipMalloc((void**)&s.dv, sizeof(double) * (4 * n + SLM_GF_NTERMS + GF_PART_DOUBLES)));   // ... | terms | spread block partials
     g->cap[slot] = n;
   }
   s.grad = s.dv + n;
@@ -820,11 +923,11 @@ int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream) {
                    "all-reduce of slm_gf_get_partial between them");
   hipStream_t st = (hipStream_t)stream;
   for (int it = 0; it < g->cfg.num_iterations; ++it) {
-    gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st);
+    gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st, it > 0 ? 1 : 0);   // (counts the previous iteration's step)
     hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev,
                        g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
-    hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
   }
+  if (g->cfg.num_iterations > 0) hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
   GFCHK(hipGetLastError());
   return SLM_OK;
 }

@@ -171,6 +171,22 @@ __global__ void __launch_bounds__(256) k_pack_target(int T, const float* __restr
   out[2 * (size_t)t + 1] = make_float4(nrm[3 * t], nrm[3 * t + 1], nrm[3 * t + 2], 0.f);
 }
 
+// per-pixel form of the same (FrameDev::tgt_px); grid = (ceil(H*W/256))
+__global__ void __launch_bounds__(256) k_pack_target_px(int HW, const int* __restrict__ index_map, const uint8_t* __restrict__ valid,
+                                                         const float* __restrict__ pts, const float* __restrict__ nrm,
+                                                         float4* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int t = index_map[p];
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, valid[p] ? 1.f : 0.f);
+  if (t >= 0) {
+    a = make_float4(pts[3 * (size_t)t], pts[3 * (size_t)t + 1], pts[3 * (size_t)t + 2], 1.f);
+    b = make_float4(nrm[3 * (size_t)t], nrm[3 * (size_t)t + 1], nrm[3 * (size_t)t + 2], b.w);
+  }
+  out[2 * (size_t)p] = a;
+  out[2 * (size_t)p + 1] = b;
+}
+
 // Reduce loss partials into out[0..3] = data, arap, rot, matched count (slm_loss).
 __global__ void __launch_bounds__(256) k_loss_out(const FrameDev* __restrict__ frames, int slot,
                                                    int n_reg_part, double* __restrict__ out) {
@@ -490,6 +506,11 @@ void launch_make_trial(const FrameDev* frames_dev, int n_frames, int maxJ, hipSt
 
 void launch_pack_target(int T, const float* pts, const float* nrm, float4* out, hipStream_t st) {
   if (T > 0) hipLaunchKernelGGL(k_pack_target, dim3((T + 255) / 256), dim3(256), 0, st, T, pts, nrm, out);
+}
+
+void launch_pack_target_px(int HW, const int* index_map, const uint8_t* valid, const float* pts, const float* nrm, float4* out,
+                           hipStream_t st) {
+  if (HW > 0) hipLaunchKernelGGL(k_pack_target_px, dim3((HW + 255) / 256), dim3(256), 0, st, HW, index_map, valid, pts, nrm, out);
 }
 
 void launch_iter_begin(const FrameDev* frames_dev, int n_frames, hipStream_t st) {

@@ -188,9 +188,10 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
     s.morph_g[i] = g;
   }
   const double a = block_sum(li_sum, sm), b = block_sum(kept, sm);
-  if (threadIdx.x == 0 && b != 0.0) {
-    atomic_add_f64(s.terms + 5, a);
-    atomic_add_f64(s.terms + 6, b);
+  if (threadIdx.x == 0 && b != 0.0) {   // (spread block partials, slm_gf.h: entries 14 / 15; k_gf_fold sums them into terms[5] / [6])
+    double* part = s.terms.get() + SLM_GF_NTERMS + 16 * (blockIdx.x % GF_NCOPY);
+    atomic_add_f64(part + 14, a);
+    atomic_add_f64(part + 15, b);
   }
 }
 

@@ -200,7 +200,8 @@ class LM_Solver():
         except Exception:
             pass
 
-    def _bind(self, h, slot, sf, inputs, new_data):
+    def _frame(self, h, slot, sf, inputs, new_data):
+        """The ``BoundFrame`` of a slot (no library call yet); settles what becomes of a model prepared ahead."""
         state = getattr(self.opt, "slm_state_dtype", None)
         dev = sf.points.device
         prepared = self._prepared[slot]
@@ -213,11 +214,24 @@ class LM_Solver():
             # counters moved).  The library compares sizes and pointers only -- with no-copy inputs (int32 tables, state
             # dtype, contiguous) it would take the stale plan for this frame's: drop it explicitly.
             _lib.check(self.lib.slm_discard_prepared(prepared[0], slot), "slm_discard_prepared")
-        bf = BoundFrame(sf, inputs, new_data, state=state, model=mv)
+        return BoundFrame(sf, inputs, new_data, state=state, model=mv)
+
+    def _bind(self, h, slot, sf, inputs, new_data):
+        bf = self._frame(h, slot, sf, inputs, new_data)
         _lib.check(self.lib.slm_bind_frame(h, slot, C.byref(bf.c), _stream_ptr(bf.device)),
                    "slm_bind_frame")
         self._bound[slot] = bf
         return bf
+
+    def _bind_batch(self, h, frames):
+        """The frames of a batch bound CONCURRENTLY (``slm_bind_frames``: one host thread, stream and scratch set per frame
+        inside the library, forked from and joined into the caller's stream) -- slots 0 .. len(frames) - 1."""
+        bfs = [self._frame(h, i, *fr) for i, fr in enumerate(frames)]
+        arr = (SlmFrame * len(bfs))(*[bf.c for bf in bfs])
+        _lib.check(self.lib.slm_bind_frames(h, 0, len(bfs), arr, _stream_ptr(bfs[0].device)), "slm_bind_frames")
+        for i, bf in enumerate(bfs):
+            self._bound[i] = bf
+        return bfs
 
     def prepare_model(self, sf, slot=0, u=10, v=7.5, minimal_loss=1e10):
         """The model-side half of the NEXT frame's ``loss_term.prepare`` (reference ``super/loss.py:212-220,408-426``),
@@ -288,7 +302,7 @@ class LM_Solver():
         if n < 1 or n > self.max_frames:
             raise ValueError(f"need 1..{self.max_frames} frames, got {n}")
         h = self._handle(u, v, minimal_loss)
-        bfs = [self._bind(h, i, *fr) for i, fr in enumerate(frames)]
+        bfs = self._bind_batch(h, frames) if n > 1 else [self._bind(h, 0, *frames[0])]
         dev = bfs[0].device
         st = _stream_ptr(dev)
         if self.sharded:
