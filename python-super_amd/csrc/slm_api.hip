@@ -21,6 +21,7 @@ void launch_data_grad_pairs(const FrameDev*, int, int, int, double, hipStream_t)
 void launch_data_loss(const FrameDev*, int, int, int, double, int, hipStream_t);
 void launch_data_resid(const FrameDev*, int, int, int, double, double*, uint8_t*, int32_t*, hipStream_t);
 void launch_data_gram(const FrameDev*, int, int, double, int, hipStream_t, const int* reuse = nullptr);
+void launch_begin_and_gram(const FrameDev*, int, int, double, hipStream_t, const int* reuse, int dag_cut);
 void launch_data_eval(const FrameDev*, int, int, double, int mode, hipStream_t, const int* reuse = nullptr);
 void launch_band_assemble(const FrameDev*, int, int, hipStream_t);
 void launch_reg_grad(const FrameDev*, int, int, int, double, int, double, hipStream_t);
@@ -326,6 +327,7 @@ struct slm_solver {
   bool no_reuse = false;        // SLM_NO_REUSE=1 (tests): every Jacobian pass recomputes its records, also after a reject
   bool hybrid_batches = true;   // solver_path 0, larger batches: per-level launches + task graph for the top levels
   long dag_max_nodes = 8000;    // solver_path 0: launches of at most this many frames x nodes run as ONE task graph (SLM_DAG_MAX_NODES)
+  bool fuse_begin = true;       // SLM_FUSE_BEGIN=0 (A/B, tests): k_iter_begin_nd as a launch of its own in front of the Jacobian pass, as in rounds 1-5
   bool pure_fill = true;        // SLM_PURE_FILL=0 (tests): every pivot-column tile is zeroed and read-modify-written, as in rounds 1-4
   bool profile = false;
   std::vector<hipEvent_t> ev_pool;            // recycled events
@@ -544,6 +546,7 @@ int slm_create(const slm_config* cfg, slm_solver** out) {
   if (const char* dm = getenv("SLM_DAG_MAX_NODES")) s->dag_max_nodes = atol(dm);   // experiments / tests
   if (const char* nr = getenv("SLM_NO_REUSE")) s->no_reuse = atoi(nr) != 0;       // tests: recompute after a reject
   if (const char* pf = getenv("SLM_PURE_FILL")) s->pure_fill = atoi(pf) != 0;     // tests: differential check of the pure-fill tiles
+  if (const char* fb = getenv("SLM_FUSE_BEGIN")) s->fuse_begin = atoi(fb) != 0;   // A/B: the zeroing as a launch of its own
   *out = s;
   return SLM_OK;
 }
@@ -802,13 +805,13 @@ static int bind_model_part(slm_solver* s, int32_t slot, const slm_frame* f, hipS
       if (!h.v1_ready && !h.vk_ready)
         return fail(SLM_ERR_UNSUPPORTED, "slm_bind_frame: sharded frames need the multifrontal data paths "
                                          "(data_path 0 or 2, J < 65536)");
-      HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + 2));
+      HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + SLM_VK_TAIL + 2));
       h.pairbuf = sl.pairbuf;
       // records (or per-run Grams) of the other ranks' workgroups stay zero for the whole frame
       if (h.v2_ready) HIPCHK(hipMemsetAsync(h.wgslab, 0, sizeof(double) * SLM_WREC * (size_t)h.n_wblk, st));
       else if (h.v1_ready) HIPCHK(hipMemsetAsync(h.slab, 0, sizeof(double) * SLM_SLAB_STRIDE * (size_t)h.n_runs, st));
     } else if (h.vk_ready) {   // the K-generic pair path always assembles through the pair records
-      HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + 2));
+      HIPCHK(grow(sl.pairbuf, sl.cap_pairbuf, (size_t)h.n_blocks * SLM_WREC + SLM_VK_TAIL + 2));
       h.pairbuf = sl.pairbuf;
     }
   }
@@ -1586,7 +1589,7 @@ static int exchange_buf(slm_solver* s, int slot, int what, double** p, int64_t* 
     case SLM_X_PAIR_BLOCKS:
       if (!h.pairbuf) return fail(SLM_ERR_UNBOUND, "slm_lm_exchange: the slot was bound without slm_set_shard");
       *p = h.pairbuf;
-      *n = (int64_t)h.n_blocks * SLM_WREC + 1;
+      *n = (int64_t)h.n_blocks * SLM_WREC + (h.vk_ready ? SLM_VK_TAIL : 1);   // records + matched count (spread on the K-generic path)
       return SLM_OK;
     case SLM_X_DELTA:
       *p = h.delta;
@@ -1650,8 +1653,10 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
   // (records of the Jacobian pass are reused after a rejected step on the multifrontal path, where the assembly
   //  re-reads them; the banded path adds into the band in place)
   const int* reuse = (d.nd && d.v1 && c.phase_test && !s->no_reuse) ? s->reuse_dev + first : nullptr;
+  // (round 6) the zeroing rides on the Jacobian pass's launch when every slot takes the workgroup-merged records
+  const bool fused_begin = d.nd && d.v1 && c.use_data && d.gram_variants == 1 && d.max_pos > 0 && s->fuse_begin;
   if (d.nd) {
-    launch_iter_begin_nd(fr, n, st, reuse, dag_cut_of(s, n, d));
+    if (!fused_begin) launch_iter_begin_nd(fr, n, st, reuse, dag_cut_of(s, n, d));
   } else {
     launch_iter_begin(fr, n, st);
   }
@@ -1663,7 +1668,8 @@ static void enqueue_lm_iteration(slm_solver* s, int first, int n, const BatchDim
       // records and runs no Jacobian pass at all); a pass of its own is only needed at the first iteration of a run
       // (skipped on the device for slots whose buffer is valid) and after a reject when records are not reused.
       if (first_iteration || (c.phase_test && !reuse)) launch_data_eval(fr, n, kLossBlocks, c.w_data, 1, st, reuse);
-      launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
+      if (fused_begin) launch_begin_and_gram(fr, n, d.max_pos, c.w_data, st, reuse, dag_cut_of(s, n, d));
+      else launch_data_gram(fr, n, d.max_pos, c.w_data, d.gram_variants, st, reuse);
     } else if (d.nd && d.vk) {
       launch_data_grad_pairs(fr, n, d.maxN, d.K, c.w_data, st);   // K-generic: per-pair records (zeroed, then filled)
     } else {

@@ -204,6 +204,8 @@ __device__ __forceinline__ const FrameIn& frame_in(const FrameDev& fd) { return 
 #define SLM_SLAB_STRIDE 768
 #define SLM_WREC 56          // doubles per (workgroup, pair) record
 #define SLM_LB_MAX 96        // records a workgroup can hold in LDS
+#define SLM_VK_TAIL 64        // K-generic pair path: the matched count behind the pair records, spread over this many doubles (one
+                             // atomic per wave onto ONE address costs 12 ns each, serialised: tools/micro/atomic_same_mb.hip)
 
 // In-kernel stamps exist only in the diagnostic build; the shipped library executes none.
 #ifdef SLM_STAMPS

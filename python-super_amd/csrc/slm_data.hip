@@ -113,10 +113,8 @@ __global__ void __launch_bounds__(64) k_data_grad_pairs(const FrameDev* __restri
   }
   const unsigned long long m = __ballot(ev.match);
   if (!m) return;
-  if (l == 0) {
-    atomicAdd(&fd.st->m_grad, __popcll(m));
-    atomic_add_f64(fd.pairbuf + (size_t)fd.n_blocks * SLM_WREC, (double)__popcll(m));   // (what k_pair_scatter reads back)
-  }
+  // the matched count rides behind the records, spread over SLM_VK_TAIL doubles (k_pair_scatter sums them into m_grad)
+  if (l == 0) atomic_add_f64(fd.pairbuf + (size_t)fd.n_blocks * SLM_WREC + (blockIdx.x % SLM_VK_TAIL), (double)__popcll(m));
   if (ev.match) {
 #pragma unroll
     for (int k = 0; k < KK; ++k) {
@@ -187,7 +185,7 @@ __global__ void __launch_bounds__(64) k_data_grad_pairs(const FrameDev* __restri
 __global__ void __launch_bounds__(256) k_zero_pairbuf(const FrameDev* __restrict__ frames) {
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || !fd.vk_ready || !fd.pairbuf || fd.st->stopped) return;
-  const size_t n = (size_t)fd.n_blocks * SLM_WREC + 1;
+  const size_t n = (size_t)fd.n_blocks * SLM_WREC + SLM_VK_TAIL;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) fd.pairbuf[e] = 0.0;
 }
 

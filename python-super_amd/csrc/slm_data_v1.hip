@@ -21,8 +21,7 @@
 #include <cstdlib>
 
 #include "slm_data.h"
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
+#include "slm_begin.h"
 
 #define ROW_STRIDE 17   // doubles per surfel half-row in LDS (odd: conflict-free 64-bit writes)
 
@@ -95,9 +94,19 @@ __global__ void __launch_bounds__(256) k_data_eval(const FrameDev* __restrict__ 
 // 7-entry J^T r pieces of the diagonal pairs) into LDS records keyed by node pair (ds_add_f64),
 // and the workgroup writes one 56-double record per distinct pair -- about 4x fewer HBM bytes
 // than one 768-double Gram per run, and the assemble kernels read contiguous records.
-template <bool MERGE>
+// BEGIN (round 6): the launch also carries the iteration's zeroing (iter_begin_nd_body, slm_begin.h) -- blocks
+// [n_gram, n_gram + n_begin) of a slot: the Jacobian pass writes records, the zeroing writes fronts / vectors / flags,
+// nothing in common; one launch boundary fewer per iteration and the zeroing's store stream (HBM-bound) runs under the
+// Gram pass (VALU / LDS-bound).
+template <bool MERGE, bool BEGIN = false>
 __global__ void __launch_bounds__(256, 2) k_data_gram(const FrameDev* __restrict__ frames, double lam,
-                                                       int dbg, const int* __restrict__ reuse) {
+                                                       int dbg, const int* __restrict__ reuse, int n_gram = 0, int n_begin = 0,
+                                                       int dag_cut = -2) {
+  if (BEGIN && (int)blockIdx.x >= n_gram) {
+    iter_begin_nd_body(frames[blockIdx.y], (int)blockIdx.x - n_gram, n_begin, reuse && reuse[blockIdx.y], dag_cut,
+                       frames[blockIdx.y].v1_ready && frames[blockIdx.y].v2_ready);
+    return;
+  }
   __shared__ double rows[4][64 * ROW_STRIDE];
   __shared__ double recs[MERGE ? SLM_LB_MAX * SLM_WREC : 1];
   __shared__ uint8_t lidx[4][MERGE ? 160 : 4];   // per wave: record of each of the 10 node pairs of its 16 groups
@@ -324,6 +333,19 @@ __global__ void __launch_bounds__(256) k_band_assemble(const FrameDev* __restric
 }
 
 // variants: bit0 = some slot uses the workgroup-merged records, bit1 = some slot uses the per-run slab
+// The Jacobian pass AND the iteration's zeroing in one launch (every slot of the batch on the workgroup-merged records):
+// what slm_run's loop enqueues instead of k_iter_begin_nd + k_data_gram.
+void launch_begin_and_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, hipStream_t st, const int* reuse,
+                           int dag_cut) {
+  int dbg = 0;
+#ifdef SLM_STAMPS
+  if (const char* e = getenv("SLM_DBG")) dbg = atoi(e);
+#endif
+  const int n_gram = (max_pos + 255) / 256, n_begin = 1024;
+  hipLaunchKernelGGL((k_data_gram<true, true>), dim3(n_gram + n_begin, n_frames), dim3(256), 0, st, frames_dev, lam, dbg, reuse, n_gram,
+                     n_begin, dag_cut);
+}
+
 void launch_data_gram(const FrameDev* frames_dev, int n_frames, int max_pos, double lam, int variants,
                       hipStream_t st, const int* reuse) {
   if (max_pos <= 0) return;

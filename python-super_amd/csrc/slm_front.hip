@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "slm_tile.h"
+#include "slm_begin.h"
 
 __device__ __forceinline__ int nd_base(const NDFront& f, int p) {
   return p < f.nv ? 7 * p : f.n1p + 7 * (p - f.nv);
@@ -184,7 +185,10 @@ __global__ void __launch_bounds__(256) k_pair_scatter(const FrameDev* __restrict
     // the rank's own count is kept apart: after a rejected step the records -- and this count -- are sent again
     // (k_iter_begin_nd restores it), and the all-reduced count must not take its place
     fd.st->m_grad_local = fd.st->m_grad;
-    fd.st->m_grad = (int)fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC];
+    double cnt = fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC];
+    if (fd.vk_ready)   // K-generic pair path: the count is spread over SLM_VK_TAIL doubles (k_data_grad_pairs)
+      for (int e = 1; e < SLM_VK_TAIL; ++e) cnt += fd.pairbuf[(size_t)fd.n_blocks * SLM_WREC + e];
+    fd.st->m_grad = (int)cnt;
   }
   if (bi >= fd.n_blocks) return;
   const int l = threadIdx.x & 63;
@@ -425,77 +429,12 @@ __global__ void __launch_bounds__(256) k_front_load_rhs(const FrameDev* __restri
   fd.fvec[f.vec_off + 7 * fd.node_pos[v] + c] = fd.rhs[e];
 }
 
-// ---- zeroing of the fronts ------------------------------------------------------------------------------------
-// A front's tiles: the pivot columns (the assembly adds into them, then the children's updates: k_fpull / the task
-// graph's pulls), then the boundary block F22 -- two thirds of the tile storage (C2: 134 MB per frame) -- which holds
-// the front's update matrix, written once by k_fschur / the SCHUR tasks (first touch is a store: never zeroed).
-typedef double dvec2_t __attribute__((ext_vector_type(2)));
-// 16 KB pieces of a contiguous region, piece-strided: pc = first, first + step, ...; non-temporal 16-byte stores
-__device__ __forceinline__ void zero_pieces(double* base, size_t n_pieces, size_t first, size_t step) {
-  const dvec2_t zz = {0.0, 0.0};
-  dvec2_t* b2 = reinterpret_cast<dvec2_t*>(base);
-  for (size_t pc = first; pc < n_pieces; pc += step) {
-    dvec2_t* q = b2 + pc * 1024 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(zz, q + 256 * k);
-  }
-}
-__device__ __forceinline__ size_t front_piv_tiles(const NDFront& f) {
-  return (size_t)f.npt * f.nt - (size_t)f.npt * (f.npt - 1) / 2;
-}
-// the slot's kind-0 pivot-column tiles (FrameDev::zero_tiles: assembled into, or touched by nothing at all), 16 KB pieces
-// strided over the launch's workgroups; pure-fill tiles (tile_kind 1) are not zeroed: their first toucher stores them
-__device__ __forceinline__ void zero_fronts(const FrameDev& fd, int b, int nb) {
-  const dvec2_t zz = {0.0, 0.0};
-  const int n = fd.n_zero_tiles;
-  for (int pc = b; pc < 2 * n; pc += nb) {
-    dvec2_t* q = reinterpret_cast<dvec2_t*>(fd.ftiles.get() + fd.zero_tiles[pc >> 1]) + (size_t)(pc & 1) * 1024 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(zz, q + 256 * k);
-  }
-}
-// Start of an iteration on the multifrontal path: zero the PIVOT columns of the fronts (the assembly adds into them; the
-// boundary blocks are written once by their own Schur kernels / tasks, never zeroed), the front vectors, rhs and the
-// counters, for ALL slots of the batch in one launch (one hipMemsetAsync pair per slot cost
-// ~25 us each, back to back).  grid = (blocks, n_frames); contiguous 16 KB pieces per workgroup.
-// dag_cut: what the task-graph launch of this iteration's solve needs reset -- its flags (ticket, abort, per-tile and
-// per-column flags) and the mailboxes of the pivot tile columns it factors: -1 all fronts (whole-tree task graph),
-// >= 0 the fronts of depth <= dag_cut (hybrid form), -2 none (per-level launches only).  This used to be a launch of its
-// own in front of k_fdag (k_dag_reset, 6-9 us of mostly launch latency per iteration); here it rides on a kernel that
-// runs anyway, after the previous iteration's k_dag_check has read the flags.  A stopped slot is reset too: slot 0's
-// flags carry the ticket of the whole batch.
+// ---- zeroing of the fronts (slm_begin.h) --------------------------------------------------------------------------
+// Start of an iteration on the multifrontal path as a launch of its own: for ALL slots of the batch (one hipMemsetAsync
+// pair per slot cost ~25 us each, back to back).  grid = (blocks, n_frames); contiguous 16 KB pieces per workgroup.
+// (The LM loop's tuple-sorted path runs the same body as the tail blocks of its Jacobian pass instead: launch_data_gram.)
 __global__ void __launch_bounds__(256) k_iter_begin_nd(const FrameDev* __restrict__ frames, const int* __restrict__ reuse, int dag_cut) {
-  const FrameDev& fd = frames[blockIdx.y];
-  if (!fd.bound) return;
-  if (dag_cut >= -1 && fd.nd_ready && fd.dag_flags) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fd.dag_n_flags; i += gridDim.x * blockDim.x) fd.dag_flags[i] = 0;
-    typedef __attribute__((address_space(1))) long long gll;
-    gll* mail = (gll*)(double*)fd.fmail;
-    for (int fi = blockIdx.x; fi < fd.n_fronts; fi += gridDim.x) {
-      const NDFront& f = fd.fronts[fi];
-      if (dag_cut >= 0 && f.depth > dag_cut) continue;
-      const size_t base = (size_t)(f.linv_off / TILE) * SLM_MAIL_DOUBLES, n = (size_t)f.npt * SLM_MAIL_DOUBLES;
-      for (size_t e = threadIdx.x; e < n; e += blockDim.x) mail[base + e] = SLM_MAIL_EMPTY;
-    }
-  }
-  if (fd.st->stopped) return;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
-  const double2 z = make_double2(0.0, 0.0);
-  if (fd.nd_ready) {
-    zero_fronts(fd, blockIdx.x, gridDim.x);
-    double2* v2 = reinterpret_cast<double2*>(fd.fvec.get());
-    const size_t nv2 = (size_t)fd.zero_vec_doubles / 2;
-    for (size_t e = tid; e < nv2; e += nthr) v2[e] = z;
-  }
-  const size_t nrhs = (size_t)fd.nt * SLM_NB;
-  for (size_t e = tid; e < nrhs; e += nthr) fd.rhs[e] = 0.0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // (a reused Jacobian pass keeps its matched count -- on a surfel-sharded frame the rank's OWN share of it, which
-    //  k_pair_scatter set aside before it stored the all-reduced count)
-    if (!(reuse && reuse[blockIdx.y])) fd.st->m_grad = 0;   // (k_data_gram takes the count of the evaluation it consumes)
-    else if (fd.pairbuf) fd.st->m_grad = fd.st->m_grad_local;
-    fd.st->chol_fail = 0;
-  }
+  iter_begin_nd_body(frames[blockIdx.y], blockIdx.x, gridDim.x, reuse && reuse[blockIdx.y], dag_cut, false);
 }
 
 // ---------------------------------------------------------------------------------
