@@ -8,6 +8,9 @@
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
+# (SLM_FUSE_BEGIN=0 for the counter passes only: the iteration's zeroing as a launch of its own, so that its bytes are not
+#  booked on k_data_gram, whose launch carries it in the default build -- round 6; same sources, same hash)
+export SLM_FUSE_BEGIN=0
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_" --output-format csv -d $R/gpurun_out/${TAG}_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $R/gpurun_out/${TAG}_pmc_$c.log 2>&1 < /dev/null
   find $R/gpurun_out/${TAG}_pmc_$c -name '*kernel_trace.csv' -delete
@@ -16,6 +19,7 @@ F=$(find $R/gpurun_out/${TAG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | h
 W=$(find $R/gpurun_out/${TAG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
 python3 $R/profiles/make_traffic.py $F $W --workload C2 --frames-per-gpu 8 --out $R/gpurun_out/${TAG}_pmc_traffic.json > /dev/null
 cp $R/gpurun_out/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json      # (on the box; install.py makes the tracked copy)
+unset SLM_FUSE_BEGIN
 timeout 400 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err < /dev/null
 timeout 300 python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_b1.json 2> $R/gpurun_out/${TAG}_bench_b1.err < /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- python3 $R/bench.py --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats.log 2>&1 < /dev/null
@@ -32,4 +36,8 @@ python3 $R/profiles/make_sq_summary.py $R/gpurun_out/${TAG}_pmc_sq_*/ --out $R/g
 # one frame per launch (the drop-in case): kernel stats of the task-graph solver
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats_b1 -name '*kernel_trace.csv' -delete
+# the rows the LM bench's trace does not contain: GraphFit at C2 (1 and 8 frames per launch), the Semantic-SuPer
+# GraphFit step at C4 (configs[4]), depth preprocessing, fusion + swap, ED-graph construction, the K-generic LM path at K = 6
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_rows -- python3 $R/tools/profile_rows.py > $R/gpurun_out/${TAG}_rows.json 2> $R/gpurun_out/${TAG}_rows.err < /dev/null
+find $R/gpurun_out/${TAG}_stats_rows -name '*kernel_trace.csv' -delete
 ls $R/gpurun_out/${TAG}_stats/* $R/gpurun_out/${TAG}_pmc_FETCH_SIZE/* < /dev/null

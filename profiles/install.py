@@ -44,6 +44,20 @@ subprocess.check_call([sys.executable, os.path.join(P, "make_traffic.py"), trimm
                        "--workload", "C2", "--frames-per-gpu", "8", "--out", os.path.join(P, f"{tag}_pmc_traffic.json")])
 subprocess.check_call([sys.executable, os.path.join(P, "make_sq_summary.py")] +
                       sorted(glob.glob(os.path.join(G, f"{tag}_pmc_sq_*/"))) + ["--out", os.path.join(P, f"{tag}_pmc_sq_summary.csv")])
+rows = glob.glob(os.path.join(G, f"{tag}_stats_rows/**/*kernel_stats.csv"), recursive=True)
+if rows:     # GraphFit / semantic GraphFit / depth / fusion / graph / K = 6 kernels (tools/profile_rows.py), our kernels only
+    with open(max(rows, key=os.path.getmtime)) as f, open(os.path.join(P, f"{tag}_rows_kernel_stats.csv"), "w", newline="") as g:
+        rd = csv.DictReader(f)
+        w = csv.DictWriter(g, rd.fieldnames)
+        w.writeheader()
+        for r in rd:
+            nm = r["Name"].replace("void ", "")
+            if nm.startswith(("k_", "kb_")) or "rocprim" in nm:
+                w.writerow(r)
+    if os.path.exists(os.path.join(G, f"{tag}_rows.json")):
+        lines = [ln for ln in open(os.path.join(G, f"{tag}_rows.json")) if ln.startswith("{")]
+        if lines:
+            open(os.path.join(P, f"{tag}_rows_timing.json"), "w").write(lines[-1])
 avail = os.path.join(G, f"{tag}_mfma_counters_available.txt")
 if os.path.exists(avail):
     shutil.copy(avail, os.path.join(P, f"{tag}_mfma_counters_available.txt"))

@@ -329,13 +329,13 @@ def test_eight_frames_as_one_task_graph_on_xcd_affine_ticket_streams():
 
 
 @pytest.mark.parametrize("env", [{"SLM_DAG_XCD": "0"}, {"SLM_DAG_WG_PER_CU": "1"}, {"SLM_DAG_DEFER_BOUNDARY": "0"},
-                                 {"SLM_DAG_DEFER_BOUNDARY": "9"}, {"SLM_DAG_MAX_NODES": "0"},
+                                 {"SLM_DAG_DEFER_BOUNDARY": "9"}, {"SLM_DAG_MAX_NODES": "0"}, {"SLM_FUSE_BEGIN": "0"},
                                  {"SLM_DAG_XCD": "0", "SLM_DAG_WG_PER_CU": "1", "SLM_DAG_DEFER_BOUNDARY": "0", "SLM_DAG_TOP_FRONTS": "2"}])
 def test_task_graph_switches_of_round_5_keep_the_result(env):
     """The round-5 switches of the task graph (read once per process, hence the subprocess): no XCD-affine ticket streams,
     one workgroup per CU, the boundary rows of a column listed with / far behind its pivot rows, no frames x nodes rule (the
-    hybrid form for a small batch), and the round-4 settings together -- 8 frames of different plans under solver_path 0 and
-    4, four iterations, against the oracle."""
+    hybrid form for a small batch), the round-4 settings together, and round 6's zeroing as a launch of its own again
+    (SLM_FUSE_BEGIN=0) -- 8 frames of different plans under solver_path 0 and 4, four iterations, against the oracle."""
     import os
     import subprocess
     import sys
