@@ -331,7 +331,8 @@ __device__ __forceinline__ void canon_ids(const int* __restrict__ knn, int i, in
 template <int KK>
 __global__ void __launch_bounds__(256) k_pair_index(int N, int J, int n_blocks, const int* __restrict__ knn,
                                                      const unsigned* __restrict__ ukeys, int* __restrict__ pidx,
-                                                     unsigned long long* __restrict__ okey, int* __restrict__ oid) {
+                                                     unsigned long long* __restrict__ okey, unsigned long long* __restrict__ okey2,
+                                                     int* __restrict__ oid) {
   constexpr int NP = KK * (KK + 1) / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -350,11 +351,21 @@ __global__ void __launch_bounds__(256) k_pair_index(int N, int J, int n_blocks, 
       }
       pidx[(size_t)NP * i + ra * (ra + 1) / 2 + rb] = lo;
     }
-  unsigned long long k64 = 0;
+  // order keys: the canonical tuple, lexicographic -- ids 0..3 in okey, ids 4..7 in okey2 (K > 4: a second, less significant
+  // sort key; tuples that share a prefix keep the pairs of that prefix in the same slots)
+  unsigned long long k64 = 0, k64b = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) k64 = (k64 << 16) | (unsigned long long)(k < KK ? c[k] : 0);
+#pragma unroll
+  for (int k = 4; k < 8; ++k) k64b = (k64b << 16) | (unsigned long long)(k < KK ? c[k] : 0);
   okey[i] = k64;
+  if (KK > 4) okey2[i] = k64b;
   oid[i] = i;
+}
+__global__ void __launch_bounds__(256) k_gather_keys(int N, const unsigned long long* __restrict__ keys, const int* __restrict__ order,
+                                                      unsigned long long* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = keys[order[i]];
 }
 __global__ void k_pair_count(int* __restrict__ scal, const unsigned* __restrict__ cnt) { scal[3] = (int)cnt[0]; }
 
@@ -1514,8 +1525,16 @@ hipError_t prep_pairs(PrepBuffers* p, const slm_frame& f, PairPlan& plan, PairSi
   PCHK(hipMemcpyAsync(plan.blk_key, p->gk, sizeof(unsigned) * (size_t)out->n_blocks, hipMemcpyDeviceToDevice, st));
   SLM_PREP_K_DISPATCH(f.K, hipLaunchKernelGGL(k_pair_index<KK>, dim3((unsigned)((N + 255) / 256)), blk, 0, st, f.N, f.J, out->n_blocks,
                                               f.sf_knn_idx, reinterpret_cast<const unsigned*>(plan.blk_key), plan.sf_pidx,
-                                              p->keys, p->ids));
+                                              p->keys, p->tkeys, p->ids));
   size_t b3 = p->cap_gtmp;
-  PCHK(rocprim::radix_sort_pairs(p->gtmp, b3, p->keys, p->skeys, p->ids, plan.sf_perm, N, 0, 64, st));
+  if (f.K <= 4) {
+    PCHK(rocprim::radix_sort_pairs(p->gtmp, b3, p->keys, p->skeys, p->ids, plan.sf_perm, N, 0, 64, st));
+  } else {
+    // lexicographic order of the full canonical tuple: stable sorts, least significant key (ids 4..7) first
+    PCHK(rocprim::radix_sort_pairs(p->gtmp, b3, p->tkeys, p->skeys, p->ids, p->sids, N, 0, 64, st));
+    hipLaunchKernelGGL(k_gather_keys, dim3((unsigned)((N + 255) / 256)), blk, 0, st, f.N, p->keys, p->sids, p->tkeys);
+    b3 = p->cap_gtmp;
+    PCHK(rocprim::radix_sort_pairs(p->gtmp, b3, p->tkeys, p->skeys, p->sids, plan.sf_perm, N, 0, 64, st));
+  }
   return hipGetLastError();
 }

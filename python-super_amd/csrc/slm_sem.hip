@@ -115,8 +115,17 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
   const FrameIn& f = s.f.base;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double li_sum = 0.0, kept = 0.0;
+  // candidates of this workgroup (surfels whose projected class differs from their own), searched cooperatively below
+  __shared__ int n_cand;
+  __shared__ double c_x[256], c_y[256], c_d1[256], c_d2[256];
+  __shared__ int c_e0[256], c_e1[256], c_i1[256], c_i2[256];
+  __shared__ double r_d[4][2];
+  __shared__ int r_i[4][2];
+  if (threadIdx.x == 0) n_cand = 0;
+  __syncthreads();
+  int my_cand = -1, my_W = 0, my_H = 0;
+  double my_x = 0.0, my_y = 0.0;
   if (i < f.N) {
-    double2 g = make_double2(0.0, 0.0);
     if (i >= s.shard_lo && i < s.shard_hi && (!s.f.sf_stable || s.f.sf_stable[i])) {
       struct { d3 P; } k;
       if (f.K == SLM_K) {   // (the default: the instantiation the other kernels use, operation for operation)
@@ -160,29 +169,93 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
         const int e0 = s.edge_off[cls], e1 = s.edge_off[cls + 1];
         if (e1 - e0 >= 2) {      // a single boundary pixel has no 2nd neighbour: treated as no boundary
           s.terms[7] = 1.0;      // the class contributes a list entry (same value from every writer)
-          double d1 = 1e300, d2 = 1e300;
-          float2 p1 = make_float2(0, 0), p2 = make_float2(0, 0);
-          for (int e = e0; e < e1; ++e) {
-            const float2 q = s.edge_xy[e];
-            const double dx = x - (double)q.x, dy = y - (double)q.y;
-            const double d = dx * dx + dy * dy;
-            if (d < d1) {
-              d2 = d1; p2 = p1;
-              d1 = d; p1 = q;
-            } else if (d < d2) {
-              d2 = d; p2 = q;
-            }
-          }
-          // drop surfels closer to the image border than to the class boundary
-          const double dte = fmin(fmin(fmin(x, y), (double)W - x), (double)H - y);
-          const bool ok = !(sqrt(d1) > dte || sqrt(d2) > dte);
-          const double li = (d1 + d2) / 2.0;
-          if (ok && li > 15.0) {
-            li_sum = li;
-            kept = 1.0;
-            g = make_double2(-(((double)p1.x - x) + ((double)p2.x - x)), -(((double)p1.y - y) + ((double)p2.y - y)));
-          }
+          // a candidate: its search is done by the WHOLE workgroup below
+          const int k = atomicAdd(&n_cand, 1);
+          c_x[k] = x;
+          c_y[k] = y;
+          c_e0[k] = e0;
+          c_e1[k] = e1;
+          my_cand = k;
+          my_x = x;
+          my_y = y;
+          my_W = W;
+          my_H = H;
         }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the two nearest boundary pixels of every candidate's class: the mismatching surfels are a thin band along the class
+  // boundaries (a few per cent), so one lane per surfel scanning ~1 000-2 000 boundary pixels left 60 lanes of its wave idle for
+  // the whole scan (534 us per launch at C4, 80 % of the Semantic-SuPer step).  The workgroup takes its candidates one after the
+  // other: 256 lanes scan the class's list strided, each keeps its two nearest in (distance, list position) order -- the order
+  // of the sequential scan with strict <, i.e. find_knn's lowest index on ties -- and a butterfly + four-way merge gives the
+  // candidate's answer to lane 0.
+  {
+    const int nc = n_cand;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = 0; k < nc; ++k) {
+      const double x = c_x[k], y = c_y[k];
+      const int e0 = c_e0[k], e1 = c_e1[k];
+      double d1 = 1e300, d2 = 1e300;
+      int i1 = 0x7fffffff, i2 = 0x7fffffff;
+      for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+        const float2 q = s.edge_xy[e];
+        const double dx = x - (double)q.x, dy = y - (double)q.y;
+        const double d = dx * dx + dy * dy;
+        if (d < d1) {
+          d2 = d1; i2 = i1;
+          d1 = d; i1 = e;
+        } else if (d < d2) {
+          d2 = d; i2 = e;
+        }
+      }
+      // merge of two sorted pairs under (distance, index) order
+      auto before = [](double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); };
+      auto merge = [&](double od1, int oi1, double od2, int oi2) {
+        // the two smallest of {(d1,i1) <= (d2,i2)} and {(od1,oi1) <= (od2,oi2)}
+        if (before(od1, oi1, d1, i1)) {
+          // other's first leads: second is min(mine first, other's second)
+          if (before(od2, oi2, d1, i1)) { d2 = od2; i2 = oi2; }
+          else { d2 = d1; i2 = i1; }
+          d1 = od1; i1 = oi1;
+        } else if (before(od1, oi1, d2, i2)) {
+          d2 = od1; i2 = oi1;
+        }
+      };
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double od1 = __shfl_xor(d1, off, 64), od2 = __shfl_xor(d2, off, 64);
+        const int oi1 = __shfl_xor(i1, off, 64), oi2 = __shfl_xor(i2, off, 64);
+        merge(od1, oi1, od2, oi2);
+      }
+      if (l == 0) {
+        r_d[w][0] = d1; r_d[w][1] = d2;
+        r_i[w][0] = i1; r_i[w][1] = i2;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) merge(r_d[ww][0], r_i[ww][0], r_d[ww][1], r_i[ww][1]);
+        c_d1[k] = d1; c_d2[k] = d2;
+        c_i1[k] = i1; c_i2[k] = i2;
+      }
+      __syncthreads();
+    }
+  }
+  if (i < f.N) {
+    double2 g = make_double2(0.0, 0.0);
+    if (my_cand >= 0) {
+      const double x = my_x, y = my_y, d1 = c_d1[my_cand], d2 = c_d2[my_cand];
+      const float2 p1 = s.edge_xy[c_i1[my_cand]], p2 = s.edge_xy[c_i2[my_cand]];
+      // drop surfels closer to the image border than to the class boundary
+      const double dte = fmin(fmin(fmin(x, y), (double)my_W - x), (double)my_H - y);
+      const bool ok = !(sqrt(d1) > dte || sqrt(d2) > dte);
+      const double li = (d1 + d2) / 2.0;
+      if (ok && li > 15.0) {
+        li_sum = li;
+        kept = 1.0;
+        g = make_double2(-(((double)p1.x - x) + ((double)p2.x - x)), -(((double)p1.y - y) + ((double)p2.y - y)));
       }
     }
     s.morph_g[i] = g;
