@@ -52,7 +52,7 @@ if rows:     # GraphFit / semantic GraphFit / depth / fusion / graph / K = 6 ker
         w.writeheader()
         for r in rd:
             nm = r["Name"].replace("void ", "")
-            if nm.startswith(("k_", "kb_")) or "rocprim" in nm:
+            if "k_" in nm or "kb_" in nm or "rocprim" in nm:       # (some kernels live in anonymous namespaces)
                 w.writerow(r)
     if os.path.exists(os.path.join(G, f"{tag}_rows.json")):
         lines = [ln for ln in open(os.path.join(G, f"{tag}_rows.json")) if ln.startswith("{")]
