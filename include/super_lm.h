@@ -116,8 +116,11 @@ typedef struct slm_frame {
   int32_t T;                /* rows of the target tables */
   int32_t H, W;             /* image size (inputs[("color",0)] shape) */
   int32_t K;                /* surfel->node neighbours (opt.num_neighbors, README.md:175 / options.py:49): 1..8.  4, the reference's
-                             * default, takes the tuple-sorted MFMA path + multifrontal solve; other values the per-entry-atomics data
-                             * path + block-banded solve (what data_path = 1 runs); the frames of one batch share their K */
+                             * default, takes the tuple-sorted MFMA assembly; any other value the K-generic pair path (one sort of
+                             * the coupled-pair keys at the bind, per-pair records filled by run-length-accumulated atomics) -- both
+                             * on the SAME nested-dissection multifrontal solver in every form, and both accepted by the
+                             * surfel-sharded mode (data_path = 1 / solver_path = 1 / J >= 65536: per-entry atomics into the band +
+                             * block-banded solve); the frames of one batch share their K */
   int32_t K_ED;             /* node->node neighbours (opt.num_ED_neighbors), 1..8 */
   float fx, fy, cx, cy;     /* inputs["K"][0] entries [0,0],[1,1],[0,2],[1,2] (float32 like the reference) */
   const void* sf_points;      /* device (N,3)      sf.points            float32, or float64 with state_f64 */

@@ -70,6 +70,48 @@ def test_random_rebinds_match_fresh_solvers(solver_path, data_path):
     eng.close()
 
 
+@pytest.mark.parametrize("solver_path", [0, 4])
+def test_slots_alternate_between_num_neighbors(solver_path):
+    """Round 6: the slots of one solver are re-bound with frames of another ``num_neighbors`` from step to step (the frames of
+    ONE step share it) -- 4 takes the tuple-sorted assembly, 3 and 6 the K-generic pair path, all on the multifrontal solver:
+    the plan cache, the pair-record buffer, the per-surfel pair indices and the descriptor of a slot survive the switch in
+    both directions, and every bind gives the state a fresh solver builds for that frame."""
+    import torch
+    from super_amd import synth
+    from super_amd.engine import DeviceFrame, Engine
+    dev = torch.device("cuda", 0)
+    shapes = [dict(N=1500, J=96, H=120, W=160), dict(N=6000, J=160, H=120, W=160, src_border=6, tgt_border=3),
+              dict(N=900, J=24, H=40, W=56, src_border=4, tgt_border=2, n_ed_neighbors=6)]
+    scs = {K: [synth.make_scene(seed=400 + 10 * K + i, n_neighbors=K, **kw) for i, kw in enumerate(shapes)] for K in (3, 4, 6)}
+    frames = {K: [DeviceFrame.from_scene(sc, dev) for sc in v] for K, v in scs.items()}
+    want = {}
+    for K, fl in frames.items():
+        for i, f in enumerate(fl):
+            e = Engine(dev, max_frames=1, num_iterations=4, solver_path=solver_path)
+            e.bind(0, f)
+            e.run(1)
+            want[K, i] = (e.beta(0).cpu().numpy().copy(), e.records(0))
+            e.close()
+    S = 3
+    eng = Engine(dev, max_frames=S, num_iterations=4, solver_path=solver_path)
+    rng = np.random.default_rng(77 + solver_path)
+    for step, K in enumerate([4, 6, 4, 3, 6, 6, 4, 3, 4]):
+        cur = [int(k) for k in rng.integers(0, len(shapes), size=S)]
+        if step % 2:
+            eng.bind_batch([frames[K][k] for k in cur])
+        else:
+            for slot in rng.permutation(S):
+                eng.bind(int(slot), frames[K][cur[slot]])
+        eng.run(S)
+        torch.cuda.synchronize()
+        for slot, k in enumerate(cur):
+            beta, recs = eng.beta(slot).cpu().numpy(), eng.records(slot)
+            key = lambda rs: [(r["status"], r["accepted"], r["M_grad"]) for r in rs]
+            assert key(recs) == key(want[K, k][1]), (step, K, slot, k)
+            np.testing.assert_allclose(beta, want[K, k][0], rtol=0, atol=1e-9, err_msg=f"step {step} K {K} slot {slot} frame {k}")
+    eng.close()
+
+
 def test_rebinding_does_not_leak_device_memory():
     """The buffers of a slot only grow: alternating two frames for a while leaves the free device memory where it
     was once both have been seen."""
