@@ -483,8 +483,11 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
 
 // grad[J] /= J, then torch.optim.SGD(momentum=0.9) or torch.optim.Adam step (float64).
 // Also turns the morphing term's sum into the reference's weighted mean (NaN over an empty set).
+// fold: this launch also sums the spread block partials of k_gf_data / k_gf_reg (what k_gf_fold(which = 1) does as a launch
+// of its own: slm_gf_run's loop saves that launch; the thread of a global-row entry sums its own 64 copies, threads 0..6 the
+// loss terms').
 __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int optimizer, double lr,
-                                                  int apply, int use_morph, double w_morph) {
+                                                  int apply, int use_morph, double w_morph, int fold) {
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
   const int J = s.f.base.J, n = (J + 1) * 7;
@@ -495,6 +498,20 @@ __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int
   }
   if (e >= n) return;
   double g = s.grad[e];
+  if (fold) {
+    double* part = s.terms.get() + SLM_GF_NTERMS;
+    if (e < 7) {   // entries 7..13 of the partials: point-plane loss / kept, correspondence loss / kept, face, arap, rot
+      const int map[7] = {3, 4, 8, 9, 0, 1, 2};
+      double t = 0.0;
+      for (int c = 0; c < GF_NCOPY; ++c) t += part[16 * c + 7 + e];
+      if (t != 0.0) s.terms[map[e]] += t;
+    }
+    if (e >= 7 * J) {
+      double t = 0.0;
+      for (int c = 0; c < GF_NCOPY; ++c) t += part[16 * c + (e - 7 * J)];
+      g += t;
+    }
+  }
   if (e >= 7 * J) {
     g /= (double)J;
     s.grad[e] = g;
@@ -653,7 +670,7 @@ static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStrea
 
 // pass 2: point-plane (+ morphing back-propagation, needs the GLOBAL kept count in terms[6]) and
 // the node terms (on rank 0 only when the surfels are sharded: the caller sums the partials)
-static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st) {
+static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, bool fold = true) {
   const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
   if ((use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0)
@@ -670,12 +687,12 @@ static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int max
   if (g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
     hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
                        c.use_rot, c.w_rot, c.use_face, c.w_face);
-  hipLaunchKernelGGL(k_gf_fold, dim3(1, n), dim3(64), 0, st, slots, 1);
+  if (fold) hipLaunchKernelGGL(k_gf_fold, dim3(1, n), dim3(64), 0, st, slots, 1);   // (else the caller's k_gf_step folds)
 }
 
-static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, int advance = 0) {
+static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, int advance = 0, bool fold = true) {
   gf_enqueue_morph(g, slots, n, maxN, st, advance);
-  gf_enqueue_losses(g, slots, n, maxN, maxReg, st);
+  gf_enqueue_losses(g, slots, n, maxN, maxReg, st, fold);
 }
 
 template <typename RT>
@@ -883,7 +900,7 @@ int slm_gf_step(slm_gf* g, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev, g->cfg.optimizer,
-                     g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
+                     g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 0);
   hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
   GFCHK(hipGetLastError());
   return SLM_OK;
@@ -923,9 +940,9 @@ int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream) {
                    "all-reduce of slm_gf_get_partial between them");
   hipStream_t st = (hipStream_t)stream;
   for (int it = 0; it < g->cfg.num_iterations; ++it) {
-    gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st, it > 0 ? 1 : 0);   // (counts the previous iteration's step)
+    gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st, it > 0 ? 1 : 0, false);   // (counts the previous iteration's step; the step folds)
     hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev,
-                       g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
+                       g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 1);
   }
   if (g->cfg.num_iterations > 0) hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
   GFCHK(hipGetLastError());
@@ -951,7 +968,7 @@ int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv, double* terms, d
   GFCHK(hipMemcpyAsync(s.dv, dv, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   gf_enqueue_eval(g, g->dev + slot, 1, maxN, maxReg, st);
   hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, 1), dim3(256), 0, st, g->dev + slot, g->cfg.optimizer,
-                     g->cfg.lr, 0, g->cfg.use_bn_morph, g->cfg.w_bn_morph);
+                     g->cfg.lr, 0, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 0);
   if (terms) GFCHK(hipMemcpyAsync(terms, s.terms, sizeof(double) * SLM_GF_NTERMS, hipMemcpyDeviceToDevice, st));
   if (grad) GFCHK(hipMemcpyAsync(grad, s.grad, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   GFCHK(hipGetLastError());
