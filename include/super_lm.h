@@ -544,7 +544,8 @@ typedef struct slm_surfel_model {  /* device pointers with room for `cap` rows; 
   double* knn_w;                  /* (cap,K) sf.knn_w */
   float* projdata;                /* (cap,2) sf.projdata */
   int32_t J;
-  int32_t K;                      /* opt.num_neighbors, 1..8; 0 is read as 4 (the field was padding through ABI version 5) */
+  int32_t K;                      /* opt.num_neighbors, 1..8; 0 is read as 4 (the field was zero padding before round 6: same struct size,
+                                     same SLM_ABI_VERSION -- a caller that leaves it 0 gets the former behaviour) */
   const double* ed_points;        /* (J,3) sf.ED_nodes.points */
   const double* ed_radii;         /* (J)   sf.ED_nodes.radii */
   int32_t* merged_into;           /* (cap) or NULL.  slm_fuse_input_data: the surfel that absorbed row i
