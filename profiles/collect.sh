@@ -36,6 +36,9 @@ python3 $R/profiles/make_sq_summary.py $R/gpurun_out/${TAG}_pmc_sq_*/ --out $R/g
 # one frame per launch (the drop-in case): kernel stats of the task-graph solver
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_b1 -- python3 $R/bench.py --frames-per-gpu 1 --no-cpu-baseline --no-latency-b1 > $R/gpurun_out/${TAG}_stats_b1.log 2>&1 < /dev/null
 find $R/gpurun_out/${TAG}_stats_b1 -name '*kernel_trace.csv' -delete
+# the other synthetic workloads (bench lines only)
+timeout 400 python3 $R/bench.py --workload C1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_C1.json 2> $R/gpurun_out/${TAG}_bench_C1.err < /dev/null
+timeout 600 python3 $R/bench.py --workload C4 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_C4.json 2> $R/gpurun_out/${TAG}_bench_C4.err < /dev/null
 # the rows the LM bench's trace does not contain: GraphFit at C2 (1 and 8 frames per launch), the Semantic-SuPer
 # GraphFit step at C4 (configs[4]), depth preprocessing, fusion + swap, ED-graph construction, the K-generic LM path at K = 6
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_rows -- python3 $R/tools/profile_rows.py > $R/gpurun_out/${TAG}_rows.json 2> $R/gpurun_out/${TAG}_rows.err < /dev/null

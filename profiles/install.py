@@ -30,6 +30,10 @@ shutil.copy(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_C2_b8_
 shutil.copy(os.path.join(G, f"{tag}_bench_b1.json"), os.path.join(P, f"{tag}_C2_b1_bench.json"))
 shutil.copy(one(f"{tag}_stats/**/*kernel_stats.csv"), os.path.join(P, f"{tag}_C2_b8_kernel_stats.csv"))
 shutil.copy(one(f"{tag}_stats_b1/**/*kernel_stats.csv"), os.path.join(P, f"{tag}_C2_b1_kernel_stats.csv"))
+for wl in ("C1", "C4"):
+    src = os.path.join(G, f"{tag}_bench_{wl}.json")
+    if os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copy(src, os.path.join(P, f"{tag}_{wl}_b8_bench.json"))
 trimmed = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     src = one(f"{tag}_pmc_{c}/**/*counter_collection.csv")
