@@ -16,12 +16,9 @@
 
 #include "slm_sem.h"
 
-// advance: the optimiser step the previous iteration applied is counted HERE (slm_gf_run: k_gf_advance was a launch of its
-// own per iteration; nothing between k_gf_step and this kernel reads the counter)
-__global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots, int advance) {
+__global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
-  if (advance && blockIdx.x == 0 && threadIdx.x == 0) s.step += 1;
   const int n = (s.f.base.J + 1) * 7;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) s.grad[e] = 0.0;
   if (blockIdx.x == 0 && threadIdx.x < SLM_GF_NTERMS) s.terms[threadIdx.x] = 0.0;
@@ -129,7 +126,15 @@ __device__ __forceinline__ void gf_flow_sample(const float* __restrict__ flow, i
   }
 }
 
-// grid = (ceil(maxN/256), n_frames)
+struct GfRegArgs {
+  int use_arap, use_rot, use_face, pad;
+  double lam_a, lam_r, lam_f;
+};
+__device__ __forceinline__ void gf_reg_body(GfSlotDev& s, const int bx, const GfRegArgs ra, double* sm);
+
+// grid = (ceil(maxN/256) [+ the regulariser's blocks], n_frames)
+// n_data_blocks: blocks [0, n_data_blocks) of a slot evaluate surfels; the blocks behind them, if any, run the node terms
+// (gf_reg_body: independent work that only meets this kernel's in the gradient's atomics -- slm_gf_run's loop saves a launch)
 // seg_mode: 0 none, 1 hard, 2 soft semantic weight on the squared residual (loss.py:379-399);
 // pp_max > 0 (and no seg_mode): squared residuals >= pp_max are dropped (loss.py:369-370);
 // use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
@@ -139,12 +144,17 @@ __device__ __forceinline__ void gf_flow_sample(const float* __restrict__ flow, i
 // instantiation the default options run: those code paths, and the registers they hold, are compiled out (round 6: the
 // kernel ran at ONE wave per SIMD with everything in one body).
 template <int KK, bool EXTRA>
-__global__ void __launch_bounds__(256, 3) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode_,
+__global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSlot* __restrict__ slots, int use_pp, double lam, int seg_mode_,
                                                      double pp_max_, int use_morph_, double w_morph, int corr_mode_,
-                                                     double lam_c) {
+                                                     double lam_c, int n_data_blocks, GfRegArgs ra) {
   const int seg_mode = EXTRA ? seg_mode_ : 0, use_morph = EXTRA ? use_morph_ : 0, corr_mode = EXTRA ? corr_mode_ : 0;
   const double pp_max = EXTRA ? pp_max_ : 0.0;
   __shared__ double sm[16];
+  if ((int)blockIdx.x >= n_data_blocks) {
+    GfSlotDev& sr = gf_dev(slots)[blockIdx.y];
+    if (sr.bound) gf_reg_body(sr, blockIdx.x - n_data_blocks, ra, sm);
+    return;
+  }
   // The 256 surfels of a workgroup are neighbours on the image and share a few dozen ED nodes: their
   // gradient rows are summed in an LDS table keyed by node (ds_add_f64) and flushed with one global
   // atomic per entry and touched node -- about 20x fewer memory-side f64 atomics than one per surfel
@@ -382,14 +392,13 @@ __global__ void __launch_bounds__(256, 3) k_gf_data(GfSlot* __restrict__ slots, 
 
 // ARAP: one thread per (node, slot); Rot: one thread per row (J+1); face: one per triangle.
 // grid = (ceil(max(J*K_ED, J+1, Tr)/256), n_frames)
-__global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int use_arap, double lam_a,
-                                                 int use_rot, double lam_r, int use_face, double lam_f) {
-  __shared__ double sm[16];
-  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
-  if (!s.bound) return;
+// bx: the block's index among the regulariser's blocks (its own launch, or the tail blocks of k_gf_data's)
+__device__ __forceinline__ void gf_reg_body(GfSlotDev& s, const int bx, const GfRegArgs ra, double* sm) {
+  const int use_arap = ra.use_arap, use_rot = ra.use_rot, use_face = ra.use_face;
+  const double lam_a = ra.lam_a, lam_r = ra.lam_r, lam_f = ra.lam_f;
   const FrameIn& f = s.f.base;
   const int J = f.J, Ke = f.K_ED;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = bx * blockDim.x + threadIdx.x;
   double la = 0.0, lr = 0.0, lf = 0.0;
   double gq[4] = {0, 0, 0, 0}, gb[3] = {0, 0, 0};   // global-row contributions of this thread
   if (use_arap && t < J * Ke) {
@@ -477,17 +486,26 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, int 
     const double tt = block_sum(vals[a], sm);
     // (spread block partials: 0..6 global row, 11 / 12 / 13 face / arap / rot)
     if (threadIdx.x == 0 && tt != 0.0)
-      atomic_add_f64(s.terms.get() + SLM_GF_NTERMS + 16 * (blockIdx.x % GF_NCOPY) + (a < 7 ? a : a + 4), tt);
+      atomic_add_f64(s.terms.get() + SLM_GF_NTERMS + 16 * (bx % GF_NCOPY) + (a < 7 ? a : a + 4), tt);
   }
+}
+__global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, GfRegArgs ra) {
+  __shared__ double sm[16];
+  GfSlotDev& s = gf_dev(slots)[blockIdx.y];
+  if (!s.bound) return;
+  gf_reg_body(s, blockIdx.x, ra, sm);
 }
 
 // grad[J] /= J, then torch.optim.SGD(momentum=0.9) or torch.optim.Adam step (float64).
 // Also turns the morphing term's sum into the reference's weighted mean (NaN over an empty set).
-// fold: this launch also sums the spread block partials of k_gf_data / k_gf_reg (what k_gf_fold(which = 1) does as a launch
-// of its own: slm_gf_run's loop saves that launch; the thread of a global-row entry sums its own 64 copies, threads 0..6 the
-// loss terms').
+// fold: bit 0 -- this launch also sums the spread block partials of k_gf_data / k_gf_reg (what k_gf_fold(which = 1) does as a
+// launch of its own: slm_gf_run's loop saves that launch; the thread of a global-row entry sums its own 64 copies, threads
+// 0..6 the loss terms');  bit 1 -- the launch OWNS the partials: it clears what it summed and ASSIGNS the loss terms (nothing
+// else wrote them since the last k_gf_zero);  bit 2 -- it leaves the gradient zeroed for the next iteration (bits 1 + 2:
+// slm_gf_run's loop without the morphing term needs no k_gf_zero between two iterations).
+// step_off: optimiser steps of this run that s.step does not count yet (k_gf_advance adds them at the end of the run)
 __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int optimizer, double lr,
-                                                  int apply, int use_morph, double w_morph, int fold) {
+                                                  int apply, int use_morph, double w_morph, int fold, int step_off) {
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound) return;
   const int J = s.f.base.J, n = (J + 1) * 7;
@@ -498,17 +516,25 @@ __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int
   }
   if (e >= n) return;
   double g = s.grad[e];
-  if (fold) {
+  const bool own = (fold & 2) != 0;
+  if (fold & 1) {
     double* part = s.terms.get() + SLM_GF_NTERMS;
     if (e < 7) {   // entries 7..13 of the partials: point-plane loss / kept, correspondence loss / kept, face, arap, rot
       const int map[7] = {3, 4, 8, 9, 0, 1, 2};
       double t = 0.0;
-      for (int c = 0; c < GF_NCOPY; ++c) t += part[16 * c + 7 + e];
-      if (t != 0.0) s.terms[map[e]] += t;
+      for (int c = 0; c < GF_NCOPY; ++c) {
+        t += part[16 * c + 7 + e];
+        if (own) part[16 * c + 7 + e] = 0.0;
+      }
+      if (own) s.terms[map[e]] = t;
+      else if (t != 0.0) s.terms[map[e]] += t;
     }
     if (e >= 7 * J) {
       double t = 0.0;
-      for (int c = 0; c < GF_NCOPY; ++c) t += part[16 * c + (e - 7 * J)];
+      for (int c = 0; c < GF_NCOPY; ++c) {
+        t += part[16 * c + (e - 7 * J)];
+        if (own) part[16 * c + (e - 7 * J)] = 0.0;
+      }
       g += t;
     }
   }
@@ -516,8 +542,9 @@ __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int
     g /= (double)J;
     s.grad[e] = g;
   }
+  if (fold & 4) s.grad[e] = 0.0;
   if (!apply) return;
-  const int t = s.step + 1;
+  const int t = s.step + 1 + step_off;
   if (optimizer == 0) {
     const double buf = (t == 1) ? g : 0.9 * s.m1[e] + g;
     s.m1[e] = buf;
@@ -534,9 +561,9 @@ __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int
   }
 }
 
-__global__ void k_gf_advance(GfSlot* __restrict__ slots) {
+__global__ void k_gf_advance(GfSlot* __restrict__ slots, int inc) {
   GfSlotDev& s = gf_dev(slots)[blockIdx.x];
-  if (s.bound && threadIdx.x == 0) s.step += 1;
+  if (s.bound && threadIdx.x == 0) s.step += inc;
 }
 
 __global__ void __launch_bounds__(256) k_gf_init(GfSlot* __restrict__ slots, int slot) {
@@ -660,8 +687,8 @@ static int gf_fail(int code, const char* msg) {
 }
 
 // pass 1: zero the gradient / terms, then the morphing term's per-surfel pass (sum, count)
-static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStream_t st, int advance = 0) {
-  hipLaunchKernelGGL(k_gf_zero, dim3(32, n), dim3(256), 0, st, slots, advance);
+static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStream_t st) {
+  hipLaunchKernelGGL(k_gf_zero, dim3(32, n), dim3(256), 0, st, slots);
   if (g->cfg.use_bn_morph) {
     launch_gf_morph(slots, n, maxN, st);
     hipLaunchKernelGGL(k_gf_fold, dim3(1, n), dim3(64), 0, st, slots, 2);   // terms[5], [6]: what the back-propagation divides by
@@ -673,25 +700,29 @@ static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStrea
 static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, bool fold = true) {
   const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
-  if ((use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0)
-  {
+  const bool data = (use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0;
+  const bool reg = g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0;
+  const GfRegArgs ra = {c.use_arap, c.use_rot, c.use_face, 0, c.w_arap, c.w_rot, c.w_face};
+  const int nd = (maxN + 255) / 256, nr = reg ? (maxReg + 255) / 256 : 0;
+  if (data) {
+    // the node terms ride on this launch as its tail blocks
     const bool extra = c.seg_mode || c.use_bn_morph || c.corr_mode || c.pp_max > 0.0;
     if (extra) {
-      GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, true>), dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
-                                                   c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr));
+      GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, true>), dim3(nd + nr, n), dim3(256), 0, st, slots, use_pp, c.w_data,
+                                                   c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr,
+                                                   nd, ra));
     } else {
-      GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, false>), dim3((maxN + 255) / 256, n), dim3(256), 0, st, slots, use_pp, c.w_data,
-                                                   0, 0.0, 0, 0.0, 0, 0.0));
+      GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, false>), dim3(nd + nr, n), dim3(256), 0, st, slots, use_pp, c.w_data,
+                                                   0, 0.0, 0, 0.0, 0, 0.0, nd, ra));
     }
+  } else if (reg) {
+    hipLaunchKernelGGL(k_gf_reg, dim3(nr, n), dim3(256), 0, st, slots, ra);
   }
-  if (g->rank == 0 && (c.use_arap || c.use_rot || c.use_face) && maxReg > 0)
-    hipLaunchKernelGGL(k_gf_reg, dim3((maxReg + 255) / 256, n), dim3(256), 0, st, slots, c.use_arap, c.w_arap,
-                       c.use_rot, c.w_rot, c.use_face, c.w_face);
   if (fold) hipLaunchKernelGGL(k_gf_fold, dim3(1, n), dim3(64), 0, st, slots, 1);   // (else the caller's k_gf_step folds)
 }
 
-static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, int advance = 0, bool fold = true) {
-  gf_enqueue_morph(g, slots, n, maxN, st, advance);
+static void gf_enqueue_eval(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, bool fold = true) {
+  gf_enqueue_morph(g, slots, n, maxN, st);
   gf_enqueue_losses(g, slots, n, maxN, maxReg, st, fold);
 }
 
@@ -900,8 +931,8 @@ int slm_gf_step(slm_gf* g, int32_t n_frames, void* stream) {
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev, g->cfg.optimizer,
-                     g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 0);
-  hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
+                     g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 0, 0);
+  hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev, 1);
   GFCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -939,12 +970,20 @@ int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream) {
                    "slm_gf_run: surfels are sharded; drive slm_gf_eval_morph / eval_losses / step with an "
                    "all-reduce of slm_gf_get_partial between them");
   hipStream_t st = (hipStream_t)stream;
-  for (int it = 0; it < g->cfg.num_iterations; ++it) {
-    gf_enqueue_eval(g, g->dev, n_frames, maxN, maxReg, st, it > 0 ? 1 : 0, false);   // (counts the previous iteration's step; the step folds)
+  // Without the morphing term an iteration is TWO launches: the losses (k_gf_data with the node terms as its tail blocks) and
+  // the step, which folds the block partials, assigns the loss terms and leaves gradient and partials zeroed for the next
+  // iteration; k_gf_zero only runs in front of the first.  With the morphing term (its own pass + fold between the zeroing
+  // and the losses) the zeroing stays a launch per iteration.  The step counter advances once, behind the loop.
+  const bool morph = g->cfg.use_bn_morph != 0;
+  const int n_it = g->cfg.num_iterations;
+  for (int it = 0; it < n_it; ++it) {
+    if (morph || it == 0) gf_enqueue_morph(g, g->dev, n_frames, maxN, st);
+    gf_enqueue_losses(g, g->dev, n_frames, maxN, maxReg, st, false);   // (the step folds)
+    const int fold = morph ? 1 : (it + 1 < n_it ? 7 : 3);
     hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev,
-                       g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 1);
+                       g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, fold, it);
   }
-  if (g->cfg.num_iterations > 0) hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev);
+  if (n_it > 0) hipLaunchKernelGGL(k_gf_advance, dim3(n_frames), dim3(64), 0, st, g->dev, n_it);
   GFCHK(hipGetLastError());
   return SLM_OK;
 }
@@ -968,7 +1007,7 @@ int slm_gf_loss_grad(slm_gf* g, int32_t slot, const double* dv, double* terms, d
   GFCHK(hipMemcpyAsync(s.dv, dv, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   gf_enqueue_eval(g, g->dev + slot, 1, maxN, maxReg, st);
   hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, 1), dim3(256), 0, st, g->dev + slot, g->cfg.optimizer,
-                     g->cfg.lr, 0, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 0);
+                     g->cfg.lr, 0, g->cfg.use_bn_morph, g->cfg.w_bn_morph, 0, 0);
   if (terms) GFCHK(hipMemcpyAsync(terms, s.terms, sizeof(double) * SLM_GF_NTERMS, hipMemcpyDeviceToDevice, st));
   if (grad) GFCHK(hipMemcpyAsync(grad, s.grad, sizeof(double) * maxP, hipMemcpyDeviceToDevice, st));
   GFCHK(hipGetLastError());
