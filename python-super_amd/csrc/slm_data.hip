@@ -84,25 +84,32 @@ __global__ void __launch_bounds__(256) k_data_resid(const FrameDev* __restrict__
 
 // ---- K-generic data term on the multifrontal path (num_neighbors != 4) ------------------------------------------------
 // The Jacobian row of a surfel has 7K entries; its outer product lands in the K(K+1)/2 node-pair blocks of the surfel.
-// One thread per surfel evaluates (as k_data_grad), then the WAVE turns round: the rows of its 64 surfels go to LDS in the
-// surfel's canonical neighbour order (ids ascending: slot (ra, rb <= ra) is the pair (c[ra], c[rb]), never transposed) and
-// every lane owns a fixed set of ENTRIES -- (slot, ca, cb) of the blocks and (node, c) of J^T r -- which it forms for the
-// wave's surfels one after the other, accumulating in a register while the destination record stays the same and issuing
-// one f64 atomic when it changes.  Surfels are walked in neighbour-set order (FrameDev::sf_perm), so the surfels of a set
-// are consecutive and their common blocks reach memory once per wave instead of once per surfel: K = 6 at C2 issues
-// ~945 atomics per RUN of surfels with one neighbour set instead of per surfel.  The records (pairbuf: 49 block entries
-// row-major (ca, cb) of the larger-id node's row index first + 7 entries of J^T r of the diagonal pair, as the wgslab
+// One thread per surfel evaluates (as k_data_grad), then the WAVE forms the Gram matrices of its surfels on the f64 MFMA:
+// the rows of its 64 surfels go to LDS in the surfel's canonical neighbour order (ids ascending: slot (ra, rb <= ra) is
+// the pair (c[ra], c[rb]), never transposed) with the residual as one more column -- A = [row | r], so that A^T A carries
+// J^T r in its last row -- padded to NT 16-column tiles; unmatched surfels are zero rows.  Surfels are walked in
+// neighbour-set order (FrameDev::sf_perm), so the surfels of a set are consecutive: per RUN of surfels with one set the
+// lower tile pairs of A^T A are accumulated over the run's 4-surfel k-steps (v_mfma_f64_16x16x4_f64; a k-step that
+// straddles a run boundary has the other run's surfels masked out of one operand), and every accumulator entry that
+// belongs to a block -- (slot, ca, cb) with the larger-id node's row index first, or (node, c) of J^T r -- is added to
+// the run's pair records with one f64 atomic.  (Round 6, first form: lane = entry, 7K(7K + 1) / 2 + 7K scalar
+// multiply-adds per surfel from LDS -- 0.45 ms per C2 frame at K = 6, bound by that loop, not by the atomics; a
+// workgroup-level LDS table of pair records on top of it cut the atomics 4 x and was SLOWER: 0.61 ms,
+// tools/studies/r06_patches/pair_table_lds.patch.)
+// The records (pairbuf: 49 block entries row-major (ca, cb) + 7 entries of J^T r of the diagonal pair, as the wgslab
 // records of the tuple-sorted path) are placed into the fronts by k_pair_scatter (slm_front.hip).
 // grid = (ceil(max positions / 64), n_frames), ONE wave per workgroup
 template <int KK>
 __global__ void __launch_bounds__(64) k_data_grad_pairs(const FrameDev* __restrict__ frames, double lam) {
-  constexpr int NP = KK * (KK + 1) / 2, NR = 7 * KK, NB49 = NP * 49, NE = NB49 + NR, NPL = (NE + 63) / 64;
-  constexpr int LDR = (NR + 1) | 1;   // odd row stride: the lanes of one surfel's row spread over the banks
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  constexpr int NP = KK * (KK + 1) / 2, NR = 7 * KK, NC = NR + 1, NT = (NC + 15) / 16, NTP = NT * (NT + 1) / 2;
+  constexpr int LDR = 16 * NT + 1;   // odd row stride
   __shared__ double s_row[64 * LDR];
   __shared__ int s_pi[64 * NP];
+  __shared__ int s_cid[64 * KK];
   const FrameDev& fd = frames[blockIdx.y];
   if (!fd.bound || fd.st->stopped || fd.f.K != KK || !fd.vk_ready) return;
-  const int l = threadIdx.x;
+  const int l = threadIdx.x, lr = l & 15, lk = l >> 4;
   const int pos = fd.sf_lo + blockIdx.x * 64 + l;   // [sf_lo, sf_hi): all positions unless the frame is sharded over several GPUs
   SurfelEvalT<KK> ev;
   ev.match = false;
@@ -115,70 +122,96 @@ __global__ void __launch_bounds__(64) k_data_grad_pairs(const FrameDev* __restri
   if (!m) return;
   // the matched count rides behind the records, spread over SLM_VK_TAIL doubles (k_pair_scatter sums them into m_grad)
   if (l == 0) atomic_add_f64(fd.pairbuf + (size_t)fd.n_blocks * SLM_WREC + (blockIdx.x % SLM_VK_TAIL), (double)__popcll(m));
-  if (ev.match) {
+  {
+    double* rw = s_row + l * LDR;
 #pragma unroll
-    for (int k = 0; k < KK; ++k) {
-      int rank = 0;
+    for (int c = 0; c < 16 * NT; ++c) rw[c] = 0.0;
+    if (ev.match) {
 #pragma unroll
-      for (int j = 0; j < KK; ++j) rank += (ev.id[j] < ev.id[k]) ? 1 : 0;
+      for (int k = 0; k < KK; ++k) {
+        int rank = 0;
 #pragma unroll
-      for (int c = 0; c < 7; ++c) s_row[l * LDR + 7 * rank + c] = ev.row[7 * k + c];
+        for (int j = 0; j < KK; ++j) rank += (ev.id[j] < ev.id[k]) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) rw[7 * rank + c] = ev.row[7 * k + c];
+        s_cid[l * KK + rank] = ev.id[k];
+      }
+      rw[NR] = ev.r;
+#pragma unroll
+      for (int sl = 0; sl < NP; ++sl) s_pi[l * NP + sl] = fd.sf_pidx[(size_t)NP * i + sl];
     }
-    s_row[l * LDR + NR] = ev.r;
-#pragma unroll
-    for (int sl = 0; sl < NP; ++sl) s_pi[l * NP + sl] = fd.sf_pidx[(size_t)NP * i + sl];
   }
   __syncthreads();
-  // this lane's entries: e = l + 64 q
-  int desc[NPL];   // slot | rowa << 6 | rowb << 12 | off << 18 | active << 24
+  // runs: a matched surfel starts one when its neighbour set differs from the previous matched surfel's
+  bool start = false;
+  if (ev.match) {
+    const unsigned long long below = m & ((1ull << l) - 1ull);
+    if (!below) start = true;
+    else {
+      const int pl = 63 - __builtin_clzll(below);
 #pragma unroll
-  for (int q = 0; q < NPL; ++q) {
-    const int e = l + 64 * q;
-    int d = 0;
-    if (e < NB49) {
-      const int slot = e / 49, rem = e - 49 * slot, ca = rem / 7, cb = rem - 7 * ca;
-      int ra = 0;
-      while ((ra + 1) * (ra + 2) / 2 <= slot) ++ra;
-      const int rb = slot - ra * (ra + 1) / 2;
-      if (!(ra == rb && ca < cb))   // (a diagonal pair's block is symmetric: its lower part is what is placed)
-        d = slot | (7 * ra + ca) << 6 | (7 * rb + cb) << 12 | (7 * ca + cb) << 18 | 1 << 24;
-    } else if (e < NE) {
-      const int k = (e - NB49) / 7, c = (e - NB49) - 7 * k;
-      d = (k * (k + 1) / 2 + k) | (7 * k + c) << 6 | NR << 12 | (49 + c) << 18 | 1 << 24;
+      for (int k = 0; k < KK; ++k) start = start || (s_cid[l * KK + k] != s_cid[pl * KK + k]);
     }
-    desc[q] = d;
   }
-  double acc[NPL];
-  int prev[NPL];
-#pragma unroll
-  for (int q = 0; q < NPL; ++q) {
-    acc[q] = 0.0;
-    prev[q] = -1;
-  }
+  unsigned long long starts = __ballot(start);
+  // A run's Gram matrix goes from the accumulators (tile pair tp = (ti, tj <= ti), register r <-> entry (16 ti + lr,
+  // 16 tj + lk + 4 r)) through LDS to RECORD order: lane e < 56 owns entry e of every pair record, so one atomic
+  // instruction of the wave touches the four cache lines of ONE record instead of a dozen records' (the L2 executes
+  // atomics line by line).
+  __shared__ double s_g[16 * NT * LDR];
   double* pb = fd.pairbuf;
-  for (unsigned long long mm = m; mm; mm &= mm - 1) {
-    const int sidx = __builtin_ctzll(mm);   // uniform: the wave's matched surfels in list order
-    const double* rw = s_row + sidx * LDR;
-    const int* pi = s_pi + sidx * NP;
+  const int eca = l / 7, ecb = l - 7 * eca;   // lane -> (ca, cb) of a block entry (l < 49), or component l - 49 of J^T r
+  while (starts) {
+    const int rs = __builtin_ctzll(starts);   // uniform
+    starts &= starts - 1;
+    const int re = starts ? __builtin_ctzll(starts) : 64;
+    double4_t acc[NTP];
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-      const int d = desc[q];
-      if (d >> 24) {
-        const int dest = pi[d & 63] * SLM_WREC + ((d >> 18) & 63);
-        const double v = rw[(d >> 6) & 63] * rw[(d >> 12) & 63];
-        if (dest != prev[q]) {
-          if (prev[q] >= 0) atomic_add_f64(pb + prev[q], acc[q]);
-          prev[q] = dest;
-          acc[q] = v;
-        } else {
-          acc[q] += v;
-        }
+    for (int tp = 0; tp < NTP; ++tp) acc[tp] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int ks = rs >> 2; ks <= (re - 1) >> 2; ++ks) {
+      const int p = 4 * ks + lk;
+      const bool inrun = p >= rs && p < re;
+      double v[NT], vm[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        v[t] = s_row[p * LDR + 16 * t + lr];
+        vm[t] = inrun ? v[t] : 0.0;
       }
-    }
-  }
+      int tp = 0;
 #pragma unroll
-  for (int q = 0; q < NPL; ++q)
-    if (prev[q] >= 0) atomic_add_f64(pb + prev[q], acc[q]);
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj, ++tp) acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(vm[tj], v[ti], acc[tp], 0, 0, 0);
+    }
+    {
+      int tp = 0;
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj, ++tp)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_g[(16 * ti + lr) * LDR + 16 * tj + lk + 4 * r] = acc[tp][r];
+    }
+    __syncthreads();
+    const int* pi = s_pi + rs * NP;
+    int sl = 0;
+#pragma unroll 1
+    for (int ra = 0; ra < KK; ++ra)
+#pragma unroll 1
+      for (int rb = 0; rb <= ra; ++rb, ++sl) {
+        double val = 0.0;
+        bool on = false;
+        if (l < 49) {
+          on = ra > rb || eca >= ecb;   // (a diagonal pair's block is symmetric: its lower part is what is placed)
+          val = s_g[(7 * ra + eca) * LDR + 7 * rb + ecb];
+        } else if (l < 56 && ra == rb) {
+          on = true;
+          val = s_g[NR * LDR + 7 * rb + (l - 49)];
+        }
+        if (on) atomic_add_f64(pb + (size_t)pi[sl] * SLM_WREC + l, val);
+      }
+    __syncthreads();   // s_g is rewritten by the next run
+  }
 }
 
 // zero the pair records (+ the matched count behind them) of the slots that take the K-generic pair path
