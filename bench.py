@@ -123,6 +123,24 @@ def pmc_phase_traffic(phase, workload, frames_per_gpu):
     return best, src
 
 
+def rows_traffic(key):
+    """HBM bytes of one slm_gf_run at C2 (`key` = "b1" / "b8") from the newest committed PMC summary of tools/profile_rows.py
+    (profiles/*rows_pmc_traffic.json, profiles/make_rows_traffic.py); (None, provenance) when it describes other sources."""
+    import glob
+    best, src = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*rows_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if key in d.get("graphfit_c2", {}):
+            best = d["graphfit_c2"][key]["traffic_bytes_per_run"]
+            src = {"file": os.path.relpath(path, ROOT), "lib_sha16": d.get("lib_sha16"), "stale": d.get("lib_sha16") != lib_sha16()}
+    if src is not None and src["stale"]:
+        best = None
+    return best, src
+
+
 def cpu_quota():
     """CPUs the container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None = unlimited:
     os.cpu_count() reports the machine, not the quota, and a host pool sized by it gets throttled."""
@@ -561,10 +579,13 @@ def graphfit_timing(dims, device, B=8):
         ms = _time_gf_run(gf, n, device)
         alg = n * it * (72.0 * scs[0].N + 440.0 * scs[0].J)
         gbs = alg / ms / 1e6
+        # (PMC bytes of one slm_gf_run when the committed summary is of these sources, the workload C2 and B = 8)
+        traffic, tsrc = rows_traffic("b1" if n == 1 else "b8") if (dims == synth.WORKLOADS["C2"] and B == 8) else (None, None)
         out[f"b{n}"] = {"ms_per_launch": ms, "ms_per_frame": ms / n, "value": n * it / (ms * 1e-3), "unit": "Adam it/s",
                         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                     "traffic": None, "algorithmic_bytes_per_launch": alg,
-                                     "kernels": "k_gf_zero + k_gf_data + k_gf_reg + k_gf_step + k_gf_advance per iteration"}}
+                                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": alg,
+                                     "kernels": "one k_gf_zero, then per iteration k_gf_data (the node terms as its tail blocks) + "
+                                                "k_gf_step (folds, steps, re-zeroes); one k_gf_advance"}}
         del keep, gf
     out["sample"] = (f"{it} Adam iterations per frame on {scs[0].N}-surfel / {scs[0].J}-node frames, float64 arithmetic, C ABI; "
                      f"b1 = one frame per slm_gf_run, b{B} = {B} frames per launch; HIP events on the launch stream")

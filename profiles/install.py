@@ -62,6 +62,15 @@ if rows:     # GraphFit / semantic GraphFit / depth / fusion / graph / K = 6 ker
         lines = [ln for ln in open(os.path.join(G, f"{tag}_rows.json")) if ln.startswith("{")]
         if lines:
             open(os.path.join(P, f"{tag}_rows_timing.json"), "w").write(lines[-1])
+rf = glob.glob(os.path.join(G, f"{tag}_rows_pmc_FETCH_SIZE/**/*counter_collection.csv"), recursive=True)
+rw = glob.glob(os.path.join(G, f"{tag}_rows_pmc_WRITE_SIZE/**/*counter_collection.csv"), recursive=True)
+if rf and rw:   # HBM bytes per launch of the same rows (re-made here: tagged with the hash of the sources in this tree)
+    subprocess.check_call([sys.executable, os.path.join(P, "make_rows_traffic.py"), max(rf, key=os.path.getmtime), max(rw, key=os.path.getmtime),
+                           "--out", os.path.join(P, f"{tag}_rows_pmc_traffic.json")])
+rsq = sorted(glob.glob(os.path.join(G, f"{tag}_rows_sq_*/")))
+if rsq:
+    subprocess.check_call([sys.executable, os.path.join(P, "make_sq_summary.py")] + rsq +
+                          ["--keep-templates", "--out", os.path.join(P, f"{tag}_rows_sq_summary.csv")])
 avail = os.path.join(G, f"{tag}_mfma_counters_available.txt")
 if os.path.exists(avail):
     shutil.copy(avail, os.path.join(P, f"{tag}_mfma_counters_available.txt"))

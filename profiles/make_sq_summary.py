@@ -19,12 +19,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--keep-templates", action="store_true", help="group by the kernel name WITH its template arguments")
     a = ap.parse_args()
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in a.dirs:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
-                name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+                name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+                if a.keep_templates:       # cut the argument list only
+                    depth, cut = 0, len(name)
+                    for i, ch in enumerate(name):
+                        if ch == "(" and depth == 0:
+                            cut = i
+                            break
+                        depth += (ch == "<") - (ch == ">")
+                    name = name[:cut].strip()
+                else:
+                    name = name.split("(")[0].split("<")[0]
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = sorted({c for k in agg.values() for c in k})
     with open(a.out, "w", newline="") as f:
