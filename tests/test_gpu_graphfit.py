@@ -191,3 +191,31 @@ def test_surfel_sharded_ranks_reproduce_the_single_gpu_solve(tag, world):
     for d in dvs[1:]:
         np.testing.assert_array_equal(d, dvs[0])           # every rank holds the same parameters
     np.testing.assert_allclose(dvs[0], g[f"gf_{tag}_final"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["sgd", "adam", "morph"])
+def test_run_loop_continues_where_the_last_run_ended(tag):
+    """slm_gf_run's loop keeps no launch of its own for the zeroing and counts its optimiser steps once, behind the loop
+    (round 6): two runs of 5 iterations on one bound frame are the 10 iterations of one run -- the step counter
+    (SGD's first-step rule, Adam's bias corrections), the momentum buffers and the zeroed state carry over -- and equal
+    the stepwise entry points (eval_morph / eval_losses / step), which keep their own zeroing and fold launches."""
+    from super_amd import _lib
+    from super_amd.deform_mesh import GraphFit
+    name = "s60x80_j48_semantic" if tag in GF_SEMANTIC_VARIANTS else "s60x80_j48"
+    g, sc, _ = load_golden(name)
+    sf, inputs, new_data = _frame(sc)
+    full = _opt(tag)
+    assert full.num_optimize_iterations == 10
+    half = GraphFit(_opt(tag, num_optimize_iterations=5))
+    half.bind(inputs, sf, new_data)
+    for _ in range(2):
+        _lib.check(half.lib.slm_gf_run(half.h, 1, half._st()), "slm_gf_run")
+    dv2 = half.deform_verts().cpu().numpy()
+    np.testing.assert_allclose(dv2, g[f"gf_{tag}_final"], rtol=0, atol=1e-9)
+    steps = GraphFit(full)
+    steps.bind(inputs, sf, new_data)
+    for _ in range(10):
+        steps.eval_morph()
+        steps.eval_losses()
+        steps.step()
+    np.testing.assert_allclose(steps.deform_verts().cpu().numpy(), dv2, rtol=0, atol=1e-12)
