@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "slm_sem.h"
+#include "slm_lane.h"
 
 __global__ void __launch_bounds__(256) k_gf_zero(GfSlot* __restrict__ slots) {
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
@@ -163,6 +164,7 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
   __shared__ double tval[GF_TAB * 7];
   __shared__ double s_gval[4][16][7 * KK];   // gradient rows of 16 surfels of each wave, canonical slot order
   __shared__ int s_gid[4][16][KK];
+  __shared__ double s_part[64];              // the four waves' sums of the 16 per-thread scalars
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound || s.f.base.K != KK) return;
   for (int t = threadIdx.x; t < GF_TAB; t += blockDim.x) tkey[t] = -1;
@@ -379,14 +381,21 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
     const double v = tval[t];
     if (node >= 0 && v != 0.0) atomic_add_f64(s.grad + 7 * node + t % 7, v);
   }
-  // global row, loss and count: block reduction, then one atomic each
-  double vals[11] = {gq[0], gq[1], gq[2], gq[3], gb[0], gb[1], gb[2], loss, cnt, lossc, cntc};
-#pragma unroll
-  for (int a = 0; a < 11; ++a) {
-    if (a >= 9 && !corr_mode) break;
-    const double t = block_sum(vals[a], sm);
-    // (spread block partials, slm_gf.h: entries 0..6 global row, 7 / 8 point-plane loss / kept, 9 / 10 correspondence loss / kept)
-    if (threadIdx.x == 0 && t != 0.0) atomic_add_f64(s.terms.get() + SLM_GF_NTERMS + 16 * (blockIdx.x % GF_NCOPY) + a, t);
+  // global row, loss and count: one butterfly over the 16 values of a thread per wave (col_reduce16, slm_lane.h: lane 4 a holds
+  // the wave's sum of value a), the four waves' sums through LDS, then one atomic each (9 block_sums with two barriers each
+  // before: 19 of the launch's 215 us at 8 C2 frames, tools/diag/gf_ablate_time.py)
+  {
+    double vals[16] = {gq[0], gq[1], gq[2], gq[3], gb[0], gb[1], gb[2], loss, cnt, lossc, cntc, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const double r = col_reduce16(vals);
+    const int l = threadIdx.x & 63;
+    if ((l & 3) == 0) s_part[(threadIdx.x >> 6) * 16 + (l >> 2)] = r;
+    __syncthreads();
+    const int a = threadIdx.x;
+    if (a < (corr_mode ? 11 : 9)) {
+      const double t = s_part[a] + s_part[16 + a] + s_part[32 + a] + s_part[48 + a];
+      // (spread block partials, slm_gf.h: entries 0..6 global row, 7 / 8 point-plane loss / kept, 9 / 10 correspondence loss / kept)
+      if (t != 0.0) atomic_add_f64(s.terms.get() + SLM_GF_NTERMS + 16 * (blockIdx.x % GF_NCOPY) + a, t);
+    }
   }
 }
 
