@@ -314,16 +314,34 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
   {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long am = __ballot(has_grad);
-    const int slot = l / 7;
+    // WG entry-lane groups of 7 KK lanes share a round's 16 surfels (K = 4: lanes 0..27 walk surfels 0..7, lanes 28..55
+    // surfels 8..15): half the steps per round for one more flush per lane and round
+    constexpr int WG = (7 * KK <= 16) ? 4 : ((7 * KK <= 32) ? 2 : 1), WS = 16 / WG;
+    const int grp = l / (7 * KK), el = l - 7 * KK * grp;   // group, entry inside the group
+    const int slot = el / 7;
     double acc = 0.0;
     int prev = -1;
     auto flush = [&]() {
       if (prev < 0) return;
       const int ts = prev & (GF_TAB - 1);
       const int old = atomicCAS(&tkey[ts], -1, prev);
-      if (old == -1 || old == prev) unsafeAtomicAdd(&tval[7 * ts + (l - 7 * slot)], acc);
-      else atomic_add_f64(s.grad + 7 * prev + (l - 7 * slot), acc);
+      if (old == -1 || old == prev) unsafeAtomicAdd(&tval[7 * ts + (el - 7 * slot)], acc);
+      else atomic_add_f64(s.grad + 7 * prev + (el - 7 * slot), acc);
     };
+    // K <= 4: every lane forms the quaternion parts of its K rows NOW, all 64 lanes at once (the node rows / positions are
+    // read again -- cache hits -- and held: 8 K registers); only the staging goes 16 surfels at a time.  (Formed inside the
+    // rounds by the 16 lanes of the round, the same instructions issued four times: 40 of the launch's 200 us at 8 C2 frames.)
+    constexpr bool EAGER = KK <= 4;
+    double jqa[EAGER ? KK : 1][4];
+    if (EAGER && has_grad) {
+      const FrameIn& f = s.f.base;
+#pragma unroll
+      for (int a = 0; a < (EAGER ? KK : 0); ++a) {
+        const double* b = s.dv + 7 * k.id[a];
+        const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
+        quat_jac_row(b[0], {b[1], b[2], b[3]}, k.p - g, cl, jqa[a]);
+      }
+    }
     if (am) {
 #pragma unroll 1
       for (int sb = 0; sb < 4; ++sb) {
@@ -335,10 +353,15 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
           const FrameIn& f = s.f.base;
 #pragma unroll
           for (int a = 0; a < KK; ++a) {
-            const double* b = s.dv + 7 * k.id[a];
-            const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
             double jq[4];
-            quat_jac_row(b[0], {b[1], b[2], b[3]}, k.p - g, cl, jq);
+            if constexpr (EAGER) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) jq[c] = jqa[a][c];
+            } else {
+              const double* b = s.dv + 7 * k.id[a];
+              const d3 g = ld_state3(f.ed_points, (size_t)k.id[a], f.state_f64);
+              quat_jac_row(b[0], {b[1], b[2], b[3]}, k.p - g, cl, jq);
+            }
             const double wk = k.w[a];
             // canonical slot of neighbour a: its rank among the surfel's node ids (two surfels with the same neighbour SET
             // have the same node in every slot, whatever the distance order of their KNN lists)
@@ -354,11 +377,11 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (l < 7 * KK) {
-          for (unsigned mm = mask16; mm; mm &= mm - 1) {
+        if (grp < WG) {
+          for (unsigned mm = mask16 & (((1u << WS) - 1u) << (WS * grp)); mm; mm &= mm - 1) {
             const int si = __builtin_ctz(mm);
             const int id = s_gid[w][si][slot];
-            const double v = s_gval[w][si][l];
+            const double v = s_gval[w][si][el];
             if (id != prev) {
               flush();
               prev = id;
@@ -372,7 +395,7 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      if (l < 7 * KK) flush();
+      if (grp < WG) flush();
     }
   }
   __syncthreads();
