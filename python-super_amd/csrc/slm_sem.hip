@@ -119,8 +119,6 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
   __shared__ int n_cand;
   __shared__ double c_x[256], c_y[256], c_d1[256], c_d2[256];
   __shared__ int c_e0[256], c_e1[256], c_i1[256], c_i2[256];
-  __shared__ double r_d[4][2];
-  __shared__ int r_i[4][2];
   if (threadIdx.x == 0) n_cand = 0;
   __syncthreads();
   int my_cand = -1, my_W = 0, my_H = 0;
@@ -187,19 +185,21 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
   __syncthreads();
   // ---- the two nearest boundary pixels of every candidate's class: the mismatching surfels are a thin band along the class
   // boundaries (a few per cent), so one lane per surfel scanning ~1 000-2 000 boundary pixels left 60 lanes of its wave idle for
-  // the whole scan (534 us per launch at C4, 80 % of the Semantic-SuPer step).  The workgroup takes its candidates one after the
-  // other: 256 lanes scan the class's list strided, each keeps its two nearest in (distance, list position) order -- the order
-  // of the sequential scan with strict <, i.e. find_knn's lowest index on ties -- and a butterfly + four-way merge gives the
-  // candidate's answer to lane 0.
+  // the whole scan (534 us per launch at C4, 80 % of the Semantic-SuPer step).  The workgroup's WAVES take its candidates one
+  // after the other (wave w the candidates w, w + 4, ...): 64 lanes scan the class's list strided, each keeps its two nearest
+  // in (distance, list position) order -- the order of the sequential scan with strict <, i.e. find_knn's lowest index on
+  // ties -- and a butterfly merge gives the candidate's answer to lane 0.  (First form of round 6: the whole workgroup per
+  // candidate, 256 lanes + a four-way merge through LDS behind two barriers per candidate -- the butterfly and the barriers
+  // were issued by four waves for one candidate: 68 us per launch at C4.)
   {
     const int nc = n_cand;
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int k = 0; k < nc; ++k) {
+    for (int k = w; k < nc; k += 4) {
       const double x = c_x[k], y = c_y[k];
       const int e0 = c_e0[k], e1 = c_e1[k];
       double d1 = 1e300, d2 = 1e300;
       int i1 = 0x7fffffff, i2 = 0x7fffffff;
-      for (int e = e0 + (int)threadIdx.x; e < e1; e += 256) {
+      for (int e = e0 + l; e < e1; e += 64) {
         const float2 q = s.edge_xy[e];
         const double dx = x - (double)q.x, dy = y - (double)q.y;
         const double d = dx * dx + dy * dy;
@@ -230,19 +230,12 @@ __global__ void __launch_bounds__(256) k_gf_morph(GfSlot* __restrict__ slots) {
         merge(od1, oi1, od2, oi2);
       }
       if (l == 0) {
-        r_d[w][0] = d1; r_d[w][1] = d2;
-        r_i[w][0] = i1; r_i[w][1] = i2;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww) merge(r_d[ww][0], r_i[ww][0], r_d[ww][1], r_i[ww][1]);
         c_d1[k] = d1; c_d2[k] = d2;
         c_i1[k] = i1; c_i2[k] = i2;
       }
-      __syncthreads();
     }
   }
+  __syncthreads();
   if (i < f.N) {
     double2 g = make_double2(0.0, 0.0);
     if (my_cand >= 0) {
