@@ -138,7 +138,7 @@ __device__ __forceinline__ void gf_reg_body(GfSlotDev& s, const int bx, const Gf
 // (gf_reg_body: independent work that only meets this kernel's in the gradient's atomics -- slm_gf_run's loop saves a launch)
 // seg_mode: 0 none, 1 hard, 2 soft semantic weight on the squared residual (loss.py:379-399);
 // pp_max > 0 (and no seg_mode): squared residuals >= pp_max are dropped (loss.py:369-370);
-// use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph.
+// use_morph: adds the back-propagation of the morphing term prepared by k_gf_morph (2: the kept count is still in the spread partials).
 // KK = opt.num_neighbors of the launch's slots (deform_source is K-generic, super/deform_mesh.py:198-221)
 #define GF_TAB 128   // LDS gradient table: slots per workgroup (power of two)
 // EXTRA = false: the plain point-plane term only (no segmentation weight, clip, morphing or correspondence term) -- the
@@ -165,10 +165,15 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
   __shared__ double s_gval[4][16][7 * KK];   // gradient rows of 16 surfels of each wave, canonical slot order
   __shared__ int s_gid[4][16][KK];
   __shared__ double s_part[64];              // the four waves' sums of the 16 per-thread scalars
+  __shared__ double s_kept;                  // the morphing term's kept count (use_morph == 2)
   GfSlotDev& s = gf_dev(slots)[blockIdx.y];
   if (!s.bound || s.f.base.K != KK) return;
   for (int t = threadIdx.x; t < GF_TAB; t += blockDim.x) tkey[t] = -1;
   for (int t = threadIdx.x; t < GF_TAB * 7; t += blockDim.x) tval[t] = 0.0;
+  if (use_morph == 2 && threadIdx.x < 64) {
+    const double v = wave_sum((double)s.terms[SLM_GF_NTERMS + 16 * threadIdx.x + 15]);
+    if (threadIdx.x == 0) s_kept = v;
+  }
   __syncthreads();
   const FrameIn& f = s.f.base;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,9 +288,11 @@ __global__ void __launch_bounds__(256, (EXTRA || KK > 4) ? 3 : 4) k_gf_data(GfSl
       }
     }
     if (use_morph && s.sem_bound) {
-      // mean over the kept surfels (count from k_gf_morph, earlier in the stream)
+      // mean over the kept surfels (count from k_gf_morph, earlier in the stream: folded into terms[6] by k_gf_fold, or --
+      // use_morph == 2, slm_gf_run's loop -- still in the 64 spread copies of entry 15: summed once per block, s_kept; a count,
+      // exact in any order)
       const double2 mg = s.morph_g[i];
-      const double kept = s.terms[6];
+      const double kept = use_morph == 2 ? s_kept : (double)s.terms[6];
       if (kept > 0.0 && (mg.x != 0.0 || mg.y != 0.0)) {
         const double sc = w_morph / kept;
         gP = {gP.x + sc * (mg.x * Pi0.x + mg.y * Pi1.x), gP.y + sc * (mg.x * Pi0.y + mg.y * Pi1.y),
@@ -534,7 +541,9 @@ __global__ void __launch_bounds__(256) k_gf_reg(GfSlot* __restrict__ slots, GfRe
 // launch of its own: slm_gf_run's loop saves that launch; the thread of a global-row entry sums its own 64 copies, threads
 // 0..6 the loss terms');  bit 1 -- the launch OWNS the partials: it clears what it summed and ASSIGNS the loss terms (nothing
 // else wrote them since the last k_gf_zero);  bit 2 -- it leaves the gradient zeroed for the next iteration (bits 1 + 2:
-// slm_gf_run's loop without the morphing term needs no k_gf_zero between two iterations).
+// slm_gf_run's loop needs no k_gf_zero between two iterations);  bit 3 -- the launch also owns the morphing term's partials
+// (entries 14 / 15: k_gf_fold(which = 2) as a launch of its own otherwise): it assigns terms[5] / [6] from them, clears them and,
+// with bit 2, resets the candidates flag terms[7] for the next iteration's k_gf_morph.
 // step_off: optimiser steps of this run that s.step does not count yet (k_gf_advance adds them at the end of the run)
 __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int optimizer, double lr,
                                                   int apply, int use_morph, double w_morph, int fold, int step_off) {
@@ -543,8 +552,21 @@ __global__ void __launch_bounds__(256) k_gf_step(GfSlot* __restrict__ slots, int
   const int J = s.f.base.J, n = (J + 1) * 7;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e == 0 && use_morph) {
-    const double kept = s.terms[6];
-    s.terms[5] = s.terms[7] != 0.0 ? (kept > 0.0 ? w_morph * s.terms[5] / kept : nan("")) : 0.0;
+    double li = s.terms[5], kept = s.terms[6];
+    if (fold & 8) {
+      double* part = s.terms.get() + SLM_GF_NTERMS;
+      li = 0.0;
+      kept = 0.0;
+      for (int c = 0; c < GF_NCOPY; ++c) {
+        li += part[16 * c + 14];
+        kept += part[16 * c + 15];
+        part[16 * c + 14] = 0.0;
+        part[16 * c + 15] = 0.0;
+      }
+      s.terms[6] = kept;
+    }
+    s.terms[5] = s.terms[7] != 0.0 ? (kept > 0.0 ? w_morph * li / kept : nan("")) : 0.0;
+    if ((fold & 12) == 12) s.terms[7] = 0.0;
   }
   if (e >= n) return;
   double g = s.grad[e];
@@ -729,7 +751,7 @@ static void gf_enqueue_morph(slm_gf* g, GfSlot* slots, int n, int maxN, hipStrea
 
 // pass 2: point-plane (+ morphing back-propagation, needs the GLOBAL kept count in terms[6]) and
 // the node terms (on rank 0 only when the surfels are sharded: the caller sums the partials)
-static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, bool fold = true) {
+static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int maxReg, hipStream_t st, bool fold = true, bool morph_in_partials = false) {
   const slm_gf_config& c = g->cfg;
   const int use_pp = (c.use_data || c.seg_mode) ? 1 : 0;   // either flag enables the term (deform_mesh.py:81)
   const bool data = (use_pp || c.use_bn_morph || c.corr_mode) && maxN > 0;
@@ -741,7 +763,7 @@ static void gf_enqueue_losses(slm_gf* g, GfSlot* slots, int n, int maxN, int max
     const bool extra = c.seg_mode || c.use_bn_morph || c.corr_mode || c.pp_max > 0.0;
     if (extra) {
       GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, true>), dim3(nd + nr, n), dim3(256), 0, st, slots, use_pp, c.w_data,
-                                                   c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph, c.w_bn_morph, c.corr_mode, c.w_corr,
+                                                   c.seg_mode, c.seg_mode ? 0.0 : c.pp_max, c.use_bn_morph ? (morph_in_partials ? 2 : 1) : 0, c.w_bn_morph, c.corr_mode, c.w_corr,
                                                    nd, ra));
     } else {
       GF_K_DISPATCH(g->batch_K, hipLaunchKernelGGL((k_gf_data<KK, false>), dim3(nd + nr, n), dim3(256), 0, st, slots, use_pp, c.w_data,
@@ -1002,16 +1024,18 @@ int slm_gf_run(slm_gf* g, int32_t n_frames, void* stream) {
                    "slm_gf_run: surfels are sharded; drive slm_gf_eval_morph / eval_losses / step with an "
                    "all-reduce of slm_gf_get_partial between them");
   hipStream_t st = (hipStream_t)stream;
-  // Without the morphing term an iteration is TWO launches: the losses (k_gf_data with the node terms as its tail blocks) and
-  // the step, which folds the block partials, assigns the loss terms and leaves gradient and partials zeroed for the next
-  // iteration; k_gf_zero only runs in front of the first.  With the morphing term (its own pass + fold between the zeroing
-  // and the losses) the zeroing stays a launch per iteration.  The step counter advances once, behind the loop.
+  // An iteration is TWO launches: the losses (k_gf_data with the node terms as its tail blocks) and the step, which folds the
+  // block partials, assigns the loss terms and leaves gradient and partials zeroed for the next iteration; k_gf_zero only
+  // runs in front of the first.  With the morphing term THREE: k_gf_morph in front -- its kept count stays in the spread
+  // partials, k_gf_data sums the 64 copies itself and the step folds them with the rest (k_gf_zero + k_gf_morph + k_gf_fold +
+  // k_gf_data + k_gf_step before: five launches of 5-85 us at configs[4]'s size).  The step counter advances once, behind the loop.
   const bool morph = g->cfg.use_bn_morph != 0;
   const int n_it = g->cfg.num_iterations;
   for (int it = 0; it < n_it; ++it) {
-    if (morph || it == 0) gf_enqueue_morph(g, g->dev, n_frames, maxN, st);
-    gf_enqueue_losses(g, g->dev, n_frames, maxN, maxReg, st, false);   // (the step folds)
-    const int fold = morph ? 1 : (it + 1 < n_it ? 7 : 3);
+    if (it == 0) hipLaunchKernelGGL(k_gf_zero, dim3(32, n_frames), dim3(256), 0, st, g->dev);
+    if (morph) launch_gf_morph(g->dev, n_frames, maxN, st);
+    gf_enqueue_losses(g, g->dev, n_frames, maxN, maxReg, st, false, morph);   // (the step folds)
+    const int fold = (it + 1 < n_it ? 7 : 3) | (morph ? 8 : 0);
     hipLaunchKernelGGL(k_gf_step, dim3((maxP + 255) / 256, n_frames), dim3(256), 0, st, g->dev,
                        g->cfg.optimizer, g->cfg.lr, 1, g->cfg.use_bn_morph, g->cfg.w_bn_morph, fold, it);
   }
