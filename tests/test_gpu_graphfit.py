@@ -143,6 +143,38 @@ def test_gradient_at_random_point_vs_autograd_oracle():
                                atol=1e-9 * max(1.0, float(gref.abs().max())))
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 8])
+def test_gradient_and_ten_steps_at_other_num_neighbors_vs_autograd_oracle(K):
+    """k_gf_data's row pass has a form per num_neighbors range (K <= 2: four entry-lane groups, 3..4: two + rows formed by all
+    lanes at once, >= 5: one group, rows formed inside the staging rounds): the gradient away from identity against torch
+    autograd and ten Adam steps against the oracle's optimiser, at a K of every range (4 and 6 have reference goldens)."""
+    import torch
+    from super_amd import synth
+    from super_amd.deform_mesh import GraphFit
+    sc = synth.make_scene(N=3000, J=48, H=60, W=80, seed=30 + K, n_neighbors=K, src_border=5, tgt_border=3, tgt_holes=0.01)
+    rng = np.random.default_rng(K)
+    dv0 = np.tile(np.array([1.0, 0, 0, 0, 0, 0, 0]), (sc.J + 1, 1))
+    dv0 += np.concatenate([rng.normal(0, 0.01, (sc.J + 1, 4)), rng.normal(0, 0.003, (sc.J + 1, 3))], axis=1)
+    opt = _opt("adam")
+    stable = rng.uniform(size=sc.N) > 0.1
+    pb = gfo.Problem(sc, stable=stable)
+    dvt = torch.from_numpy(dv0.copy()).requires_grad_(True)
+    loss, terms = gfo.total_loss(pb, dvt, opt)
+    gref, = torch.autograd.grad(loss, dvt)
+    gref = gref.clone()
+    gref[-1] /= sc.J
+    sf, inputs, new_data = _frame(sc)
+    sf.isStable = torch.from_numpy(stable).cuda()
+    gf = GraphFit(opt)
+    t, matched, grad = gf.loss_and_grad(inputs, sf, new_data, torch.from_numpy(dv0).cuda())
+    assert matched == terms["_matched"] and matched > 0
+    np.testing.assert_allclose(sum(t.values()), float(loss.detach()), rtol=1e-10)
+    np.testing.assert_allclose(grad.cpu().numpy(), gref.numpy(), rtol=0, atol=1e-9 * max(1.0, float(gref.abs().max())))
+    want = gfo.graphfit(pb, opt)
+    got = GraphFit(opt)(inputs, sf, new_data, None).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+
+
 def test_update_autograd_variant_matches_reference():
     import torch
     from super_amd import nodes
