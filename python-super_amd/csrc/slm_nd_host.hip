@@ -483,8 +483,29 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
   }
   // Earliest start times from a duration model (microseconds; only the ORDER matters): tasks sorted by
   // them are in a topological order, and workgroups that take tasks in that order find them ready
-  // about when they get to them.
+  // about when they get to them.  The model runs once per task list: the whole tree, and the top of the tree for the hybrid solve
+  // with everything below the cut final at time 0.  (Through the first half of round 6 the top list was the whole-tree list
+  // filtered by depth: the fronts of the cut level kept the start times of their SUBTREES, so the two with the smaller subtrees
+  // were listed first, their waiting tasks held a frame's 64 workgroups, and the other two -- the longer chains, the ones their
+  // parents wait for -- got theirs 50-120 us late: the 4-front level of C2 took 205 us at 8 frames per launch for 5 columns.)
+  if (T >= (1 << 24) || out.max_nt > 255) return false;
   {
+    static const int top_fronts = [] {
+      const char* e = getenv("SLM_DAG_TOP_FRONTS");
+      // (2 through round 4; with two workgroups per CU in the task graph the 4-front level pays as tasks too: C2, 8 frames,
+      //  ms per LM iteration at 2 / 4 / 8 fronts per level: 2.448 / 2.397 / 2.429)
+      return e && atoi(e) > 0 ? atoi(e) : 4;
+    }();
+    int max_depth = 0;
+    for (int i = 0; i < T; ++i) max_depth = std::max(max_depth, (int)out.fronts[i].depth);
+    std::vector<int> per_depth(max_depth + 1, 0);
+    for (int i = 0; i < T; ++i) ++per_depth[out.fronts[i].depth];
+    int cut = -1;
+    while (cut + 1 <= max_depth && per_depth[cut + 1] <= top_fronts) ++cut;
+    if (cut >= max_depth) cut = max_depth - 1;        // leave at least the deepest level to the launches
+    out.dag_cut_depth = cut;
+  }
+  auto model_list = [&](const int top_cut, std::vector<int32_t>& list) {
     struct Task { double start; int32_t w0, w1; };
     std::vector<Task> tasks;
     const double HOP = 1.0;   // flag + payload hand-off between workgroups
@@ -497,6 +518,9 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       auto tix = [&](int r, int c) { return (size_t)c * f.nt - (size_t)c * (c - 1) / 2 + (size_t)(r - c); };
       std::vector<double>& done = done_all[i];
       done.assign((size_t)f.nt * (f.nt + 1) / 2, 0.0);
+      // a list for the top of the tree (top_cut >= 0): the fronts below the cut are factored by the per-level launches BEFORE the
+      // list runs -- their tiles are final at time 0 and they have no factor tasks here (only their substitution tasks, below)
+      if (top_cut >= 0 && f.depth > top_cut) continue;
       // when are the children's update tiles that tile (r,s) of this front gathers from complete?
       auto pulled = [&](int r, int s) {
         double t = 0.0;
@@ -608,41 +632,31 @@ bool nd_build_plan(int J, int K_ED, const float* pts, const int32_t* ed_knn, con
       back_done[i] = prev;
       t_end = std::max(t_end, prev);
     }
-    out.dag_critical_us = t_end;
+    if (top_cut < 0) out.dag_critical_us = t_end;
     std::stable_sort(tasks.begin(), tasks.end(), [](const Task& a, const Task& b) { return a.start < b.start; });
-    out.dag_tasks.resize(2 * tasks.size());
+    list.resize(2 * tasks.size());
     for (size_t k = 0; k < tasks.size(); ++k) {
-      out.dag_tasks[2 * k] = tasks[k].w0;
-      out.dag_tasks[2 * k + 1] = tasks[k].w1;
+      list[2 * k] = tasks[k].w0;
+      list[2 * k + 1] = tasks[k].w1;
     }
-    if (T >= (1 << 24) || out.max_nt > 255) return false;
-    // top of the tree for the hybrid solve
-    {
-      static const int top_fronts = [] {
-        const char* e = getenv("SLM_DAG_TOP_FRONTS");
-        // (2 through round 4; with two workgroups per CU in the task graph the 4-front level pays as tasks too: C2, 8 frames,
-        //  ms per LM iteration at 2 / 4 / 8 fronts per level: 2.448 / 2.397 / 2.429)
-        return e && atoi(e) > 0 ? atoi(e) : 4;
-      }();
-      int max_depth = 0;
-      for (int i = 0; i < T; ++i) max_depth = std::max(max_depth, (int)out.fronts[i].depth);
-      std::vector<int> per_depth(max_depth + 1, 0);
-      for (int i = 0; i < T; ++i) ++per_depth[out.fronts[i].depth];
-      int cut = -1;
-      while (cut + 1 <= max_depth && per_depth[cut + 1] <= top_fronts) ++cut;
-      if (cut >= max_depth) cut = max_depth - 1;        // leave at least the deepest level to the launches
-      out.dag_cut_depth = cut;
-      out.dag_top_tasks.clear();
-      // ... plus the back substitution of the WHOLE tree: the deeper fronts are factored (and forward-substituted) by the
-      // per-level launches before this list runs, so their BACKB / BACK tasks need nothing but their parent's solution
-      for (size_t k = 0; k < tasks.size(); ++k) {
-        const bool top = out.fronts[tasks[k].w0 & 0xFFFFFF].depth <= cut;
-        const int type = tasks[k].w0 >> 24;
-        if (cut >= 0 && (top || type == ND_T_BACKB || type == ND_T_BACK)) {
-          out.dag_top_tasks.push_back(tasks[k].w0);
-          out.dag_top_tasks.push_back(tasks[k].w1);
+  };
+  model_list(-1, out.dag_tasks);
+  // top of the tree for the hybrid solve: the factor tasks of the fronts above the cut plus the back substitution of the
+  // WHOLE tree (the deeper fronts are factored and forward-substituted by the per-level launches before this list runs, so
+  // their BACKB / BACK tasks need nothing but their parent's solution)
+  out.dag_top_tasks.clear();
+  if (out.dag_cut_depth >= 0) {
+    static const bool legacy_top = getenv("SLM_DAG_TOP_LEGACY") != nullptr;   // (A/B: the whole-tree order filtered by depth)
+    if (legacy_top) {
+      for (size_t k = 0; 2 * k < out.dag_tasks.size(); ++k) {
+        const int w0 = out.dag_tasks[2 * k], type = w0 >> 24;
+        if (out.fronts[w0 & 0xFFFFFF].depth <= out.dag_cut_depth || type == ND_T_BACKB || type == ND_T_BACK) {
+          out.dag_top_tasks.push_back(w0);
+          out.dag_top_tasks.push_back(out.dag_tasks[2 * k + 1]);
         }
       }
+    } else {
+      model_list(out.dag_cut_depth, out.dag_top_tasks);
     }
   }
   // ---- destinations of the assembled blocks -------------------------------------------------

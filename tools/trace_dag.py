@@ -97,7 +97,7 @@ if "--kids" in sys.argv:
     # the chains of the root's two children (the fronts below the root with the most pivot columns): per POTRF start / ready / end,
     # and when the COL tasks of each column ran -- at 8 frames per launch these chains compete for workgroups with 7 other slots
     npt_of = {f: len(v) for f, v in lvl_front.items()}
-    kids = sorted((f for f in npt_of if f != root), key=lambda f: -npt_of[f])[:2]
+    kids = sorted((f for f in npt_of if f != root), key=lambda f: -npt_of[f])[:int(os.environ.get("TRACE_KIDS", "2"))]   # (TRACE_KIDS=6: the level below too)
     for k in kids:
         print(f"child front {k} (npt {npt_of[k]}): s | POTRF start ready end wg | COL tasks: n, first ready, last end")
         for sc in range(npt_of[k]):
