@@ -105,3 +105,15 @@ if "--kids" in sys.argv:
             mc = (typ == 1) & (front == k) & (s == sc)
             extra = f"{mc.sum():3d} {rd[mc].min():8.1f} {en[mc].max():8.1f} (start {st[mc].min():.1f} .. {st[mc].max():.1f})" if mc.any() else ""
             print(f"   s={sc}  {st[i]:8.1f} {rd[i]:8.1f} {en[i]:8.1f} wg {tr[i, 3]:3d} | {extra}")
+
+if "--schur" in sys.argv:
+    # the update-matrix tasks per front: when were they taken, when ready, when done (a level transition = the last of them + the parent's gather)
+    for k in sorted(set(front[typ == 2])):
+        m = (typ == 2) & (front == k)
+        print(f"SCHUR of front {k}: {m.sum():3d} tasks, start {st[m].min():7.1f} .. {st[m].max():7.1f}, ready {rd[m].min():7.1f} .. {rd[m].max():7.1f}, "
+              f"end {en[m].min():7.1f} .. {en[m].max():7.1f}, busy sum {np.sum(en[m] - rd[m]):7.1f} us, mean {np.mean(en[m] - rd[m]):5.1f}")
+    # how many workgroups hold a task at time t / work on one (past their last dependency)
+    for t in range(0, int(en.max()) + 1, 20):
+        held = int(((st <= t) & (en > t)).sum())
+        work = int(((rd <= t) & (en > t)).sum())
+        print(f"  t = {t:4d} us: {held:3d} tasks held, {work:3d} past their last dependency")
