@@ -117,3 +117,17 @@ if "--schur" in sys.argv:
         held = int(((st <= t) & (en > t)).sum())
         work = int(((rd <= t) & (en > t)).sum())
         print(f"  t = {t:4d} us: {held:3d} tasks held, {work:3d} past their last dependency")
+
+if "--fronts" in sys.argv:
+    # per front: pivot tile columns, when its first chain task was taken / ready, when its last one ended, when its last update task ended
+    print("front npt | first POTRF taken, ready | last POTRF end | us per column | last SCHUR end | COL tasks taken late by (mean, max us)")
+    for k in sorted(set(front[typ == 0]), key=lambda k: en[(typ == 0) & (front == k)].max()):
+        mp = (typ == 0) & (front == k)
+        i0 = np.nonzero(mp & (s == 0))[0][0]
+        ms = (typ == 2) & (front == k)
+        mc = (typ == 1) & (front == k)
+        npt = int(s[mp].max()) + 1
+        # a COL task is "late" by how long after its column's POTRF ended it was taken (<= 0: it was waiting already)
+        late = np.array([st[i] - en[np.nonzero(mp & (s == s[i]))[0][0]] for i in np.nonzero(mc)[0]]) if mc.any() else np.zeros(1)
+        print(f"  {k:4d} {npt:2d} | {st[i0]:7.1f} {rd[i0]:7.1f} | {en[mp].max():7.1f} | {(en[mp].max() - rd[i0]) / npt:5.1f} | "
+              f"{(en[ms].max() if ms.any() else float('nan')):7.1f} | {np.maximum(late, 0).mean():5.1f} {late.max():6.1f}")
